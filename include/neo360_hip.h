@@ -1,0 +1,176 @@
+/*
+ * neo360_hip.h — C ABI of libneo360_hip.so, the MI355X (gfx950) implementation of
+ * the NeO-360 ray-marching hot path.
+ *
+ * The reference (zubair-irshad/NeO-360) is pure Python/PyTorch and has no FFI of
+ * its own; each entry point below replaces a reference *function* (cited as
+ * file:line, paths relative to the reference root) at the granularity a
+ * maintainer would bind with ctypes.
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes, no torch / C++ types.  `stream` is a hipStream_t
+ *    passed as void* (NULL = default stream).
+ *  - Unless marked [host], every pointer is a DEVICE pointer owned by the caller
+ *    (e.g. a PyTorch-ROCm tensor's data_ptr()).  The library never frees caller
+ *    memory and keeps no reference past the call, except neo_*_upload / set_*
+ *    which copy / re-layout into context-owned buffers before returning
+ *    (stream-ordered).
+ *  - All tensors are dense, row-major fp32 unless stated.
+ *  - Return value: 0 on success, negative neo_status otherwise (never throws).
+ *    neo_last_error() gives a human-readable message for the calling thread.
+ *  - No call synchronises the device; all work is enqueued on `stream`.
+ *  - A context is bound to one device; calls on one context must not overlap
+ *    from several host threads (same rule as the reference's nn.Module).
+ */
+#ifndef NEO360_HIP_H
+#define NEO360_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct neo_ctx neo_ctx;
+
+typedef enum {
+    NEO_OK = 0,
+    NEO_ERR_INVALID = -1,   /* bad argument (null pointer, unsupported size)  */
+    NEO_ERR_HIP = -2,       /* a HIP runtime call failed (see neo_last_error) */
+    NEO_ERR_STATE = -3,     /* weights / scene not uploaded yet               */
+    NEO_ERR_NOMEM = -4
+} neo_status;
+
+/* ---- lifecycle -------------------------------------------------------- */
+int neo_abi_version(void);                       /* bumps on any signature change */
+const char* neo_last_error(void);
+int neo_ctx_create(int device, neo_ctx** out);
+int neo_ctx_destroy(neo_ctx* ctx);
+/* Read-and-clear the device-side assertion word (bit0: a ray missed the unit
+ * sphere — the reference's AssertionError at models/neo360/helper.py:271,:426).
+ * Synchronises `stream`.  [flags: host out] */
+int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream);
+
+/* torch.linspace(start, end, steps) for fp32 on the host (symmetric fill,
+ * step=(end-start)/(steps-1)) — the constant tables the samplers start from
+ * (vanilla_nerf/helper.py:425, :589; neo360/helper.py:36, :197).  No GPU needed.
+ * out [host]. */
+void neo_linspace_host(float start, float end, int steps, float* out);
+
+/* ---- ray generation ---------------------------------------------------- */
+/* datasets/ray_utils.py:84-104 get_ray_directions + :133-176 get_rays
+ * (output_view_dirs=True, output_radii=True).  c2w [host]: 12 floats, row-major
+ * 3x4.  Outputs (H*W,3),(H*W,3),(H*W,3),(H*W); rays_d == viewdirs (the
+ * reference aliases them); radii may be NULL. */
+int neo_raygen(neo_ctx* ctx, int H, int W, float focal, const float* c2w,
+               float* rays_o, float* viewdirs, float* rays_d, float* radii, void* stream);
+
+/* datasets/ray_utils.py:17-68 == models/neo360/helper.py:275-323
+ * bbox_intersection_batch: float64 slab test, rays already in the box frame.
+ * bounds [host]: 6 doubles (min xyz, max xyz).  hit: uint8 0/1 (bit-exact
+ * contract); tmin/tmax: doubles, 0 where missed; either may be NULL. */
+int neo_aabb_intersect(neo_ctx* ctx, const double* bounds, const double* rays_o,
+                       const double* rays_d, int R, uint8_t* hit, double* tmin,
+                       double* tmax, void* stream);
+
+/* models/neo360/helper.py:253-273 intersect_sphere.  far (R); ok (R) uint8 =
+ * (1-|p|^2 >= 0), may be NULL; a miss also raises flag bit0. */
+int neo_intersect_sphere(neo_ctx* ctx, const float* rays_o, const float* rays_d, int R,
+                         float* far, uint8_t* ok, void* stream);
+
+/* ---- stage-level operators (stage-isolated parity) ---------- */
+/* helper.py pos_enc (neo360/helper.py:121-125 == vanilla_nerf/helper.py:445-449):
+ * x (n,C) -> out (n, C*(2*(max_deg-min_deg)+1)). */
+int neo_pos_enc(neo_ctx* ctx, const float* x, int n, int C, int min_deg, int max_deg,
+                float* out, void* stream);
+
+/* sorted_piecewise_constant_pdf + sample_pdf's sort
+ * (vanilla_nerf/helper.py:567-616, neo360/helper.py:174-231), randomized=False.
+ * t_prev (R,n_prev), weights (R,n_prev): bins are the n_prev-1 midpoints of
+ * t_prev, pdf weights are weights[:,1:-1] (the slicing the callers do at
+ * vanilla_nerf/model.py:171-175, neo360/model.py:308-318).  t_out
+ * (R, n_prev+n_new) sorted ascending, or descending when `descending` != 0
+ * (the background branch's flip, neo360/helper.py:234-239). */
+int neo_resample(neo_ctx* ctx, const float* t_prev, const float* weights, int R, int n_prev,
+                 int n_new, int descending, float* t_out, void* stream);
+
+/* volumetric_rendering.  mode 0: vanilla (vanilla_nerf/helper.py:521-559);
+ * mode 1: NeO-360 inside sphere (neo360/helper.py:128-171, in_sphere=True,
+ * needs t_far (R)); mode 2: NeO-360 outside sphere (t descending).
+ * rgbsigma (R,N,4) = (r,g,b,sigma); t (R,N); rays_d (R,3).
+ * Outputs: rgb (R,3), acc (R), depth (R), weights (R,N), lambda (R) [mode 1];
+ * any output may be NULL. */
+int neo_composite(neo_ctx* ctx, int mode, const float* rgbsigma, const float* t,
+                  const float* rays_d, const float* t_far, int R, int N, int white_bkgd,
+                  float* rgb, float* acc, float* depth, float* weights, float* lambda,
+                  void* stream);
+
+/* ---- vanilla NeRF (models/vanilla_nerf/model.py) -------------------------- */
+/* Upload one NeRFMLP (vanilla_nerf/model.py:44-98).  slot 0 = coarse_mlp,
+ * 1 = fine_mlp.  weights/biases [host arrays of 12 device pointers], order:
+ * pts_linears.0..7, views_linear.0, bottleneck_layer, density_layer, rgb_layer;
+ * torch.nn.Linear layout (out,in).  Re-packed on the device into the MFMA
+ * fragment order; the caller's tensors are not referenced afterwards. */
+int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights,
+                           const float* const* biases, void* stream);
+
+/* pos_enc + NeRFMLP.forward + activations for R*N points
+ * (vanilla_nerf/model.py:183-204): points o + t*dirs; t is (R,N) when
+ * t_row_stride == N, or one shared row when t_row_stride == 0.
+ * out (R,N,4) = (rgb after sigmoid+padding, sigma after softplus(raw-1)). */
+int neo_vanilla_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* dirs,
+                    const float* t, int t_row_stride, int R, int N, float* out, void* stream);
+
+/* NeRF.forward (vanilla_nerf/model.py:154-216), randomized=False, both levels.
+ * Samples are cast along `viewdirs`, compositing scales by |rays_d| (as the
+ * reference).  Per level l: rgb_l (R,3), acc_l (R), depth_l (R); level-0
+ * outputs may be NULL. */
+int neo_vanilla_render(neo_ctx* ctx, const float* rays_o, const float* viewdirs,
+                       const float* rays_d, int R, float near, float far, int n_coarse,
+                       int n_fine, int white_bkgd, float* rgb0, float* acc0, float* depth0,
+                       float* rgb1, float* acc1, float* depth1, void* stream);
+
+/* ---- NeO-360 decoder (models/neo360/model.py NeRF_TP) ---------------------- */
+/* Upload one NeRFPPMLP (neo360/model.py:37-108).  slot 0..3 = fg_coarse,
+ * fg_fine, bg_coarse, bg_fine.  input_ch = 3 (fg) or 4 (bg).  weights/biases
+ * [host arrays of 9 device pointers], order: pts_linears.0..3,
+ * views_linear.0, views_linear.1, bottleneck_layer, density_layer, rgb_layer. */
+int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* weights,
+                      const float* const* biases, void* stream);
+
+/* Scene features = the encoder outputs the reference recomputes per chunk
+ * (neo360/model.py:272-274).  planes: 3 x (NV,Cw,Hp,Wp) NCHW; latent
+ * (NV,Cl,Hf,Wf) NCHW; re-laid out channels-last into context-owned buffers.
+ * Cw must be 128 and Cl 512 (the reference's fixed widths). */
+int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
+                     const float* plane_yz, int NV, int Cw, int Hp, int Wp,
+                     const float* latent, int Cl, int Hf, int Wf, float image_w,
+                     float image_h, void* stream);
+
+/* NeRF_TP.forward decoder half (neo360/model.py:276-581), randomized=False,
+ * out_depth=True semantics, for R rays processed in reference-sized chunks
+ * (`chunk` rays per forward call: the view-direction tiling of
+ * neo360/model.py:357-360 makes results depend on chunk membership).
+ * src_poses [host]: NV*16 floats (c2w 4x4 row-major); focal/cx/cy: source view
+ * 0's intrinsics (neo360/model.py:242-244).  Outputs per level l (any may be
+ * NULL): rgb_l (R,3), fg_rgb_l (R,3), bg_rgb_l (R,3), fg_acc_l (R),
+ * bg_lambda_l (R), depth_l (R). */
+typedef struct {
+    float* rgb; float* fg_rgb; float* bg_rgb; float* fg_acc; float* bg_lambda; float* depth;
+} neo_tp_level_out;
+int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d,
+                  const float* viewdirs, int R, int chunk, const float* src_poses, int NV,
+                  float focal, float cx, float cy, int n_coarse, int n_fine, int white_bkgd,
+                  const neo_tp_level_out* level0, const neo_tp_level_out* level1, void* stream);
+
+/* ---- profiling aid ---------------------------------------------------------- */
+/* Average duration (ms) of the dominant MLP kernel launches recorded with HIP
+ * events on their own stream since the last reset; count returned in *launches.
+ * Enable with neo_ctx_set_timing(ctx, 1).  Reading synchronises the events. */
+int neo_ctx_set_timing(neo_ctx* ctx, int enable);
+int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEO360_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libneo360_hip.so (include/neo360_hip.h).
+
+This is the binding a maintainer of the reference would add:
+plain pointers and sizes, tensors passed as `tensor.data_ptr()`.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libneo360_hip.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+
+class TpLevelOut(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth")]
+
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES = {
+    "neo_abi_version": (_i, []),
+    "neo_last_error": (ctypes.c_char_p, []),
+    "neo_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "neo_ctx_destroy": (_i, [_vp]),
+    "neo_ctx_poll_flags": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32), _vp]),
+    "neo_linspace_host": (None, [_f, _f, _i, c_float_p]),
+    "neo_raygen": (_i, [_vp, _i, _i, _f, c_float_p, _vp, _vp, _vp, _vp, _vp]),
+    "neo_aabb_intersect": (_i, [_vp, ctypes.POINTER(ctypes.c_double), _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "neo_intersect_sphere": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "neo_pos_enc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "neo_resample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "neo_composite": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "neo_vanilla_upload_mlp": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "neo_vanilla_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "neo_vanilla_render": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "neo_tp_upload_mlp": (_i, [_vp, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "neo_tp_set_scene": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
+    "neo_tp_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i,
+                           ctypes.POINTER(TpLevelOut), ctypes.POINTER(TpLevelOut), _vp]),
+    "neo_ctx_set_timing": (_i, [_vp, _i]),
+    "neo_ctx_read_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i),
+                                 ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NeoError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and attach prototypes.  Raises if it is missing:
+    there is deliberately no fallback path."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NeoError(
+                "libneo360_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(expected at %s)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().neo_last_error()
+        raise NeoError("libneo360_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def linspace(start, end, steps):
+    """Host helper (no GPU): the library's restatement of torch.linspace fp32."""
+    buf = (ctypes.c_float * steps)()
+    load().neo_linspace_host(start, end, steps, buf)
+    return list(buf)

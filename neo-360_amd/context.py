@@ -1,0 +1,89 @@
+"""Per-device library context and tensor marshalling helpers."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_contexts = {}
+
+
+def _require_gpu(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise _lib.NeoError(
+            "%s is on %s: the neo360_amd path runs only on a ROCm device (there is no CPU fallback)" % (name, t.device))
+
+
+def f32(t, name="tensor"):
+    """Dense fp32 device tensor (copies only if needed)."""
+    _require_gpu(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def f64(t, name="tensor"):
+    _require_gpu(t, name)
+    if t.dtype != torch.float64:
+        t = t.double()
+    return t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream_of(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Context:
+    """Owns one `neo_ctx` (packed weights, scene features, workspaces) on one device."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NeoError("neo360_amd needs a ROCm device, got %s" % self.device)
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.neo_ctx_create(self.index, ctypes.byref(h)))
+        self.handle = h
+        self.uploaded = {}   # slot key -> fingerprint of the parameters packed on the device
+
+    def stream(self):
+        return stream_of(self.device)
+
+    def poll_flags(self):
+        flags = ctypes.c_uint32(0)
+        _lib.check(self.lib.neo_ctx_poll_flags(self.handle, ctypes.byref(flags), self.stream()))
+        return flags.value
+
+    def set_timing(self, enable):
+        _lib.check(self.lib.neo_ctx_set_timing(self.handle, 1 if enable else 0))
+
+    def read_timing(self):
+        ms, n, pts = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
+        _lib.check(self.lib.neo_ctx_read_timing(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(pts)))
+        return ms.value, n.value, pts.value
+
+    def close(self):
+        if self.handle:
+            self.lib.neo_ctx_destroy(self.handle)
+            self.handle = None
+
+
+def get_context(device):
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ctx = _contexts.get(idx)
+    if ctx is None:
+        ctx = _contexts[idx] = Context(torch.device("cuda", idx))
+    return ctx
+
+
+def new_context(device):
+    """A private context (own packed weights / scene), e.g. one per nn.Module."""
+    return Context(device)

@@ -1,0 +1,390 @@
+// extern "C" surface of libneo360_hip.so (see include/neo360_hip.h).
+#include "../../include/neo360_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(NEO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define REQUIRE(cond, msg)                                      \
+    do {                                                        \
+        if (!(cond)) return fail(NEO_ERR_INVALID, "%s", msg);   \
+    } while (0)
+
+// A grow-only device buffer: the steady state of a render loop allocates nothing.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(NEO_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct VanillaSlot {
+    DevBuf wpack, bias, heads;
+    bool ready = false;
+};
+
+}  // namespace
+
+// torch.linspace(start, end, steps) in fp32, CPU algorithm (symmetric fill from both
+// ends, step = (end-start)/(steps-1), fused multiply-add per element), restated so the library needs no torch.
+extern "C" void neo_linspace_host(float start, float end, int steps, float* out) {
+    if (steps <= 0) return;
+    if (steps == 1) { out[0] = start; return; }
+    const float step = (end - start) / static_cast<float>(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i) {
+        // torch's CPU kernel evaluates both branches with a fused multiply-add
+        if (i < half) out[i] = fmaf(step, static_cast<float>(i), start);
+        else out[i] = fmaf(-step, static_cast<float>(steps - i - 1), end);
+    }
+}
+
+struct neo_ctx {
+    int device = 0;
+    uint32_t* flags = nullptr;  // device word, bit0 = ray missed the unit sphere
+    VanillaSlot vanilla[2];
+    std::map<int, DevBuf> quantiles;          // n_new -> linspace(0, fl32(1-2^-32), n_new)
+    std::map<std::pair<int, uint64_t>, DevBuf> edges;  // (n, near/far bits) -> level-0 t row
+    DevBuf ws_out0, ws_w0, ws_t1, ws_out1;    // vanilla render workspace
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    double timed_points = 0.0;
+
+    const float* get_quantiles(int n_new, hipStream_t s) {
+        auto it = quantiles.find(n_new);
+        if (it != quantiles.end()) return it->second.as<float>();
+        std::vector<float> h(n_new);
+        // linspace(0, 1 - 2^-32, n): the end point rounds to exactly 1.0f in fp32
+        neo_linspace_host(0.0f, static_cast<float>(1.0 - 1.0 / 4294967296.0), n_new, h.data());
+        DevBuf& b = quantiles[n_new];
+        if (b.reserve(n_new * sizeof(float))) return nullptr;
+        if (hipMemcpyAsync(b.p, h.data(), n_new * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+        (void)hipStreamSynchronize(s);  // h goes out of scope; first use only
+        return b.as<float>();
+    }
+
+    // near*(1-s) + far*s over linspace(0,1,n+1), separate fp32 ops (vanilla_nerf/helper.py:425-429)
+    const float* get_edges(int n, float near, float far, hipStream_t s) {
+        uint32_t a, b2;
+        memcpy(&a, &near, 4);
+        memcpy(&b2, &far, 4);
+        const auto key = std::make_pair(n, (static_cast<uint64_t>(a) << 32) | b2);
+        auto it = edges.find(key);
+        if (it != edges.end()) return it->second.as<float>();
+        std::vector<float> h(n + 1);
+        neo_linspace_host(0.0f, 1.0f, n + 1, h.data());
+        for (int i = 0; i <= n; ++i) {
+            const float om = 1.0f - h[i];
+            const float lo = near * om;
+            const float hi = far * h[i];
+            h[i] = lo + hi;
+        }
+        DevBuf& buf = edges[key];
+        if (buf.reserve((n + 1) * sizeof(float))) return nullptr;
+        if (hipMemcpyAsync(buf.p, h.data(), (n + 1) * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+        (void)hipStreamSynchronize(s);
+        return buf.as<float>();
+    }
+
+    void span_begin(hipStream_t s) {
+        if (!timing) return;
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, s);
+        spans.emplace_back(a, b);
+    }
+    void span_end(hipStream_t s, double points) {
+        if (!timing) return;
+        (void)hipEventRecord(spans.back().second, s);
+        timed_points += points;
+    }
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != prev && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+#define ENTER(ctx)                                             \
+    REQUIRE((ctx) != nullptr, "null context");                 \
+    DeviceGuard guard_((ctx)->device);                         \
+    if (!guard_.ok) return fail(NEO_ERR_HIP, "hipSetDevice failed")
+
+int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NEO_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int neo_abi_version(void) { return 1; }
+
+const char* neo_last_error(void) { return g_err.c_str(); }
+
+int neo_ctx_create(int device, neo_ctx** out) {
+    REQUIRE(out != nullptr, "null out pointer");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(NEO_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(NEO_ERR_HIP, "hipSetDevice(%d) failed", device);
+    neo_ctx* c = new neo_ctx();
+    c->device = device;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->flags), sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->flags, 0, sizeof(uint32_t));
+    if (e != hipSuccess) {
+        delete c;
+        return fail(NEO_ERR_HIP, "context allocation: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return NEO_OK;
+}
+
+int neo_ctx_destroy(neo_ctx* ctx) {
+    if (!ctx) return NEO_OK;
+    DeviceGuard g(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& sl : ctx->vanilla) { sl.wpack.release(); sl.bias.release(); sl.heads.release(); }
+    for (auto& kv : ctx->quantiles) kv.second.release();
+    for (auto& kv : ctx->edges) kv.second.release();
+    ctx->ws_out0.release(); ctx->ws_w0.release(); ctx->ws_t1.release(); ctx->ws_out1.release();
+    for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
+    if (ctx->flags) (void)hipFree(ctx->flags);
+    delete ctx;
+    return NEO_OK;
+}
+
+int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream) {
+    ENTER(ctx);
+    REQUIRE(flags != nullptr, "null flags");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(flags, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return NEO_OK;
+}
+
+int neo_ctx_set_timing(neo_ctx* ctx, int enable) {
+    ENTER(ctx);
+    for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
+    ctx->spans.clear();
+    ctx->timed_points = 0.0;
+    ctx->timing = enable != 0;
+    return NEO_OK;
+}
+
+int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points) {
+    ENTER(ctx);
+    double ms = 0.0;
+    for (auto& sp : ctx->spans) {
+        HIP_TRY(hipEventSynchronize(sp.second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, sp.first, sp.second));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = static_cast<int>(ctx->spans.size());
+    if (total_points) *total_points = ctx->timed_points;
+    return NEO_OK;
+}
+
+int neo_raygen(neo_ctx* ctx, int H, int W, float focal, const float* c2w, float* rays_o, float* viewdirs,
+               float* rays_d, float* radii, void* stream) {
+    ENTER(ctx);
+    REQUIRE(H >= 3 && W >= 1, "image must be at least 3 rows (the radii rule reads row H-3)");
+    REQUIRE(c2w && rays_o && viewdirs && rays_d, "null pointer");
+    neo::launch_raygen(H, W, focal, c2w, rays_o, viewdirs, rays_d, radii, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_aabb_intersect(neo_ctx* ctx, const double* bounds, const double* rays_o, const double* rays_d, int R,
+                       uint8_t* hit, double* tmin, double* tmax, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0, "negative ray count");
+    if (R == 0) return NEO_OK;
+    REQUIRE(bounds && rays_o && rays_d, "null pointer");
+    neo::launch_aabb(bounds, rays_o, rays_d, R, hit, tmin, tmax, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_intersect_sphere(neo_ctx* ctx, const float* rays_o, const float* rays_d, int R, float* far, uint8_t* ok,
+                         void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0, "negative ray count");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && rays_d && far, "null pointer");
+    neo::launch_sphere(rays_o, rays_d, R, far, ok, ctx->flags, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_pos_enc(neo_ctx* ctx, const float* x, int n, int C, int min_deg, int max_deg, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(n >= 0 && C >= 1 && max_deg >= min_deg, "bad shape");
+    if (n == 0) return NEO_OK;
+    REQUIRE(x && out, "null pointer");
+    neo::launch_pos_enc(x, n, C, min_deg, max_deg, out, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_resample(neo_ctx* ctx, const float* t_prev, const float* weights, int R, int n_prev, int n_new,
+                 int descending, float* t_out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && n_new >= 1, "bad shape");
+    REQUIRE(n_prev >= 4 && n_prev <= 257 && n_prev + n_new <= 1024, "unsupported sample counts");
+    if (R == 0) return NEO_OK;
+    REQUIRE(t_prev && weights && t_out, "null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* u = ctx->get_quantiles(n_new, s);
+    if (!u) return fail(NEO_ERR_HIP, "quantile table upload failed");
+    if (neo::launch_resample(t_prev, n_prev, weights, u, R, n_prev, n_new, descending, t_out, s))
+        return fail(NEO_ERR_INVALID, "unsupported sample counts");
+    return check_launch();
+}
+
+int neo_composite(neo_ctx* ctx, int mode, const float* rgbsigma, const float* t, const float* rays_d,
+                  const float* t_far, int R, int N, int white_bkgd, float* rgb, float* acc, float* depth,
+                  float* weights, float* lambda, void* stream) {
+    ENTER(ctx);
+    REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+    REQUIRE(R >= 0 && N >= 1, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rgbsigma && t, "null pointer");
+    REQUIRE(mode == 2 || rays_d, "rays_d required");
+    REQUIRE(mode != 1 || t_far, "t_far required for mode 1");
+    neo::launch_composite(mode, rgbsigma, t, N, rays_d, t_far, R, N, white_bkgd, rgb, acc, depth, weights, lambda,
+                          static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, const float* const* biases,
+                           void* stream) {
+    ENTER(ctx);
+    REQUIRE(slot == 0 || slot == 1, "slot must be 0 (coarse) or 1 (fine)");
+    REQUIRE(weights && biases, "null pointer table");
+    for (int i = 0; i < 12; ++i) REQUIRE(weights[i] && biases[i], "null layer pointer");
+    VanillaSlot& sl = ctx->vanilla[slot];
+    if (sl.wpack.reserve(neo::vanilla_wpack_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.bias.reserve(neo::vanilla_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.heads.reserve(neo::vanilla_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_vanilla_pack(weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
+                             static_cast<hipStream_t>(stream));
+    sl.ready = true;
+    return check_launch();
+}
+
+static int vanilla_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* dirs, const float* t,
+                              int t_row_stride, int R, int N, float* out, hipStream_t s) {
+    const VanillaSlot& sl = ctx->vanilla[slot];
+    if (!sl.ready) return fail(NEO_ERR_STATE, "vanilla MLP slot %d has no weights", slot);
+    neo::VanillaMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
+    ctx->span_begin(s);
+    neo::launch_vanilla_mlp(m, rays_o, dirs, t, t_row_stride, R, N, out, s);
+    ctx->span_end(s, static_cast<double>(R) * N);
+    return check_launch();
+}
+
+int neo_vanilla_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* dirs, const float* t,
+                    int t_row_stride, int R, int N, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1");
+    REQUIRE(R >= 0 && N >= 1, "bad shape");
+    REQUIRE(t_row_stride == 0 || t_row_stride == N, "t_row_stride must be 0 or N");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && dirs && t && out, "null pointer");
+    return vanilla_mlp_launch(ctx, slot, rays_o, dirs, t, t_row_stride, R, N, out, static_cast<hipStream_t>(stream));
+}
+
+int neo_vanilla_render(neo_ctx* ctx, const float* rays_o, const float* viewdirs, const float* rays_d, int R,
+                       float near, float far, int n_coarse, int n_fine, int white_bkgd, float* rgb0, float* acc0,
+                       float* depth0, float* rgb1, float* acc1, float* depth1, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0, "negative ray count");
+    REQUIRE(n_coarse >= 3 && n_coarse <= 256 && n_fine >= 1 && n_coarse + 1 + n_fine <= 1024,
+            "unsupported sample counts");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && viewdirs && rays_d, "null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int N0 = n_coarse + 1, N1 = N0 + n_fine;
+    const float* t0 = ctx->get_edges(n_coarse, near, far, s);
+    const float* u = ctx->get_quantiles(n_fine, s);
+    if (!t0 || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
+    if (ctx->ws_out0.reserve(static_cast<size_t>(R) * N0 * 16)) return NEO_ERR_NOMEM;
+    if (ctx->ws_w0.reserve(static_cast<size_t>(R) * N0 * 4)) return NEO_ERR_NOMEM;
+    if (ctx->ws_t1.reserve(static_cast<size_t>(R) * N1 * 4)) return NEO_ERR_NOMEM;
+    if (ctx->ws_out1.reserve(static_cast<size_t>(R) * N1 * 16)) return NEO_ERR_NOMEM;
+    float* out0 = ctx->ws_out0.as<float>();
+    float* w0 = ctx->ws_w0.as<float>();
+    float* t1 = ctx->ws_t1.as<float>();
+    float* out1 = ctx->ws_out1.as<float>();
+    // level 0: shared t row (stride 0); samples along viewdirs (vanilla_nerf/model.py:158-167)
+    int rc = vanilla_mlp_launch(ctx, 0, rays_o, viewdirs, t0, 0, R, N0, out0, s);
+    if (rc) return rc;
+    neo::launch_composite(0, out0, t0, 0, rays_d, nullptr, R, N0, white_bkgd, rgb0, acc0, depth0, w0, nullptr, s);
+    // level 1: bins = mids(t0), weights[1:-1] (model.py:171-181); sort-merge
+    if (neo::launch_resample(t0, 0, w0, u, R, N0, n_fine, 0, t1, s)) return fail(NEO_ERR_INVALID, "unsupported sample counts");
+    rc = vanilla_mlp_launch(ctx, 1, rays_o, viewdirs, t1, N1, R, N1, out1, s);
+    if (rc) return rc;
+    neo::launch_composite(0, out1, t1, N1, rays_d, nullptr, R, N1, white_bkgd, rgb1, acc1, depth1, nullptr, nullptr, s);
+    return check_launch();
+}
+
+}  // extern "C"
+
+// ---- NeO-360 decoder entry points: implemented in api_tp.hip ----

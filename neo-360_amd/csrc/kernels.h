@@ -1,0 +1,40 @@
+// Host-side launch wrappers implemented by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace neo {
+
+// rays.hip
+void launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* viewdirs, float* rays_d,
+                   float* radii, hipStream_t s);
+void launch_aabb(const double* bounds, const double* rays_o, const double* rays_d, int R, uint8_t* hit,
+                 double* tmin, double* tmax, hipStream_t s);
+void launch_sphere(const float* rays_o, const float* rays_d, int R, float* far, uint8_t* ok, uint32_t* flags,
+                   hipStream_t s);
+
+// sampling.hip
+void launch_pos_enc(const float* x, int n, int C, int min_deg, int max_deg, float* out, hipStream_t s);
+// mode 0 vanilla, 1 NeO-360 inside sphere, 2 NeO-360 outside sphere.
+void launch_composite(int mode, const float* rgbsigma, const float* t, int t_row_stride, const float* rays_d,
+                      const float* t_far, int R, int N, int white_bkgd, float* rgb, float* acc, float* depth, float* weights,
+                      float* lambda, hipStream_t s);
+// u: n_new quantiles (device), see Ctx::quantiles.
+int launch_resample(const float* t_prev, int t_prev_stride, const float* weights, const float* u, int R, int n_prev, int n_new,
+                    int descending, float* t_out, hipStream_t s);
+
+// mlp_vanilla.hip
+struct VanillaMlpDev {
+    const float* wpack;   // packed GEMM stages (fragment order)
+    const float* bias;    // concatenated per-stage biases
+    const float* heads;   // density w[256], density b, rgb w[3][128], rgb b[3]
+};
+size_t vanilla_wpack_floats();
+size_t vanilla_bias_floats();
+size_t vanilla_heads_floats();
+void launch_vanilla_pack(const float* const* weights, const float* const* biases, float* wpack, float* bias,
+                         float* heads, hipStream_t s);
+void launch_vanilla_mlp(const VanillaMlpDev& m, const float* rays_o, const float* dirs, const float* t,
+                        int t_row_stride, int R, int N, float* out, hipStream_t s);
+
+}  // namespace neo

@@ -1,0 +1,147 @@
+"""Seeded synthetic inputs owned by the build.
+
+Everything is derived from a counter-based integer hash (splitmix64), never
+from a torch / numpy RNG stream, so the golden-fixture generator, the tests
+and bench.py regenerate bit-identical weights, feature planes and cameras on
+any machine and any library version.  Fixtures therefore only need to store
+expected OUTPUTS.
+"""
+import math
+
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def _stream_id(tag):
+    """Stable 64-bit id of a string tag (FNV-1a)."""
+    h = 0xCBF29CE484222325
+    for ch in tag.encode():
+        h = ((h ^ ch) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def uniform01(seed, tag, n):
+    """n float64 values in [0,1), a pure function of (seed, tag, index)."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.uint64(seed) ^ np.uint64(_stream_id(tag)))
+        idx = np.arange(n, dtype=np.uint64)
+        bits = _splitmix64(base + idx * np.uint64(0xD1342543DE82EF95))
+    return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def uniform(seed, tag, shape, lo, hi):
+    n = int(np.prod(shape))
+    v = lo + (hi - lo) * uniform01(seed, tag, n)
+    return torch.from_numpy(v.astype(np.float32).reshape(shape))
+
+
+def normal(seed, tag, shape, std=1.0):
+    n = int(np.prod(shape))
+    m = (n + 1) // 2
+    u1 = uniform01(seed, tag + "/a", m)
+    u2 = uniform01(seed, tag + "/b", m)
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))
+    v = np.concatenate([r * np.cos(2 * math.pi * u2), r * np.sin(2 * math.pi * u2)])[:n]
+    return torch.from_numpy((std * v).astype(np.float32).reshape(shape))
+
+
+# ----------------------------------------------------------------------------
+# weights: same distributions as the reference's initialisers
+# ----------------------------------------------------------------------------
+
+def _linear(seed, sd, name, fan_out, fan_in, xavier=True, gain=1.0):
+    """xavier_uniform_ weight (bound sqrt(6/(in+out))) or torch's default
+    Linear init (bound 1/sqrt(in)); bias always the default U(+-1/sqrt(in))."""
+    wb = math.sqrt(6.0 / (fan_in + fan_out)) if xavier else 1.0 / math.sqrt(fan_in)
+    sd[name + ".weight"] = uniform(seed, name + ".weight", (fan_out, fan_in), -wb, wb) * gain
+    bb = 1.0 / math.sqrt(fan_in)
+    sd[name + ".bias"] = uniform(seed, name + ".bias", (fan_out,), -bb, bb)
+
+
+def vanilla_mlp_state(seed, prefix, sd=None, density_gain=1.0):
+    """Parameters of one vanilla NeRFMLP under reference key names
+    (vanilla_nerf/model.py:44-98): 8x256 trunk, skip at 4, 63/27-d encodings."""
+    sd = {} if sd is None else sd
+    width, pos, view = 256, 63, 27
+    _linear(seed, sd, prefix + "pts_linears.0", width, pos)
+    for i in range(1, 8):
+        _linear(seed, sd, prefix + "pts_linears.%d" % i, width, width + pos if i == 5 else width)
+    _linear(seed, sd, prefix + "views_linear.0", 128, width + view, xavier=False)
+    _linear(seed, sd, prefix + "bottleneck_layer", width, width)
+    _linear(seed, sd, prefix + "density_layer", 1, width, gain=density_gain)
+    _linear(seed, sd, prefix + "rgb_layer", 3, 128)
+    return sd
+
+
+def vanilla_state(seed=0, density_gain=1.0):
+    sd = {}
+    vanilla_mlp_state(seed, "coarse_mlp.", sd, density_gain)
+    vanilla_mlp_state(seed, "fine_mlp.", sd, density_gain)
+    return sd
+
+
+def nerfpp_mlp_state(seed, prefix, sd=None, input_ch=3, local=512, world=128, density_gain=1.0):
+    """Parameters of one NeRFPPMLP (neo360/model.py:37-108): 4x128 trunk,
+    skip at 2, input = posenc(10 deg) + local + world."""
+    sd = {} if sd is None else sd
+    width, cond = 128, 64
+    pos = (2 * 10 + 1) * input_ch + local + world
+    _linear(seed, sd, prefix + "pts_linears.0", width, pos)
+    for i in range(1, 4):
+        _linear(seed, sd, prefix + "pts_linears.%d" % i, width, width + pos if i == 3 else width)
+    _linear(seed, sd, prefix + "views_linear.0", cond, width + 27, xavier=False)
+    _linear(seed, sd, prefix + "views_linear.1", cond, cond)
+    _linear(seed, sd, prefix + "bottleneck_layer", width, width)
+    _linear(seed, sd, prefix + "density_layer", 1, width, gain=density_gain)
+    _linear(seed, sd, prefix + "rgb_layer", 3, cond)
+    return sd
+
+
+def nerf_tp_state(seed=0, density_gain=1.0):
+    sd = {}
+    for name, ch in (("fg_coarse_mlp.", 3), ("fg_fine_mlp.", 3), ("bg_coarse_mlp.", 4), ("bg_fine_mlp.", 4)):
+        nerfpp_mlp_state(seed, name, sd, input_ch=ch, density_gain=density_gain)
+    return sd
+
+
+# ----------------------------------------------------------------------------
+# cameras / rays / scene features
+# ----------------------------------------------------------------------------
+
+def look_at_origin(azimuth_deg, radius=0.6, height=0.3):
+    """c2w (4,4) fp32 of a camera on an orbit, looking at the origin, z up;
+    camera convention of the reference's rays: x right, y up, looking along -z."""
+    a = math.radians(azimuth_deg)
+    eye = np.array([radius * math.cos(a), radius * math.sin(a), height])
+    back = eye / np.linalg.norm(eye)
+    right = np.cross(np.array([0.0, 0.0, 1.0]), back)
+    right /= np.linalg.norm(right)
+    up = np.cross(back, right)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, up, back, eye
+    return torch.from_numpy(m.astype(np.float32))
+
+
+def source_views(nv=3, W=640, H=480):
+    az = [0.0, 115.0, 229.0, 300.0, 60.0][:nv]
+    poses = torch.stack([look_at_origin(a) for a in az])
+    focal = torch.full((nv,), 0.8 * W)
+    centre = torch.tensor([[W / 2.0, H / 2.0]]).repeat(nv, 1)
+    return poses, focal, centre
+
+
+def scene_features(seed=0, nv=3, world_ch=128, plane_hw=(120, 160), local_ch=512, latent_hw=(240, 320), std=0.1):
+    """Stand-ins for the scene encoder's outputs, reference layout (NCHW)."""
+    planes = {k: normal(seed, "plane_" + k, (nv, world_ch) + tuple(plane_hw), std) for k in ("xz", "xy", "yz")}
+    latent = normal(seed, "latent", (nv, local_ch) + tuple(latent_hw), std)
+    return dict(plane_xz=planes["xz"], plane_xy=planes["xy"], plane_yz=planes["yz"], latent=latent)

@@ -1,0 +1,98 @@
+"""Oracle: NeO-360 decoder render (tri-planar + pixel-aligned features,
+inside/outside-sphere two-region NeRF++).  Test infrastructure (oracle/__init__.py).
+
+The scene encoder (GridEncoder / ResNet) is outside the hot path; its outputs —
+three tri-planes (NV,128,Hp,Wp) and the pixel-aligned latent (NV,512,Hf,Wf) —
+are inputs here (`scene`).
+"""
+import torch
+
+from . import compositing, encoding, gather, mlp, rays as rays_mod, sampling
+
+
+def _predict(params, prefix, cam_pts, dir_cam, world, local, B, N, nv):
+    """neo360/model.py:343-407.  Reproduces the view-direction tiling of
+    :357-360 literally: the (NV,B,27) encoding is tiled with (1,N,1), so the
+    row for (view v, ray b, sample s) carries the direction of ray
+    (b*N+s) mod B of THIS call."""
+    x_enc = encoding.pos_enc(cam_pts, 0, 10)
+    d_enc = encoding.pos_enc(dir_cam, 0, 4)
+    d_rows = torch.tile(d_enc[:, None, :], (1, N, 1)).reshape(-1, d_enc.shape[-1])
+    raw_rgb, raw_sigma = mlp.nerfpp_mlp(params, prefix, x_enc, d_rows, world, local, nv)
+    return mlp.colour_activation(raw_rgb.reshape(B, N, -1)), mlp.density_activation(raw_sigma.reshape(B, N, -1))
+
+
+def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_depth=True, keep=False):
+    """Return value of NeRF_TP.forward for randomized=False
+    (neo360/model.py:266-581, decoder half from :276).
+
+    rays: rays_o, rays_d, viewdirs (B,3), src_poses (NV,4,4), src_focal (NV,),
+    src_c (NV,2).  scene: plane_xz/xy/yz (NV,C,Hp,Wp), latent (NV,512,Hf,Wf),
+    image_wh (W,H).  Per level: out_depth -> (rgb, fg_rgb, bg_rgb, fg_acc,
+    bg_lambda, depth); else (rgb, fg_w, bg_w, fg_sdist, bg_sdist, bg_acc).
+    """
+    o, d, vd = rays["rays_o"], rays["rays_d"], rays["viewdirs"]
+    poses, focal, centre = rays["src_poses"], rays["src_focal"], rays["src_c"]
+    nv = poses.shape[0]
+    near = torch.full_like(o[..., -1:], 1e-4)                      # model.py:277
+    far, _ = rays_mod.sphere_exit_depth(o, d)                      # model.py:278
+    dir_cam = gather.world_to_camera_dirs(vd, poses)               # model.py:339-341
+    planes = (scene["plane_xz"], scene["plane_xy"], scene["plane_yz"])
+
+    def feats(p3):
+        return (gather.triplane_features(p3, *planes, poses),
+                gather.pixel_aligned_features(p3, scene["latent"], poses, focal, centre, scene["image_wh"]))
+
+    out, extra = [], []
+    fg_t = bg_s = fg_w = bg_w = None
+    for level in range(2):
+        if level == 0:
+            fg_t, fg_p = sampling.neo_fg_level0(o, d, n_coarse, near, far)
+            bg_s, bg_p4, bg_lin = sampling.neo_bg_level0(o, d, n_coarse, far, 3.0)
+            fg_name, bg_name = "fg_coarse_mlp.", "bg_coarse_mlp."
+        else:
+            fg_mid = 0.5 * (fg_t[..., 1:] + fg_t[..., :-1])
+            bg_mid = 0.5 * (bg_s[..., 1:] + bg_s[..., :-1])
+            fg_t, fg_p = sampling.neo_fg_level1(fg_mid, fg_w[..., 1:-1], o, d, fg_t, n_fine)
+            bg_s, bg_p4, bg_lin = sampling.neo_bg_level1(bg_mid, bg_w[..., 1:-1], o, d, bg_s, n_fine, far, 3.0)
+            fg_name, bg_name = "fg_fine_mlp.", "bg_fine_mlp."
+        B, N, _ = fg_p.shape
+        fg_world, fg_local = feats(fg_p)
+        bg_world, bg_local = feats(bg_lin[:, :, :3])
+        fg_cam = gather.world_to_camera(fg_p.reshape(-1, 3), poses)
+        bg_cam = gather.world_to_camera(bg_p4[:, :, :3].reshape(-1, 3), poses)
+        inv_r = bg_p4[:, :, 3].reshape(-1, 1).unsqueeze(0).repeat(nv, 1, 1)
+        bg_cam = torch.cat((bg_cam, inv_r), dim=-1)                # model.py:454-464
+        fg_rgb, fg_sigma = _predict(params, fg_name, fg_cam, dir_cam, fg_world, fg_local, B, N, nv)
+        bg_rgb, bg_sigma = _predict(params, bg_name, bg_cam, dir_cam, bg_world, bg_local, B, N, nv)
+        wb = False if out_depth else white_bkgd
+        fg_c, fg_acc, fg_w, lam, fg_depth = compositing.neo_composite(fg_rgb, fg_sigma, fg_t, d, True, far, wb)
+        bg_c, bg_acc, bg_w, _, bg_depth = compositing.neo_composite(bg_rgb, bg_sigma, bg_s, d, False, None, wb)
+        rgb = fg_c + lam * bg_c
+        if out_depth:
+            out.append((rgb, fg_c, bg_c, fg_acc, lam, fg_depth + lam.squeeze(-1) * bg_depth))
+        else:
+            fg_sd = 0.5 * (fg_t[..., 1:] + fg_t[..., :-1])
+            fg_sd = torch.cat([fg_sd, (fg_sd[:, -1] + (fg_sd[:, -1] - fg_sd[:, -2])).unsqueeze(-1)], dim=-1)
+            bg_sd = 0.5 * (bg_s[..., 1:] + bg_s[..., :-1])
+            bg_sd = torch.cat([bg_sd, bg_s[..., -1].unsqueeze(-1)], dim=-1)
+            out.append((rgb, fg_w, bg_w, fg_sd, bg_sd, bg_acc))
+        extra.append(dict(fg_t=fg_t, bg_s=bg_s, fg_sigma=fg_sigma, bg_sigma=bg_sigma, fg_rgb=fg_rgb,
+                          bg_rgb=bg_rgb, fg_w=fg_w, bg_w=bg_w, far=far))
+    return (out, extra) if keep else out
+
+
+_WHOLE = ("src_imgs", "src_poses", "src_focal", "src_c")
+
+
+def render_chunked(params, rays, scene, chunk, **kw):
+    """The caller's chunk loop (neo360/model.py:861-907): per-ray keys are
+    sliced, src_* passed whole; keeps level-1 rgb ([1][0]) and depth ([1][5])."""
+    B = rays["rays_o"].shape[0]
+    rgb, depth = [], []
+    for i in range(0, B, chunk):
+        part = {k: (v if k in _WHOLE else v[i:i + chunk]) for k, v in rays.items()}
+        res = render(params, part, scene, out_depth=True, **kw)
+        rgb.append(res[1][0])
+        depth.append(res[1][5])
+    return torch.cat(rgb, 0), torch.cat(depth, 0)

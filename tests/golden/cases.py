@@ -1,0 +1,108 @@
+"""Seeded input builders shared by the golden generator and the tests.
+
+Pure functions of integer seeds (neo360_amd.synth): the fixtures under
+tests/golden/*.npz hold only EXPECTED OUTPUTS of the reference; every input is
+regenerated here, identically, on any machine.  No reference imports.
+"""
+import math
+
+import numpy as np
+import torch
+
+from neo360_amd import synth
+
+# ---- small scene used by every NeO-360 fixture ----------------------------------
+NV = 3
+IMG_WH = (64, 48)          # source image size the latents were "encoded" from
+PLANE_HW = (12, 16)
+LATENT_HW = (24, 32)
+
+
+def crop_rays(H, W, azimuth=40.0, radius=0.6, height=0.3):
+    """Rays of an H x W pinhole camera (focal 0.8 W) on the test orbit, built with
+    plain fp64 NumPy so that fixtures do not depend on either implementation of
+    ray generation.  Every ray hits the unit sphere (camera is inside it)."""
+    c2w = synth.look_at_origin(azimuth, radius, height).double().numpy()
+    f = 0.8 * W
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    cam = np.stack([(ii - W / 2) / f, -(jj - H / 2) / f, -np.ones_like(ii)], -1).reshape(-1, 3)
+    d = cam @ c2w[:3, :3].T
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.broadcast_to(c2w[:3, 3], d.shape)
+    o32 = torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32))
+    d32 = torch.from_numpy(d.astype(np.float32))
+    return dict(rays_o=o32, rays_d=d32.clone(), viewdirs=d32.clone())
+
+
+def take(rays, idx):
+    return {k: v[idx].contiguous() for k, v in rays.items()}
+
+
+def neo_batch(rays):
+    """Adds the src_* keys of the reference's batch dict (datasets/nerds360_ae.py)."""
+    poses, focal, centre = synth.source_views(NV, IMG_WH[0], IMG_WH[1])
+    out = dict(rays)
+    out.update(src_poses=poses, src_focal=focal, src_c=centre,
+               src_imgs=torch.zeros(NV, 3, IMG_WH[1], IMG_WH[0]))
+    return out
+
+
+def small_scene(seed=7):
+    sc = synth.scene_features(seed, NV, 128, PLANE_HW, 512, LATENT_HW, std=0.5)
+    sc["image_wh"] = (float(IMG_WH[0]), float(IMG_WH[1]))
+    return sc
+
+
+def strided_rays(n, H=48, W=64, **kw):
+    """n rays spread over an H x W frame (deterministic stride pattern)."""
+    rays = crop_rays(H, W, **kw)
+    total = H * W
+    idx = torch.from_numpy(((np.arange(n, dtype=np.int64) * 2654435761) % total))
+    return take(rays, idx)
+
+
+def aabb_cases(seed=3, n=4096):
+    """Rays in box frame (float64) vs three boxes; includes exact-zero direction
+    components, origins inside the box, and rays parallel to faces."""
+    u = synth.uniform01(seed, "aabb_o", n * 3).reshape(n, 3) * 4.0 - 2.0
+    d = synth.uniform01(seed, "aabb_d", n * 3).reshape(n, 3) * 2.0 - 1.0
+    aim = synth.uniform01(seed, "aabb_aim", n * 3).reshape(n, 3) * 1.6 - 0.8
+    d[::2] = (aim - u)[::2]          # half of the rays are aimed at the boxes' neighbourhood
+    d[::7, 0] = 0.0
+    d[::11, 1] = 0.0
+    d[::13, 2] = 0.0
+    d[5::97] = np.array([0.0, 0.0, 1.0])
+    u[3::17] *= 0.1  # origins inside the unit-ish boxes
+    boxes = np.array([
+        [[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]],
+        [[-1.0, -0.25, 0.0], [0.25, 0.75, 0.5]],
+        [[0.2, 0.2, 0.2], [1.5, 0.4, 1.2]],
+    ])
+    return boxes, u, d
+
+
+def pdf_cases(seed=5, R=96, nb=64):
+    """(bins, weights) pairs for the inverse-CDF sampler: ascending bins with
+    positive weights, descending bins (the background branch), all-zero weights,
+    one spiky row and tied bins."""
+    w = synth.uniform(seed, "pdf_w", (R, nb - 1), 0.0, 1.0)
+    w[1] = 0.0
+    w[2] = 0.0
+    w[2, 17] = 5.0
+    w[3, : nb // 2] = 0.0
+    edges = torch.cumsum(synth.uniform(seed, "pdf_e", (R, nb + 1), 0.01, 1.0), dim=-1)
+    edges = edges / edges[:, -1:]
+    mids = 0.5 * (edges[:, 1:] + edges[:, :-1])
+    mids[4, 10:14] = mids[4, 10]
+    return dict(asc=(mids.contiguous(), w), desc=(torch.flip(mids, dims=[-1]).contiguous(), w))
+
+
+def composite_case(seed=9, R=64, N=129):
+    rgb = synth.uniform(seed, "c_rgb", (R, N, 3), 0.0, 1.0)
+    sigma = synth.uniform(seed, "c_sig", (R, N, 1), 0.0, 6.0)
+    sigma[0] = 0.0
+    sigma[1] = 80.0
+    t = torch.cumsum(synth.uniform(seed, "c_t", (R, N), 0.002, 0.03), dim=-1)
+    dirs = torch.nn.functional.normalize(synth.uniform(seed, "c_d", (R, 3), -1.0, 1.0), dim=-1) * 1.0
+    far = t[:, -1:] + 0.02
+    return rgb, sigma, t, dirs, far

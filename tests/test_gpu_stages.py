@@ -1,0 +1,138 @@
+"""GPU: each HIP kernel against the CPU oracle and the reference-generated
+fixtures, stage by stage (SURVEY.md §4 level 2).  Calls go through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+import oracle
+from conftest import max_abs
+from neo360_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_raygen_vs_golden(golden):
+    g = golden("g1_raygen")
+    for tag, (H, W) in (("s", (32, 32)), ("f", (480, 640))):
+        for pi, az in enumerate((10.0, 130.0, 250.0)):
+            c2w = synth.look_at_origin(az, 0.6 + 0.1 * pi, 0.3 - 0.2 * pi)
+            ro, vd, rd, rad = [x.cpu() for x in ops.get_ray_directions_and_rays(H, W, 0.8 * W, c2w)]
+            if tag == "f":
+                idx = g["idx_f"]
+                ro, vd, rd, rad = ro[idx], vd[idx], rd[idx], rad[idx]
+            assert max_abs(ro, g["o_%s%d" % (tag, pi)]) == 0.0
+            assert max_abs(vd, g["v_%s%d" % (tag, pi)]) < 2e-7
+            assert max_abs(rd, g["d_%s%d" % (tag, pi)]) < 2e-7
+            assert max_abs(rad, g["r_%s%d" % (tag, pi)]) < 1e-9 + 1e-5 * float(g["r_%s%d" % (tag, pi)].max())
+
+
+def test_aabb_hit_mask_bit_exact(golden):
+    g = golden("g2_aabb")
+    boxes, o, d = cases.aabb_cases()
+    od, dd = torch.from_numpy(o).to(DEV), torch.from_numpy(d).to(DEV)
+    for bi, b in enumerate(boxes):
+        hit, tmin, tmax = ops.bbox_intersection_batch(b, od, dd)
+        assert torch.equal(hit.cpu(), g["hit%d" % bi])                       # integer mask: bit-exact
+        assert np.array_equal(tmin.cpu().numpy(), g["tmin%d" % bi].numpy())  # fp64 slab distances: bit-exact too
+        assert np.array_equal(tmax.cpu().numpy(), g["tmax%d" % bi].numpy())
+
+
+def test_aabb_empty_and_single():
+    b = [[-1, -1, -1], [1, 1, 1]]
+    hit, _, _ = ops.bbox_intersection_batch(b, torch.zeros(0, 3, dtype=torch.float64, device=DEV),
+                                            torch.zeros(0, 3, dtype=torch.float64, device=DEV))
+    assert hit.numel() == 0
+    o = torch.tensor([[0.0, 0.0, -3.0], [0.0, 0.0, 0.0]], dtype=torch.float64, device=DEV)
+    d = torch.tensor([[0.0, 0.0, 1.0], [0.0, 0.0, 1.0]], dtype=torch.float64, device=DEV)
+    hit, tmin, tmax = ops.bbox_intersection_batch(b, o, d)
+    assert hit.tolist() == [1, 0] and tmin.tolist() == [2.0, 0.0] and tmax.tolist() == [4.0, 0.0]
+
+
+def test_sphere_mask_and_depth(golden):
+    g = golden("g3_stages")
+    rays = cases.strided_rays(96)
+    far, ok = ops.intersect_sphere(rays["rays_o"].to(DEV), rays["rays_d"].to(DEV))
+    assert bool(ok.all())
+    assert max_abs(far.cpu(), g["far"]) < 1e-6
+    # a ray that misses the unit sphere: mask bit and the reference's AssertionError
+    o = torch.tensor([[0.0, 0.0, 3.0], [0.0, 0.0, 0.5]], device=DEV)
+    d = torch.tensor([[1.0, 0.0, 0.0], [1.0, 0.0, 0.0]], device=DEV)
+    _, ok = ops.intersect_sphere(o, d, check=False)
+    assert ok.tolist() == [0, 1]
+    ops.get_context = ops.get_context  # keep linters quiet
+    with pytest.raises(AssertionError):
+        ops.intersect_sphere(o, d)
+    _, ok = ops.intersect_sphere(o[1:], d[1:])  # flag was cleared by the poll
+    assert ok.tolist() == [1]
+
+
+def test_pos_enc(golden):
+    g = golden("g3_stages")
+    x3 = synth.uniform(11, "pe3", (257, 3), -1.7, 1.7)
+    x4 = synth.uniform(11, "pe4", (129, 4), -1.0, 1.0)
+    assert max_abs(ops.pos_enc(x3.to(DEV), 0, 10).cpu(), g["pe3"]) < 5e-7
+    assert max_abs(ops.pos_enc(x4.to(DEV), 0, 10).cpu(), g["pe4"]) < 5e-7
+    assert max_abs(ops.pos_enc(x3.to(DEV), 0, 4).cpu(), g["pe3v"]) < 5e-7
+
+
+@pytest.mark.parametrize("desc", [False, True])
+def test_resample_matches_oracle(desc):
+    """Full resample op = pdf sampling with the callers' slicing + sort (+ flip)."""
+    R, n_prev, n_new = 96, 65, 128
+    t_prev = torch.cumsum(synth.uniform(5, "rs_t", (R, n_prev), 0.01, 1.0), dim=-1)
+    t_prev = t_prev / t_prev[:, -1:]
+    w = synth.uniform(5, "rs_w", (R, n_prev), 0.0, 1.0)
+    w[1] = 0.0
+    w[2] = 0.0
+    w[2, 20] = 3.0
+    if desc:
+        t_prev = torch.flip(t_prev, dims=[-1]).contiguous()
+    mids = 0.5 * (t_prev[:, 1:] + t_prev[:, :-1])
+    want = oracle.sampling.merge_sorted(t_prev, oracle.sampling.piecewise_constant_samples(mids, w[:, 1:-1], n_new))
+    if desc:
+        want = torch.flip(want, dims=[-1])
+    got = ops.resample(t_prev.to(DEV), w.to(DEV), n_new, descending=desc).cpu()
+    assert got.shape == want.shape
+    assert max_abs(got, want) < 2e-6
+
+
+def test_resample_golden_bins(golden):
+    """The fixture's (bins, weights) pairs are reproduced by feeding t_prev whose midpoints are the bins."""
+    g = golden("g3_stages")
+    pc = cases.pdf_cases()
+    for tag in ("asc", "desc"):
+        bins, w = pc[tag]
+        # construct t_prev with those midpoints: t[0] free, t[k+1] = 2 b[k] - t[k]
+        t_prev = torch.zeros(bins.shape[0], bins.shape[1] + 1, dtype=torch.float64)
+        t_prev[:, 0] = bins[:, 0].double()
+        for k in range(bins.shape[1]):
+            t_prev[:, k + 1] = 2 * bins[:, k].double() - t_prev[:, k]
+        t_prev = t_prev.float()
+        mids = 0.5 * (t_prev[:, 1:] + t_prev[:, :-1])
+        if max_abs(mids, bins) > 0:   # only rows whose midpoints reproduce exactly are comparable
+            keep = (mids == bins).all(dim=1)
+        else:
+            keep = torch.ones(bins.shape[0], dtype=torch.bool)
+        wfull = torch.cat([torch.zeros(w.shape[0], 1), w, torch.zeros(w.shape[0], 1)], dim=1)
+        got = ops.resample(t_prev.to(DEV), wfull.to(DEV), 128).cpu()
+        want = torch.sort(torch.cat([t_prev, g["pdf_" + tag]], dim=-1), dim=-1).values
+        assert int(keep.sum()) > 10
+        assert max_abs(got[keep], want[keep]) < 2e-6
+
+
+def test_composite_modes(golden):
+    g = golden("g3_stages")
+    rgb, sigma, t, dirs, far = cases.composite_case()
+    rs = torch.cat([rgb, sigma], dim=-1).to(DEV)
+    r = ops.composite(1, rs, t.to(DEV), dirs.to(DEV), far.to(DEV))
+    for nm, key in (("rgb", "rgb"), ("acc", "acc"), ("w", "weights"), ("lam", "bg_lambda"), ("depth", "depth")):
+        assert max_abs(r[key].cpu(), g["cfg_" + nm]) < 2e-6, nm
+    t_desc = torch.flip(t / t.max(), dims=[-1]).contiguous()
+    r = ops.composite(2, rs, t_desc.to(DEV))
+    for nm, key in (("rgb", "rgb"), ("acc", "acc"), ("w", "weights"), ("depth", "depth")):
+        assert max_abs(r[key].cpu(), g["cbg_" + nm]) < 2e-6, nm
+    r = ops.composite(0, rs, t.to(DEV), (dirs * 1.3).to(DEV), white_bkgd=True)
+    for nm, key in (("rgb", "rgb"), ("acc", "acc"), ("w", "weights"), ("depth", "depth")):
+        assert max_abs(r[key].cpu(), g["cv_" + nm]) < 2e-6, nm
