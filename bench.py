@@ -34,7 +34,9 @@ def cpu_baseline(state, rays_cpu, got_rgb, got_depth, budget_rays):
     """Oracle (CPU restatement of the reference, 'port') timed on a bounded sample of
     the same frame; also returns the parity of the GPU frame on those rays."""
     import oracle
-    torch.set_num_threads(os.cpu_count() or 1)
+    # 32 threads is the fastest setting of an 8..256 sweep on the GPU box's 2x64-core EPYC 9575F
+    # (profiles/cpu_threads_r01.log: 625 rays/s at 32, 40 rays/s at 256 threads)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     sample = {k: v[:budget_rays] for k, v in rays_cpu.items()}
     t0 = time.perf_counter()
     rgb, depth = oracle.vanilla.render_chunked(state, sample, NEAR, FAR, chunk=1024)
@@ -54,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
