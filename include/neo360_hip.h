@@ -147,6 +147,16 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
                      const float* latent, int Cl, int Hf, int Wf, float image_w,
                      float image_h, void* stream);
 
+/* `predict` + the feature lookups for one region at given sample positions
+ * (neo360/model.py:343-464): slot 0/1 inside the sphere (tvals = t, ascending),
+ * slot 2/3 outside (tvals = inverse radius, descending; needs far (R) from
+ * neo_intersect_sphere).  tvals (R,N); out (R,N,4) = (rgb, sigma) after activations.
+ * `chunk`, src_poses [host], focal/cx/cy as for neo_tp_render. */
+int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
+               const float* viewdirs, const float* tvals, const float* far, int R, int N,
+               int chunk, const float* src_poses, int NV, float focal, float cx, float cy,
+               float* out, void* stream);
+
 /* NeRF_TP.forward decoder half (neo360/model.py:276-581), randomized=False,
  * out_depth=True semantics, for R rays processed in reference-sized chunks
  * (`chunk` rays per forward call: the view-direction tiling of

@@ -39,6 +39,7 @@ SIGNATURES = {
     "neo_vanilla_render": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "neo_tp_upload_mlp": (_i, [_vp, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "neo_tp_set_scene": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
+    "neo_tp_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i,
                            ctypes.POINTER(TpLevelOut), ctypes.POINTER(TpLevelOut), _vp]),
     "neo_ctx_set_timing": (_i, [_vp, _i]),

@@ -1,22 +1,13 @@
-// extern "C" surface of libneo360_hip.so (see include/neo360_hip.h).
-#include "../../include/neo360_hip.h"
+// extern "C" surface of libneo360_hip.so (see include/neo360_hip.h): lifecycle, ray
+// generation, stage-level operators and the vanilla NeRF path.
+#include "ctx.h"
 
-#include <hip/hip_runtime.h>
+using namespace neo_host;
 
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <map>
-#include <string>
-#include <utility>
-#include <vector>
+namespace neo_host {
 
-#include "kernels.h"
-
-namespace {
-
-thread_local std::string g_err;
+static thread_local std::string g_err;
+std::string& last_error() { return g_err; }
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -28,45 +19,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail(NEO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-#define REQUIRE(cond, msg)                                      \
-    do {                                                        \
-        if (!(cond)) return fail(NEO_ERR_INVALID, "%s", msg);   \
-    } while (0)
-
-// A grow-only device buffer: the steady state of a render loop allocates nothing.
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) return fail(NEO_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-        cap = bytes;
-        return 0;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
-
-struct VanillaSlot {
-    DevBuf wpack, bias, heads;
-    bool ready = false;
-};
-
-}  // namespace
+}  // namespace neo_host
 
 // torch.linspace(start, end, steps) in fp32, CPU algorithm (symmetric fill from both
 // ends, step = (end-start)/(steps-1), fused multiply-add per element), restated so the library needs no torch.
@@ -82,101 +35,61 @@ extern "C" void neo_linspace_host(float start, float end, int steps, float* out)
     }
 }
 
-struct neo_ctx {
-    int device = 0;
-    uint32_t* flags = nullptr;  // device word, bit0 = ray missed the unit sphere
-    VanillaSlot vanilla[2];
-    std::map<int, DevBuf> quantiles;          // n_new -> linspace(0, fl32(1-2^-32), n_new)
-    std::map<std::pair<int, uint64_t>, DevBuf> edges;  // (n, near/far bits) -> level-0 t row
-    DevBuf ws_out0, ws_w0, ws_t1, ws_out1;    // vanilla render workspace
-    bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
-    double timed_points = 0.0;
-
-    const float* get_quantiles(int n_new, hipStream_t s) {
-        auto it = quantiles.find(n_new);
-        if (it != quantiles.end()) return it->second.as<float>();
-        std::vector<float> h(n_new);
-        // linspace(0, 1 - 2^-32, n): the end point rounds to exactly 1.0f in fp32
-        neo_linspace_host(0.0f, static_cast<float>(1.0 - 1.0 / 4294967296.0), n_new, h.data());
-        DevBuf& b = quantiles[n_new];
-        if (b.reserve(n_new * sizeof(float))) return nullptr;
-        if (hipMemcpyAsync(b.p, h.data(), n_new * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
-        (void)hipStreamSynchronize(s);  // h goes out of scope; first use only
-        return b.as<float>();
-    }
-
-    // near*(1-s) + far*s over linspace(0,1,n+1), separate fp32 ops (vanilla_nerf/helper.py:425-429)
-    const float* get_edges(int n, float near, float far, hipStream_t s) {
-        uint32_t a, b2;
-        memcpy(&a, &near, 4);
-        memcpy(&b2, &far, 4);
-        const auto key = std::make_pair(n, (static_cast<uint64_t>(a) << 32) | b2);
-        auto it = edges.find(key);
-        if (it != edges.end()) return it->second.as<float>();
-        std::vector<float> h(n + 1);
-        neo_linspace_host(0.0f, 1.0f, n + 1, h.data());
-        for (int i = 0; i <= n; ++i) {
-            const float om = 1.0f - h[i];
-            const float lo = near * om;
-            const float hi = far * h[i];
-            h[i] = lo + hi;
-        }
-        DevBuf& buf = edges[key];
-        if (buf.reserve((n + 1) * sizeof(float))) return nullptr;
-        if (hipMemcpyAsync(buf.p, h.data(), (n + 1) * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
-        (void)hipStreamSynchronize(s);
-        return buf.as<float>();
-    }
-
-    void span_begin(hipStream_t s) {
-        if (!timing) return;
-        hipEvent_t a, b;
-        (void)hipEventCreate(&a);
-        (void)hipEventCreate(&b);
-        (void)hipEventRecord(a, s);
-        spans.emplace_back(a, b);
-    }
-    void span_end(hipStream_t s, double points) {
-        if (!timing) return;
-        (void)hipEventRecord(spans.back().second, s);
-        timed_points += points;
-    }
-};
-
-namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-    }
-    ~DeviceGuard() {
-        int cur = -1;
-        if (hipGetDevice(&cur) == hipSuccess && cur != prev && prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-#define ENTER(ctx)                                             \
-    REQUIRE((ctx) != nullptr, "null context");                 \
-    DeviceGuard guard_((ctx)->device);                         \
-    if (!guard_.ok) return fail(NEO_ERR_HIP, "hipSetDevice failed")
-
-int check_launch() {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(NEO_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
-    return 0;
+const float* neo_ctx::get_quantiles(int n_new, hipStream_t s) {
+    auto it = quantiles.find(n_new);
+    if (it != quantiles.end()) return it->second.as<float>();
+    std::vector<float> h(n_new);
+    // linspace(0, 1 - 2^-32, n): the end point rounds to exactly 1.0f in fp32
+    neo_linspace_host(0.0f, static_cast<float>(1.0 - 1.0 / 4294967296.0), n_new, h.data());
+    DevBuf& b = quantiles[n_new];
+    if (b.reserve(n_new * sizeof(float))) return nullptr;
+    if (hipMemcpyAsync(b.p, h.data(), n_new * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    (void)hipStreamSynchronize(s);  // h goes out of scope; first use only
+    return b.as<float>();
 }
 
-}  // namespace
+// near*(1-s) + far*s over linspace(0,1,n+1), separate fp32 ops (vanilla_nerf/helper.py:425-429)
+const float* neo_ctx::get_edges(int n, float near, float far, hipStream_t s) {
+    uint32_t a, b2;
+    memcpy(&a, &near, 4);
+    memcpy(&b2, &far, 4);
+    const auto key = std::make_pair(n, (static_cast<uint64_t>(a) << 32) | b2);
+    auto it = edges.find(key);
+    if (it != edges.end()) return it->second.as<float>();
+    std::vector<float> h(n + 1);
+    neo_linspace_host(0.0f, 1.0f, n + 1, h.data());
+    for (int i = 0; i <= n; ++i) {
+        const float om = 1.0f - h[i];
+        const float lo = near * om;
+        const float hi = far * h[i];
+        h[i] = lo + hi;
+    }
+    DevBuf& buf = edges[key];
+    if (buf.reserve((n + 1) * sizeof(float))) return nullptr;
+    if (hipMemcpyAsync(buf.p, h.data(), (n + 1) * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    (void)hipStreamSynchronize(s);
+    return buf.as<float>();
+}
+
+void neo_ctx::span_begin(hipStream_t s) {
+    if (!timing) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    spans.emplace_back(a, b);
+}
+void neo_ctx::span_end(hipStream_t s, double points) {
+    if (!timing) return;
+    (void)hipEventRecord(spans.back().second, s);
+    timed_points += points;
+}
 
 extern "C" {
 
 int neo_abi_version(void) { return 1; }
 
-const char* neo_last_error(void) { return g_err.c_str(); }
+const char* neo_last_error(void) { return neo_host::last_error().c_str(); }
 
 int neo_ctx_create(int device, neo_ctx** out) {
     REQUIRE(out != nullptr, "null out pointer");
@@ -201,10 +114,13 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     if (!ctx) return NEO_OK;
     DeviceGuard g(ctx->device);
     (void)hipDeviceSynchronize();
-    for (auto& sl : ctx->vanilla) { sl.wpack.release(); sl.bias.release(); sl.heads.release(); }
+    for (auto& sl : ctx->vanilla) sl.release();
     for (auto& kv : ctx->quantiles) kv.second.release();
     for (auto& kv : ctx->edges) kv.second.release();
-    ctx->ws_out0.release(); ctx->ws_w0.release(); ctx->ws_t1.release(); ctx->ws_out1.release();
+    for (auto& b : ctx->ws) b.release();
+    for (auto& sl : ctx->tp) sl.release();
+    ctx->latent.release();
+    for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     if (ctx->flags) (void)hipFree(ctx->flags);
     delete ctx;
@@ -319,7 +235,7 @@ int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, 
     REQUIRE(slot == 0 || slot == 1, "slot must be 0 (coarse) or 1 (fine)");
     REQUIRE(weights && biases, "null pointer table");
     for (int i = 0; i < 12; ++i) REQUIRE(weights[i] && biases[i], "null layer pointer");
-    VanillaSlot& sl = ctx->vanilla[slot];
+    MlpSlot& sl = ctx->vanilla[slot];
     if (sl.wpack.reserve(neo::vanilla_wpack_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.bias.reserve(neo::vanilla_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.heads.reserve(neo::vanilla_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
@@ -331,7 +247,7 @@ int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, 
 
 static int vanilla_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* dirs, const float* t,
                               int t_row_stride, int R, int N, float* out, hipStream_t s) {
-    const VanillaSlot& sl = ctx->vanilla[slot];
+    const MlpSlot& sl = ctx->vanilla[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "vanilla MLP slot %d has no weights", slot);
     neo::VanillaMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
     ctx->span_begin(s);
@@ -365,14 +281,14 @@ int neo_vanilla_render(neo_ctx* ctx, const float* rays_o, const float* viewdirs,
     const float* t0 = ctx->get_edges(n_coarse, near, far, s);
     const float* u = ctx->get_quantiles(n_fine, s);
     if (!t0 || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
-    if (ctx->ws_out0.reserve(static_cast<size_t>(R) * N0 * 16)) return NEO_ERR_NOMEM;
-    if (ctx->ws_w0.reserve(static_cast<size_t>(R) * N0 * 4)) return NEO_ERR_NOMEM;
-    if (ctx->ws_t1.reserve(static_cast<size_t>(R) * N1 * 4)) return NEO_ERR_NOMEM;
-    if (ctx->ws_out1.reserve(static_cast<size_t>(R) * N1 * 16)) return NEO_ERR_NOMEM;
-    float* out0 = ctx->ws_out0.as<float>();
-    float* w0 = ctx->ws_w0.as<float>();
-    float* t1 = ctx->ws_t1.as<float>();
-    float* out1 = ctx->ws_out1.as<float>();
+    if (ctx->ws[0].reserve(static_cast<size_t>(R) * N0 * 16)) return NEO_ERR_NOMEM;
+    if (ctx->ws[1].reserve(static_cast<size_t>(R) * N0 * 4)) return NEO_ERR_NOMEM;
+    if (ctx->ws[2].reserve(static_cast<size_t>(R) * N1 * 4)) return NEO_ERR_NOMEM;
+    if (ctx->ws[3].reserve(static_cast<size_t>(R) * N1 * 16)) return NEO_ERR_NOMEM;
+    float* out0 = ctx->ws[0].as<float>();
+    float* w0 = ctx->ws[1].as<float>();
+    float* t1 = ctx->ws[2].as<float>();
+    float* out1 = ctx->ws[3].as<float>();
     // level 0: shared t row (stride 0); samples along viewdirs (vanilla_nerf/model.py:158-167)
     int rc = vanilla_mlp_launch(ctx, 0, rays_o, viewdirs, t0, 0, R, N0, out0, s);
     if (rc) return rc;
@@ -387,4 +303,3 @@ int neo_vanilla_render(neo_ctx* ctx, const float* rays_o, const float* viewdirs,
 
 }  // extern "C"
 
-// ---- NeO-360 decoder entry points: implemented in api_tp.hip ----

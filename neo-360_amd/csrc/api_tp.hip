@@ -1,16 +1,193 @@
-// NeO-360 (NeRF_TP) entry points of the C ABI.
-#include "../../include/neo360_hip.h"
+// NeO-360 (NeRF_TP) entry points of the C ABI: weight / scene upload and the
+// two-level, two-region render (neo360/model.py:266-581).
+#include "ctx.h"
 
-#include <hip/hip_runtime.h>
+using namespace neo_host;
+
+namespace {
+
+// rot = c2w[:3,:3]^T ; trans = -rot @ c2w[:3,3]   (neo360/util.py:64-66), fp32
+void fill_views(const float* poses, int nv, neo::TpViews& v) {
+    for (int i = 0; i < nv; ++i) {
+        const float* m = poses + i * 16;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) v.rot[i][r * 3 + c] = m[c * 4 + r];
+        for (int r = 0; r < 3; ++r) {
+            float acc = v.rot[i][r * 3 + 0] * m[0 * 4 + 3];
+            acc = acc + v.rot[i][r * 3 + 1] * m[1 * 4 + 3];
+            acc = acc + v.rot[i][r * 3 + 2] * m[2 * 4 + 3];
+            v.trans[i][r] = -acc;
+        }
+    }
+}
+
+}  // namespace
 
 extern "C" {
 
-int neo_tp_upload_mlp(neo_ctx*, int, int, const float* const*, const float* const*, void*) { return NEO_ERR_STATE; }
+int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* weights,
+                      const float* const* biases, void* stream) {
+    ENTER(ctx);
+    REQUIRE(slot >= 0 && slot < 4, "slot must be 0..3 (fg_coarse, fg_fine, bg_coarse, bg_fine)");
+    REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (fg) or 4 (bg)");
+    REQUIRE(weights && biases, "null pointer table");
+    for (int i = 0; i < 9; ++i) REQUIRE(weights[i] && biases[i], "null layer pointer");
+    MlpSlot& sl = ctx->tp[slot];
+    if (sl.wpack.reserve(neo::tp_wpack_floats(input_ch) * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.bias.reserve(neo::tp_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.heads.reserve(neo::tp_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_tp_pack(input_ch, weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
+                        static_cast<hipStream_t>(stream));
+    sl.input_ch = input_ch;
+    sl.ready = true;
+    return check_launch();
+}
 
-int neo_tp_set_scene(neo_ctx*, const float*, const float*, const float*, int, int, int, int, const float*, int, int,
-                     int, float, float, void*) { return NEO_ERR_STATE; }
+int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy, const float* plane_yz, int NV,
+                     int Cw, int Hp, int Wp, const float* latent, int Cl, int Hf, int Wf, float image_w,
+                     float image_h, void* stream) {
+    ENTER(ctx);
+    REQUIRE(plane_xz && plane_xy && plane_yz && latent, "null pointer");
+    REQUIRE(NV >= 1 && NV <= neo::TP_MAX_VIEWS, "1..8 source views supported");
+    REQUIRE(Cw == 128 && Cl == 512, "feature widths are fixed by the reference MLP (128 world, 512 local)");
+    REQUIRE(Hp >= 2 && Wp >= 2 && Hf >= 2 && Wf >= 2, "feature maps must be at least 2x2");
+    REQUIRE(static_cast<long>(NV) * Hf * Wf * 128 < 2147483647L, "latent too large for 32-bit texel offsets");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* planes[3] = {plane_xz, plane_xy, plane_yz};
+    for (int j = 0; j < 3; ++j) {
+        if (ctx->plane[j].reserve(static_cast<size_t>(NV) * Cw * Hp * Wp * 4)) return NEO_ERR_NOMEM;
+        neo::launch_channels_last(planes[j], NV, Cw, Hp, Wp, ctx->plane[j].as<float>(), s);
+        ctx->scene.plane[j] = ctx->plane[j].as<float>();
+    }
+    if (ctx->latent.reserve(static_cast<size_t>(NV) * Cl * Hf * Wf * 4)) return NEO_ERR_NOMEM;
+    neo::launch_channels_last(latent, NV, Cl, Hf, Wf, ctx->latent.as<float>(), s);
+    ctx->scene.latent = ctx->latent.as<float>();
+    ctx->scene.nv = NV;
+    ctx->scene.Hf = Hf; ctx->scene.Wf = Wf; ctx->scene.Hp = Hp; ctx->scene.Wp = Wp;
+    // latent_scaling = [Wf,Hf]/([Wf,Hf]-1)*2 (encoder_pn.py:204-206); scale = latent_scaling/image_size (:121-123)
+    const float wf = static_cast<float>(Wf), hf = static_cast<float>(Hf);
+    const float lsx = (wf / (wf - 1.0f)) * 2.0f, lsy = (hf / (hf - 1.0f)) * 2.0f;
+    ctx->scene.sx = lsx / image_w;
+    ctx->scene.sy = lsy / image_h;
+    ctx->scene_ready = true;
+    return check_launch();
+}
 
-int neo_tp_render(neo_ctx*, const float*, const float*, const float*, int, int, const float*, int, float, float,
-                  float, int, int, int, const neo_tp_level_out*, const neo_tp_level_out*, void*) { return NEO_ERR_STATE; }
+int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d, const float* viewdirs,
+               const float* tvals, const float* far, int R, int N, int chunk, const float* src_poses, int NV,
+               float focal, float cx, float cy, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(slot >= 0 && slot < 4, "slot must be 0..3");
+    REQUIRE(R >= 0 && N >= 1 && chunk >= 1, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && rays_d && viewdirs && tvals && src_poses && out, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    const MlpSlot& sl = ctx->tp[slot];
+    if (!sl.ready) return fail(NEO_ERR_STATE, "NeRF_TP MLP slot %d has no weights", slot);
+    REQUIRE(sl.input_ch == (slot < 2 ? 3 : 4), "slots 0,1 must hold fg weights, 2,3 bg weights");
+    REQUIRE(slot < 2 || far, "far required for the outside-sphere slots");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::TpMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
+    ctx->span_begin(s);
+    neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+    ctx->span_end(s, static_cast<double>(R) * N);
+    return check_launch();
+}
+
+int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* viewdirs, int R, int chunk,
+                  const float* src_poses, int NV, float focal, float cx, float cy, int n_coarse, int n_fine,
+                  int white_bkgd, const neo_tp_level_out* level0, const neo_tp_level_out* level1, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && chunk >= 1, "bad ray count / chunk");
+    REQUIRE(n_coarse >= 3 && n_coarse <= 256 && n_fine >= 1 && n_coarse + 1 + n_fine <= 1024, "unsupported sample counts");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && rays_d && viewdirs && src_poses, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    for (int i = 0; i < 4; ++i)
+        if (!ctx->tp[i].ready) return fail(NEO_ERR_STATE, "NeRF_TP MLP slot %d has no weights", i);
+    REQUIRE(ctx->tp[0].input_ch == 3 && ctx->tp[1].input_ch == 3 && ctx->tp[2].input_ch == 4 && ctx->tp[3].input_ch == 4,
+            "slots 0,1 must be fg (input_ch 3), slots 2,3 bg (input_ch 4)");
+    (void)white_bkgd;  // out_depth=True semantics: the reference composites with white_bkgd=False (model.py:477-501)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+
+    const int N0 = n_coarse + 1, N1 = N0 + n_fine;
+    const float near = 1e-4f;                                         // model.py:277
+    const float* edges = ctx->get_edges(n_coarse, 0.0f, 1.0f, s);     // linspace(0,1,n+1)
+    const float* u = ctx->get_quantiles(n_fine, s);
+    if (!edges || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
+
+    // workspaces
+    auto& W = ctx->ws;
+    const size_t r = static_cast<size_t>(R);
+    if (W[0].reserve(r * 4) || W[1].reserve(r * N0 * 4) || W[2].reserve(r * N0 * 4) || W[3].reserve(r * N1 * 16) ||
+        W[4].reserve(r * N1 * 16) || W[5].reserve(r * N0 * 4) || W[6].reserve(r * N0 * 4) || W[7].reserve(r * N1 * 4) ||
+        W[8].reserve(r * N1 * 4) || W[9].reserve(r * 16 * 4))
+        return NEO_ERR_NOMEM;
+    float* far = W[0].as<float>();
+    float* fg_t0 = W[1].as<float>();
+    float* bg_s0 = W[2].as<float>();
+    float* fg_out = W[3].as<float>();
+    float* bg_out = W[4].as<float>();
+    float* fg_w0 = W[5].as<float>();
+    float* bg_w0 = W[6].as<float>();
+    float* fg_t1 = W[7].as<float>();
+    float* bg_s1 = W[8].as<float>();
+    float* scratch = W[9].as<float>();   // per-ray: fg_rgb(3) fg_depth fg_acc lambda bg_rgb(3) bg_depth
+    float* s_fg_rgb = scratch;
+    float* s_fg_depth = scratch + r * 3;
+    float* s_fg_acc = scratch + r * 4;
+    float* s_lambda = scratch + r * 5;
+    float* s_bg_rgb = scratch + r * 6;
+    float* s_bg_depth = scratch + r * 9;
+
+    neo::launch_sphere(rays_o, rays_d, R, far, nullptr, ctx->flags, s);
+    neo::launch_tp_level0(far, edges, R, N0, near, fg_t0, bg_s0, s);
+
+    const float* fg_t = fg_t0;
+    const float* bg_s = bg_s0;
+    for (int level = 0; level < 2; ++level) {
+        const int N = level == 0 ? N0 : N1;
+        const neo_tp_level_out* lo = level == 0 ? level0 : level1;
+        const MlpSlot& fg = ctx->tp[level];
+        const MlpSlot& bg = ctx->tp[2 + level];
+        neo::TpMlpDev mfg{fg.wpack.as<float>(), fg.bias.as<float>(), fg.heads.as<float>()};
+        neo::TpMlpDev mbg{bg.wpack.as<float>(), bg.bias.as<float>(), bg.heads.as<float>()};
+        ctx->span_begin(s);
+        neo::launch_tp_mlp(3, mfg, sc, views, rays_o, rays_d, viewdirs, fg_t, nullptr, R, N, chunk, ctx->flags, fg_out, s);
+        ctx->span_end(s, static_cast<double>(R) * N);
+        ctx->span_begin(s);
+        neo::launch_tp_mlp(4, mbg, sc, views, rays_o, rays_d, viewdirs, bg_s, far, R, N, chunk, ctx->flags, bg_out, s);
+        ctx->span_end(s, static_cast<double>(R) * N);
+        float* fg_rgb = (lo && lo->fg_rgb) ? lo->fg_rgb : s_fg_rgb;
+        float* bg_rgb = (lo && lo->bg_rgb) ? lo->bg_rgb : s_bg_rgb;
+        float* fg_acc = (lo && lo->fg_acc) ? lo->fg_acc : s_fg_acc;
+        float* lam = (lo && lo->bg_lambda) ? lo->bg_lambda : s_lambda;
+        neo::launch_composite(1, fg_out, fg_t, N, rays_d, far, R, N, 0, fg_rgb, fg_acc, s_fg_depth,
+                              level == 0 ? fg_w0 : nullptr, lam, s);
+        neo::launch_composite(2, bg_out, bg_s, N, nullptr, nullptr, R, N, 0, bg_rgb, nullptr, s_bg_depth,
+                              level == 0 ? bg_w0 : nullptr, nullptr, s);
+        if (lo && (lo->rgb || lo->depth))
+            neo::launch_tp_merge(fg_rgb, s_fg_depth, lam, bg_rgb, s_bg_depth, R, lo->rgb, lo->depth, s);
+        if (level == 0) {
+            // hierarchical resampling (model.py:306-332): fg ascending; bg on the descending inverse radius
+            if (neo::launch_resample(fg_t0, N0, fg_w0, u, R, N0, n_fine, 0, fg_t1, s) ||
+                neo::launch_resample(bg_s0, N0, bg_w0, u, R, N0, n_fine, 1, bg_s1, s))
+                return fail(NEO_ERR_INVALID, "unsupported sample counts");
+            fg_t = fg_t1;
+            bg_s = bg_s1;
+        }
+    }
+    return check_launch();
+}
 
 }  // extern "C"

@@ -37,4 +37,38 @@ void launch_vanilla_pack(const float* const* weights, const float* const* biases
 void launch_vanilla_mlp(const VanillaMlpDev& m, const float* rays_o, const float* dirs, const float* t,
                         int t_row_stride, int R, int N, float* out, hipStream_t s);
 
+// mlp_tp.hip — NeO-360 decoder
+constexpr int TP_MAX_VIEWS = 8;
+struct TpMlpDev {
+    const float* wpack;
+    const float* bias;
+    const float* heads;
+};
+struct TpScene {                     // channels-last feature maps owned by the context
+    const float* latent;            // (NV, Hf, Wf, 512)
+    const float* plane[3];          // xz, xy, yz: (NV, Hp, Wp, 128)
+    int nv, Hf, Wf, Hp, Wp;
+    float focal, cx, cy;            // source view 0's intrinsics (neo360/model.py:242-244)
+    float sx, sy;                   // latent_scaling / image_size (encoder_pn.py:121-123, :204-206)
+};
+struct TpViews {                     // world -> camera per source view (neo360/util.py:52-70)
+    float rot[TP_MAX_VIEWS][9];     // c2w[:3,:3]^T, row-major
+    float trans[TP_MAX_VIEWS][3];   // -rot @ c2w[:3,3]
+};
+size_t tp_wpack_floats(int input_ch);
+size_t tp_bias_floats();
+size_t tp_heads_floats();
+void launch_tp_pack(int input_ch, const float* const* w, const float* const* b, float* wpack, float* bias,
+                    float* heads, hipStream_t s);
+void launch_channels_last(const float* src, int NV, int C, int H, int W, float* dst, hipStream_t s);
+void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+                   const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
+                   int chunk, uint32_t* flags, float* out, hipStream_t s);
+
+// sampling.hip — NeO-360 level-0 sample rows and fg/bg merge
+void launch_tp_level0(const float* far, const float* edges, int R, int N, float near, float* fg_t, float* bg_s,
+                      hipStream_t s);
+void launch_tp_merge(const float* fg_rgb, const float* fg_depth, const float* lambda, const float* bg_rgb,
+                     const float* bg_depth, int R, float* rgb, float* depth, hipStream_t s);
+
 }  // namespace neo

@@ -1,0 +1,662 @@
+// Fused NeO-360 decoder point evaluator (neo360/model.py:343-407 `predict`
+// + NeRFPPMLP.forward :110-158 + the feature lookups of :409-447), fp32 MFMA.
+//
+// For a tile of 64 sample points and each of the NV source views in turn:
+//   world2camera -> [pos_enc | pixel-aligned 512 | tri-plane 128] (703 / 724 features)
+//   -> L0,L1,L2,L3(+skip) -> per-view bottleneck -> view layer 0,
+// with the trunk (after L3) and the view branch averaged over the views in
+// registers; then density head, 64->64, rgb head, activations.
+//
+// The 703-wide input is never materialised (the reference builds a rows x 703 fp32
+// matrix: 1.1-3.3 GB per chunk).  It is produced 64 features at a time straight into
+// a double-buffered LDS tile by the same waves that run the MFMAs:
+//   * channels-last (NHWC) feature maps, one bilinear tap = one contiguous run;
+//   * per (row, view) tap offsets / weights are computed once into LDS descriptors;
+//   * the loads of stage s+1 are issued before the MFMAs of stage s and blended after
+//     them (loads in flight under the matrix work), one barrier per 64-feature stage.
+// L0 and the skip half of L3 share the operand, so they run as ONE 256-wide GEMM over
+// the streamed input; the L3 half stays in accumulator registers until L3's turn.
+//
+// Work per point-view: 255,424 MAC (fg) / 260,800 MAC (bg); + 4,416 MAC per point.
+#include "kernels.h"
+#include "mfma_tile.h"
+
+namespace neo {
+
+namespace {
+
+constexpr int TM = 64;
+constexpr int ACT_LD = 128;   // activation tile [64][128]
+constexpr int XB_LD = 64;     // streamed-input tile [64][64], two of them alias the activation tile
+constexpr int DIR_LD = 32;
+
+// LDS carve (floats)
+constexpr int OFF_ACT = 0;
+constexpr int OFF_DIR = OFF_ACT + TM * ACT_LD;
+constexpr int OFF_LOC_OFF = OFF_DIR + TM * DIR_LD;       // int[64][4]
+constexpr int OFF_LOC_W = OFF_LOC_OFF + TM * 4;
+constexpr int OFF_PL_OFF = OFF_LOC_W + TM * 4;           // int[3][64][4]
+constexpr int OFF_PL_W = OFF_PL_OFF + 3 * TM * 4;
+constexpr int OFF_CAM = OFF_PL_W + 3 * TM * 4;           // float[64][4]: camera-frame point (+1/r) for pos_enc
+constexpr int OFF_PE = OFF_CAM + TM * 4;                 // float[64][4]: world point to encode (+1/r)
+constexpr int OFF_FEAT = OFF_PE + TM * 4;                // float[64][4]: world point for feature lookups
+constexpr int OFF_VDIR = OFF_FEAT + TM * 4;              // float[64][4]: world view direction (Q1-indexed ray)
+constexpr int LDS_FLOATS = OFF_VDIR + TM * 4;
+
+// ---- packed weight layout -----------------------------------------------------
+// stage X : N=256 (rows 0-127 = pts_linears.0, rows 128-255 = pts_linears.3[:, 128:]),
+//           K order = [local 512 | world 128 | pos_enc padded to 8*pe_chunks]
+// stages 1,2 : pts_linears.1/.2 ; 3a : pts_linears.3[:, :128] ; B : bottleneck
+// stage V0 : views_linear.0 (64 x (128 + 27->32)) ; V1 : views_linear.1 (64 x 64)
+__host__ __device__ constexpr int pe_chunks(int pe_c) { return pe_c == 3 ? 8 : 11; }
+__host__ __device__ constexpr int kc_x(int pe_c) { return 64 + 16 + pe_chunks(pe_c); }
+__host__ __device__ constexpr int off_x() { return 0; }
+__host__ __device__ constexpr int off_1(int pe_c) { return 8 * kc_x(pe_c) * 256; }
+__host__ __device__ constexpr int off_2(int pe_c) { return off_1(pe_c) + 4 * 16 * 256; }
+__host__ __device__ constexpr int off_3a(int pe_c) { return off_2(pe_c) + 4 * 16 * 256; }
+__host__ __device__ constexpr int off_b(int pe_c) { return off_3a(pe_c) + 4 * 16 * 256; }
+__host__ __device__ constexpr int off_v0(int pe_c) { return off_b(pe_c) + 4 * 16 * 256; }
+__host__ __device__ constexpr int off_v1(int pe_c) { return off_v0(pe_c) + 2 * 20 * 256; }
+__host__ __device__ constexpr int wpack_floats(int pe_c) { return off_v1(pe_c) + 2 * 8 * 256; }
+// biases: b0 | b3 | b1 | b2 | bb | bv0 | bv1
+constexpr int B_0 = 0, B_3 = 128, B_1 = 256, B_2 = 384, B_B = 512, B_V0 = 640, B_V1 = 704, BIAS_FLOATS = 768;
+// heads: density w[128] | density b (4) | rgb w[3][64] | rgb b (4)
+constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 324, HEADS_FLOATS = 328;
+
+struct TapSet {
+    int off[4];
+    float w[4];
+};
+
+// Bilinear taps of F.grid_sample(align_corners=True, padding zeros) at normalised (gx, gy)
+// on a Wd x Hd map; offsets in texels, invalid taps get weight 0 / offset 0.
+// Tap order nw, ne, sw, se; weights (x1-x)(y1-y), (x-x0)(y1-y), (x1-x)(y-y0), (x-x0)(y-y0).
+__device__ __forceinline__ TapSet bilinear_taps(float gx, float gy, int Wd, int Hd) {
+    const float x = ((gx + 1.0f) / 2.0f) * (float)(Wd - 1);
+    const float y = ((gy + 1.0f) / 2.0f) * (float)(Hd - 1);
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    const float wx0 = x1 - x, wx1 = x - x0, wy0 = y1 - y, wy1 = y - y0;
+    const float xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
+    const float ws[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+    TapSet t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok = xs[k] >= 0.0f && xs[k] <= (float)(Wd - 1) && ys[k] >= 0.0f && ys[k] <= (float)(Hd - 1);
+        t.off[k] = ok ? (int)ys[k] * Wd + (int)xs[k] : 0;
+        t.w[k] = ok ? ws[k] : 0.0f;
+    }
+    return t;
+}
+
+__device__ __forceinline__ f32x4 blend4(const f32x4 (&tap)[4], const f32x4 w) {
+    // nw*w0 + ne*w1 + sw*w2 + se*w3, accumulated in that order (separate multiply / add)
+    f32x4 v = tap[0] * w[0];
+    v = v + tap[1] * w[1];
+    v = v + tap[2] * w[2];
+    v = v + tap[3] * w[3];
+    return v;
+}
+
+// feature f of the positional encoding of a C-vector x (C = 3 or 4, 10 octaves): pad -> 0
+template <int C>
+__device__ __forceinline__ float pe_feature(const float* x, int f) {
+    if (f < C) return x[f];
+    const int g = f - C;
+    if (g < 10 * C) return sinf(ldexpf(x[g % C], g / C));
+    const int h = g - 10 * C;
+    if (h < 10 * C) return sinf(ldexpf(x[h % C], h / C) + HALF_PI_F32);
+    return 0.0f;
+}
+
+template <int NTW>
+__device__ __forceinline__ void mma_chunk2(const f32x4 (&a)[NTW], const f32x4 (&b)[2], f32x16 (&acc)[NTW][2]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = NEO_MFMA(a[nt][e], b[mt][e], acc[nt][mt]);
+}
+
+// acc[nt][mt] += W-stage chunks [kc0, kc0+n) x tile chunks [0, n); N-tiles nts[], both M-tiles.
+template <int NTW, int LD, int KM>
+__device__ __forceinline__ void gemm2(f32x16 (&acc)[NTW][2], const f32x4* __restrict__ wp, int KC,
+                                      const int (&nts)[NTW], int kc0, int n, const float* __restrict__ tile,
+                                      const LaneCtx& L) {
+    f32x4 a[2][NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) a[0][nt] = load_a(wp, KC, nts[nt], kc0, L.lane);
+#pragma unroll 1
+    for (int c = 0; c < n; c += 2) {
+        f32x4 b[2];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) a[1][nt] = load_a(wp, KC, nts[nt], kc0 + (c + 1 < n ? c + 1 : c), L.lane);
+        b[0] = load_b<LD, KM>(tile, 0, c, L);
+        b[1] = load_b<LD, KM>(tile, 1, c, L);
+        mma_chunk2<NTW>(a[0], b, acc);
+        if (c + 1 < n) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) a[0][nt] = load_a(wp, KC, nts[nt], kc0 + (c + 2 < n ? c + 2 : c + 1), L.lane);
+            b[0] = load_b<LD, KM>(tile, 0, c + 1, L);
+            b[1] = load_b<LD, KM>(tile, 1, c + 1, L);
+            mma_chunk2<NTW>(a[1], b, acc);
+        }
+    }
+}
+
+// same, reading tile chunks [tc0, tc0+n) against weight chunks [kc0+tc0, ...)
+template <int NTW, int LD, int KM>
+__device__ __forceinline__ void gemm2x(f32x16 (&acc)[NTW][2], const f32x4* __restrict__ wp, int KC,
+                                       const int (&nts)[NTW], int kc0, int tc0, int n,
+                                       const float* __restrict__ tile, const LaneCtx& L) {
+    f32x4 a[2][NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) a[0][nt] = load_a(wp, KC, nts[nt], kc0 + tc0, L.lane);
+#pragma unroll 1
+    for (int c = 0; c < n; c += 2) {
+        f32x4 b[2];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) a[1][nt] = load_a(wp, KC, nts[nt], kc0 + tc0 + (c + 1 < n ? c + 1 : c), L.lane);
+        b[0] = load_b<LD, KM>(tile, 0, tc0 + c, L);
+        b[1] = load_b<LD, KM>(tile, 1, tc0 + c, L);
+        mma_chunk2<NTW>(a[0], b, acc);
+        if (c + 1 < n) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) a[0][nt] = load_a(wp, KC, nts[nt], kc0 + tc0 + (c + 2 < n ? c + 2 : c + 1), L.lane);
+            b[0] = load_b<LD, KM>(tile, 0, tc0 + c + 1, L);
+            b[1] = load_b<LD, KM>(tile, 1, tc0 + c + 1, L);
+            mma_chunk2<NTW>(a[1], b, acc);
+        }
+    }
+}
+
+// single accumulator tile (nt, mt): used by the 64-wide view layers
+template <int LD, int KM>
+__device__ __forceinline__ void gemm1(f32x16& acc, const f32x4* __restrict__ wp, int KC, int nt, int mt, int kc0,
+                                      int n, const float* __restrict__ tile, const LaneCtx& L) {
+    f32x4 a = load_a(wp, KC, nt, kc0, L.lane);
+#pragma unroll 1
+    for (int c = 0; c < n; ++c) {
+        const f32x4 an = load_a(wp, KC, nt, kc0 + (c + 1 < n ? c + 1 : c), L.lane);
+        const f32x4 b = load_b<LD, KM>(tile, mt, c, L);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = NEO_MFMA(a[e], b[e], acc);
+        a = an;
+    }
+}
+
+template <int PE_C>
+__global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpViews views,
+                                                    const float* __restrict__ rays_o,
+                                                    const float* __restrict__ rays_d,
+                                                    const float* __restrict__ viewdirs,
+                                                    const float* __restrict__ tvals,
+                                                    const float* __restrict__ far_arr, int R, int N, int chunk,
+                                                    uint32_t* __restrict__ flags, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = smem + OFF_ACT;
+    float* dsm = smem + OFF_DIR;
+    int* loc_off = reinterpret_cast<int*>(smem + OFF_LOC_OFF);
+    float* loc_w = smem + OFF_LOC_W;
+    int* pl_off = reinterpret_cast<int*>(smem + OFF_PL_OFF);
+    float* pl_w = smem + OFF_PL_W;
+    float* cam_enc = smem + OFF_CAM;
+    float* pe_world = smem + OFF_PE;
+    float* feat_world = smem + OFF_FEAT;
+    float* vdir_world = smem + OFF_VDIR;
+
+    LaneCtx L;
+    L.init();
+    const int tid = threadIdx.x;
+    const long P = (long)R * N;
+    const long tile0 = (long)blockIdx.x * TM;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(m.wpack);
+    constexpr int KCX = kc_x(PE_C);
+    constexpr int NST = PE_C == 3 ? 11 : 12;   // streamed-input stages: 8 local, 2 world, 1-2 pos_enc
+
+    // ---- per-point world-space quantities (once per tile) ----------------------
+    if (tid < TM) {
+        long g = tile0 + tid;
+        if (g >= P) g = P - 1;
+        const int ray = (int)(g / N);
+        const int s = (int)(g - (long)ray * N);
+        const int c0 = (ray / chunk) * chunk;                    // first ray of this ray's reference chunk
+        const int bc = min(chunk, R - c0);                       // rays in that chunk (last one may be short)
+        const int gl = (ray - c0) * N + s;                       // flattened (ray, sample) index inside the chunk
+        const int dray = c0 + gl % bc;                           // neo360/model.py:357-360 tiling: direction of ray (b*N+s) mod B
+        const float tv = tvals[g];
+        float o[3], d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o[a] = rays_o[ray * 3 + a]; d[a] = rays_d[ray * 3 + a]; }
+        if (PE_C == 3) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float x = o[a] + tv * d[a];
+                pe_world[tid * 4 + a] = x;
+                feat_world[tid * 4 + a] = x;
+            }
+            pe_world[tid * 4 + 3] = 0.0f;
+        } else {
+            // inverted-sphere point (neo360/helper.py:401-451) and the linear lookup point
+            // o + (far(1-s) + 3 s) d (helper.py:59-73, :232-246)
+            const float far = far_arr[ray];
+            const float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const float d1 = -(d[0] * o[0] + d[1] * o[1] + d[2] * o[2]) / dd;
+            float pm[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pm[a] = o[a] + d1 * d[a];
+            const float rmid = sqrtf(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
+            const float inv_len = 1.0f / sqrtf(dd);
+            const float margin = 1.0f - rmid * rmid;
+            if (!(margin >= 0.0f)) atomicOr(flags, 1u);
+            const float d2 = sqrtf(margin) * inv_len;
+            float ps[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ps[a] = o[a] + (d1 + d2) * d[a];
+            float ax[3] = {o[1] * ps[2] - o[2] * ps[1], o[2] * ps[0] - o[0] * ps[2], o[0] * ps[1] - o[1] * ps[0]};
+            const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ax[a] = ax[a] / an;
+            const float ang = asinf(rmid) - asinf(rmid * tv);
+            const float ca = cosf(ang), sa = sinf(ang);
+            const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
+            const float dotp = ax[0] * ps[0] + ax[1] * ps[1] + ax[2] * ps[2];
+            float tn[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) tn[a] = ps[a] * ca + cr[a] * sa + ax[a] * dotp * (1.0f - ca);
+            const float nn = sqrtf(tn[0] * tn[0] + tn[1] * tn[1] + tn[2] * tn[2]) + 1e-10f;
+            const float tl = far * (1.0f - tv) + 3.0f * tv;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                pe_world[tid * 4 + a] = tn[a] / nn;
+                feat_world[tid * 4 + a] = o[a] + tl * d[a];
+            }
+            pe_world[tid * 4 + 3] = tv;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vdir_world[tid * 4 + a] = viewdirs[dray * 3 + a];
+    }
+    __syncthreads();
+
+    f32x16 hsum[2], ysum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; ysum[r] = 0.f; }
+    const int nts_x[2] = {L.wv, 4 + L.wv};
+    const int nts_1[1] = {L.wv};
+    const int vnt = L.wv & 1, vmt = L.wv >> 1;   // view layers: 2 N-tiles x 2 M-tiles, one per wave
+
+#pragma unroll 1
+    for (int v = 0; v < sc.nv; ++v) {
+        const float* rot = views.rot[v];
+        const float* trn = views.trans[v];
+        // ---- descriptors for this view ---------------------------------------
+        {
+            const int p = L.lane;
+            const float fx = feat_world[p * 4], fy = feat_world[p * 4 + 1], fz = feat_world[p * 4 + 2];
+            // world2camera (neo360/util.py:52-70): R^T x then + (-R^T t)
+            const float cx_ = (rot[0] * fx + rot[1] * fy + rot[2] * fz) + trn[0];
+            const float cy_ = (rot[3] * fx + rot[4] * fy + rot[5] * fz) + trn[1];
+            const float cz_ = (rot[6] * fx + rot[7] * fy + rot[8] * fz) + trn[2];
+            TapSet t;
+            int* dst_off;
+            float* dst_w;
+            int base;
+            if (L.wv == 0) {
+                // pixel-aligned latent (neo360/model.py:239-264, encoder_pn.py:116-150), view 0's intrinsics
+                const float den = cz_ + 1e-9f;
+                const float u = (-cx_ / den) * sc.focal + sc.cx;
+                const float w_ = (-cy_ / den) * (-sc.focal) + sc.cy;
+                t = bilinear_taps(u * sc.sx - 1.0f, w_ * sc.sy - 1.0f, sc.Wf, sc.Hf);
+                dst_off = loc_off; dst_w = loc_w;
+                base = v * sc.Hf * sc.Wf;
+                // camera-frame point that gets encoded (fg: same point; bg: the unit-sphere point)
+                const float ex = pe_world[p * 4], ey = pe_world[p * 4 + 1], ez = pe_world[p * 4 + 2];
+                cam_enc[p * 4 + 0] = (rot[0] * ex + rot[1] * ey + rot[2] * ez) + trn[0];
+                cam_enc[p * 4 + 1] = (rot[3] * ex + rot[4] * ey + rot[5] * ez) + trn[1];
+                cam_enc[p * 4 + 2] = (rot[6] * ex + rot[7] * ey + rot[8] * ez) + trn[2];
+                cam_enc[p * 4 + 3] = pe_world[p * 4 + 3];
+            } else {
+                // tri-planes (encoder_tp_fusion_conv.py:122-209): camera coordinates used directly as
+                // grid coordinates; xz -> (x,z), xy -> (x,y), yz -> (y,z)
+                const float ga = L.wv == 3 ? cy_ : cx_;
+                const float gb = L.wv == 2 ? cy_ : cz_;
+                t = bilinear_taps(ga, gb, sc.Wp, sc.Hp);
+                dst_off = pl_off + (L.wv - 1) * TM * 4; dst_w = pl_w + (L.wv - 1) * TM * 4;
+                base = v * sc.Hp * sc.Wp;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dst_off[p * 4 + k] = base + t.off[k]; dst_w[p * 4 + k] = t.w[k]; }
+            // view-direction encoding in this view's camera frame; wave q takes octave q
+            const float dx = vdir_world[p * 4], dy = vdir_world[p * 4 + 1], dz = vdir_world[p * 4 + 2];
+            const float dc[3] = {rot[0] * dx + rot[1] * dy + rot[2] * dz, rot[3] * dx + rot[4] * dy + rot[5] * dz,
+                                 rot[6] * dx + rot[7] * dy + rot[8] * dz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float sn, cs;
+                enc_pair(dc[a], L.wv, sn, cs);
+                dsm[swz_index<DIR_LD, 7>(p, 3 + L.wv * 3 + a)] = sn;
+                dsm[swz_index<DIR_LD, 7>(p, 15 + L.wv * 3 + a)] = cs;
+            }
+            if (L.wv == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) dsm[swz_index<DIR_LD, 7>(p, a)] = dc[a];
+            }
+            if (L.wv == 1) {
+#pragma unroll
+                for (int f = 27; f < 32; ++f) dsm[swz_index<DIR_LD, 7>(p, f)] = 0.0f;
+            }
+        }
+        __syncthreads();
+
+        // ---- streamed-input GEMM: [L0 | L3 skip half] (256 outputs) over 703 / 724 features ----
+        f32x16 accx[2][2];
+        bias_tile(accx[0][0], m.bias + B_0, L.wv, L);
+        accx[0][1] = accx[0][0];
+        bias_tile(accx[1][0], m.bias + B_3, L.wv, L);
+        accx[1][1] = accx[1][0];
+        {
+            const int col4 = tid & 15, rg = tid >> 4;
+            const f32x4* lat4 = reinterpret_cast<const f32x4*>(sc.latent);
+            // Each 64-feature stage is produced in two half-tiles (32 rows each) so only 8 taps
+            // (32 VGPR) are in flight: issue half A of stage s+1 | MFMA chunks 0-3 of stage s |
+            // blend+write A | issue half B | MFMA chunks 4-7 | blend+write B | barrier.
+            f32x4 tap[2][4];
+            auto issue_local = [&](int s, int hf) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tap[i][k] = lat4[(long)loc_off[row * 4 + k] * 128 + 16 * s + col4];
+                }
+            };
+            auto issue_plane = [&](int j, int s2, int hf) {
+                const f32x4* pl4 = reinterpret_cast<const f32x4*>(sc.plane[j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        tap[i][k] = pl4[(long)pl_off[(j * TM + row) * 4 + k] * 32 + 16 * s2 + col4];
+                }
+            };
+            auto write_x = [&](float* buf, int row, const f32x4 v) {
+                *reinterpret_cast<f32x4*>(buf + row * XB_LD + ((col4 ^ (row & 15)) << 2)) = v;
+            };
+            auto finish_local = [&](float* buf, int hf) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+                    write_x(buf, row, blend4(tap[i], *reinterpret_cast<const f32x4*>(loc_w + row * 4)));
+                }
+            };
+            // tri-plane sum: (xz + xy) + yz (encoder_tp_fusion_conv.py:204-206); plane 0 was prefetched
+            auto finish_planes = [&](float* buf, int s2, int hf) {
+                f32x4 sum[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    sum[i] = blend4(tap[i], *reinterpret_cast<const f32x4*>(pl_w + (rg + 16 * (2 * hf + i)) * 4));
+#pragma unroll
+                for (int j = 1; j < 3; ++j) {
+                    issue_plane(j, s2, hf);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        sum[i] = sum[i] + blend4(tap[i], *reinterpret_cast<const f32x4*>(pl_w + (j * TM + rg + 16 * (2 * hf + i)) * 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) write_x(buf, rg + 16 * (2 * hf + i), sum[i]);
+            };
+            // pos_enc of the camera-frame point: 64 features per stage; half hf = feature chunks 8hf..8hf+7
+            auto finish_pe = [&](float* buf, int pstage, int hf) {
+                const int row = tid & 63, q = tid >> 6;
+                const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int ch = hf * 8 + q * 2 + c;
+                    f32x4 vv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] = pe_feature<PE_C>(xc, pstage * 64 + ch * 4 + e);
+                    *reinterpret_cast<f32x4*>(buf + row * XB_LD + ((ch ^ (row & 15)) << 2)) = vv;
+                }
+            };
+            // prologue: stage 0
+            issue_local(0, 0);
+            finish_local(act, 0);
+            issue_local(0, 1);
+            finish_local(act, 1);
+            __syncthreads();
+#pragma unroll 1
+            for (int s = 0; s < NST; ++s) {
+                float* cur = act + (s & 1) * (TM * XB_LD);
+                float* nxt = act + ((s + 1) & 1) * (TM * XB_LD);
+                const int sn = s + 1;
+                const int nchunks = (PE_C == 4 && s == NST - 1) ? 3 : 8;
+                const int first = nchunks < 4 ? nchunks : 4;
+#pragma unroll 1
+                for (int hf = 0; hf < 2; ++hf) {
+                    if (sn < 8) issue_local(sn, hf);
+                    else if (sn < 10) issue_plane(0, sn - 8, hf);
+                    if (hf == 0) gemm2<2, XB_LD, 15>(accx, wp + off_x() / 4, KCX, nts_x, s * 8, first, cur, L);
+                    else if (nchunks > 4) gemm2x<2, XB_LD, 15>(accx, wp + off_x() / 4, KCX, nts_x, s * 8, 4, nchunks - 4, cur, L);
+                    if (sn < 8) finish_local(nxt, hf);
+                    else if (sn < 10) finish_planes(nxt, sn - 8, hf);
+                    else if (sn < NST) finish_pe(nxt, sn - 10, hf);
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- L0 epilogue, L1, L2 ------------------------------------------------
+        f32x16 acc[1][2];
+        store_tile<ACT_LD, 15, true>(accx[0][0], act, L.wv, 0, L);
+        store_tile<ACT_LD, 15, true>(accx[0][1], act, L.wv, 1, L);
+        __syncthreads();
+#pragma unroll 1
+        for (int layer = 0; layer < 2; ++layer) {
+            bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : B_2), L.wv, L);
+            acc[0][1] = acc[0][0];
+            gemm2<1, ACT_LD, 15>(acc, wp + (layer == 0 ? off_1(PE_C) : off_2(PE_C)) / 4, 16, nts_1, 0, 16, act, L);
+            __syncthreads();
+            store_tile<ACT_LD, 15, true>(acc[0][0], act, L.wv, 0, L);
+            store_tile<ACT_LD, 15, true>(acc[0][1], act, L.wv, 1, L);
+            __syncthreads();
+        }
+        // ---- L3 = skip half (already in accx[1]) + W3[:, :128] h2 ; ReLU; accumulate the view mean ----
+        acc[0][0] = accx[1][0];
+        acc[0][1] = accx[1][1];
+        gemm2<1, ACT_LD, 15>(acc, wp + off_3a(PE_C) / 4, 16, nts_1, 0, 16, act, L);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
+            hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
+        }
+        store_tile<ACT_LD, 15, true>(acc[0][0], act, L.wv, 0, L);
+        store_tile<ACT_LD, 15, true>(acc[0][1], act, L.wv, 1, L);
+        __syncthreads();
+        // ---- per-view bottleneck (no activation) ----
+        bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
+        acc[0][1] = acc[0][0];
+        gemm2<1, ACT_LD, 15>(acc, wp + off_b(PE_C) / 4, 16, nts_1, 0, 16, act, L);
+        __syncthreads();
+        store_tile<ACT_LD, 15, false>(acc[0][0], act, L.wv, 0, L);
+        store_tile<ACT_LD, 15, false>(acc[0][1], act, L.wv, 1, L);
+        __syncthreads();
+        // ---- view layer 0: [bottleneck | dir enc] -> 64, summed over views before the ReLU ----
+        {
+            f32x16 y;
+            bias_tile(y, m.bias + B_V0, vnt, L);
+            gemm1<ACT_LD, 15>(y, wp + off_v0(PE_C) / 4, 20, vnt, vmt, 0, 16, act, L);
+            gemm1<DIR_LD, 7>(y, wp + off_v0(PE_C) / 4, 20, vnt, vmt, 16, 4, dsm, L);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ysum[r] += y[r];
+        }
+        __syncthreads();   // act / dsm / descriptors are rewritten by the next view
+    }
+
+    // ---- view mean of the trunk -> density head ----
+    const float nvf = (float)sc.nv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] / nvf; hsum[1][r] = hsum[1][r] / nvf; }
+    store_tile<ACT_LD, 15, false>(hsum[0], act, L.wv, 0, L);
+    store_tile<ACT_LD, 15, false>(hsum[1], act, L.wv, 1, L);
+    __syncthreads();
+    float raw_sigma;
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int chunk_i = part * 8 + ((c + 2 * part) & 7);
+            const f32x4 h = *reinterpret_cast<const f32x4*>(act + pt * ACT_LD + ((chunk_i ^ (pt & 15)) << 2));
+            const f32x4 w = *reinterpret_cast<const f32x4*>(m.heads + HD_DW + chunk_i * 4);
+            s += h[0] * w[0] + h[1] * w[1] + h[2] * w[2] + h[3] * w[3];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        raw_sigma = s + m.heads[HD_DB];
+    }
+    __syncthreads();
+    // ---- view mean of the view branch -> ReLU -> 64x64 -> ReLU -> rgb head ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ysum[r] = ysum[r] / nvf;
+    store_tile<ACT_LD, 15, true>(ysum, act, vnt, vmt, L);
+    __syncthreads();
+    {
+        f32x16 y;
+        bias_tile(y, m.bias + B_V1, vnt, L);
+        gemm1<ACT_LD, 15>(y, wp + off_v1(PE_C) / 4, 8, vnt, vmt, 0, 8, act, L);
+        __syncthreads();
+        store_tile<ACT_LD, 15, true>(y, act, vnt, vmt, L);
+    }
+    __syncthreads();
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const float* wr = m.heads + HD_RW;
+        float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int chunk_i = part * 4 + ((c + part) & 3);
+            const f32x4 h = *reinterpret_cast<const f32x4*>(act + pt * ACT_LD + ((chunk_i ^ (pt & 15)) << 2));
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk_i * 4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 64 + chunk_i * 4);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk_i * 4);
+            r += h[0] * w0[0] + h[1] * w0[1] + h[2] * w0[2] + h[3] * w0[3];
+            g += h[0] * w1[0] + h[1] * w1[1] + h[2] * w1[2] + h[3] * w1[3];
+            b += h[0] * w2[0] + h[1] * w2[1] + h[2] * w2[2] + h[3] * w2[3];
+        }
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+        g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        const long gi = tile0 + pt;
+        if (part == 0 && gi < P) {
+            out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
+                                  colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));
+        }
+    }
+}
+
+// ---- weight packing -------------------------------------------------------------
+// dst N-tiles [nt0, nt0 + rows/32) of a stage with KC chunks <- src[rows][ld], packed k -> source column
+// through up to three segments (k_start, k_len, col_start); everything else is zero.
+struct PackSegs { int k0[3], len[3], col[3]; };
+
+__global__ void k_pack_block(const float* __restrict__ src, int ld, int rows, int KC, int nt0, PackSegs sg,
+                             float* __restrict__ dst) {
+    const int total = (rows / 32) * KC * 256;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8;
+        const int kc = blk % KC, ntl = blk / KC;
+        const int n = ntl * 32 + (lane & 31);
+        const int k = kc * 8 + 4 * (lane >> 5) + e;
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (k >= sg.k0[q] && k < sg.k0[q] + sg.len[q]) v = src[(long)n * ld + sg.col[q] + (k - sg.k0[q])];
+        dst[((long)(nt0 + ntl) * KC + kc) * 256 + (lane << 2) + e] = v;
+    }
+}
+
+__global__ void k_copy_f(const float* __restrict__ src, int n, float* __restrict__ dst) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// NCHW (NV, C, H, W) -> NHWC (NV, H, W, C)
+__global__ void k_to_channels_last(const float* __restrict__ src, int C, int HW, long total, float* __restrict__ dst) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const long rest = idx / C;
+        const int hw = (int)(rest % HW);
+        const long v = rest / HW;
+        dst[idx] = src[(v * C + c) * HW + hw];
+    }
+}
+
+void pack_block(const float* src, int ld, int rows, int KC, int nt0, PackSegs sg, float* dst, hipStream_t s) {
+    const int total = (rows / 32) * KC * 256;
+    hipLaunchKernelGGL(k_pack_block, dim3((total + 255) / 256), dim3(256), 0, s, src, ld, rows, KC, nt0, sg, dst);
+}
+
+}  // namespace
+
+size_t tp_wpack_floats(int input_ch) { return wpack_floats(input_ch); }
+size_t tp_bias_floats() { return BIAS_FLOATS; }
+size_t tp_heads_floats() { return HEADS_FLOATS; }
+
+void launch_tp_pack(int input_ch, const float* const* w, const float* const* b, float* wpack, float* bias,
+                    float* heads, hipStream_t s) {
+    // w/b order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
+    const int pe = input_ch * 21;                 // 63 or 84
+    const int x0w = pe + 512 + 128;               // 703 or 724
+    const int kcx = kc_x(input_ch);
+    const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    // stage X: packed k = [local 512 | world 128 | pe]; source x0 columns = [pe | local | world]
+    PackSegs sx = {{0, 512, 640}, {512, 128, pe}, {pe, pe + 512, 0}};
+    pack_block(w[0], x0w, 128, kcx, 0, sx, wpack + off_x(), s);
+    PackSegs sx3 = sx;
+    for (int q = 0; q < 3; ++q) sx3.col[q] += 128;   // L3 input = [h(128) | x0]
+    pack_block(w[3], 128 + x0w, 128, kcx, 4, sx3, wpack + off_x(), s);
+    PackSegs plain128 = none;
+    plain128.len[0] = 128;
+    pack_block(w[1], 128, 128, 16, 0, plain128, wpack + off_1(input_ch), s);
+    pack_block(w[2], 128, 128, 16, 0, plain128, wpack + off_2(input_ch), s);
+    pack_block(w[3], 128 + x0w, 128, 16, 0, plain128, wpack + off_3a(input_ch), s);
+    pack_block(w[6], 128, 128, 16, 0, plain128, wpack + off_b(input_ch), s);
+    PackSegs v0 = none;
+    v0.len[0] = 155;                              // [bottleneck 128 | dir enc 27], zero padded to 160
+    pack_block(w[4], 155, 64, 20, 0, v0, wpack + off_v0(input_ch), s);
+    PackSegs v1 = none;
+    v1.len[0] = 64;
+    pack_block(w[5], 64, 64, 8, 0, v1, wpack + off_v1(input_ch), s);
+    auto cp = [&](const float* src, int n, float* dst) {
+        hipLaunchKernelGGL(k_copy_f, dim3(1), dim3(256), 0, s, src, n, dst);
+    };
+    cp(b[0], 128, bias + B_0); cp(b[3], 128, bias + B_3); cp(b[1], 128, bias + B_1); cp(b[2], 128, bias + B_2);
+    cp(b[6], 128, bias + B_B); cp(b[4], 64, bias + B_V0); cp(b[5], 64, bias + B_V1);
+    (void)hipMemsetAsync(heads, 0, HEADS_FLOATS * sizeof(float), s);
+    cp(w[7], 128, heads + HD_DW); cp(b[7], 1, heads + HD_DB); cp(w[8], 192, heads + HD_RW); cp(b[8], 3, heads + HD_RB);
+}
+
+void launch_channels_last(const float* src, int NV, int C, int H, int W, float* dst, hipStream_t s) {
+    const long total = (long)NV * C * H * W;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_to_channels_last, dim3(blocks), dim3(256), 0, s, src, C, H * W, total, dst);
+}
+
+void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+                   const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
+                   int chunk, uint32_t* flags, float* out, hipStream_t s) {
+    const long P = (long)R * N;
+    if (P <= 0) return;
+    const size_t lds = LDS_FLOATS * sizeof(float);
+    const long tiles = (P + TM - 1) / TM;
+    if (input_ch == 3)
+        hipLaunchKernelGGL(k_tp_mlp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(k_tp_mlp<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+}
+
+}  // namespace neo

@@ -268,4 +268,51 @@ int launch_resample(const float* t_prev, int t_prev_stride, const float* weights
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// NeO-360 level-0 sample rows (neo360/helper.py:24-75, randomized=False):
+//   inside : t = near*(1-e) + far*e                     (per-ray far, ascending)
+//   outside: inverse radius = the edges flipped          (1 -> 0, same for every ray)
+// ---------------------------------------------------------------------------
+__global__ void k_tp_level0(const float* __restrict__ far, const float* __restrict__ edges, int R, int N, float near,
+                            float* __restrict__ fg_t, float* __restrict__ bg_s) {
+    const long total = (long)R * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ray = (int)(idx / N), i = (int)(idx - (long)ray * N);
+        const float e = edges[i];
+        const float lo = near * (1.0f - e);
+        const float hi = far[ray] * e;
+        fg_t[idx] = lo + hi;
+        bg_s[idx] = edges[N - 1 - i];
+    }
+}
+
+void launch_tp_level0(const float* far, const float* edges, int R, int N, float near, float* fg_t, float* bg_s,
+                      hipStream_t s) {
+    const long total = (long)R * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_tp_level0, dim3(blocks), dim3(256), 0, s, far, edges, R, N, near, fg_t, bg_s);
+}
+
+// rgb = fg + lambda*bg ; depth = fg_depth + lambda*bg_depth (neo360/model.py:521-527)
+__global__ void k_tp_merge(const float* __restrict__ fg_rgb, const float* __restrict__ fg_depth,
+                           const float* __restrict__ lambda, const float* __restrict__ bg_rgb,
+                           const float* __restrict__ bg_depth, int R, float* __restrict__ rgb,
+                           float* __restrict__ depth) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float lam = lambda[r];
+    if (rgb) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) rgb[r * 3 + a] = fg_rgb[r * 3 + a] + lam * bg_rgb[r * 3 + a];
+    }
+    if (depth) depth[r] = fg_depth[r] + lam * bg_depth[r];
+}
+
+void launch_tp_merge(const float* fg_rgb, const float* fg_depth, const float* lambda, const float* bg_rgb,
+                     const float* bg_depth, int R, float* rgb, float* depth, hipStream_t s) {
+    hipLaunchKernelGGL(k_tp_merge, dim3((R + 255) / 256), dim3(256), 0, s, fg_rgb, fg_depth, lambda, bg_rgb, bg_depth,
+                       R, rgb, depth);
+}
+
 }  // namespace neo

@@ -148,3 +148,183 @@ class NeRF(_HipModule):
         _lib.check(ctx.lib.neo_vanilla_mlp(ctx.handle, level, ptr(rays_o), ptr(dirs), ptr(t), N, B, N, ptr(out),
                                            ctx.stream()))
         return out
+
+
+class NeRFPPMLP(nn.Module):
+    """Parameter container with the layout of neo360/model.py:37-108: pts_linears.0..3
+    (128 wide; input = pos_enc + 512 local + 128 world; skip concat feeds index 3),
+    views_linear.0/.1 (64), bottleneck_layer, density_layer, rgb_layer."""
+
+    def __init__(self, min_deg_point=0, max_deg_point=10, deg_view=4, netdepth=4, netwidth=128,
+                 netdepth_condition=2, netwidth_condition=64, skip_layer=2, input_ch=3, input_ch_view=3,
+                 num_rgb_channels=3, num_density_channels=1, local_latent_size=512, world_latent_size=128,
+                 combine_layer=3, combine_type="average", out_nocs=False, num_src_views=3):
+        super().__init__()
+        if (netdepth, netwidth, netdepth_condition, netwidth_condition, skip_layer, input_ch_view, num_rgb_channels,
+                num_density_channels, local_latent_size, world_latent_size, combine_layer, combine_type, out_nocs,
+                min_deg_point, max_deg_point, deg_view) != (4, 128, 2, 64, 2, 3, 3, 1, 512, 128, 3, "average", False,
+                                                            0, 10, 4) or input_ch not in (3, 4):
+            raise NotImplementedError("the HIP kernel is specialised for the reference's default NeRFPPMLP shape")
+        self.input_ch = input_ch
+        self.num_src_views = num_src_views
+        pos = ((max_deg_point - min_deg_point) * 2 + 1) * input_ch + local_latent_size + world_latent_size
+        view = (deg_view * 2 + 1) * input_ch_view
+        layers = [_xavier_linear(pos, netwidth)]
+        for idx in range(netdepth - 1):
+            layers.append(_xavier_linear(netwidth + pos if (idx % skip_layer == 0 and idx > 0) else netwidth, netwidth))
+        self.pts_linears = nn.ModuleList(layers)
+        self.views_linear = nn.ModuleList([_xavier_linear(netwidth + view, netwidth_condition, xavier=False),
+                                           _xavier_linear(netwidth_condition, netwidth_condition)])
+        self.bottleneck_layer = _xavier_linear(netwidth, netwidth)
+        self.density_layer = _xavier_linear(netwidth, num_density_channels)
+        self.rgb_layer = _xavier_linear(netwidth_condition, num_rgb_channels)
+
+    def ordered_layers(self):
+        """Upload order fixed by include/neo360_hip.h (neo_tp_upload_mlp)."""
+        return list(self.pts_linears) + [self.views_linear[0], self.views_linear[1], self.bottleneck_layer,
+                                         self.density_layer, self.rgb_layer]
+
+
+class NeRF_TP(_HipModule):
+    """NeO-360 decoder renderer (neo360/model.py:162-581).
+
+    `forward(rays, randomized, white_bkgd, near, far, out_depth=False)` keeps the
+    reference's signature and return tuples.  The scene features the reference's
+    GridEncoder produces (three tri-planes + the pixel-aligned latent) are outside the
+    accelerated path: provide them once per scene with `set_scene(...)`, or attach any
+    `encoder` module with the reference's interface (callable -> three planes, and
+    `.spatial_encoder.latent`); an attached encoder is run once per distinct `src_imgs`
+    tensor instead of once per chunk (results are identical in eval mode).
+    """
+
+    def __init__(self, num_levels=2, min_deg_point=0, max_deg_point=10, deg_view=4, num_coarse_samples=128,
+                 num_fine_samples=256, use_viewdirs=True, num_src_views=3, density_noise=0.0, lindisp=False,
+                 xyz_min=None, xyz_max=None, is_optimize=False, encoder_type="resnet", feats_c_size=0, attn=False,
+                 input_ch_view=3, use_same_stride=False, encoder=None):
+        super().__init__()
+        if num_levels != 2 or not use_viewdirs or lindisp:
+            raise NotImplementedError("only the reference's default 2-level, view-dependent, linear-depth setup")
+        self.num_levels, self.num_src_views = num_levels, num_src_views
+        self.min_deg_point, self.max_deg_point, self.deg_view = min_deg_point, max_deg_point, deg_view
+        self.num_coarse_samples, self.num_fine_samples = num_coarse_samples, num_fine_samples
+        self.density_noise, self.lindisp, self.is_optimize = density_noise, lindisp, is_optimize
+        if encoder is not None:
+            self.encoder = encoder
+        self.fg_coarse_mlp = NeRFPPMLP(min_deg_point, max_deg_point, deg_view, num_src_views=num_src_views)
+        self.fg_fine_mlp = NeRFPPMLP(min_deg_point, max_deg_point, deg_view, num_src_views=num_src_views)
+        self.bg_coarse_mlp = NeRFPPMLP(min_deg_point, max_deg_point, deg_view, num_src_views=num_src_views, input_ch=4)
+        self.bg_fine_mlp = NeRFPPMLP(min_deg_point, max_deg_point, deg_view, num_src_views=num_src_views, input_ch=4)
+        self.chunk = 1024            # rays per reference forward call (opt.py:195-200)
+        self._scene_key = None
+        self._scene_ctx = None
+
+    def _mlps(self):
+        return (self.fg_coarse_mlp, self.fg_fine_mlp, self.bg_coarse_mlp, self.bg_fine_mlp)
+
+    def _sync_weights(self, ctx):
+        for slot, mlp in enumerate(self._mlps()):
+            layers = mlp.ordered_layers()
+            ws = [f32(l.weight.detach(), "weight") for l in layers]
+            bs = [f32(l.bias.detach(), "bias") for l in layers]
+            fp = _fingerprint(ws + bs)
+            if ctx.uploaded.get(("tp", slot)) == fp:
+                continue
+            _lib.check(ctx.lib.neo_tp_upload_mlp(ctx.handle, slot, mlp.input_ch, _ptr_table(ws), _ptr_table(bs),
+                                                 ctx.stream()))
+            ctx.uploaded[("tp", slot)] = fp
+
+    @torch.no_grad()
+    def set_scene(self, plane_xz, plane_xy, plane_yz, latent, image_wh):
+        """Scene features in the reference's layout: planes (NV,128,Hp,Wp), latent
+        (NV,512,Hf,Wf), image_wh = (W,H) of the source images the latent was encoded from
+        (neo360/model.py:267-269).  Re-laid out channels-last on the device, once."""
+        planes = [f32(p, "plane") for p in (plane_xz, plane_xy, plane_yz)]
+        latent = f32(latent, "latent")
+        ctx = self._context(latent.device)
+        NV, Cw, Hp, Wp = planes[0].shape
+        _, Cl, Hf, Wf = latent.shape
+        _lib.check(ctx.lib.neo_tp_set_scene(ctx.handle, ptr(planes[0]), ptr(planes[1]), ptr(planes[2]), NV, Cw, Hp, Wp,
+                                            ptr(latent), Cl, Hf, Wf, float(image_wh[0]), float(image_wh[1]),
+                                            ctx.stream()))
+        torch.cuda.current_stream(latent.device).synchronize()   # inputs may be freed by the caller
+        self._scene_ctx = ctx
+
+    def _ensure_scene(self, rays, dev):
+        enc = getattr(self, "encoder", None)
+        if enc is None:
+            if self._scene_ctx is None:
+                raise _lib.NeoError("no scene features: call set_scene(...) or attach an encoder module")
+            return
+        src = rays["src_imgs"]
+        key = (src.data_ptr(), src._version, tuple(src.shape), rays["src_poses"].data_ptr())
+        if key == self._scene_key and self._scene_ctx is not None:
+            return
+        planes = enc(rays["src_imgs"], rays["src_poses"], rays["src_focal"], rays["src_c"])
+        self.set_scene(planes[0], planes[1], planes[2], enc.spatial_encoder.latent,
+                       (src.shape[-1], src.shape[-2]))
+        self._scene_key = key
+
+    @staticmethod
+    def _camera_args(rays):
+        poses = rays["src_poses"].detach().float().cpu().contiguous()
+        NV = poses.shape[0]
+        host_poses = (ctypes.c_float * (16 * NV))(*poses.reshape(-1).tolist())
+        focal = float(rays["src_focal"][0])                 # view 0's intrinsics for every view (model.py:242-244)
+        cx, cy = (float(x) for x in rays["src_c"][0])
+        return host_poses, NV, focal, cx, cy
+
+    @torch.no_grad()
+    def eval_mlp(self, slot, rays, tvals, far=None, chunk=None):
+        """Stage-level access for parity tests: feature lookups + pos_enc + NeRFPPMLP +
+        activations of one region at given sample positions.  slot 0/1 = fg coarse/fine
+        (tvals = t), 2/3 = bg coarse/fine (tvals = descending inverse radius, needs far).
+        Returns (B,N,4) = (rgb, sigma)."""
+        rays_o, rays_d, viewdirs = f32(rays["rays_o"]), f32(rays["rays_d"]), f32(rays["viewdirs"])
+        tvals = f32(tvals, "tvals")
+        far = f32(far, "far") if far is not None else None
+        ctx = self._context(rays_o.device)
+        self._ensure_scene(rays, rays_o.device)
+        self._sync_weights(ctx)
+        B, N = tvals.shape
+        host_poses, NV, focal, cx, cy = self._camera_args(rays)
+        out = torch.empty(B, N, 4, device=rays_o.device)
+        _lib.check(ctx.lib.neo_tp_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(tvals), ptr(far),
+                                      B, N, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy, ptr(out),
+                                      ctx.stream()))
+        return out
+
+    @torch.no_grad()
+    def forward(self, rays, randomized, white_bkgd, near, far, out_depth=False, chunk=None):
+        """Per level: (comp_rgb, fg_rgb, bg_rgb, fg_acc, bg_lambda, comp_depth) — the
+        reference's out_depth=True tuple (neo360/model.py:521-527).  `near`/`far` are
+        ignored exactly as in the reference (:277-278).  All rays of the call form ONE
+        reference chunk unless `chunk` is given (whole-frame rendering, see render.py)."""
+        self._check_mode(randomized)
+        if not out_depth:
+            raise NotImplementedError("out_depth=False returns training-only tensors (weights / sdist); "
+                                      "the accelerated path implements the evaluation call (out_depth=True)")
+        rays_o = f32(rays["rays_o"], "rays_o")
+        rays_d = f32(rays["rays_d"], "rays_d")
+        viewdirs = f32(rays["viewdirs"], "viewdirs")
+        dev = rays_o.device
+        ctx = self._context(dev)
+        self._ensure_scene(rays, dev)
+        if self._scene_ctx is not ctx:
+            raise _lib.NeoError("scene features were uploaded on a different device")
+        self._sync_weights(ctx)
+        B = rays_o.shape[0]
+        host_poses, NV, focal, cx, cy = self._camera_args(rays)
+        levels, structs = [], []
+        for _ in range(2):
+            t = dict(rgb=torch.empty(B, 3, device=dev), fg_rgb=torch.empty(B, 3, device=dev),
+                     bg_rgb=torch.empty(B, 3, device=dev), fg_acc=torch.empty(B, device=dev),
+                     bg_lambda=torch.empty(B, 1, device=dev), depth=torch.empty(B, device=dev))
+            levels.append(t)
+            structs.append(_lib.TpLevelOut(*(t[k].data_ptr() for k in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth"))))
+        _lib.check(ctx.lib.neo_tp_render(
+            ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
+            self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
+            ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
+        if ctx.poll_flags() & 1:
+            raise AssertionError("1.0 - p_norm_sq should be greater than 0")
+        return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]

@@ -22,6 +22,33 @@ def _predict(params, prefix, cam_pts, dir_cam, world, local, B, N, nv):
     return mlp.colour_activation(raw_rgb.reshape(B, N, -1)), mlp.density_activation(raw_sigma.reshape(B, N, -1))
 
 
+def region_eval(params, prefix, rays, scene, tvals, inside, far=None):
+    """One region's per-point outputs at GIVEN sample positions: rgb (B,N,3), sigma (B,N,1).
+    inside: tvals = t ascending, points o + t d.  outside: tvals = inverse radius
+    descending; encoded point = inverted-sphere point, lookups at the linear point
+    o + (far(1-s) + 3 s) d (neo360/helper.py:59-73, model.py:409-464).
+    Used by the stage-isolated parity tests (identical sample positions on both sides)."""
+    o, d, vd = rays["rays_o"], rays["rays_d"], rays["viewdirs"]
+    poses, focal, centre = rays["src_poses"], rays["src_focal"], rays["src_c"]
+    nv = poses.shape[0]
+    dir_cam = gather.world_to_camera_dirs(vd, poses)
+    B, N = tvals.shape
+    if inside:
+        look = enc = sampling.points_on_rays(tvals, o, d)
+        extra = None
+    else:
+        p4 = sampling.inverted_sphere_points(o, d, tvals)
+        enc = p4[:, :, :3]
+        extra = p4[:, :, 3].reshape(-1, 1).unsqueeze(0).repeat(nv, 1, 1)
+        look = sampling.points_on_rays(far * (1.0 - tvals) + 3.0 * tvals, o, d)
+    world = gather.triplane_features(look, scene["plane_xz"], scene["plane_xy"], scene["plane_yz"], poses)
+    local = gather.pixel_aligned_features(look, scene["latent"], poses, focal, centre, scene["image_wh"])
+    cam = gather.world_to_camera(enc.reshape(-1, 3), poses)
+    if extra is not None:
+        cam = torch.cat((cam, extra), dim=-1)
+    return _predict(params, prefix, cam, dir_cam, world, local, B, N, nv)
+
+
 def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_depth=True, keep=False):
     """Return value of NeRF_TP.forward for randomized=False
     (neo360/model.py:266-581, decoder half from :276).

@@ -120,8 +120,8 @@ def test_resample_matches_oracle(desc, n_prev, n_new):
     good = torch.ones(R, dtype=torch.bool)
     good[2] = good[3] = False
     # positions, well-conditioned rows; with descending bins every sample interpolates across the
-    # WHOLE range (bin0 = first bin, bin1 = last bin), so an ulp of the cdf moves it 64x further
-    assert max_abs(got[good], want[good]) < (3e-5 if desc else 5e-6)
+    # WHOLE range (bin0 = first bin, bin1 = last bin), so an ulp of the cdf moves it n_bins times further
+    assert max_abs(got[good], want[good]) < (2e-4 if desc else 5e-6)
     if not desc:                                                         # cdf space, every row (ascending bins)
         assert max_abs(_cdf_space(got, mids, w[:, 1:-1]), _cdf_space(want, mids, w[:, 1:-1])) < 2e-6
 
