@@ -1,15 +1,18 @@
 """Headline benchmark: rays/s of the full-frame render path on synthetic 640x480
-frames (BASELINE.json metric; workload = configs[1], vanilla NeRF 64 coarse + 128
-fine samples per ray, random-init MLP), one process per GPU.
+frames (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py [--gpus 1] [--steps K] [--warmup W] [--workload vanilla|neo360]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = ray generation for one frame + coarse and fine render of this rank's
-contiguous ray range (+ one RCCL all-gather of the packed (rgb,depth,acc) tiles
-when N > 1: the frame is fixed, so scaling is "strong").  Prints ONE JSON line on
-rank 0.
+Default workload = BASELINE.json configs[1] (the configuration the metric is quoted on):
+vanilla NeRF, 640x480, 64 coarse + 128 fine samples/ray, random-init MLP.
+`--workload neo360` = configs[2]/[3]: the NeO-360 tri-planar decoder, 3 source views,
+128 coarse + 256 fine samples, inside + outside sphere, reference chunk 1024.
+
+A step = ray generation for one frame + coarse and fine render of this rank's contiguous
+range of whole 1024-ray chunks (+ ONE RCCL all-gather of the packed (rgb,depth,acc) tiles
+when N > 1).  The frame is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -23,32 +26,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 H, W = 480, 640
-N_COARSE, N_FINE = 64, 128
-NEAR, FAR = 0.2, 3.0
-FLOP_PER_POINT = 2 * 593408           # NeRFMLP MACs x 2 (vanilla_nerf/model.py:44-125)
-POINTS_PER_RAY = (N_COARSE + 1) + (N_COARSE + 1 + N_FINE)
-PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, dense fp32 MFMA
+CHUNK = 1024
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector peak)
+CPU_THREADS = 32                      # fastest of an 8..256 sweep on the GPU box (profiles/cpu_threads_r01.log)
 
 
-def cpu_baseline(state, rays_cpu, got_rgb, got_depth, budget_rays):
-    """Oracle (CPU restatement of the reference, 'port') timed on a bounded sample of
-    the same frame; also returns the parity of the GPU frame on those rays."""
+def build_vanilla(dev):
+    from neo360_amd import models, synth
+    state = synth.vanilla_state(0)
+    net = models.NeRF(num_coarse_samples=64, num_fine_samples=128).to(dev)
+    net.load_state_dict(state)
+    extra = {}
+    desc = ("vanilla_nerf 640x480 full frame, 64 coarse + 128 fine samples/ray (65+193 = 258 MLP points/ray), "
+            "random-init 8x256 MLP, raygen + both levels")
+    return net, state, extra, None, desc, dict(near=0.2, far=3.0), "k_vanilla_mlp", 1024
+
+
+def build_neo360(dev):
+    from neo360_amd import models, synth
+    nv = 3
+    state = synth.nerf_tp_state(0)
+    net = models.NeRF_TP(num_coarse_samples=128, num_fine_samples=256, num_src_views=nv).to(dev)
+    net.load_state_dict(state)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    # stand-ins for the scene encoder's outputs, reference shapes: N(0, 0.1^2)
+    scene = {k: torch.randn(nv, 128, 120, 160, device=dev, generator=g) * 0.1 for k in ("plane_xz", "plane_xy", "plane_yz")}
+    scene["latent"] = torch.randn(nv, 512, 240, 320, device=dev, generator=g) * 0.1
+    scene["image_wh"] = (float(W), float(H))
+    net.set_scene(scene["plane_xz"], scene["plane_xy"], scene["plane_yz"], scene["latent"], scene["image_wh"])
+    poses, focal, centre = synth.source_views(nv, W, H)
+    extra = dict(src_poses=poses.to(dev), src_focal=focal.to(dev), src_c=centre.to(dev),
+                 src_imgs=torch.zeros(nv, 3, H, W, device=dev))
+    desc = ("neo360 tri-planar decoder 640x480 full frame, 3 source views, 128 coarse + 256 fine samples/ray, "
+            "inside + outside sphere ((129+385)x2 = 1028 MLP points/ray x 3 views), reference chunk 1024, "
+            "random-init MLPs, synthetic N(0,0.1) tri-planes (3x128x120x160) + latents (3x512x240x320)")
+    return net, state, extra, scene, desc, dict(near=0.0, far=0.0), "k_tp_mlp", 256
+
+
+def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
+    """The oracle (CPU restatement of the reference: kind 'port') timed on a bounded sample
+    of the same frame on the host cores."""
     import oracle
-    # 32 threads is the fastest setting of an 8..256 sweep on the GPU box's 2x64-core EPYC 9575F
-    # (profiles/cpu_threads_r01.log: 625 rays/s at 32, 40 rays/s at 256 threads)
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    sample = {k: v[:budget_rays] for k, v in rays_cpu.items()}
+    torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
+    sample = {k: v[:n] for k, v in rays_cpu.items()}
     t0 = time.perf_counter()
-    rgb, depth = oracle.vanilla.render_chunked(state, sample, NEAR, FAR, chunk=1024)
+    if workload == "vanilla":
+        rgb, depth = oracle.vanilla.render_chunked(state, sample, kw["near"], kw["far"], chunk=CHUNK)
+    else:
+        batch = dict(sample)
+        batch.update({k: v.cpu() for k, v in extra.items()})
+        sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
+        rgb, depth = oracle.neo360.render_chunked(state, batch, sc, chunk=n)
     dt = time.perf_counter() - t0
-    err_rgb = float((got_rgb[:budget_rays] - rgb).abs().max())
-    err_depth = float((got_depth[:budget_rays] - depth).abs().max())
-    mse = float(((got_rgb[:budget_rays].clamp(0, 1) - rgb.clamp(0, 1)) ** 2).mean())
-    psnr = float("inf") if mse == 0 else -10.0 * torch.log10(torch.tensor(mse)).item()
-    return dict(value=budget_rays / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample="first %d rays (%d reference chunks of 1024) of the same 640x480 frame, 64+128 samples, "
-                       "torch fp32 on host cores, %.1f s" % (budget_rays, (budget_rays + 1023) // 1024, dt)), \
-        dict(max_abs_rgb=err_rgb, max_abs_depth=err_depth, psnr_db=psnr)
+    base = dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
+                sample="first %d rays of the same 640x480 frame as one%s reference chunk%s, same weights / features, "
+                       "torch fp32 CPU oracle, %.1f s" % (n, "" if n <= CHUNK else " run of", "" if n <= CHUNK else "s", dt))
+    return base, rgb, depth
 
 
 def main():
@@ -56,7 +90,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--cpu-rays", type=int, default=8192, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--workload", choices=("vanilla", "neo360"), default="vanilla")
+    ap.add_argument("--cpu-rays", type=int, default=-1, help="rays in the CPU-baseline sample (0 = skip, -1 = default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,27 +101,26 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from neo360_amd import models, ops, synth
-    from neo360_amd.parallel import shard_bounds, gather_tiles
+    from neo360_amd import ops, render, synth
 
-    state = synth.vanilla_state(0)
-    net = models.NeRF(num_coarse_samples=N_COARSE, num_fine_samples=N_FINE).to(dev)
-    net.load_state_dict(state)
+    net, state, extra, scene, desc, kw, kernel_name, cpu_default = (build_vanilla if args.workload == "vanilla" else build_neo360)(dev)
     c2w = synth.look_at_origin(40.0)
     R = H * W
-    lo, hi = shard_bounds(R, world, rank, unit=1024)
     ctx = net._context(dev)
 
-    def step():
+    def frame_rays():
         ro, vd, rd, _ = ops.get_ray_directions_and_rays(H, W, 0.8 * W, c2w, ctx=ctx)
-        rays = dict(rays_o=ro[lo:hi], viewdirs=vd[lo:hi], rays_d=rd[lo:hi])
-        res = net(rays, False, False, NEAR, FAR)
-        tile = torch.cat([res[1][0], res[1][2][:, None], res[1][1][:, None]], dim=1)   # (r, 5)
-        return gather_tiles(tile, R, world, unit=1024) if world > 1 else tile
+        batch = dict(rays_o=ro, viewdirs=vd, rays_d=rd)
+        batch.update(extra)
+        return batch
+
+    def step():
+        return render.render_frame_sharded(net, frame_rays(), world, rank, chunk=CHUNK, **kw)
 
     def fence():
         if world > 1:
@@ -102,7 +136,7 @@ def main():
         frame = step()
     fence()
     dt = time.perf_counter() - t0
-    kern_ms, launches, points = ctx.read_timing()
+    kern_ms, launches, points, flops = ctx.read_timing()
     ctx.set_timing(False)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -110,31 +144,40 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        achieved = points * FLOP_PER_POINT / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         out = {
             "metric": "rays/sec (128 samples/ray) + PSNR vs ref, 640x480",
             "value": R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "vanilla_nerf 640x480 full frame, 64 coarse + 128 fine samples/ray "
-                                   "(258 MLP points/ray), random-init 8x256 MLP, raygen + both levels"
-                                   + (", rays sharded by 1024-ray chunks + RCCL all-gather of (rgb,depth,acc) tiles"
-                                      if world > 1 else ""),
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc + (", rays sharded by whole 1024-ray chunks + one RCCL all-gather of "
+                                           "(rgb,depth,acc) tiles" if world > 1 else ""),
                        "rays_per_frame": R, "parallelism": "ray-shard x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "k_vanilla_mlp", "launches": launches,
-                         "avg_launch_ms": kern_ms / max(launches, 1),
-                         "flop_per_point": FLOP_PER_POINT, "points_per_launch_avg": points / max(launches, 1)},
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": kernel_name,
+                         "launches": launches, "avg_launch_ms": kern_ms / max(launches, 1),
+                         "algorithmic_flop_per_launch": flops / max(launches, 1),
+                         "points_per_launch": points / max(launches, 1),
+                         "note": "rank 0's launches; algorithmic flops = reference formulation MACs x 2 (SURVEY.md 8d)"},
         }
-        if world == 1 and args.cpu_rays > 0:
-            ro, vd, rd, _ = ops.get_ray_directions_and_rays(H, W, 0.8 * W, c2w, ctx=ctx)
-            n = min(args.cpu_rays, R)
-            rays_cpu = dict(rays_o=ro[:n].cpu(), viewdirs=vd[:n].cpu(), rays_d=rd[:n].cpu())
-            base, parity = cpu_baseline(state, rays_cpu, frame[:n, :3].cpu(), frame[:n, 3].cpu(), n)
+        n_cpu = cpu_default if args.cpu_rays < 0 else args.cpu_rays
+        if world == 1 and n_cpu > 0:
+            batch = frame_rays()
+            n = min(n_cpu, R)
+            rays_cpu = {k: batch[k][:n].cpu() for k in ("rays_o", "viewdirs", "rays_d")}
+            base, rgb_c, depth_c = cpu_baseline(args.workload, state, scene, rays_cpu, extra, kw, n)
+            if args.workload == "neo360" and n != CHUNK:
+                # NeO-360 results depend on chunk membership: render the same rays as their own chunk
+                sub = {k: (v[:n] if k in ("rays_o", "viewdirs", "rays_d") else v) for k, v in batch.items()}
+                got = render.render_rays_test(net, sub, chunk=n, **kw)
+                rgb_g, depth_g = got["rgb"].cpu(), got["depth"].cpu()
+            else:
+                rgb_g, depth_g = frame[:n, :3].cpu(), frame[:n, 3].cpu()
+            err = (rgb_g - rgb_c).abs().amax(dim=-1)
             out["cpu_baseline"] = base
-            out["parity_vs_cpu"] = parity
+            out["parity_vs_cpu"] = {"max_abs_rgb": float(err.max()), "p99_abs_rgb": float(err.quantile(0.99)),
+                                    "max_abs_depth": float((depth_g - depth_c).abs().max()),
+                                    "psnr_db": render.psnr(rgb_g, rgb_c), "rays": n}
             out["speedup_vs_cpu"] = out["value"] / base["value"]
         print(json.dumps(out))
     if world > 1:

@@ -174,11 +174,13 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d,
                   const neo_tp_level_out* level0, const neo_tp_level_out* level1, void* stream);
 
 /* ---- profiling aid ---------------------------------------------------------- */
-/* Average duration (ms) of the dominant MLP kernel launches recorded with HIP
- * events on their own stream since the last reset; count returned in *launches.
- * Enable with neo_ctx_set_timing(ctx, 1).  Reading synchronises the events. */
+/* Total duration (ms) of the dominant (fused MLP) kernel launches, bracketed with HIP
+ * events on the stream they were launched on, since timing was enabled; with the
+ * launch count, the points evaluated and their ALGORITHMIC flops (reference
+ * formulation, MAC x 2).  Reading synchronises the events. */
 int neo_ctx_set_timing(neo_ctx* ctx, int enable);
-int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points);
+int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points,
+                        double* total_flops);
 
 #ifdef __cplusplus
 }

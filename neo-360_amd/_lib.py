@@ -44,7 +44,7 @@ SIGNATURES = {
                            ctypes.POINTER(TpLevelOut), ctypes.POINTER(TpLevelOut), _vp]),
     "neo_ctx_set_timing": (_i, [_vp, _i]),
     "neo_ctx_read_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i),
-                                 ctypes.POINTER(ctypes.c_double)]),
+                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lock = threading.Lock()

@@ -65,9 +65,10 @@ class Context:
         _lib.check(self.lib.neo_ctx_set_timing(self.handle, 1 if enable else 0))
 
     def read_timing(self):
-        ms, n, pts = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0)
-        _lib.check(self.lib.neo_ctx_read_timing(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(pts)))
-        return ms.value, n.value, pts.value
+        ms, n, pts, fl = ctypes.c_double(0), ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+        _lib.check(self.lib.neo_ctx_read_timing(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(pts),
+                                                ctypes.byref(fl)))
+        return ms.value, n.value, pts.value, fl.value
 
     def close(self):
         if self.handle:

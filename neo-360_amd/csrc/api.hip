@@ -79,10 +79,11 @@ void neo_ctx::span_begin(hipStream_t s) {
     (void)hipEventRecord(a, s);
     spans.emplace_back(a, b);
 }
-void neo_ctx::span_end(hipStream_t s, double points) {
+void neo_ctx::span_end(hipStream_t s, double points, double flop_per_point) {
     if (!timing) return;
     (void)hipEventRecord(spans.back().second, s);
     timed_points += points;
+    timed_flops += points * flop_per_point;
 }
 
 extern "C" {
@@ -142,11 +143,12 @@ int neo_ctx_set_timing(neo_ctx* ctx, int enable) {
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     ctx->spans.clear();
     ctx->timed_points = 0.0;
+    ctx->timed_flops = 0.0;
     ctx->timing = enable != 0;
     return NEO_OK;
 }
 
-int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points) {
+int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points, double* total_flops) {
     ENTER(ctx);
     double ms = 0.0;
     for (auto& sp : ctx->spans) {
@@ -158,6 +160,7 @@ int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* t
     if (total_ms) *total_ms = ms;
     if (launches) *launches = static_cast<int>(ctx->spans.size());
     if (total_points) *total_points = ctx->timed_points;
+    if (total_flops) *total_flops = ctx->timed_flops;
     return NEO_OK;
 }
 
@@ -252,7 +255,7 @@ static int vanilla_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const
     neo::VanillaMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
     ctx->span_begin(s);
     neo::launch_vanilla_mlp(m, rays_o, dirs, t, t_row_stride, R, N, out, s);
-    ctx->span_end(s, static_cast<double>(R) * N);
+    ctx->span_end(s, static_cast<double>(R) * N, 2.0 * 593408.0);  // NeRFMLP MACs/point (vanilla_nerf/model.py:44-125)
     return check_launch();
 }
 

@@ -6,6 +6,13 @@ using namespace neo_host;
 
 namespace {
 
+// algorithmic MACs of NeRFPPMLP (neo360/model.py:37-158): per point-view 255,424 (fg) / 260,800 (bg),
+// per point 4,416 (density 128 + 64x64 + rgb 192); SURVEY.md §8a row a13.
+double tp_flop_per_point(int input_ch, int nv) {
+    const double per_view = input_ch == 3 ? 255424.0 : 260800.0;
+    return 2.0 * (nv * per_view + 4416.0);
+}
+
 // rot = c2w[:3,:3]^T ; trans = -rot @ c2w[:3,3]   (neo360/util.py:64-66), fp32
 void fill_views(const float* poses, int nv, neo::TpViews& v) {
     for (int i = 0; i < nv; ++i) {
@@ -95,7 +102,7 @@ int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
     neo::TpMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
     ctx->span_begin(s);
     neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
-    ctx->span_end(s, static_cast<double>(R) * N);
+    ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(sl.input_ch, NV));
     return check_launch();
 }
 
@@ -164,10 +171,10 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const 
         neo::TpMlpDev mbg{bg.wpack.as<float>(), bg.bias.as<float>(), bg.heads.as<float>()};
         ctx->span_begin(s);
         neo::launch_tp_mlp(3, mfg, sc, views, rays_o, rays_d, viewdirs, fg_t, nullptr, R, N, chunk, ctx->flags, fg_out, s);
-        ctx->span_end(s, static_cast<double>(R) * N);
+        ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(3, NV));
         ctx->span_begin(s);
         neo::launch_tp_mlp(4, mbg, sc, views, rays_o, rays_d, viewdirs, bg_s, far, R, N, chunk, ctx->flags, bg_out, s);
-        ctx->span_end(s, static_cast<double>(R) * N);
+        ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(4, NV));
         float* fg_rgb = (lo && lo->fg_rgb) ? lo->fg_rgb : s_fg_rgb;
         float* bg_rgb = (lo && lo->bg_rgb) ? lo->bg_rgb : s_bg_rgb;
         float* fg_acc = (lo && lo->fg_acc) ? lo->fg_acc : s_fg_acc;

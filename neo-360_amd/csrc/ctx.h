@@ -102,10 +102,10 @@ struct neo_ctx {
     neo_host::DevBuf ws[12];                                      // render workspaces (grow-only)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
-    double timed_points = 0.0;
+    double timed_points = 0.0, timed_flops = 0.0;
 
     const float* get_quantiles(int n_new, hipStream_t s);
     const float* get_edges(int n, float near, float far, hipStream_t s);
     void span_begin(hipStream_t s);
-    void span_end(hipStream_t s, double points);
+    void span_end(hipStream_t s, double points, double flop_per_point);
 };

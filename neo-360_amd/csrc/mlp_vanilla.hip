@@ -367,7 +367,7 @@ void launch_vanilla_pack(const float* const* weights, const float* const* biases
                            ST_KIN[st], ST_KC[st], wpack + stage_w_off(st));
         hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, biases[src], ST_N[st], bias + stage_b_off(st));
     }
-    hipMemsetAsync(heads, 0, HEADS_FLOATS * sizeof(float), s);
+    (void)hipMemsetAsync(heads, 0, HEADS_FLOATS * sizeof(float), s);
     hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, weights[10], 256, heads + HD_DW);
     hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, biases[10], 1, heads + HD_DB);
     hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, weights[11], 384, heads + HD_RW);
@@ -381,7 +381,7 @@ void launch_vanilla_mlp(const VanillaMlpDev& m, const float* rays_o, const float
     const size_t lds = (TM * ACT_LD + TM * DIR_LD) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
         attr_set = true;
     }

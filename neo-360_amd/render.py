@@ -1,0 +1,66 @@
+"""Whole-frame rendering: the counterpart of the reference's Lit*.render_rays_test
+chunk loops (vanilla_nerf/model.py:336-363, neo360/model.py:861-907) without the
+Python loop — one library call per frame (or per rank's shard of it), with the
+reference chunk size passed down so NeO-360's chunk-dependent view-direction tiling
+is reproduced — plus the single-frame replacement of the reference's only collective
+(LitModel.alter_gather_cat, models/interface.py:30-50) and its PSNR (:53-61).
+"""
+import math
+
+import torch
+
+from . import models
+from .parallel import gather_tiles, shard_bounds
+
+_WHOLE = ("src_imgs", "src_poses", "src_focal", "src_c")
+
+
+def _slice(batch, lo, hi):
+    out = {}
+    for k, v in batch.items():
+        if k in _WHOLE or not isinstance(v, torch.Tensor):
+            out[k] = v
+        elif k == "radii" and v.dim() == 2 and v.shape[0] == 1:
+            out[k] = v[:, lo:hi]
+        else:
+            out[k] = v[lo:hi]
+    return out
+
+
+@torch.no_grad()
+def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0):
+    """Fine-level rgb / depth of every ray in `batch` (one image), as the reference's
+    render_rays_test returns them: dict(rgb (R,3), depth (R,)) plus `target` /
+    `instance_mask` passed through when present."""
+    if isinstance(model, models.NeRF_TP):
+        res = model(batch, False, white_bkgd, near, far, out_depth=True, chunk=chunk)
+        out = dict(rgb=res[1][0], depth=res[1][5], fg_rgb=res[1][1], bg_rgb=res[1][2], acc=res[1][3])
+    elif isinstance(model, models.NeRF):
+        res = model(batch, False, white_bkgd, near, far)     # chunking does not change vanilla results
+        out = dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
+    else:
+        raise TypeError("unsupported renderer %r" % type(model))
+    for k in ("target", "instance_mask"):
+        if k in batch:
+            out[k] = batch[k]
+    return out
+
+
+@torch.no_grad()
+def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False, near=0.2, far=3.0, group=None,
+                         gather=True):
+    """This rank renders its contiguous range of whole chunks; `gather=True` reassembles
+    the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather."""
+    R = batch["rays_o"].shape[0]
+    lo, hi = shard_bounds(R, world, rank, unit=chunk)
+    part = render_rays_test(model, _slice(batch, lo, hi), chunk, white_bkgd, near, far)
+    tile = torch.cat([part["rgb"], part["depth"][:, None], part["acc"][:, None]], dim=1)
+    if world == 1 or not gather:
+        return tile
+    return gather_tiles(tile, R, world, unit=chunk, group=group)
+
+
+def psnr(pred, gt):
+    """-10 ln(mse)/ln 10 on images clipped to [0,1] (models/interface.py:53-61)."""
+    mse = torch.mean((torch.clip(pred, 0, 1) - torch.clip(gt, 0, 1)) ** 2)
+    return float("inf") if float(mse) == 0.0 else float(-10.0 * torch.log(mse) / math.log(10))

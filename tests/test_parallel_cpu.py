@@ -1,0 +1,67 @@
+"""CPU: the ray-sharding / tile all-gather layer.  world_size-2 (and 3) runs over the
+gloo backend stand in for RCCL: same torch.distributed calls, same code path."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from neo360_amd import parallel
+
+
+@pytest.mark.parametrize("n,world,unit", [(307200, 8, 1024), (307200, 1, 1024), (1500, 2, 1024), (1500, 4, 1024),
+                                          (300, 2, 256), (5, 3, 2), (0, 2, 1024), (1024, 8, 1024)])
+def test_shard_counts_cover_whole_chunks(n, world, unit):
+    counts = parallel.shard_counts(n, world, unit)
+    assert len(counts) == world and sum(counts) == n
+    # every shard except possibly the one holding the short last chunk is a whole number of chunks,
+    # and shards are contiguous: concatenating them in rank order reproduces the frame
+    lo = 0
+    for r in range(world):
+        a, b = parallel.shard_bounds(n, world, r, unit)
+        assert a == lo and b - a == counts[r]
+        assert a % unit == 0 or counts[r] == 0      # shards start on a chunk boundary (empty trailing shards aside)
+        lo = b
+    assert lo == n
+    if n == 307200 and world == 8:
+        assert counts == [38 * 1024] * 4 + [37 * 1024] * 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, unit, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frame = torch.arange(n * 5, dtype=torch.float32).reshape(n, 5)     # stand-in for (rgb, depth, acc)
+        lo, hi = parallel.shard_bounds(n, world, rank, unit)
+        got = parallel.gather_tiles(frame[lo:hi].clone(), n, world, unit)
+        ret[rank] = bool(torch.equal(got, frame))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,unit", [(1500, 2, 1024), (2048, 2, 1024), (700, 3, 256)])
+def test_gather_tiles_gloo(n, world, unit):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, n, unit, ret), nprocs=world, join=True)
+        assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_psnr_formula():
+    from neo360_amd import render
+    a = torch.full((4, 3), 0.5)
+    assert render.psnr(a, a) == float("inf")
+    b = a + 0.1
+    assert abs(render.psnr(b, a) - 20.0) < 1e-4     # mse = 0.01 -> 20 dB
+    # inputs are clipped to [0,1] before the mse, as the reference does
+    assert render.psnr(torch.full((2, 3), 2.0), torch.full((2, 3), 1.0)) == float("inf")
