@@ -114,6 +114,35 @@ def nerf_tp_state(seed=0, density_gain=1.0):
     return sd
 
 
+def _kaiming_linear(seed, sd, name, fan_out, fan_in, kaiming=True, gain=1.0):
+    """kaiming_uniform_ (a=0: bound sqrt(6/in)) or torch's default Linear init (1/sqrt(in))."""
+    wb = math.sqrt(6.0 / fan_in) if kaiming else 1.0 / math.sqrt(fan_in)
+    sd[name + ".weight"] = uniform(seed, name + ".weight", (fan_out, fan_in), -wb, wb) * gain
+    bb = 1.0 / math.sqrt(fan_in)
+    sd[name + ".bias"] = uniform(seed, name + ".bias", (fan_out,), -bb, bb)
+
+
+def mip360_state(seed=0, density_gain=1.0, weight_gain=1.0):
+    """Parameters of MipNeRF360 under reference key names (mipnerf360/model.py:30-233):
+    mlps.0/.1 = PropMLP (4x256, no rgb branch), mlps.2 = NeRFMLP (8x1024, skip at 4).
+    `weight_gain` < 1 tames the 1024-wide kaiming init so random-init densities stay O(1)."""
+    from .geopoly import icosahedron_basis
+    sd = {}
+    pos = 504
+    for lvl, (depth, width, rgb) in enumerate(((4, 256, False), (4, 256, False), (8, 1024, True))):
+        pre = "mlps.%d." % lvl
+        sd[pre + "pos_basis_t"] = icosahedron_basis()
+        _kaiming_linear(seed, sd, pre + "pts_linear.0", width, pos, gain=weight_gain)
+        for i in range(1, depth):
+            _kaiming_linear(seed, sd, pre + "pts_linear.%d" % i, width, width + pos if i == 5 else width, gain=weight_gain)
+        _kaiming_linear(seed, sd, pre + "density_layer", 1, width, gain=density_gain * weight_gain)
+        if rgb:
+            _kaiming_linear(seed, sd, pre + "bottleneck_layer", 256, width, gain=weight_gain)
+            _kaiming_linear(seed, sd, pre + "views_linear.0", 128, 256 + 27, gain=weight_gain)
+            _kaiming_linear(seed, sd, pre + "rgb_layer", 3, 128, gain=weight_gain)
+    return sd
+
+
 # ----------------------------------------------------------------------------
 # cameras / rays / scene features
 # ----------------------------------------------------------------------------

@@ -106,3 +106,12 @@ def composite_case(seed=9, R=64, N=129):
     dirs = torch.nn.functional.normalize(synth.uniform(seed, "c_d", (R, 3), -1.0, 1.0), dim=-1) * 1.0
     far = t[:, -1:] + 0.02
     return rgb, sigma, t, dirs, far
+
+
+def mip_rays(n, radius_px=0.0012):
+    """Rays + per-ray cone radii for the Mip-NeRF 360 fixtures (radii as get_rays would give
+    for a ~640-wide frame, with a deterministic +-20% spread so the radius really matters)."""
+    rays = strided_rays(n)
+    spread = synth.uniform(61, "mip_radii", (n, 1), 0.8, 1.2)
+    rays["radii"] = spread * radius_px
+    return rays

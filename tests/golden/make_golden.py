@@ -251,6 +251,47 @@ def g4_neo(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0):
     save("g4_neo_" + tag, **{k: torch.cat(v, 0) for k, v in acc.items()})
 
 
+# ---------------------------------------------------------------------------------
+# G6 Mip-NeRF 360 (models/mipnerf360)
+# ---------------------------------------------------------------------------------
+
+def g6_mip360():
+    M = ref.load("models.mipnerf360.model")
+    H = ref.load("models.mipnerf360.helper")
+    out = {"basis": H.generate_basis("icosahedron", 2)}
+    rays = cases.mip_rays(160)
+    for tag, tf, gain, (n_prop, n_nerf) in (("a", 1.0, 1.0, (64, 32)), ("b", 0.3, 1.0, (64, 32)),
+                                             ("sharp", 1.0, 6.0, (64, 32)), ("c", 1.0, 1.0, (64, 128))):
+        net = M.MipNeRF360(num_prop_samples=n_prop, num_nerf_samples=n_nerf)
+        net.load_state_dict(synth.mip360_state(0, density_gain=gain, weight_gain=0.5), strict=True)
+        with torch.enable_grad():
+            rend, hist = net(rays, tf, False, False, 0.2, 3.0)
+        for lv in range(3):
+            out["rgb%d_%s" % (lv, tag)] = rend[lv]["rgb"].detach()
+            out["sdist%d_%s" % (lv, tag)] = hist[lv]["sdist"].detach()
+            out["w%d_%s" % (lv, tag)] = hist[lv]["weights"].detach()
+            out["dens%d_%s" % (lv, tag)] = hist[lv]["density"].detach()
+        out["prgb2_%s" % tag] = hist[2]["rgb"].detach()
+    # stage fixtures: contraction (incl. the autograd Jacobian), lifting, IPE, dilation, interval sampling
+    means = synth.uniform(51, "mip_mean", (40, 7, 3), -2.5, 2.5)
+    means[0] *= 0.2                                       # inside the unit ball
+    A = synth.uniform(51, "mip_cov", (40, 7, 3, 3), -0.05, 0.05)
+    covs = A @ A.transpose(-1, -2)
+    with torch.enable_grad():
+        cm, cc = H.contract(means, covs, is_train=False)
+    lm, lv_ = H.lift_and_diagonalize(cm, cc, out["basis"])
+    out.update(con_mean=cm, con_cov=cc, lift_mean=lm, lift_var=lv_, ipe=H.integrated_pos_enc(lm, lv_, 0, 12))
+    t = torch.sort(synth.uniform(53, "mip_t", (24, 33), 0.0, 1.0), dim=-1).values
+    w = synth.uniform(53, "mip_w", (24, 32), 0.0, 1.0)
+    w[1] = 0.0
+    w[1, 5] = 1.0
+    td, wd = H.max_dilate_weights(t, w, 0.01, domain=(0.0, 1.0), renormalize=True)
+    out.update(dil_t=td, dil_w=wd)
+    logits = torch.where(td[..., 2:-1] > td[..., 1:-2], torch.log(wd[..., 1:-1]), torch.full_like(wd[..., 1:-1], -torch.inf))
+    out["intervals"] = H.sample_intervals(False, td[..., 1:-1], logits, 32, single_jitter=True, domain=(0.0, 1.0))
+    save("g6_mip360", **out)
+
+
 def main(which):
     jobs = {
         "g1": g1_raygen, "g2": g2_aabb, "g3": g3_stages, "g4v": g4_vanilla,
@@ -263,6 +304,7 @@ def main(which):
         "g4n_1024": lambda: g4_neo("1024", 1024, 1024),
         "g4n_1500": lambda: g4_neo("1500", 1500, 1024),
         "g4n_sharp": lambda: g4_neo("sharp", 256, 256, 32, 64, gain=8.0),
+        "g6": g6_mip360,
     }
     for name, fn in jobs.items():
         if not which or name in which:
