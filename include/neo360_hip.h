@@ -173,6 +173,47 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d,
                   float focal, float cx, float cy, int n_coarse, int n_fine, int white_bkgd,
                   const neo_tp_level_out* level0, const neo_tp_level_out* level1, void* stream);
 
+/* ---- Mip-NeRF 360 (models/mipnerf360/model.py) -------------------------------- */
+/* Upload one MipNeRF360MLP (model.py:30-107).  slot 0..2 = mlps.0, mlps.1 (PropMLP: width 256,
+ * depth 4, rgb 0) and mlps.2 (NeRFMLP: width 1024, depth 8, rgb 1) — the shapes the kernels are
+ * specialised for.  weights/biases [host arrays of device pointers], order: pts_linear.0..depth-1,
+ * density_layer, then (rgb) bottleneck_layer, views_linear.0, rgb_layer.  basis: the module's
+ * pos_basis_t buffer, (3,21) row-major. */
+int neo_mip_upload_mlp(neo_ctx* ctx, int slot, int width, int depth, int rgb,
+                       const float* const* weights, const float* const* biases,
+                       const float* basis, void* stream);
+
+/* One proposal-resampling step (model.py:258-310; helper.py:154-243, :337-394), randomized=False:
+ * s_prev (R,n_prev+1) / w_prev (R,n_prev) = previous level's normalised distances and weights
+ * (level 0: s_prev = [0,1], w_prev = [1]); dilate != 0 applies max_dilate_weights(dilation,
+ * domain (0,1), renormalize) and the [1:-1] trims first; logits = anneal*log(w) (-inf on empty
+ * intervals).  Outputs sdist (R,n+1) and tdist = 1/(s/far + (1-s)/near) (R,n+1). */
+int neo_mip_resample(neo_ctx* ctx, const float* s_prev, const float* w_prev, int R, int n_prev,
+                     int dilate, float dilation, float anneal, int n, float near, float far,
+                     float* sdist, float* tdist, void* stream);
+
+/* cast_rays (cone, full covariance) + MipNeRF360MLP.forward for the R*n intervals of tdist (R,n+1)
+ * (helper.py:278-334, model.py:109-176): out (R,n,4) = (rgb, density); rgb = 0 for a PropMLP. */
+int neo_mip_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
+                const float* viewdirs, const float* radii, const float* tdist, int R, int n,
+                float* out, void* stream);
+
+/* compute_alpha_weights(opaque_background=True) + volumetric_rendering (helper.py:246-274):
+ * rgbdens (R,n,4), tdist (R,n+1) -> weights (R,n), rgb (R,3) = sum w c + max(0,1-acc)*bg. */
+int neo_mip_composite(neo_ctx* ctx, const float* rgbdens, const float* tdist, const float* rays_d,
+                      int R, int n, float bg, float* weights, float* rgb, void* stream);
+
+/* MipNeRF360.forward(batch, train_frac, randomized=False, is_train=False, near, far)
+ * (model.py:236-365), 3 levels (n_prop, n_prop, n_nerf samples).  Per level l (any pointer may be
+ * NULL): rgb_l (R,3), sdist_l (R,n_l+1), weights_l (R,n_l), rgbdens_l (R,n_l,4) = per-interval
+ * (rgb, density). */
+typedef struct {
+    float* rgb; float* sdist; float* weights; float* rgbdens;
+} neo_mip_level_out;
+int neo_mip_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* viewdirs,
+                   const float* radii, int R, float train_frac, float near, float far, int n_prop,
+                   int n_nerf, const neo_mip_level_out* levels /* [3] */, void* stream);
+
 /* ---- profiling aid ---------------------------------------------------------- */
 /* Total duration (ms) of the dominant (fused MLP) kernel launches, bracketed with HIP
  * events on the stream they were launched on, since timing was enabled; with the

@@ -16,6 +16,10 @@ _i = ctypes.c_int
 _f = ctypes.c_float
 
 
+class MipLevelOut(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("rgb", "sdist", "weights", "rgbdens")]
+
+
 class TpLevelOut(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth")]
 
@@ -42,6 +46,11 @@ SIGNATURES = {
     "neo_tp_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i,
                            ctypes.POINTER(TpLevelOut), ctypes.POINTER(TpLevelOut), _vp]),
+    "neo_mip_upload_mlp": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp]),
+    "neo_mip_resample": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _f, _vp, _vp, _vp]),
+    "neo_mip_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "neo_mip_composite": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "neo_mip_render": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _i, ctypes.POINTER(MipLevelOut), _vp]),
     "neo_ctx_set_timing": (_i, [_vp, _i]),
     "neo_ctx_read_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i),
                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),

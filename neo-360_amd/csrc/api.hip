@@ -48,6 +48,20 @@ const float* neo_ctx::get_quantiles(int n_new, hipStream_t s) {
     return b.as<float>();
 }
 
+// helper.py:349-351 (deterministic_center): linspace(pad, 1 - pad - eps, n), pad = 1/(2n), in fp32
+const float* neo_ctx::get_centre_quantiles(int n, hipStream_t s) {
+    auto it = centre_quantiles.find(n);
+    if (it != centre_quantiles.end()) return it->second.as<float>();
+    std::vector<float> h(n);
+    const double pad = 1.0 / (2.0 * n);
+    neo_linspace_host(static_cast<float>(pad), static_cast<float>(1.0 - pad - 1.1920929e-07), n, h.data());
+    DevBuf& b = centre_quantiles[n];
+    if (b.reserve(n * sizeof(float))) return nullptr;
+    if (hipMemcpyAsync(b.p, h.data(), n * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
+    (void)hipStreamSynchronize(s);
+    return b.as<float>();
+}
+
 // near*(1-s) + far*s over linspace(0,1,n+1), separate fp32 ops (vanilla_nerf/helper.py:425-429)
 const float* neo_ctx::get_edges(int n, float near, float far, hipStream_t s) {
     uint32_t a, b2;
@@ -117,6 +131,9 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (auto& sl : ctx->vanilla) sl.release();
     for (auto& kv : ctx->quantiles) kv.second.release();
+    for (auto& kv : ctx->centre_quantiles) kv.second.release();
+    for (auto& sl : ctx->mip) sl.release();
+    ctx->mip_basis.release();
     for (auto& kv : ctx->edges) kv.second.release();
     for (auto& b : ctx->ws) b.release();
     for (auto& sl : ctx->tp) sl.release();

@@ -93,6 +93,10 @@ struct neo_ctx {
     uint32_t* flags = nullptr;  // device word, bit0 = ray missed the unit sphere
     neo_host::MlpSlot vanilla[2];
     neo_host::MlpSlot tp[4];
+    neo_host::MlpSlot mip[3];
+    int mip_shape[3][3] = {};          // width, depth, rgb per slot
+    neo_host::DevBuf mip_basis;
+    std::map<int, neo_host::DevBuf> centre_quantiles;             // n -> linspace(1/2n, 1-1/2n-eps, n)
     // NeO-360 scene features, channels-last, context-owned
     neo_host::DevBuf latent, plane[3];
     neo::TpScene scene{};
@@ -105,6 +109,7 @@ struct neo_ctx {
     double timed_points = 0.0, timed_flops = 0.0;
 
     const float* get_quantiles(int n_new, hipStream_t s);
+    const float* get_centre_quantiles(int n, hipStream_t s);
     const float* get_edges(int n, float near, float far, hipStream_t s);
     void span_begin(hipStream_t s);
     void span_end(hipStream_t s, double points, double flop_per_point);

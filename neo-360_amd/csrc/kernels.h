@@ -65,6 +65,36 @@ void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpV
                    const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
                    int chunk, uint32_t* flags, float* out, hipStream_t s);
 
+// weight re-packing into MFMA fragment order (defined in mlp_tp.hip)
+struct PackSegs { int k0[3], len[3], col[3]; };
+void pack_block(const float* src, int ld, int rows, int KC, int nt0, PackSegs sg, float* dst, hipStream_t s);
+void copy_floats(const float* src, int n, float* dst, hipStream_t s);
+
+// mlp_mip.hip / mip_sampling.hip — Mip-NeRF 360
+struct MipMlpDev {
+    const float* wpack;
+    const float* bias;
+    const float* heads;
+    const float* basis;   // (3,21) row-major
+};
+size_t mip_wpack_floats(int width, int depth, int rgb);
+size_t mip_bias_floats(int width, int depth, int rgb);
+size_t mip_heads_floats(int width);
+// w/b order: pts_linear.0..depth-1, density_layer[, bottleneck_layer, views_linear.0, rgb_layer]
+void launch_mip_pack(int width, int depth, int rgb, const float* const* w, const float* const* b, float* wpack,
+                     float* bias, float* heads, hipStream_t s);
+int launch_mip_mlp(int width, int depth, int rgb, const MipMlpDev& m, const float* rays_o, const float* rays_d,
+                   const float* viewdirs, const float* radii, const float* tdist, int R, int n, float* out,
+                   hipStream_t s);
+// one wave per ray: (optional max-dilate of the previous histogram) -> annealed logits -> softmax cdf ->
+// n centre quantiles (u, device table) -> interval endpoints sdist (R,n+1) and metric distances tdist
+int launch_mip_resample(const float* s_prev, const float* w_prev, int n_prev, int dilate, float dilation,
+                        float anneal, const float* u, int R, int n, float s_near, float s_far, float* sdist,
+                        float* tdist, hipStream_t s);
+// weights = alpha * exp(-cumsum) with an opaque last interval; rgb = sum w c + max(0,1-acc) * bg
+void launch_mip_composite(const float* rgbdens, const float* tdist, const float* rays_d, int R, int n, float bg,
+                          float* weights, float* rgb, hipStream_t s);
+
 // sampling.hip — NeO-360 level-0 sample rows and fg/bg merge
 void launch_tp_level0(const float* far, const float* edges, int R, int N, float near, float* fg_t, float* bg_s,
                       hipStream_t s);

@@ -559,7 +559,6 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
 // ---- weight packing -------------------------------------------------------------
 // dst N-tiles [nt0, nt0 + rows/32) of a stage with KC chunks <- src[rows][ld], packed k -> source column
 // through up to three segments (k_start, k_len, col_start); everything else is zero.
-struct PackSegs { int k0[3], len[3], col[3]; };
 
 __global__ void k_pack_block(const float* __restrict__ src, int ld, int rows, int KC, int nt0, PackSegs sg,
                              float* __restrict__ dst) {
@@ -592,12 +591,16 @@ __global__ void k_to_channels_last(const float* __restrict__ src, int C, int HW,
     }
 }
 
+}  // namespace
+
 void pack_block(const float* src, int ld, int rows, int KC, int nt0, PackSegs sg, float* dst, hipStream_t s) {
     const int total = (rows / 32) * KC * 256;
     hipLaunchKernelGGL(k_pack_block, dim3((total + 255) / 256), dim3(256), 0, s, src, ld, rows, KC, nt0, sg, dst);
 }
 
-}  // namespace
+void copy_floats(const float* src, int n, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_copy_f, dim3((n + 255) / 256 > 64 ? 64 : (n + 255) / 256), dim3(256), 0, s, src, n, dst);
+}
 
 size_t tp_wpack_floats(int input_ch) { return wpack_floats(input_ch); }
 size_t tp_bias_floats() { return BIAS_FLOATS; }

@@ -328,3 +328,110 @@ class NeRF_TP(_HipModule):
         if ctx.poll_flags() & 1:
             raise AssertionError("1.0 - p_norm_sq should be greater than 0")
         return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]
+
+
+class MipNeRF360MLP(nn.Module):
+    """Parameter container with the layout of mipnerf360/model.py:30-107: pts_linear.0..depth-1
+    (input = 504-d integrated positional encoding over the 21-direction geodesic basis, skip concat
+    feeds index 5), density_layer and — unless disable_rgb — bottleneck_layer (256),
+    views_linear.0 (128), rgb_layer; buffer pos_basis_t (3,21).  kaiming_uniform_ initialisers."""
+
+    def __init__(self, netdepth=8, netwidth=256, disable_rgb=False):
+        super().__init__()
+        from .geopoly import icosahedron_basis
+        self.netdepth, self.netwidth, self.disable_rgb = netdepth, netwidth, disable_rgb
+        self.register_buffer("pos_basis_t", icosahedron_basis())
+        pos = 12 * 2 * self.pos_basis_t.shape[-1]
+
+        def lin(n_in, n_out):
+            layer = nn.Linear(n_in, n_out)
+            nn.init.kaiming_uniform_(layer.weight)
+            return layer
+
+        layers = [lin(pos, netwidth)]
+        for idx in range(netdepth - 1):
+            layers.append(lin(netwidth + pos if (idx % 4 == 0 and idx > 0) else netwidth, netwidth))
+        self.pts_linear = nn.ModuleList(layers)
+        self.density_layer = lin(netwidth, 1)
+        if not disable_rgb:
+            self.bottleneck_layer = lin(netwidth, 256)
+            self.views_linear = nn.ModuleList([lin(256 + 27, 128)])
+            self.rgb_layer = lin(128, 3)
+
+    def ordered_layers(self):
+        """Upload order fixed by include/neo360_hip.h (neo_mip_upload_mlp)."""
+        out = list(self.pts_linear) + [self.density_layer]
+        if not self.disable_rgb:
+            out += [self.bottleneck_layer, self.views_linear[0], self.rgb_layer]
+        return out
+
+
+class MipNeRF360(_HipModule):
+    """Mip-NeRF 360 renderer (mipnerf360/model.py:199-365): two proposal MLPs (4x256) + one NeRF MLP
+    (8x1024).  `forward(batch, train_frac, randomized, is_train, near, far)` returns
+    (renderings, ray_history) exactly as the reference: renderings[l] = {"rgb": (B,3)},
+    ray_history[l] = dict(density (B,n), rgb (B,n,3), sdist (B,n+1), weights (B,n))."""
+
+    def __init__(self, num_prop_samples=64, num_nerf_samples=32, num_levels=3, bg_intensity_range=(1.0, 1.0),
+                 anneal_slope=10, stop_level_grad=True, use_viewdirs=True, ray_shape="cone",
+                 disable_integration=False, single_jitter=True, dilation_multiplier=0.5, dilation_bias=0.0025,
+                 num_glo_features=0, num_glo_embeddings=1000, learned_exposure_scaling=False, near_anneal_rate=None,
+                 near_anneal_init=0.95, single_mlp=False, resample_padding=0.0, use_gpu_resampling=False,
+                 opaque_background=True):
+        super().__init__()
+        if (num_levels, tuple(bg_intensity_range), anneal_slope, ray_shape, disable_integration, dilation_multiplier,
+                dilation_bias, near_anneal_rate, resample_padding, opaque_background, use_viewdirs) != (
+                3, (1.0, 1.0), 10, "cone", False, 0.5, 0.0025, None, 0.0, True, True):
+            raise NotImplementedError("the HIP path implements the reference's default MipNeRF360 configuration")
+        self.num_prop_samples, self.num_nerf_samples, self.num_levels = num_prop_samples, num_nerf_samples, num_levels
+        self.mlps = nn.ModuleList([MipNeRF360MLP(4, 256, disable_rgb=True), MipNeRF360MLP(4, 256, disable_rgb=True),
+                                   MipNeRF360MLP(8, 1024)])
+
+    def _sync_weights(self, ctx):
+        for slot, mlp in enumerate(self.mlps):
+            layers = mlp.ordered_layers()
+            ws = [f32(l.weight.detach(), "weight") for l in layers]
+            bs = [f32(l.bias.detach(), "bias") for l in layers]
+            basis = f32(mlp.pos_basis_t, "pos_basis_t")
+            fp = _fingerprint(ws + bs + [basis])
+            if ctx.uploaded.get(("mip", slot)) == fp:
+                continue
+            _lib.check(ctx.lib.neo_mip_upload_mlp(ctx.handle, slot, mlp.netwidth, mlp.netdepth,
+                                                  0 if mlp.disable_rgb else 1, _ptr_table(ws), _ptr_table(bs),
+                                                  ptr(basis), ctx.stream()))
+            ctx.uploaded[("mip", slot)] = fp
+
+    @torch.no_grad()
+    def forward(self, batch, train_frac, randomized, is_train, near, far):
+        self._check_mode(randomized)
+        rays_o, rays_d = f32(batch["rays_o"], "rays_o"), f32(batch["rays_d"], "rays_d")
+        viewdirs, radii = f32(batch["viewdirs"], "viewdirs"), f32(batch["radii"], "radii")
+        dev = rays_o.device
+        ctx = self._context(dev)
+        self._sync_weights(ctx)
+        B = rays_o.shape[0]
+        counts = (self.num_prop_samples, self.num_prop_samples, self.num_nerf_samples)
+        bufs = [dict(rgb=torch.empty(B, 3, device=dev), sdist=torch.empty(B, n + 1, device=dev),
+                     weights=torch.empty(B, n, device=dev), rgbdens=torch.empty(B, n, 4, device=dev)) for n in counts]
+        arr = (_lib.MipLevelOut * 3)(*[_lib.MipLevelOut(*(b[k].data_ptr() for k in ("rgb", "sdist", "weights", "rgbdens")))
+                                       for b in bufs])
+        _lib.check(ctx.lib.neo_mip_render(ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), B,
+                                          float(train_frac), float(near), float(far), self.num_prop_samples,
+                                          self.num_nerf_samples, arr, ctx.stream()))
+        renderings = [{"rgb": b["rgb"]} for b in bufs]
+        history = [dict(density=b["rgbdens"][..., 3], rgb=b["rgbdens"][..., :3], sdist=b["sdist"], weights=b["weights"])
+                   for b in bufs]
+        return renderings, history
+
+    @torch.no_grad()
+    def eval_mlp(self, slot, batch, tdist):
+        """Stage-level access: cast_rays + MLP for the intervals of tdist (B,n+1) -> (B,n,4) = (rgb, density)."""
+        rays_o, rays_d = f32(batch["rays_o"]), f32(batch["rays_d"])
+        viewdirs, radii, tdist = f32(batch["viewdirs"]), f32(batch["radii"]), f32(tdist)
+        ctx = self._context(rays_o.device)
+        self._sync_weights(ctx)
+        B, n1 = tdist.shape
+        out = torch.empty(B, n1 - 1, 4, device=rays_o.device)
+        _lib.check(ctx.lib.neo_mip_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), ptr(tdist),
+                                       B, n1 - 1, ptr(out), ctx.stream()))
+        return out

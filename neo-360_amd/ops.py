@@ -101,3 +101,28 @@ def composite(mode, rgbsigma, t, rays_d=None, t_far=None, white_bkgd=False, ctx=
                                      int(bool(white_bkgd)), ptr(rgb), ptr(acc), ptr(depth), ptr(w), ptr(lam),
                                      ctx.stream()))
     return dict(rgb=rgb, acc=acc, depth=depth, weights=w, bg_lambda=lam)
+
+
+def mip_resample(s_prev, w_prev, n, near, far, dilate=False, dilation=0.0, anneal=1.0, ctx=None):
+    """One Mip-NeRF 360 proposal-resampling step (mipnerf360/model.py:258-310).  Returns sdist, tdist (R,n+1)."""
+    s_prev, w_prev = f32(s_prev, "s_prev"), f32(w_prev, "w_prev")
+    ctx = _ctx(s_prev, ctx)
+    R, n_prev = w_prev.shape
+    sdist = torch.empty(R, n + 1, device=s_prev.device)
+    tdist = torch.empty(R, n + 1, device=s_prev.device)
+    _lib.check(ctx.lib.neo_mip_resample(ctx.handle, ptr(s_prev), ptr(w_prev), R, n_prev, int(bool(dilate)),
+                                        float(dilation), float(anneal), n, float(near), float(far), ptr(sdist),
+                                        ptr(tdist), ctx.stream()))
+    return sdist, tdist
+
+
+def mip_composite(rgbdens, tdist, rays_d, bg=1.0, ctx=None):
+    """compute_alpha_weights(opaque_background=True) + volumetric_rendering (mipnerf360/helper.py:246-274)."""
+    rgbdens, tdist, rays_d = f32(rgbdens), f32(tdist), f32(rays_d)
+    ctx = _ctx(tdist, ctx)
+    R, n1 = tdist.shape
+    w = torch.empty(R, n1 - 1, device=tdist.device)
+    rgb = torch.empty(R, 3, device=tdist.device)
+    _lib.check(ctx.lib.neo_mip_composite(ctx.handle, ptr(rgbdens), ptr(tdist), ptr(rays_d), R, n1 - 1, float(bg), ptr(w),
+                                         ptr(rgb), ctx.stream()))
+    return w, rgb

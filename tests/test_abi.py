@@ -53,7 +53,8 @@ def test_cpu_tensors_rejected(built_lib):
 
 
 @pytest.mark.parametrize("start,end,steps", [(0.0, 1.0, 65), (0.0, 1.0, 129), (0.0, 1.0, 128), (0.0, 1.0, 256),
-                                              (0.0, 1.0, 2), (0.0, 1.0, 33), (0.2, 3.0, 65), (-1.5, 0.25, 100)])
+                                              (0.0, 1.0, 2), (0.0, 1.0, 33), (0.2, 3.0, 65), (-1.5, 0.25, 100),
+                                              (1 / 128, 1 - 1 / 128 - 1.1920929e-07, 64), (1 / 64, 1 - 1 / 64 - 1.1920929e-07, 32)])
 def test_linspace_host_matches_torch(built_lib, start, end, steps):
     from neo360_amd import _lib
     mine = torch.tensor(_lib.linspace(start, end, steps))

@@ -1,0 +1,98 @@
+"""GPU: Mip-NeRF 360 path (BASELINE config 5) against the reference-generated fixtures and the
+oracle, stage by stage and end to end.  Tolerance 1e-4 abs on rgb."""
+import pytest
+import torch
+
+import cases
+import oracle
+from conftest import max_abs
+from oracle import mip360
+from neo360_amd import models, ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+def _net(gain=1.0, counts=(64, 32)):
+    net = models.MipNeRF360(num_prop_samples=counts[0], num_nerf_samples=counts[1]).to(DEV)
+    net.load_state_dict(synth.mip360_state(0, density_gain=gain, weight_gain=0.5))
+    return net
+
+
+def _to(b):
+    return {k: v.to(DEV) for k, v in b.items()}
+
+
+def test_state_dict_layout():
+    net = models.MipNeRF360()
+    want = synth.mip360_state(0)
+    got = net.state_dict()
+    assert sorted(got) == sorted(want) and all(got[k].shape == want[k].shape for k in want)
+
+
+def test_resample_stage(golden):
+    g = golden("g6_mip360")
+    t = torch.sort(synth.uniform(53, "mip_t", (24, 33), 0.0, 1.0), dim=-1).values
+    w = synth.uniform(53, "mip_w", (24, 32), 0.0, 1.0)
+    w[1] = 0.0
+    w[1, 5] = 1.0
+    sdist, tdist = ops.mip_resample(t.to(DEV), w.to(DEV), 32, 0.2, 3.0, dilate=True, dilation=0.01, anneal=1.0)
+    assert max_abs(sdist.cpu(), g["intervals"]) < 2e-6
+    want_t = 1 / (g["intervals"] * (1 / 3.0) + (1 - g["intervals"]) * (1 / 0.2))
+    assert max_abs(tdist.cpu(), want_t) < 2e-5
+    # level-0 form: histogram [0,1] with weight 1
+    s0, _ = ops.mip_resample(torch.tensor([[0.0, 1.0]] * 5, device=DEV), torch.ones(5, 1, device=DEV), 64, 0.2, 3.0)
+    want0 = mip360.sample_intervals(torch.tensor([[0.0, 1.0]] * 5), torch.zeros(5, 1), 64, (0.0, 1.0))
+    assert max_abs(s0.cpu(), want0) < 1e-6
+
+
+def test_mlp_stages_vs_oracle():
+    """cast_rays + contraction + IPE + MLP, both MLP shapes, on oracle-produced intervals."""
+    net = _net()
+    params = synth.mip360_state(0, weight_gain=0.5)
+    rays = cases.mip_rays(50)          # ragged: 50*64 = 3200 = 100 tiles; 50*32 = 1600 = 50 tiles
+    basis = mip360.icosahedron_basis()
+    for slot, n, depth, rgb in ((0, 64, 4, False), (2, 32, 8, True)):
+        s = torch.sort(synth.uniform(71, "mip_s%d" % slot, (50, n + 1), 0.0, 1.0), dim=-1).values
+        tdist = 1 / (s * (1 / 3.0) + (1 - s) * (1 / 0.2))
+        got = net.eval_mlp(slot, _to(rays), tdist.to(DEV)).cpu()
+        means, covs = mip360.conical_frustum_gaussians(tdist, rays["rays_o"], rays["rays_d"], rays["radii"])
+        dens, col = mip360.mlp(params, "mlps.%d." % slot, basis, means, covs, rays["viewdirs"], depth, rgb)
+        assert max_abs(got[..., 3], dens) < 2e-5
+        assert max_abs(got[..., :3], col) < 2e-5
+
+
+def test_composite_stage():
+    rd = torch.cat([synth.uniform(73, "mc_rgb", (40, 32, 3), 0, 1), synth.uniform(73, "mc_d", (40, 32, 1), 0, 4)], -1)
+    t = torch.cumsum(synth.uniform(73, "mc_t", (40, 33), 0.01, 0.2), dim=-1)
+    dirs = torch.nn.functional.normalize(synth.uniform(73, "mc_dir", (40, 3), -1, 1), dim=-1)
+    w, rgb = ops.mip_composite(rd.to(DEV), t.to(DEV), dirs.to(DEV))
+    want_w = mip360.alpha_weights(rd[..., 3], t, dirs)
+    assert max_abs(w.cpu(), want_w) < 2e-6
+    acc = want_w.sum(-1)
+    want_rgb = (want_w[..., None] * rd[..., :3]).sum(-2) + torch.clip(1 - acc[..., None], min=0)
+    assert max_abs(rgb.cpu(), want_rgb) < 2e-6
+
+
+@pytest.mark.parametrize("tag,tf,gain,counts", [("a", 1.0, 1.0, (64, 32)), ("b", 0.3, 1.0, (64, 32)),
+                                                ("sharp", 1.0, 6.0, (64, 32)), ("c", 1.0, 1.0, (64, 128))])
+def test_end_to_end_vs_golden(golden, tag, tf, gain, counts):
+    g = golden("g6_mip360")
+    rend, hist = _net(gain, counts)(_to(cases.mip_rays(160)), tf, False, False, 0.2, 3.0)
+    for lv in range(3):
+        assert max_abs(rend[lv]["rgb"].cpu(), g["rgb%d_%s" % (lv, tag)]) < TOL
+        assert max_abs(hist[lv]["sdist"].cpu(), g["sdist%d_%s" % (lv, tag)]) < TOL
+        assert max_abs(hist[lv]["weights"].cpu(), g["w%d_%s" % (lv, tag)]) < 2e-4
+        assert max_abs(hist[lv]["density"].cpu(), g["dens%d_%s" % (lv, tag)]) < 2e-4
+    assert max_abs(hist[2]["rgb"].cpu(), g["prgb2_%s" % tag]) < TOL
+    assert float(hist[0]["rgb"].abs().max()) == 0.0          # proposal levels carry no colour
+
+
+def test_randomized_refused_and_empty():
+    net = _net()
+    with pytest.raises(NotImplementedError):
+        net(_to(cases.mip_rays(4)), 1.0, True, True, 0.2, 3.0)
+    rays = _to(cases.mip_rays(4))
+    rend, hist = net({k: v[:0] for k, v in rays.items()}, 1.0, False, False, 0.2, 3.0)
+    assert rend[2]["rgb"].shape == (0, 3) and hist[2]["sdist"].shape == (0, 33)
