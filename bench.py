@@ -64,6 +64,16 @@ def build_neo360(dev):
     return net, state, extra, scene, desc, dict(near=0.0, far=0.0), "k_tp_mlp", 256
 
 
+def build_mip360(dev, n_nerf=32):
+    from neo360_amd import models, synth
+    state = synth.mip360_state(0, weight_gain=0.5)
+    net = models.MipNeRF360(num_prop_samples=64, num_nerf_samples=n_nerf).to(dev)
+    net.load_state_dict(state)
+    desc = ("mipnerf360 640x480 full frame, 2 proposal levels x 64 samples (PropMLP 4x256) + %d NeRF samples "
+            "(NeRFMLP 8x1024), cone casting + contraction + 504-d IPE, random-init MLPs (kaiming x0.5)" % n_nerf)
+    return net, state, {}, None, desc, dict(near=0.2, far=3.0, train_frac=1.0), "k_mip_mlp", (4096 if n_nerf == 128 else 8192)
+
+
 def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
     """The oracle (CPU restatement of the reference: kind 'port') timed on a bounded sample
     of the same frame on the host cores."""
@@ -73,6 +83,11 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
     t0 = time.perf_counter()
     if workload == "vanilla":
         rgb, depth = oracle.vanilla.render_chunked(state, sample, kw["near"], kw["far"], chunk=CHUNK)
+    elif workload.startswith("mip360"):
+        from oracle import mip360
+        rend, _ = mip360.render(state, sample, kw["train_frac"], kw["near"], kw["far"], num_prop_samples=64,
+                                num_nerf_samples=128 if workload.endswith("128") else 32)
+        rgb, depth = rend[-1]["rgb"], torch.zeros(n)
     else:
         batch = dict(sample)
         batch.update({k: v.cpu() for k, v in extra.items()})
@@ -85,12 +100,28 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
     return base, rgb, depth
 
 
+def pmc_traffic(workload):
+    """HBM bytes per dominant-kernel launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_vanilla_pmc_summary.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB, averaged over
+    the launches of a frame.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
+    (wide coalesced reads are tallied at half their bytes).  None when no profile is committed."""
+    if workload != "vanilla":
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_vanilla_pmc_summary.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        disp = json.load(f)["dispatches"]
+    per = [(2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for d in disp.values() if "FETCH_SIZE" in d and "WRITE_SIZE" in d]
+    return sum(per) / len(per) if per else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("vanilla", "neo360"), default="vanilla")
+    ap.add_argument("--workload", choices=("vanilla", "neo360", "mip360", "mip360_128"), default="vanilla")
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays in the CPU-baseline sample (0 = skip, -1 = default)")
     args = ap.parse_args()
 
@@ -108,14 +139,22 @@ def main():
 
     from neo360_amd import ops, render, synth
 
-    net, state, extra, scene, desc, kw, kernel_name, cpu_default = (build_vanilla if args.workload == "vanilla" else build_neo360)(dev)
+    if args.workload == "vanilla":
+        built = build_vanilla(dev)
+    elif args.workload == "neo360":
+        built = build_neo360(dev)
+    else:       # reference defaults (64,64,32), or BASELINE.json's wording "64 proposal + 128 fine"
+        built = build_mip360(dev, 128 if args.workload.endswith("128") else 32)
+    net, state, extra, scene, desc, kw, kernel_name, cpu_default = built
     c2w = synth.look_at_origin(40.0)
     R = H * W
     ctx = net._context(dev)
 
     def frame_rays():
-        ro, vd, rd, _ = ops.get_ray_directions_and_rays(H, W, 0.8 * W, c2w, ctx=ctx)
+        ro, vd, rd, radii = ops.get_ray_directions_and_rays(H, W, 0.8 * W, c2w, ctx=ctx)
         batch = dict(rays_o=ro, viewdirs=vd, rays_d=rd)
+        if args.workload.startswith("mip360"):
+            batch["radii"] = radii[:, None]
         batch.update(extra)
         return batch
 
@@ -154,17 +193,20 @@ def main():
                                            "(rgb,depth,acc) tiles" if world > 1 else ""),
                        "rays_per_frame": R, "parallelism": "ray-shard x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": kernel_name,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(args.workload), "kernel": kernel_name,
                          "launches": launches, "avg_launch_ms": kern_ms / max(launches, 1),
                          "algorithmic_flop_per_launch": flops / max(launches, 1),
                          "points_per_launch": points / max(launches, 1),
-                         "note": "rank 0's launches; algorithmic flops = reference formulation MACs x 2 (SURVEY.md 8d)"},
+                         "algorithmic_bytes_per_launch": points / max(launches, 1) * 20.0 if args.workload == "vanilla" else None,
+                         "note": "rank 0's launches; algorithmic flops = reference formulation MACs x 2 (SURVEY.md 8d); "
+                                 "traffic = HBM bytes/launch from the committed PMC passes (profiles/), algorithmic "
+                                 "bytes = 4 B t in + 16 B (rgb,sigma) out per point"},
         }
         n_cpu = cpu_default if args.cpu_rays < 0 else args.cpu_rays
         if world == 1 and n_cpu > 0:
             batch = frame_rays()
             n = min(n_cpu, R)
-            rays_cpu = {k: batch[k][:n].cpu() for k in ("rays_o", "viewdirs", "rays_d")}
+            rays_cpu = {k: batch[k][:n].cpu() for k in ("rays_o", "viewdirs", "rays_d", "radii") if k in batch}
             base, rgb_c, depth_c = cpu_baseline(args.workload, state, scene, rays_cpu, extra, kw, n)
             if args.workload == "neo360" and n != CHUNK:
                 # NeO-360 results depend on chunk membership: render the same rays as their own chunk

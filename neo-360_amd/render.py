@@ -28,13 +28,18 @@ def _slice(batch, lo, hi):
 
 
 @torch.no_grad()
-def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0):
+def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0, train_frac=1.0):
     """Fine-level rgb / depth of every ray in `batch` (one image), as the reference's
     render_rays_test returns them: dict(rgb (R,3), depth (R,)) plus `target` /
     `instance_mask` passed through when present."""
     if isinstance(model, models.NeRF_TP):
         res = model(batch, False, white_bkgd, near, far, out_depth=True, chunk=chunk)
         out = dict(rgb=res[1][0], depth=res[1][5], fg_rgb=res[1][1], bg_rgb=res[1][2], acc=res[1][3])
+    elif isinstance(model, models.MipNeRF360):
+        # mipnerf360/model.py:471-505: train_frac = global_step / max_steps of the trainer; near/far as given
+        rend, hist = model(batch, train_frac, False, False, near, far)
+        w = hist[-1]["weights"]
+        out = dict(rgb=rend[-1]["rgb"], acc=w.sum(-1), depth=torch.zeros_like(w[:, 0]))   # the reference returns rgb only
     elif isinstance(model, models.NeRF):
         res = model(batch, False, white_bkgd, near, far)     # chunking does not change vanilla results
         out = dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
@@ -48,12 +53,12 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
 
 @torch.no_grad()
 def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False, near=0.2, far=3.0, group=None,
-                         gather=True):
+                         gather=True, train_frac=1.0):
     """This rank renders its contiguous range of whole chunks; `gather=True` reassembles
     the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather."""
     R = batch["rays_o"].shape[0]
     lo, hi = shard_bounds(R, world, rank, unit=chunk)
-    part = render_rays_test(model, _slice(batch, lo, hi), chunk, white_bkgd, near, far)
+    part = render_rays_test(model, _slice(batch, lo, hi), chunk, white_bkgd, near, far, train_frac)
     tile = torch.cat([part["rgb"], part["depth"][:, None], part["acc"][:, None]], dim=1)
     if world == 1 or not gather:
         return tile
