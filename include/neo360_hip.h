@@ -51,6 +51,12 @@ int neo_ctx_destroy(neo_ctx* ctx);
  * Synchronises `stream`.  [flags: host out] */
 int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream);
 
+/* Arithmetic of the vanilla per-point MLP GEMMs.  0 (default): exact fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32).  1: fp16 MFMA with every fp32 operand split into hi+lo fp16 and
+ * three products per term (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate) — fp32-class
+ * error at a 5.3x higher matrix-pipe ceiling.  Both meet the 1e-4 parity contract. */
+int neo_ctx_set_precision(neo_ctx* ctx, int mode);
+
 /* torch.linspace(start, end, steps) for fp32 on the host (symmetric fill,
  * step=(end-start)/(steps-1)) — the constant tables the samplers start from
  * (vanilla_nerf/helper.py:425, :589; neo360/helper.py:36, :197).  No GPU needed.

@@ -31,6 +31,7 @@ SIGNATURES = {
     "neo_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "neo_ctx_destroy": (_i, [_vp]),
     "neo_ctx_poll_flags": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32), _vp]),
+    "neo_ctx_set_precision": (_i, [_vp, _i]),
     "neo_linspace_host": (None, [_f, _f, _i, c_float_p]),
     "neo_raygen": (_i, [_vp, _i, _i, _f, c_float_p, _vp, _vp, _vp, _vp, _vp]),
     "neo_aabb_intersect": (_i, [_vp, ctypes.POINTER(ctypes.c_double), _vp, _vp, _i, _vp, _vp, _vp, _vp]),

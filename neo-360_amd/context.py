@@ -61,6 +61,11 @@ class Context:
         _lib.check(self.lib.neo_ctx_poll_flags(self.handle, ctypes.byref(flags), self.stream()))
         return flags.value
 
+    def set_precision(self, mode):
+        """'f32' (exact fp32 MFMA) or 'f16x3' (fp16 MFMA, hi/lo-split operands, fp32-equivalent)."""
+        code = {"f32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]
+        _lib.check(self.lib.neo_ctx_set_precision(self.handle, code))
+
     def set_timing(self, enable):
         _lib.check(self.lib.neo_ctx_set_timing(self.handle, 1 if enable else 0))
 

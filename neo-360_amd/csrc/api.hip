@@ -155,6 +155,13 @@ int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream) {
     return NEO_OK;
 }
 
+int neo_ctx_set_precision(neo_ctx* ctx, int mode) {
+    ENTER(ctx);
+    REQUIRE(mode == 0 || mode == 1, "precision mode must be 0 (fp32 MFMA) or 1 (fp16 MFMA, hi/lo-split operands)");
+    ctx->precision = mode;
+    return NEO_OK;
+}
+
 int neo_ctx_set_timing(neo_ctx* ctx, int enable) {
     ENTER(ctx);
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
@@ -259,8 +266,10 @@ int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, 
     if (sl.wpack.reserve(neo::vanilla_wpack_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.bias.reserve(neo::vanilla_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.heads.reserve(neo::vanilla_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.wpack_h.reserve(neo::vanilla_wpack_h_bytes())) return NEO_ERR_NOMEM;
     neo::launch_vanilla_pack(weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
                              static_cast<hipStream_t>(stream));
+    neo::launch_vanilla_pack_h(weights, sl.wpack_h.p, static_cast<hipStream_t>(stream));
     sl.ready = true;
     return check_launch();
 }
@@ -269,9 +278,14 @@ static int vanilla_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const
                               int t_row_stride, int R, int N, float* out, hipStream_t s) {
     const MlpSlot& sl = ctx->vanilla[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "vanilla MLP slot %d has no weights", slot);
-    neo::VanillaMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
     ctx->span_begin(s);
-    neo::launch_vanilla_mlp(m, rays_o, dirs, t, t_row_stride, R, N, out, s);
+    if (ctx->precision == 1) {
+        neo::VanillaMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>()};
+        neo::launch_vanilla_mlp_h(mh, rays_o, dirs, t, t_row_stride, R, N, out, s);
+    } else {
+        neo::VanillaMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
+        neo::launch_vanilla_mlp(m, rays_o, dirs, t, t_row_stride, R, N, out, s);
+    }
     ctx->span_end(s, static_cast<double>(R) * N, 2.0 * 593408.0);  // NeRFMLP MACs/point (vanilla_nerf/model.py:44-125)
     return check_launch();
 }

@@ -55,9 +55,10 @@ struct DevBuf {
 
 struct MlpSlot {
     DevBuf wpack, bias, heads;
+    DevBuf wpack_h;      // fp16 hi/lo split fragments (vanilla path, precision mode 1)
     int input_ch = 0;
     bool ready = false;
-    void release() { wpack.release(); bias.release(); heads.release(); ready = false; }
+    void release() { wpack.release(); bias.release(); heads.release(); wpack_h.release(); ready = false; }
 };
 
 struct DeviceGuard {
@@ -104,6 +105,7 @@ struct neo_ctx {
     std::map<int, neo_host::DevBuf> quantiles;                    // n_new -> linspace(0, fl32(1-2^-32), n_new)
     std::map<std::pair<int, uint64_t>, neo_host::DevBuf> edges;   // (n, near/far bits) -> level-0 t row
     neo_host::DevBuf ws[12];                                      // render workspaces (grow-only)
+    int precision = 0;   // 0: fp32 MFMA, 1: fp16 MFMA with hi/lo-split operands (fp32-equivalent)
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
     double timed_points = 0.0, timed_flops = 0.0;

@@ -34,6 +34,16 @@ size_t vanilla_bias_floats();
 size_t vanilla_heads_floats();
 void launch_vanilla_pack(const float* const* weights, const float* const* biases, float* wpack, float* bias,
                          float* heads, hipStream_t s);
+// mlp_vanilla_h.hip — the same MLP on the fp16 matrix cores with hi/lo-split operands (fp32-equivalent)
+struct VanillaMlpHDev {
+    const void* wpack;    // fp16 hi/lo fragments
+    const float* bias;    // shared with the fp32 path
+    const float* heads;
+};
+size_t vanilla_wpack_h_bytes();
+void launch_vanilla_pack_h(const float* const* weights, void* wpack_h, hipStream_t s);
+void launch_vanilla_mlp_h(const VanillaMlpHDev& m, const float* rays_o, const float* dirs, const float* t,
+                          int t_row_stride, int R, int N, float* out, hipStream_t s);
 void launch_vanilla_mlp(const VanillaMlpDev& m, const float* rays_o, const float* dirs, const float* t,
                         int t_row_stride, int R, int N, float* out, hipStream_t s);
 

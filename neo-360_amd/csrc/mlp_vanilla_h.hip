@@ -1,0 +1,351 @@
+// Fused  pos_enc -> NeRFMLP -> activations  for the vanilla NeRF path, fp32-EQUIVALENT
+// arithmetic on the fp16 matrix cores ("f16x3 split").
+//
+// gfx950 has no TF32-class fast path and its exact fp32 MFMA runs at the fp32 vector rate
+// (157 TFLOP/s); fp16 MFMA is 16x faster.  Every fp32 operand x is therefore split into two
+// fp16 numbers  x = hi + lo  (hi = rn16(x), lo = rn16(x - hi): 22 significand bits) and each
+// product is evaluated as
+//        a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi            (drops a_lo*b_lo ~ 2^-22 |ab|)
+// with three v_mfma_f32_32x32x16_f16 accumulating into the same fp32 accumulator.  fp16 x fp16
+// products are exact in fp32 and accumulation is fp32, so the result carries fp32-class error
+// (measured against the fp32-MFMA kernel and the CPU oracle in tests/test_gpu_vanilla.py); three
+// fp16 MFMAs cost 3/16 of one fp32 MFMA of the same shape: a 5.3x higher matrix-pipe ceiling.
+//
+// Structure is that of mlp_vanilla.hip (tile = 64 points, 4 waves, 2 workgroups/CU, D[out][point]
+// orientation, weights streamed from L2 in fragment order, activations in a swizzled LDS tile);
+// what changes is the data format:
+//   * weights are split ONCE at upload into [stage][n_tile][k_step(16)][hi|lo][lane][8 halves];
+//   * activations are split ONCE per element in the layer epilogue and stored as two fp16 planes
+//     (same 4 B/element LDS footprint as fp32), so the inner loop has no conversion work: per
+//     16-deep k step a wave issues 4 weight loads (1 KiB each), 4 ds_read_b128 and 12 MFMAs.
+#include <hip/hip_fp16.h>
+
+#include "kernels.h"
+#include "mfma_tile.h"
+
+namespace neo {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 64;
+constexpr int ACT_LDH = 256;     // halves per activation row
+constexpr int SIDE_LDH = 64;     // halves per side-buffer row (x0, later the view-direction encoding)
+constexpr int NUM_STAGES = 10;   // L0..L7, bottleneck, view layer
+constexpr int ST_N[NUM_STAGES] = {256, 256, 256, 256, 256, 256, 256, 256, 256, 128};
+constexpr int ST_KS[NUM_STAGES] = {4, 16, 16, 16, 16, 20, 16, 16, 16, 18};     // 16-deep k steps
+constexpr int ST_SRC[NUM_STAGES] = {0, 1, 2, 3, 4, 5, 6, 7, 9, 8};
+constexpr int ST_KIN[NUM_STAGES] = {63, 256, 256, 256, 256, 319, 256, 256, 256, 283};
+
+constexpr int stage_w_off(int s) {   // in h8 units (16 B): per (n_tile, k_step) = 2 x 64 lanes
+    int o = 0;
+    for (int i = 0; i < s; ++i) o += (ST_N[i] / 32) * ST_KS[i] * 128;
+    return o;
+}
+constexpr int stage_b_off(int s) {
+    int o = 0;
+    for (int i = 0; i < s; ++i) o += ST_N[i];
+    return o;
+}
+constexpr int WPACK_H8 = stage_w_off(NUM_STAGES);
+constexpr int HD_DW = 0, HD_DB = 256, HD_RW = 260, HD_RB = 644;
+
+#define NEO_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+struct HTile {          // a swizzled fp16 hi/lo tile in LDS
+    _Float16* hi;
+    _Float16* lo;
+};
+
+template <int LDH, int KM>
+__device__ __forceinline__ int chunk_off(int row, int chunk) { return row * LDH + ((chunk ^ (row & KM)) << 3); }
+
+__device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int LDH, int KM>
+__device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) {
+    _Float16 h, l;
+    split(v, h, l);
+    const int o = chunk_off<LDH, KM>(p, f >> 3) + (f & 7);
+    t.hi[o] = h;
+    t.lo[o] = l;
+}
+
+// acc[nt][mt] += W[:, ks0*16 .. (ks0+n)*16) x tile^T over n k-steps: 3 fp16 MFMAs per product tile.
+template <int NTW, int LDH, int KM>
+__device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][2], const h8* __restrict__ wp, int KS, int nt0, int ks0,
+                                       int n, const HTile& tile, const LaneCtx& L) {
+    h8 ah[2][NTW], al[2][NTW];
+    auto load_w = [&](int slot, int ks) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const h8* p = wp + (((nt0 + nt) * KS + ks) * 2) * 64 + L.lane;
+            ah[slot][nt] = p[0];
+            al[slot][nt] = p[64];
+        }
+    };
+    load_w(0, ks0);
+#pragma unroll 1
+    for (int s = 0; s < n; s += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (s + u < n) {
+                if (s + u + 1 < n) load_w((u + 1) & 1, ks0 + s + u + 1);
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<LDH, KM>(mt * 32 + L.l31, ((s + u) << 1) + L.half);
+                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[nt][mt] = NEO_MFMA_H(al[u][nt], bh[mt], acc[nt][mt]);
+                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bl[mt], acc[nt][mt]);
+                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
+                    }
+            }
+        }
+    }
+}
+
+template <int NTW>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][2], const float* __restrict__ bias, int nt0,
+                                          const LaneCtx& L) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        bias_tile(acc[nt][0], bias, nt0 + nt, L);
+        acc[nt][1] = acc[nt][0];
+    }
+}
+
+// epilogue: (ReLU) -> split -> two fp16 planes.  D holds outputs 8g+4*half+e (e<4) of point l31 in
+// 4 consecutive registers: one 8-byte store per plane; lanes l and l+32 fill the two halves of a chunk.
+template <int NTW, bool RELU>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][2], const HTile& act, int nt0, const LaneCtx& L) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[nt][mt][4 * g + e];
+                    if (RELU) x = fmaxf(x, 0.0f);
+                    _Float16 h, l;
+                    split(x, h, l);
+                    vh[e] = h;
+                    vl[e] = l;
+                }
+                const int o = chunk_off<ACT_LDH, 15>(mt * 32 + L.l31, (nt0 + nt) * 4 + g) + 4 * L.half;
+                *reinterpret_cast<h4*>(act.hi + o) = vh;
+                *reinterpret_cast<h4*>(act.lo + o) = vl;
+            }
+}
+
+__global__ __launch_bounds__(256, 2) void k_vanilla_mlp_h(VanillaMlpHDev m, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ dirs,
+                                                           const float* __restrict__ t, int t_row_stride, long P,
+                                                           int N, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
+    HTile act{smem_h, smem_h + TM * ACT_LDH};
+    HTile side{smem_h + 2 * TM * ACT_LDH, smem_h + 2 * TM * ACT_LDH + TM * SIDE_LDH};
+    LaneCtx L;
+    L.init();
+    const long tile0 = (long)blockIdx.x * TM;
+    const h8* wp = reinterpret_cast<const h8*>(m.wpack);
+
+    // ---- pos_enc of the 64 points into the side buffer (wave q: octaves q, q+4, q+8) ----
+    int my_ray;
+    {
+        const int p = L.lane;
+        long g = tile0 + p;
+        if (g >= P) g = P - 1;
+        const int ray = (int)(g / N);
+        const int s = (int)(g - (long)ray * N);
+        my_ray = ray;
+        const float tt = t[(long)ray * t_row_stride + s];
+        float x[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) x[a] = rays_o[ray * 3 + a] + tt * dirs[ray * 3 + a];   // mul then add (helper.py:20-21)
+#pragma unroll 1
+        for (int k = L.wv; k < 10; k += 4) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float sn, cs;
+                enc_pair(x[a], k, sn, cs);
+                put_feat<SIDE_LDH, 7>(side, p, 3 + k * 3 + a, sn);
+                put_feat<SIDE_LDH, 7>(side, p, 33 + k * 3 + a, cs);
+            }
+        }
+        if (L.wv == 3) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) put_feat<SIDE_LDH, 7>(side, p, a, x[a]);
+            put_feat<SIDE_LDH, 7>(side, p, 63, 0.0f);
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+    const int nt0 = L.wv * 2;
+    // ---- L0: 63 -> 256 ----
+    init_bias<2>(acc, m.bias + stage_b_off(0), nt0, L);
+    gemm_h<2, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 4, side, L);
+    store_act<2, true>(acc, act, nt0, L);      // the activation planes are idle here
+    __syncthreads();
+    // ---- L1..L7 (skip concat feeds L5) ----
+#pragma unroll 1
+    for (int s = 1; s <= 7; ++s) {
+        const int woff = stage_w_off(1) + (s - 1) * (8 * 16 * 128) + (s > 5 ? 8 * 4 * 128 : 0);
+        const int KS = s == 5 ? 20 : 16;
+        init_bias<2>(acc, m.bias + s * 256, nt0, L);
+        gemm_h<2, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 16, act, L);
+        if (s == 5) gemm_h<2, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 16, 4, side, L);
+        __syncthreads();
+        store_act<2, true>(acc, act, nt0, L);
+        if (s == 5) {
+            // x0 is dead: the side buffer takes the view-direction encoding (wave q = octave q)
+            const int p = L.lane;
+            float d[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) d[a] = dirs[my_ray * 3 + a];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float sn, cs;
+                enc_pair(d[a], L.wv, sn, cs);
+                put_feat<SIDE_LDH, 7>(side, p, 3 + L.wv * 3 + a, sn);
+                put_feat<SIDE_LDH, 7>(side, p, 15 + L.wv * 3 + a, cs);
+            }
+            if (L.wv == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) put_feat<SIDE_LDH, 7>(side, p, a, d[a]);
+            }
+            if (L.wv == 1) {
+#pragma unroll
+                for (int f = 27; f < 32; ++f) put_feat<SIDE_LDH, 7>(side, p, f, 0.0f);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- density head on h8 (VALU, 4 lanes per point; x = hi + lo) ----
+    float raw_sigma;
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const float* wd = m.heads + HD_DW;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int chunk = part * 8 + ((c + 2 * part) & 7);
+            const int o = chunk_off<ACT_LDH, 15>(pt, chunk);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += ((float)vh[e] + (float)vl[e]) * wd[chunk * 8 + e];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        raw_sigma = s + m.heads[HD_DB];
+    }
+    // ---- bottleneck: 256 -> 256, no activation ----
+    init_bias<2>(acc, m.bias + stage_b_off(8), nt0, L);
+    gemm_h<2, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 16, act, L);
+    __syncthreads();
+    store_act<2, false>(acc, act, nt0, L);
+    __syncthreads();
+    // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU ----
+    {
+        f32x16 accv[1][2];
+        init_bias<1>(accv, m.bias + stage_b_off(9), L.wv, L);
+        gemm_h<1, ACT_LDH, 15>(accv, wp + stage_w_off(9), 18, L.wv, 0, 16, act, L);
+        gemm_h<1, SIDE_LDH, 7>(accv, wp + stage_w_off(9), 18, L.wv, 16, 2, side, L);
+        __syncthreads();
+        store_act<1, true>(accv, act, L.wv, L);
+        __syncthreads();
+    }
+    // ---- rgb head (VALU) + activations + store ----
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const float* wr = m.heads + HD_RW;
+        float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int chunk = part * 4 + ((c + part) & 3);
+            const int o = chunk_off<ACT_LDH, 15>(pt, chunk);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = (float)vh[e] + (float)vl[e];
+                r += h * wr[chunk * 8 + e];
+                g += h * wr[128 + chunk * 8 + e];
+                b += h * wr[256 + chunk * 8 + e];
+            }
+        }
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+        g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        const long gi = tile0 + pt;
+        if (part == 0 && gi < P) {
+            out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
+                                  colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));
+        }
+    }
+}
+
+// Split one nn.Linear (out,in) into fp16 hi/lo fragments: dst[(nt*KS + ks)*2 + {0 hi,1 lo}][lane][8]
+// = W[nt*32 + (lane&31)][ks*16 + 8*(lane>>5) + e], zero beyond k_in.
+__global__ void k_pack_stage_h(const float* __restrict__ W, int n_out, int k_in, int KS, _Float16* __restrict__ dst) {
+    const int total = (n_out / 32) * KS * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9;
+        const int ks = blk % KS, nt = blk / KS;
+        const int n = nt * 32 + (lane & 31);
+        const int k = ks * 16 + 8 * (lane >> 5) + e;
+        const float w = (k < k_in) ? W[(long)n * k_in + k] : 0.0f;
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        const long base = ((long)(nt * KS + ks) * 2) * 512 + lane * 8 + e;
+        dst[base] = hi;
+        dst[base + 512] = lo;
+    }
+}
+
+}  // namespace
+
+size_t vanilla_wpack_h_bytes() { return (size_t)WPACK_H8 * 16; }
+
+void launch_vanilla_pack_h(const float* const* weights, void* wpack_h, hipStream_t s) {
+    _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
+    for (int st = 0; st < NUM_STAGES; ++st) {
+        const int total = (ST_N[st] / 32) * ST_KS[st] * 512;
+        hipLaunchKernelGGL(k_pack_stage_h, dim3((total + 255) / 256), dim3(256), 0, s, weights[ST_SRC[st]], ST_N[st],
+                           ST_KIN[st], ST_KS[st], base + (long)stage_w_off(st) * 8);
+    }
+}
+
+void launch_vanilla_mlp_h(const VanillaMlpHDev& m, const float* rays_o, const float* dirs, const float* t,
+                          int t_row_stride, int R, int N, float* out, hipStream_t s) {
+    const long P = (long)R * N;
+    if (P <= 0) return;
+    const size_t lds = (size_t)(2 * TM * ACT_LDH + 2 * TM * SIDE_LDH) * sizeof(_Float16);   // 80 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long tiles = (P + TM - 1) / TM;
+    hipLaunchKernelGGL(k_vanilla_mlp_h, dim3((unsigned)tiles), dim3(256), lds, s, m, rays_o, dirs, t, t_row_stride, P,
+                       N, reinterpret_cast<float4*>(out));
+}
+
+}  // namespace neo

@@ -12,6 +12,7 @@ Inference path only (`randomized=False`, no autograd), as SURVEY.md §8b scopes 
 """
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -76,11 +77,19 @@ class _HipModule(nn.Module):
         super().__init__()
         self._ctx_cache = {}
 
+    # MLP GEMM arithmetic (vanilla path): "f16x3" = fp16 matrix cores on hi/lo-split fp32 operands
+    # (fp32-equivalent, ~3x faster), "f32" = exact fp32 MFMA.  None -> $NEO360_PRECISION or "f16x3".
+    precision = None
+
     def _context(self, device):
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         ctx = self._ctx_cache.get(key)
         if ctx is None:
             ctx = self._ctx_cache[key] = new_context(device)
+        want = self.precision or os.environ.get("NEO360_PRECISION", "f16x3")
+        if getattr(ctx, "_precision", None) != want:
+            ctx.set_precision(want)
+            ctx._precision = want
         return ctx
 
     @staticmethod

@@ -110,3 +110,26 @@ def test_full_frame_properties():
     want = oracle.vanilla.render(synth.vanilla_state(0), strip, 0.2, 3.0)
     assert max_abs(rgb[rows].cpu(), want[1][0]) < TOL
     assert max_abs(depth[rows].cpu(), want[1][2]) < TOL
+
+
+@pytest.mark.parametrize("gain", [1.0, 8.0])
+def test_f16x3_split_path(golden, gain):
+    """The fp16-matrix-core path (hi/lo-split operands) against the fixtures, the oracle MLP stage and
+    the exact-fp32 MFMA path: same 1e-4 contract, fp32-class error."""
+    g = golden("g4_vanilla")
+    tag = "" if gain == 1.0 else "_sharp"
+    net = _net(gain)
+    net.precision = "f16x3"
+    rays = _to(cases.crop_rays(32, 32))
+    res = net(rays, False, False, 0.2, 3.0)
+    for lv in (0, 1):
+        assert max_abs(res[lv][0].cpu(), g["rgb%d%s" % (lv, tag)]) < TOL
+        assert max_abs(res[lv][2].cpu(), g["depth%d%s" % (lv, tag)]) < TOL
+    # stage level, vs the oracle and vs the fp32-MFMA kernel on identical points
+    r = cases.strided_rays(37)
+    t = torch.sort(synth.uniform(17, "mlp_t", (37, 65), 0.2, 3.0), dim=-1).values
+    got = net.eval_mlp(0, r["rays_o"].to(DEV), r["viewdirs"].to(DEV), t.to(DEV)).cpu()
+    ref32 = _net(gain)
+    ref32.precision = "f32"
+    exact = ref32.eval_mlp(0, r["rays_o"].to(DEV), r["viewdirs"].to(DEV), t.to(DEV)).cpu()
+    assert max_abs(got, exact) < 1e-5

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden
 from neo360_amd import models, synth, ops
 torch.set_grad_enabled(False)
 dev = torch.device("cuda")
-net = models.NeRF().to(dev); net.load_state_dict(synth.vanilla_state(0))
+net = models.NeRF().to(dev); net.load_state_dict(synth.vanilla_state(0)); net.precision = os.environ.get('PREC', 'f32')
 R, N = int(os.environ.get("R", 65536)), int(os.environ.get("N", 193))
 ro, vd, rd, _ = ops.get_ray_directions_and_rays(480, 640, 512.0, synth.look_at_origin(40.0))
 ro, vd = ro[:R].contiguous(), vd[:R].contiguous()
