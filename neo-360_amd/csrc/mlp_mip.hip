@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp(MipMlpDev 
                 const int k = g / NB, j = g - k * NB;
                 const float mean = lift[row * 44 + j], var = lift[row * 44 + NB + j];
                 const float arg = ldexpf(mean, k);
-                val = expf(-0.5f * ldexpf(var, 2 * k)) * sinf(shifted ? arg + HALF_PI_F32 : arg);
+                val = expf(-0.5f * ldexpf(var, 2 * k)) * sin_cw(shifted ? arg + HALF_PI_F32 : arg);
             }
             v[e] = val;
         }

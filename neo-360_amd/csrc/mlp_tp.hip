@@ -103,9 +103,9 @@ template <int C>
 __device__ __forceinline__ float pe_feature(const float* x, int f) {
     if (f < C) return x[f];
     const int g = f - C;
-    if (g < 10 * C) return sinf(ldexpf(x[g % C], g / C));
+    if (g < 10 * C) return sin_cw(ldexpf(x[g % C], g / C));
     const int h = g - 10 * C;
-    if (h < 10 * C) return sinf(ldexpf(x[h % C], h / C) + HALF_PI_F32);
+    if (h < 10 * C) return sin_cw(ldexpf(x[h % C], h / C) + HALF_PI_F32);
     return 0.0f;
 }
 

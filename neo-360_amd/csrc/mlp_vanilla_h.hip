@@ -20,6 +20,8 @@
 //     16-deep k step a wave issues 4 weight loads (1 KiB each), 4 ds_read_b128 and 12 MFMAs.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 #include "mfma_tile.h"
 
@@ -77,9 +79,10 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 }
 
 // acc[nt][mt] += W[:, ks0*16 .. (ks0+n)*16) x tile^T over n k-steps: 3 fp16 MFMAs per product tile.
-template <int NTW, int LDH, int KM>
-__device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][2], const h8* __restrict__ wp, int KS, int nt0, int ks0,
-                                       int n, const HTile& tile, const LaneCtx& L) {
+// N-tiles nt0..nt0+NTW-1, M-tiles mt0..mt0+MTW-1.
+template <int NTW, int MTW, int LDH, int KM>
+__device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __restrict__ wp, int KS, int nt0, int mt0,
+                                       int ks0, int n, const HTile& tile, const LaneCtx& L) {
     h8 ah[2][NTW], al[2][NTW];
     auto load_w = [&](int slot, int ks) {
 #pragma unroll
@@ -96,17 +99,17 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][2], const h8* __restri
         for (int u = 0; u < 2; ++u) {
             if (s + u < n) {
                 if (s + u + 1 < n) load_w((u + 1) & 1, ks0 + s + u + 1);
-                h8 bh[2], bl[2];
+                h8 bh[MTW], bl[MTW];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int o = chunk_off<LDH, KM>(mt * 32 + L.l31, ((s + u) << 1) + L.half);
+                for (int mt = 0; mt < MTW; ++mt) {
+                    const int o = chunk_off<LDH, KM>((mt0 + mt) * 32 + L.l31, ((s + u) << 1) + L.half);
                     bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
                     bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < MTW; ++mt) {
                         acc[nt][mt] = NEO_MFMA_H(al[u][nt], bh[mt], acc[nt][mt]);
                         acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bl[mt], acc[nt][mt]);
                         acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
@@ -116,24 +119,26 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][2], const h8* __restri
     }
 }
 
-template <int NTW>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][2], const float* __restrict__ bias, int nt0,
+template <int NTW, int MTW>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][MTW], const float* __restrict__ bias, int nt0,
                                           const LaneCtx& L) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         bias_tile(acc[nt][0], bias, nt0 + nt, L);
-        acc[nt][1] = acc[nt][0];
+#pragma unroll
+        for (int mt = 1; mt < MTW; ++mt) acc[nt][mt] = acc[nt][0];
     }
 }
 
 // epilogue: (ReLU) -> split -> two fp16 planes.  D holds outputs 8g+4*half+e (e<4) of point l31 in
 // 4 consecutive registers: one 8-byte store per plane; lanes l and l+32 fill the two halves of a chunk.
-template <int NTW, bool RELU>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][2], const HTile& act, int nt0, const LaneCtx& L) {
+template <int NTW, int MTW, bool RELU>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][MTW], const HTile& act, int nt0, int mt0,
+                                          const LaneCtx& L) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 h4 vh, vl;
@@ -146,25 +151,35 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][2], const HTi
                     vh[e] = h;
                     vl[e] = l;
                 }
-                const int o = chunk_off<ACT_LDH, 15>(mt * 32 + L.l31, (nt0 + nt) * 4 + g) + 4 * L.half;
+                const int o = chunk_off<ACT_LDH, 15>((mt0 + mt) * 32 + L.l31, (nt0 + nt) * 4 + g) + 4 * L.half;
                 *reinterpret_cast<h4*>(act.hi + o) = vh;
                 *reinterpret_cast<h4*>(act.lo + o) = vl;
             }
 }
 
-__global__ __launch_bounds__(256, 2) void k_vanilla_mlp_h(VanillaMlpHDev m, const float* __restrict__ rays_o,
-                                                           const float* __restrict__ dirs,
-                                                           const float* __restrict__ t, int t_row_stride, long P,
-                                                           int N, float4* __restrict__ out) {
+// NW = 4 or 8 waves per 64-point tile.  With 8 waves each owns ONE 32-output N-tile of the 256-wide
+// layers (for both 32-point M-tiles): twice the resident waves per SIMD (4) to cover the VALU-heavy
+// epilogues, L2 round trips and barriers that the 5x shorter matrix phases no longer hide, at unchanged
+// weight traffic (every weight fragment is still fetched once per tile).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(VanillaMlpHDev m,
+                                                                                const float* __restrict__ rays_o,
+                                                                                const float* __restrict__ dirs,
+                                                                                const float* __restrict__ t,
+                                                                                int t_row_stride, long P, int N,
+                                                                                float4* __restrict__ out) {
+    constexpr int NTW = 8 / NW;                 // N-tiles per wave in the 256-wide layers
+    constexpr int LP = NW;                      // lanes per point in the VALU heads
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     HTile act{smem_h, smem_h + TM * ACT_LDH};
     HTile side{smem_h + 2 * TM * ACT_LDH, smem_h + 2 * TM * ACT_LDH + TM * SIDE_LDH};
     LaneCtx L;
     L.init();
+    const int tid = threadIdx.x;
     const long tile0 = (long)blockIdx.x * TM;
     const h8* wp = reinterpret_cast<const h8*>(m.wpack);
 
-    // ---- pos_enc of the 64 points into the side buffer (wave q: octaves q, q+4, q+8) ----
+    // ---- pos_enc of the 64 points into the side buffer (wave q: octaves q, q+NW, ...) ----
     int my_ray;
     {
         const int p = L.lane;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_vanilla_mlp_h(VanillaMlpHDev m, cons
 #pragma unroll
         for (int a = 0; a < 3; ++a) x[a] = rays_o[ray * 3 + a] + tt * dirs[ray * 3 + a];   // mul then add (helper.py:20-21)
 #pragma unroll 1
-        for (int k = L.wv; k < 10; k += 4) {
+        for (int k = L.wv; k < 10; k += NW) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 float sn, cs;
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_vanilla_mlp_h(VanillaMlpHDev m, cons
                 put_feat<SIDE_LDH, 7>(side, p, 33 + k * 3 + a, cs);
             }
         }
-        if (L.wv == 3) {
+        if (L.wv == NW - 1) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) put_feat<SIDE_LDH, 7>(side, p, a, x[a]);
             put_feat<SIDE_LDH, 7>(side, p, 63, 0.0f);
@@ -195,90 +210,96 @@ __global__ __launch_bounds__(256, 2) void k_vanilla_mlp_h(VanillaMlpHDev m, cons
     }
     __syncthreads();
 
-    f32x16 acc[2][2];
-    const int nt0 = L.wv * 2;
+    f32x16 acc[NTW][2];
+    const int nt0 = L.wv * NTW;
     // ---- L0: 63 -> 256 ----
-    init_bias<2>(acc, m.bias + stage_b_off(0), nt0, L);
-    gemm_h<2, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 4, side, L);
-    store_act<2, true>(acc, act, nt0, L);      // the activation planes are idle here
+    init_bias<NTW, 2>(acc, m.bias + stage_b_off(0), nt0, L);
+    gemm_h<NTW, 2, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 0, 4, side, L);
+    store_act<NTW, 2, true>(acc, act, nt0, 0, L);      // the activation planes are idle here
     __syncthreads();
     // ---- L1..L7 (skip concat feeds L5) ----
 #pragma unroll 1
     for (int s = 1; s <= 7; ++s) {
         const int woff = stage_w_off(1) + (s - 1) * (8 * 16 * 128) + (s > 5 ? 8 * 4 * 128 : 0);
         const int KS = s == 5 ? 20 : 16;
-        init_bias<2>(acc, m.bias + s * 256, nt0, L);
-        gemm_h<2, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 16, act, L);
-        if (s == 5) gemm_h<2, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 16, 4, side, L);
+        init_bias<NTW, 2>(acc, m.bias + s * 256, nt0, L);
+        gemm_h<NTW, 2, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 0, 16, act, L);
+        if (s == 5) gemm_h<NTW, 2, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L);
         __syncthreads();
-        store_act<2, true>(acc, act, nt0, L);
+        store_act<NTW, 2, true>(acc, act, nt0, 0, L);
         if (s == 5) {
-            // x0 is dead: the side buffer takes the view-direction encoding (wave q = octave q)
+            // x0 is dead: the side buffer takes the view-direction encoding (wave q < 4: octave q)
             const int p = L.lane;
             float d[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) d[a] = dirs[my_ray * 3 + a];
+            if (L.wv < 4) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float sn, cs;
-                enc_pair(d[a], L.wv, sn, cs);
-                put_feat<SIDE_LDH, 7>(side, p, 3 + L.wv * 3 + a, sn);
-                put_feat<SIDE_LDH, 7>(side, p, 15 + L.wv * 3 + a, cs);
+                for (int a = 0; a < 3; ++a) {
+                    float sn, cs;
+                    enc_pair(d[a], L.wv, sn, cs);
+                    put_feat<SIDE_LDH, 7>(side, p, 3 + L.wv * 3 + a, sn);
+                    put_feat<SIDE_LDH, 7>(side, p, 15 + L.wv * 3 + a, cs);
+                }
             }
-            if (L.wv == 0) {
+            if (L.wv == NW - 1) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) put_feat<SIDE_LDH, 7>(side, p, a, d[a]);
             }
-            if (L.wv == 1) {
+            if (L.wv == NW - 2) {
 #pragma unroll
                 for (int f = 27; f < 32; ++f) put_feat<SIDE_LDH, 7>(side, p, f, 0.0f);
             }
         }
         __syncthreads();
     }
-    // ---- density head on h8 (VALU, 4 lanes per point; x = hi + lo) ----
+    // ---- density head on h8 (VALU, LP lanes per point; x = hi + lo) ----
     float raw_sigma;
     {
-        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const int pt = tid / LP, part = tid % LP;
+        constexpr int CH = 32 / LP;          // 16-B chunks (8 features) per lane
         const float* wd = m.heads + HD_DW;
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int chunk = part * 8 + ((c + 2 * part) & 7);
+        for (int c = 0; c < CH; ++c) {
+            const int chunk = part * CH + ((c + part) % CH);
             const int o = chunk_off<ACT_LDH, 15>(pt, chunk);
             const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
             const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += ((float)vh[e] + (float)vl[e]) * wd[chunk * 8 + e];
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
+#pragma unroll
+        for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o, 64);
         raw_sigma = s + m.heads[HD_DB];
     }
     // ---- bottleneck: 256 -> 256, no activation ----
-    init_bias<2>(acc, m.bias + stage_b_off(8), nt0, L);
-    gemm_h<2, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 16, act, L);
+    init_bias<NTW, 2>(acc, m.bias + stage_b_off(8), nt0, L);
+    gemm_h<NTW, 2, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L);
     __syncthreads();
-    store_act<2, false>(acc, act, nt0, L);
+    store_act<NTW, 2, false>(acc, act, nt0, 0, L);
     __syncthreads();
-    // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU ----
+    // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU (4 N-tiles: split over M as well when NW = 8) ----
     {
-        f32x16 accv[1][2];
-        init_bias<1>(accv, m.bias + stage_b_off(9), L.wv, L);
-        gemm_h<1, ACT_LDH, 15>(accv, wp + stage_w_off(9), 18, L.wv, 0, 16, act, L);
-        gemm_h<1, SIDE_LDH, 7>(accv, wp + stage_w_off(9), 18, L.wv, 16, 2, side, L);
+        constexpr int MTV = NW == 8 ? 1 : 2;
+        const int ntv = L.wv & 3, mtv = NW == 8 ? (L.wv >> 2) : 0;
+        f32x16 accv[1][MTV];
+        init_bias<1, MTV>(accv, m.bias + stage_b_off(9), ntv, L);
+        gemm_h<1, MTV, ACT_LDH, 15>(accv, wp + stage_w_off(9), 18, ntv, mtv, 0, 16, act, L);
+        gemm_h<1, MTV, SIDE_LDH, 7>(accv, wp + stage_w_off(9), 18, ntv, mtv, 16, 2, side, L);
         __syncthreads();
-        store_act<1, true>(accv, act, L.wv, L);
+        store_act<1, MTV, true>(accv, act, ntv, mtv, L);
         __syncthreads();
     }
     // ---- rgb head (VALU) + activations + store ----
     {
-        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const int pt = tid / LP, part = tid % LP;
+        constexpr int CH = 16 / LP;
         const float* wr = m.heads + HD_RW;
         float r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int chunk = part * 4 + ((c + part) & 3);
+        for (int c = 0; c < CH; ++c) {
+            const int chunk = part * CH + ((c + part) % CH);
             const int o = chunk_off<ACT_LDH, 15>(pt, chunk);
             const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
             const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
@@ -290,9 +311,12 @@ __global__ __launch_bounds__(256, 2) void k_vanilla_mlp_h(VanillaMlpHDev m, cons
                 b += h * wr[256 + chunk * 8 + e];
             }
         }
-        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
-        g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
-        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+#pragma unroll
+        for (int o = 1; o < LP; o <<= 1) {
+            r += __shfl_xor(r, o, 64);
+            g += __shfl_xor(g, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
         const long gi = tile0 + pt;
         if (part == 0 && gi < P) {
             out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
@@ -337,15 +361,22 @@ void launch_vanilla_mlp_h(const VanillaMlpHDev& m, const float* rays_o, const fl
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = (size_t)(2 * TM * ACT_LDH + 2 * TM * SIDE_LDH) * sizeof(_Float16);   // 80 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h),
+    static int nw = 0;
+    if (nw == 0) {
+        nw = 4;   // measured: 4 waves 396 TFLOP/s, 8 waves 381 (profiles/r01_vanilla_h_variants.log)
+        if (const char* e = getenv("NEO_VANILLA_H_WAVES")) nw = atoi(e) == 8 ? 8 : 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<4>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const long tiles = (P + TM - 1) / TM;
-    hipLaunchKernelGGL(k_vanilla_mlp_h, dim3((unsigned)tiles), dim3(256), lds, s, m, rays_o, dirs, t, t_row_stride, P,
-                       N, reinterpret_cast<float4*>(out));
+    if (nw == 8)
+        hipLaunchKernelGGL(k_vanilla_mlp_h<8>, dim3((unsigned)tiles), dim3(512), lds, s, m, rays_o, dirs, t, t_row_stride,
+                           P, N, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(k_vanilla_mlp_h<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, rays_o, dirs, t, t_row_stride,
+                           P, N, reinterpret_cast<float4*>(out));
 }
 
 }  // namespace neo

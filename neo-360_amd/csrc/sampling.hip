@@ -31,7 +31,7 @@ __global__ void k_pos_enc(const float* __restrict__ x, int n, int C, int min_deg
             const int h = shifted ? g - L * C : g;
             const int k = min_deg + h / C, c = h % C;
             const float a = ldexpf(x[(long)row * C + c], k);
-            v = shifted ? sinf(a + HALF_PI_F32) : sinf(a);
+            v = shifted ? sin_cw(a + HALF_PI_F32) : sin_cw(a);
         }
         out[idx] = v;
     }
