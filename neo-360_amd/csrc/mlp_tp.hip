@@ -18,30 +18,22 @@
 // the streamed input; the L3 half stays in accumulator registers until L3's turn.
 //
 // Work per point-view: 255,424 MAC (fg) / 260,800 MAC (bg); + 4,416 MAC per point.
-#include "kernels.h"
-#include "mfma_tile.h"
+#include "tp_common.h"
 
 namespace neo {
 
 namespace {
 
-constexpr int TM = 64;
+using tp::TM;
+using tp::blend4;
+using tp::pe_feature;
 constexpr int ACT_LD = 128;   // activation tile [64][128]
 constexpr int XB_LD = 64;     // streamed-input tile [64][64], two of them alias the activation tile
 constexpr int DIR_LD = 32;
 
-// LDS carve (floats)
-constexpr int OFF_ACT = 0;
-constexpr int OFF_DIR = OFF_ACT + TM * ACT_LD;
-constexpr int OFF_LOC_OFF = OFF_DIR + TM * DIR_LD;       // int[64][4]
-constexpr int OFF_LOC_W = OFF_LOC_OFF + TM * 4;
-constexpr int OFF_PL_OFF = OFF_LOC_W + TM * 4;           // int[3][64][4]
-constexpr int OFF_PL_W = OFF_PL_OFF + 3 * TM * 4;
-constexpr int OFF_CAM = OFF_PL_W + 3 * TM * 4;           // float[64][4]: camera-frame point (+1/r) for pos_enc
-constexpr int OFF_PE = OFF_CAM + TM * 4;                 // float[64][4]: world point to encode (+1/r)
-constexpr int OFF_FEAT = OFF_PE + TM * 4;                // float[64][4]: world point for feature lookups
-constexpr int OFF_VDIR = OFF_FEAT + TM * 4;              // float[64][4]: world view direction (Q1-indexed ray)
-constexpr int LDS_FLOATS = OFF_VDIR + TM * 4;
+using tp::OFF_ACT;
+using tp::OFF_DIR;
+constexpr int LDS_FLOATS = tp::LDS_WORDS;
 
 // ---- packed weight layout -----------------------------------------------------
 // stage X : N=256 (rows 0-127 = pts_linears.0, rows 128-255 = pts_linears.3[:, 128:]),
@@ -62,52 +54,6 @@ __host__ __device__ constexpr int wpack_floats(int pe_c) { return off_v1(pe_c) +
 constexpr int B_0 = 0, B_3 = 128, B_1 = 256, B_2 = 384, B_B = 512, B_V0 = 640, B_V1 = 704, BIAS_FLOATS = 768;
 // heads: density w[128] | density b (4) | rgb w[3][64] | rgb b (4)
 constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 324, HEADS_FLOATS = 328;
-
-struct TapSet {
-    int off[4];
-    float w[4];
-};
-
-// Bilinear taps of F.grid_sample(align_corners=True, padding zeros) at normalised (gx, gy)
-// on a Wd x Hd map; offsets in texels, invalid taps get weight 0 / offset 0.
-// Tap order nw, ne, sw, se; weights (x1-x)(y1-y), (x-x0)(y1-y), (x1-x)(y-y0), (x-x0)(y-y0).
-__device__ __forceinline__ TapSet bilinear_taps(float gx, float gy, int Wd, int Hd) {
-    const float x = ((gx + 1.0f) / 2.0f) * (float)(Wd - 1);
-    const float y = ((gy + 1.0f) / 2.0f) * (float)(Hd - 1);
-    const float x0 = floorf(x), y0 = floorf(y);
-    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
-    const float wx0 = x1 - x, wx1 = x - x0, wy0 = y1 - y, wy1 = y - y0;
-    const float xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
-    const float ws[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
-    TapSet t;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bool ok = xs[k] >= 0.0f && xs[k] <= (float)(Wd - 1) && ys[k] >= 0.0f && ys[k] <= (float)(Hd - 1);
-        t.off[k] = ok ? (int)ys[k] * Wd + (int)xs[k] : 0;
-        t.w[k] = ok ? ws[k] : 0.0f;
-    }
-    return t;
-}
-
-__device__ __forceinline__ f32x4 blend4(const f32x4 (&tap)[4], const f32x4 w) {
-    // nw*w0 + ne*w1 + sw*w2 + se*w3, accumulated in that order (separate multiply / add)
-    f32x4 v = tap[0] * w[0];
-    v = v + tap[1] * w[1];
-    v = v + tap[2] * w[2];
-    v = v + tap[3] * w[3];
-    return v;
-}
-
-// feature f of the positional encoding of a C-vector x (C = 3 or 4, 10 octaves): pad -> 0
-template <int C>
-__device__ __forceinline__ float pe_feature(const float* x, int f) {
-    if (f < C) return x[f];
-    const int g = f - C;
-    if (g < 10 * C) return sin_cw(ldexpf(x[g % C], g / C));
-    const int h = g - 10 * C;
-    if (h < 10 * C) return sin_cw(ldexpf(x[h % C], h / C) + HALF_PI_F32);
-    return 0.0f;
-}
 
 template <int NTW>
 __device__ __forceinline__ void mma_chunk2(const f32x4 (&a)[NTW], const f32x4 (&b)[2], f32x16 (&acc)[NTW][2]) {
@@ -197,14 +143,12 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* act = smem + OFF_ACT;
     float* dsm = smem + OFF_DIR;
-    int* loc_off = reinterpret_cast<int*>(smem + OFF_LOC_OFF);
-    float* loc_w = smem + OFF_LOC_W;
-    int* pl_off = reinterpret_cast<int*>(smem + OFF_PL_OFF);
-    float* pl_w = smem + OFF_PL_W;
-    float* cam_enc = smem + OFF_CAM;
-    float* pe_world = smem + OFF_PE;
-    float* feat_world = smem + OFF_FEAT;
-    float* vdir_world = smem + OFF_VDIR;
+    const tp::Scratch S = tp::carve(smem);
+    int* loc_off = S.loc_off;
+    float* loc_w = S.loc_w;
+    int* pl_off = S.pl_off;
+    float* pl_w = S.pl_w;
+    float* cam_enc = S.cam_enc;
 
     LaneCtx L;
     L.init();
@@ -215,68 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
     constexpr int KCX = kc_x(PE_C);
     constexpr int NST = PE_C == 3 ? 11 : 12;   // streamed-input stages: 8 local, 2 world, 1-2 pos_enc
 
-    // ---- per-point world-space quantities (once per tile) ----------------------
-    if (tid < TM) {
-        long g = tile0 + tid;
-        if (g >= P) g = P - 1;
-        const int ray = (int)(g / N);
-        const int s = (int)(g - (long)ray * N);
-        const int c0 = (ray / chunk) * chunk;                    // first ray of this ray's reference chunk
-        const int bc = min(chunk, R - c0);                       // rays in that chunk (last one may be short)
-        const int gl = (ray - c0) * N + s;                       // flattened (ray, sample) index inside the chunk
-        const int dray = c0 + gl % bc;                           // neo360/model.py:357-360 tiling: direction of ray (b*N+s) mod B
-        const float tv = tvals[g];
-        float o[3], d[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { o[a] = rays_o[ray * 3 + a]; d[a] = rays_d[ray * 3 + a]; }
-        if (PE_C == 3) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float x = o[a] + tv * d[a];
-                pe_world[tid * 4 + a] = x;
-                feat_world[tid * 4 + a] = x;
-            }
-            pe_world[tid * 4 + 3] = 0.0f;
-        } else {
-            // inverted-sphere point (neo360/helper.py:401-451) and the linear lookup point
-            // o + (far(1-s) + 3 s) d (helper.py:59-73, :232-246)
-            const float far = far_arr[ray];
-            const float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            const float d1 = -(d[0] * o[0] + d[1] * o[1] + d[2] * o[2]) / dd;
-            float pm[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) pm[a] = o[a] + d1 * d[a];
-            const float rmid = sqrtf(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
-            const float inv_len = 1.0f / sqrtf(dd);
-            const float margin = 1.0f - rmid * rmid;
-            if (!(margin >= 0.0f)) atomicOr(flags, 1u);
-            const float d2 = sqrtf(margin) * inv_len;
-            float ps[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) ps[a] = o[a] + (d1 + d2) * d[a];
-            float ax[3] = {o[1] * ps[2] - o[2] * ps[1], o[2] * ps[0] - o[0] * ps[2], o[0] * ps[1] - o[1] * ps[0]};
-            const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) ax[a] = ax[a] / an;
-            const float ang = asinf(rmid) - asinf(rmid * tv);
-            const float ca = cosf(ang), sa = sinf(ang);
-            const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
-            const float dotp = ax[0] * ps[0] + ax[1] * ps[1] + ax[2] * ps[2];
-            float tn[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) tn[a] = ps[a] * ca + cr[a] * sa + ax[a] * dotp * (1.0f - ca);
-            const float nn = sqrtf(tn[0] * tn[0] + tn[1] * tn[1] + tn[2] * tn[2]) + 1e-10f;
-            const float tl = far * (1.0f - tv) + 3.0f * tv;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                pe_world[tid * 4 + a] = tn[a] / nn;
-                feat_world[tid * 4 + a] = o[a] + tl * d[a];
-            }
-            pe_world[tid * 4 + 3] = tv;
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) vdir_world[tid * 4 + a] = viewdirs[dray * 3 + a];
-    }
+    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     __syncthreads();
 
     f32x16 hsum[2], ysum;
@@ -290,63 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
     for (int v = 0; v < sc.nv; ++v) {
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
-        // ---- descriptors for this view ---------------------------------------
-        {
-            const int p = L.lane;
-            const float fx = feat_world[p * 4], fy = feat_world[p * 4 + 1], fz = feat_world[p * 4 + 2];
-            // world2camera (neo360/util.py:52-70): R^T x then + (-R^T t)
-            const float cx_ = (rot[0] * fx + rot[1] * fy + rot[2] * fz) + trn[0];
-            const float cy_ = (rot[3] * fx + rot[4] * fy + rot[5] * fz) + trn[1];
-            const float cz_ = (rot[6] * fx + rot[7] * fy + rot[8] * fz) + trn[2];
-            TapSet t;
-            int* dst_off;
-            float* dst_w;
-            int base;
-            if (L.wv == 0) {
-                // pixel-aligned latent (neo360/model.py:239-264, encoder_pn.py:116-150), view 0's intrinsics
-                const float den = cz_ + 1e-9f;
-                const float u = (-cx_ / den) * sc.focal + sc.cx;
-                const float w_ = (-cy_ / den) * (-sc.focal) + sc.cy;
-                t = bilinear_taps(u * sc.sx - 1.0f, w_ * sc.sy - 1.0f, sc.Wf, sc.Hf);
-                dst_off = loc_off; dst_w = loc_w;
-                base = v * sc.Hf * sc.Wf;
-                // camera-frame point that gets encoded (fg: same point; bg: the unit-sphere point)
-                const float ex = pe_world[p * 4], ey = pe_world[p * 4 + 1], ez = pe_world[p * 4 + 2];
-                cam_enc[p * 4 + 0] = (rot[0] * ex + rot[1] * ey + rot[2] * ez) + trn[0];
-                cam_enc[p * 4 + 1] = (rot[3] * ex + rot[4] * ey + rot[5] * ez) + trn[1];
-                cam_enc[p * 4 + 2] = (rot[6] * ex + rot[7] * ey + rot[8] * ez) + trn[2];
-                cam_enc[p * 4 + 3] = pe_world[p * 4 + 3];
-            } else {
-                // tri-planes (encoder_tp_fusion_conv.py:122-209): camera coordinates used directly as
-                // grid coordinates; xz -> (x,z), xy -> (x,y), yz -> (y,z)
-                const float ga = L.wv == 3 ? cy_ : cx_;
-                const float gb = L.wv == 2 ? cy_ : cz_;
-                t = bilinear_taps(ga, gb, sc.Wp, sc.Hp);
-                dst_off = pl_off + (L.wv - 1) * TM * 4; dst_w = pl_w + (L.wv - 1) * TM * 4;
-                base = v * sc.Hp * sc.Wp;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { dst_off[p * 4 + k] = base + t.off[k]; dst_w[p * 4 + k] = t.w[k]; }
-            // view-direction encoding in this view's camera frame; wave q takes octave q
-            const float dx = vdir_world[p * 4], dy = vdir_world[p * 4 + 1], dz = vdir_world[p * 4 + 2];
-            const float dc[3] = {rot[0] * dx + rot[1] * dy + rot[2] * dz, rot[3] * dx + rot[4] * dy + rot[5] * dz,
-                                 rot[6] * dx + rot[7] * dy + rot[8] * dz};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float sn, cs;
-                enc_pair(dc[a], L.wv, sn, cs);
-                dsm[swz_index<DIR_LD, 7>(p, 3 + L.wv * 3 + a)] = sn;
-                dsm[swz_index<DIR_LD, 7>(p, 15 + L.wv * 3 + a)] = cs;
-            }
-            if (L.wv == 0) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) dsm[swz_index<DIR_LD, 7>(p, a)] = dc[a];
-            }
-            if (L.wv == 1) {
-#pragma unroll
-                for (int f = 27; f < 32; ++f) dsm[swz_index<DIR_LD, 7>(p, f)] = 0.0f;
-            }
-        }
+        tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) { dsm[swz_index<DIR_LD, 7>(p, f)] = val; });
         __syncthreads();
 
         // ---- streamed-input GEMM: [L0 | L3 skip half] (256 outputs) over 703 / 724 features ----

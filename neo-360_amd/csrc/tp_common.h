@@ -1,0 +1,231 @@
+// Device code shared by the NeO-360 point evaluators (fp32-MFMA kernel mlp_tp.hip and the
+// split-fp16 kernel mlp_tp_h.hip): LDS carve of the per-tile scratch, bilinear tap descriptors,
+// per-point world-space setup (incl. the inverted-sphere parameterisation) and the per-view
+// descriptor pass (world2camera, projection, 4-tap offsets / weights, view-direction encoding).
+#pragma once
+#include "kernels.h"
+#include "mfma_tile.h"
+
+namespace neo {
+namespace tp {
+
+constexpr int TM = 64;
+
+// LDS carve (in 4-byte words).  The first 10240 words hold the kernel-specific activation /
+// streamed-input tiles (32 KB) and the view-direction encoding (8 KB); the rest is shared scratch.
+constexpr int OFF_ACT = 0;
+constexpr int OFF_DIR = OFF_ACT + TM * 128;
+constexpr int OFF_LOC_OFF = OFF_DIR + TM * 32;           // int[64][4]
+constexpr int OFF_LOC_W = OFF_LOC_OFF + TM * 4;
+constexpr int OFF_PL_OFF = OFF_LOC_W + TM * 4;           // int[3][64][4]
+constexpr int OFF_PL_W = OFF_PL_OFF + 3 * TM * 4;
+constexpr int OFF_CAM = OFF_PL_W + 3 * TM * 4;           // float[64][4]: camera-frame point (+1/r) for pos_enc
+constexpr int OFF_PE = OFF_CAM + TM * 4;                 // float[64][4]: world point to encode (+1/r)
+constexpr int OFF_FEAT = OFF_PE + TM * 4;                // float[64][4]: world point for feature lookups
+constexpr int OFF_VDIR = OFF_FEAT + TM * 4;              // float[64][4]: world view direction (Q1-indexed ray)
+constexpr int LDS_WORDS = OFF_VDIR + TM * 4;
+
+struct Scratch {
+    int* loc_off; float* loc_w; int* pl_off; float* pl_w;
+    float* cam_enc; float* pe_world; float* feat_world; float* vdir_world;
+};
+__device__ __forceinline__ Scratch carve(float* smem) {
+    Scratch S;
+    S.loc_off = reinterpret_cast<int*>(smem + OFF_LOC_OFF);
+    S.loc_w = smem + OFF_LOC_W;
+    S.pl_off = reinterpret_cast<int*>(smem + OFF_PL_OFF);
+    S.pl_w = smem + OFF_PL_W;
+    S.cam_enc = smem + OFF_CAM;
+    S.pe_world = smem + OFF_PE;
+    S.feat_world = smem + OFF_FEAT;
+    S.vdir_world = smem + OFF_VDIR;
+    return S;
+}
+
+struct TapSet {
+    int off[4];
+    float w[4];
+};
+
+// Bilinear taps of F.grid_sample(align_corners=True, padding zeros) at normalised (gx, gy)
+// on a Wd x Hd map; offsets in texels, invalid taps get weight 0 / offset 0.
+// Tap order nw, ne, sw, se; weights (x1-x)(y1-y), (x-x0)(y1-y), (x1-x)(y-y0), (x-x0)(y-y0).
+__device__ __forceinline__ TapSet bilinear_taps(float gx, float gy, int Wd, int Hd) {
+    const float x = ((gx + 1.0f) / 2.0f) * (float)(Wd - 1);
+    const float y = ((gy + 1.0f) / 2.0f) * (float)(Hd - 1);
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    const float wx0 = x1 - x, wx1 = x - x0, wy0 = y1 - y, wy1 = y - y0;
+    const float xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
+    const float ws[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+    TapSet t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool ok = xs[k] >= 0.0f && xs[k] <= (float)(Wd - 1) && ys[k] >= 0.0f && ys[k] <= (float)(Hd - 1);
+        t.off[k] = ok ? (int)ys[k] * Wd + (int)xs[k] : 0;
+        t.w[k] = ok ? ws[k] : 0.0f;
+    }
+    return t;
+}
+
+__device__ __forceinline__ f32x4 blend4(const f32x4 (&tap)[4], const f32x4 w) {
+    // nw*w0 + ne*w1 + sw*w2 + se*w3, accumulated in that order (separate multiply / add)
+    f32x4 v = tap[0] * w[0];
+    v = v + tap[1] * w[1];
+    v = v + tap[2] * w[2];
+    v = v + tap[3] * w[3];
+    return v;
+}
+
+// feature f of the positional encoding of a C-vector x (C = 3 or 4, 10 octaves): pad -> 0
+template <int C>
+__device__ __forceinline__ float pe_feature(const float* x, int f) {
+    if (f < C) return x[f];
+    const int g = f - C;
+    if (g < 10 * C) return sin_cw(ldexpf(x[g % C], g / C));
+    const int h = g - 10 * C;
+    if (h < 10 * C) return sin_cw(ldexpf(x[h % C], h / C) + HALF_PI_F32);
+    return 0.0f;
+}
+
+
+// ---- per-point world-space quantities (once per tile; threads 0..63) ---------------------------
+template <int PE_C>
+__device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile0, long P, int N, int R, int chunk,
+                                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                            const float* __restrict__ viewdirs, const float* __restrict__ tvals,
+                                            const float* __restrict__ far_arr, uint32_t* __restrict__ flags) {
+    float* pe_world = S.pe_world;
+    float* feat_world = S.feat_world;
+    float* vdir_world = S.vdir_world;
+    if (tid < TM) {
+        long g = tile0 + tid;
+        if (g >= P) g = P - 1;
+        const int ray = (int)(g / N);
+        const int s = (int)(g - (long)ray * N);
+        const int c0 = (ray / chunk) * chunk;                    // first ray of this ray's reference chunk
+        const int bc = min(chunk, R - c0);                       // rays in that chunk (last one may be short)
+        const int gl = (ray - c0) * N + s;                       // flattened (ray, sample) index inside the chunk
+        const int dray = c0 + gl % bc;                           // neo360/model.py:357-360 tiling: direction of ray (b*N+s) mod B
+        const float tv = tvals[g];
+        float o[3], d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o[a] = rays_o[ray * 3 + a]; d[a] = rays_d[ray * 3 + a]; }
+        if (PE_C == 3) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float x = o[a] + tv * d[a];
+                pe_world[tid * 4 + a] = x;
+                feat_world[tid * 4 + a] = x;
+            }
+            pe_world[tid * 4 + 3] = 0.0f;
+        } else {
+            // inverted-sphere point (neo360/helper.py:401-451) and the linear lookup point
+            // o + (far(1-s) + 3 s) d (helper.py:59-73, :232-246)
+            const float far = far_arr[ray];
+            const float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            const float d1 = -(d[0] * o[0] + d[1] * o[1] + d[2] * o[2]) / dd;
+            float pm[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) pm[a] = o[a] + d1 * d[a];
+            const float rmid = sqrtf(pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
+            const float inv_len = 1.0f / sqrtf(dd);
+            const float margin = 1.0f - rmid * rmid;
+            if (!(margin >= 0.0f)) atomicOr(flags, 1u);
+            const float d2 = sqrtf(margin) * inv_len;
+            float ps[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ps[a] = o[a] + (d1 + d2) * d[a];
+            float ax[3] = {o[1] * ps[2] - o[2] * ps[1], o[2] * ps[0] - o[0] * ps[2], o[0] * ps[1] - o[1] * ps[0]};
+            const float an = sqrtf(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ax[a] = ax[a] / an;
+            const float ang = asinf(rmid) - asinf(rmid * tv);
+            const float ca = cosf(ang), sa = sinf(ang);
+            const float cr[3] = {ax[1] * ps[2] - ax[2] * ps[1], ax[2] * ps[0] - ax[0] * ps[2], ax[0] * ps[1] - ax[1] * ps[0]};
+            const float dotp = ax[0] * ps[0] + ax[1] * ps[1] + ax[2] * ps[2];
+            float tn[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) tn[a] = ps[a] * ca + cr[a] * sa + ax[a] * dotp * (1.0f - ca);
+            const float nn = sqrtf(tn[0] * tn[0] + tn[1] * tn[1] + tn[2] * tn[2]) + 1e-10f;
+            const float tl = far * (1.0f - tv) + 3.0f * tv;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                pe_world[tid * 4 + a] = tn[a] / nn;
+                feat_world[tid * 4 + a] = o[a] + tl * d[a];
+            }
+            pe_world[tid * 4 + 3] = tv;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vdir_world[tid * 4 + a] = viewdirs[dray * 3 + a];
+    }
+}
+
+// ---- per-view descriptors (all 4 waves; lane = row) ---------------------------------------------------
+// put_dir(row, feature, value) stores one feature of the 27(+5 pad)-wide view-direction encoding.
+template <class PutDir>
+__device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx& L, const TpScene& sc,
+                                                 const float* rot, const float* trn, int v, PutDir put_dir) {
+    int* loc_off = S.loc_off; float* loc_w = S.loc_w; int* pl_off = S.pl_off; float* pl_w = S.pl_w;
+    float* cam_enc = S.cam_enc; const float* pe_world = S.pe_world; const float* feat_world = S.feat_world;
+    const float* vdir_world = S.vdir_world;
+        {
+            const int p = L.lane;
+            const float fx = feat_world[p * 4], fy = feat_world[p * 4 + 1], fz = feat_world[p * 4 + 2];
+            // world2camera (neo360/util.py:52-70): R^T x then + (-R^T t)
+            const float cx_ = (rot[0] * fx + rot[1] * fy + rot[2] * fz) + trn[0];
+            const float cy_ = (rot[3] * fx + rot[4] * fy + rot[5] * fz) + trn[1];
+            const float cz_ = (rot[6] * fx + rot[7] * fy + rot[8] * fz) + trn[2];
+            TapSet t;
+            int* dst_off;
+            float* dst_w;
+            int base;
+            if (L.wv == 0) {
+                // pixel-aligned latent (neo360/model.py:239-264, encoder_pn.py:116-150), view 0's intrinsics
+                const float den = cz_ + 1e-9f;
+                const float u = (-cx_ / den) * sc.focal + sc.cx;
+                const float w_ = (-cy_ / den) * (-sc.focal) + sc.cy;
+                t = bilinear_taps(u * sc.sx - 1.0f, w_ * sc.sy - 1.0f, sc.Wf, sc.Hf);
+                dst_off = loc_off; dst_w = loc_w;
+                base = v * sc.Hf * sc.Wf;
+                // camera-frame point that gets encoded (fg: same point; bg: the unit-sphere point)
+                const float ex = pe_world[p * 4], ey = pe_world[p * 4 + 1], ez = pe_world[p * 4 + 2];
+                cam_enc[p * 4 + 0] = (rot[0] * ex + rot[1] * ey + rot[2] * ez) + trn[0];
+                cam_enc[p * 4 + 1] = (rot[3] * ex + rot[4] * ey + rot[5] * ez) + trn[1];
+                cam_enc[p * 4 + 2] = (rot[6] * ex + rot[7] * ey + rot[8] * ez) + trn[2];
+                cam_enc[p * 4 + 3] = pe_world[p * 4 + 3];
+            } else {
+                // tri-planes (encoder_tp_fusion_conv.py:122-209): camera coordinates used directly as
+                // grid coordinates; xz -> (x,z), xy -> (x,y), yz -> (y,z)
+                const float ga = L.wv == 3 ? cy_ : cx_;
+                const float gb = L.wv == 2 ? cy_ : cz_;
+                t = bilinear_taps(ga, gb, sc.Wp, sc.Hp);
+                dst_off = pl_off + (L.wv - 1) * TM * 4; dst_w = pl_w + (L.wv - 1) * TM * 4;
+                base = v * sc.Hp * sc.Wp;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dst_off[p * 4 + k] = base + t.off[k]; dst_w[p * 4 + k] = t.w[k]; }
+            // view-direction encoding in this view's camera frame; wave q takes octave q
+            const float dx = vdir_world[p * 4], dy = vdir_world[p * 4 + 1], dz = vdir_world[p * 4 + 2];
+            const float dc[3] = {rot[0] * dx + rot[1] * dy + rot[2] * dz, rot[3] * dx + rot[4] * dy + rot[5] * dz,
+                                 rot[6] * dx + rot[7] * dy + rot[8] * dz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float sn, cs;
+                enc_pair(dc[a], L.wv, sn, cs);
+                put_dir(p, 3 + L.wv * 3 + a, sn);
+                put_dir(p, 15 + L.wv * 3 + a, cs);
+            }
+            if (L.wv == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) put_dir(p, a, dc[a]);
+            }
+            if (L.wv == 1) {
+#pragma unroll
+                for (int f = 27; f < 32; ++f) put_dir(p, f, 0.0f);
+            }
+        }
+}
+
+}  // namespace tp
+}  // namespace neo
