@@ -123,8 +123,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("vanilla", "neo360", "mip360", "mip360_128"), default="vanilla")
-    ap.add_argument("--precision", choices=("f32", "f16x3"), default="f16x3",
-                    help="vanilla MLP arithmetic: exact fp32 MFMA, or fp16 MFMA with hi/lo-split operands (fp32-equivalent)")
+    ap.add_argument("--precision", choices=("auto", "f32", "f16x3"), default="auto",
+                    help="vanilla / neo360 MLP arithmetic: exact fp32 MFMA, or fp16 MFMA with hi/lo-split operands "
+                         "(fp32-equivalent); mip360 runs on fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays in the CPU-baseline sample (0 = skip, -1 = default)")
     args = ap.parse_args()
 
@@ -149,10 +150,12 @@ def main():
     else:       # reference defaults (64,64,32), or BASELINE.json's wording "64 proposal + 128 fine"
         built = build_mip360(dev, 128 if args.workload.endswith("128") else 32)
     net, state, extra, scene, desc, kw, kernel_name, cpu_default = built
-    split = args.workload == "vanilla" and args.precision == "f16x3"
-    if args.workload == "vanilla":
+    if args.precision == "auto":
+        args.precision = getattr(net, "default_precision", "f32")
+    split = args.workload in ("vanilla", "neo360") and args.precision == "f16x3"
+    if args.workload in ("vanilla", "neo360"):
         net.precision = args.precision
-        kernel_name = "k_vanilla_mlp_h" if split else "k_vanilla_mlp"
+        kernel_name = kernel_name + "_h" if split else kernel_name
     c2w = synth.look_at_origin(40.0)
     R = H * W
     ctx = net._context(dev)

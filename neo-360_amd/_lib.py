@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libneo360_hip.so")
+# $NEO360_HIP_LIB points the loader at another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("NEO360_HIP_LIB") or os.path.join(_HERE, "lib", "libneo360_hip.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 _vp = ctypes.c_void_p

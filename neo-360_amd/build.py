@@ -17,6 +17,16 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 
+# Per-file additions.  mlp_tp_h.hip: no packed-fp32 VALU ops (v_pk_mul/add/fma_f32).  Measured on MI355X
+# (tools/diag_det_all.py, profiles/r01_tp_h_race_bisect.log): with two workgroups of that kernel sharing a CU,
+# the packed-fp32 bilinear blends that run next to the other workgroup's v_mfma_f32_32x32x16_f16 stream
+# returned wrong values in lanes 48-63 for ~0.3 % of the points, differently on every launch; one workgroup
+# per CU, or the same code with scalar fp32 VALU ops, is bitwise repeatable.  The fp32-MFMA kernels and the
+# vanilla split kernel are repeatable as built (tests/test_gpu_repeatable.py keeps checking all of them).
+EXTRA_FLAGS = {
+    "mlp_tp_h.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+}
+
 
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -42,7 +52,7 @@ def build(force=False, verbose=False):
         op = os.path.join(OUT_DIR, src[:-4] + ".o")
         objs.append(op)
         if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), newest_header):
-            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", op]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -28,6 +28,21 @@ void fill_views(const float* poses, int nv, neo::TpViews& v) {
     }
 }
 
+// one region's evaluator launch in the context's arithmetic mode
+void tp_launch(neo_ctx* ctx, const MlpSlot& sl, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
+               const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N, int chunk,
+               float* out, hipStream_t s) {
+    ctx->span_begin(s);
+    if (ctx->precision == 1) {
+        neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>()};
+        neo::launch_tp_mlp_h(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+    } else {
+        neo::TpMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
+        neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+    }
+    ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(sl.input_ch, sc.nv));
+}
+
 }  // namespace
 
 extern "C" {
@@ -43,8 +58,10 @@ int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* 
     if (sl.wpack.reserve(neo::tp_wpack_floats(input_ch) * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.bias.reserve(neo::tp_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.heads.reserve(neo::tp_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.wpack_h.reserve(neo::tp_wpack_h_bytes(input_ch))) return NEO_ERR_NOMEM;
     neo::launch_tp_pack(input_ch, weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
                         static_cast<hipStream_t>(stream));
+    neo::launch_tp_pack_h(input_ch, weights, sl.wpack_h.p, static_cast<hipStream_t>(stream));
     sl.input_ch = input_ch;
     sl.ready = true;
     return check_launch();
@@ -99,10 +116,7 @@ int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
     fill_views(src_poses, NV, views);
     neo::TpScene sc = ctx->scene;
     sc.focal = focal; sc.cx = cx; sc.cy = cy;
-    neo::TpMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
-    ctx->span_begin(s);
-    neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
-    ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(sl.input_ch, NV));
+    tp_launch(ctx, sl, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, out, s);
     return check_launch();
 }
 
@@ -167,14 +181,8 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const 
         const neo_tp_level_out* lo = level == 0 ? level0 : level1;
         const MlpSlot& fg = ctx->tp[level];
         const MlpSlot& bg = ctx->tp[2 + level];
-        neo::TpMlpDev mfg{fg.wpack.as<float>(), fg.bias.as<float>(), fg.heads.as<float>()};
-        neo::TpMlpDev mbg{bg.wpack.as<float>(), bg.bias.as<float>(), bg.heads.as<float>()};
-        ctx->span_begin(s);
-        neo::launch_tp_mlp(3, mfg, sc, views, rays_o, rays_d, viewdirs, fg_t, nullptr, R, N, chunk, ctx->flags, fg_out, s);
-        ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(3, NV));
-        ctx->span_begin(s);
-        neo::launch_tp_mlp(4, mbg, sc, views, rays_o, rays_d, viewdirs, bg_s, far, R, N, chunk, ctx->flags, bg_out, s);
-        ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(4, NV));
+        tp_launch(ctx, fg, sc, views, rays_o, rays_d, viewdirs, fg_t, nullptr, R, N, chunk, fg_out, s);
+        tp_launch(ctx, bg, sc, views, rays_o, rays_d, viewdirs, bg_s, far, R, N, chunk, bg_out, s);
         float* fg_rgb = (lo && lo->fg_rgb) ? lo->fg_rgb : s_fg_rgb;
         float* bg_rgb = (lo && lo->bg_rgb) ? lo->bg_rgb : s_bg_rgb;
         float* fg_acc = (lo && lo->fg_acc) ? lo->fg_acc : s_fg_acc;

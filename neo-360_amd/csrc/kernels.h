@@ -105,6 +105,18 @@ int launch_mip_resample(const float* s_prev, const float* w_prev, int n_prev, in
 void launch_mip_composite(const float* rgbdens, const float* tdist, const float* rays_d, int R, int n, float bg,
                           float* weights, float* rgb, hipStream_t s);
 
+// mlp_tp_h.hip — the NeO-360 evaluator on the fp16 matrix cores (hi/lo-split operands, fp32-equivalent)
+struct TpMlpHDev {
+    const void* wpack;    // fp16 hi/lo fragments
+    const float* bias;    // shared with the fp32 path
+    const float* heads;
+};
+size_t tp_wpack_h_bytes(int input_ch);
+void launch_tp_pack_h(int input_ch, const float* const* w, void* wpack_h, hipStream_t s);
+void launch_tp_mlp_h(int input_ch, const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+                     const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
+                     int chunk, uint32_t* flags, float* out, hipStream_t s);
+
 // sampling.hip — NeO-360 level-0 sample rows and fg/bg merge
 void launch_tp_level0(const float* far, const float* edges, int R, int N, float near, float* fg_t, float* bg_s,
                       hipStream_t s);

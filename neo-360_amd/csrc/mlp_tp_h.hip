@@ -1,0 +1,487 @@
+// NeO-360 decoder point evaluator on the fp16 matrix cores with hi/lo-split fp32 operands
+// (fp32-equivalent arithmetic, see mlp_vanilla_h.hip for the numerics): the structure of
+// mlp_tp.hip — per 64-point tile, looped over the source views: descriptors, the 703/724-wide
+// input streamed 64 features at a time into a double-buffered LDS tile while the previous stage
+// is multiplied, L0 || L3-skip as one 256-wide GEMM, L1, L2, L3, bottleneck, view layer 0, running
+// view means in registers — with every LDS tile stored as two fp16 planes (hi, lo) and every
+// product evaluated as a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16.
+// The gathered features are blended in fp32 and split once when they are written to the stage tile.
+// This translation unit is compiled without packed-fp32 VALU ops (build.py:EXTRA_FLAGS): with them, two
+// co-resident workgroups produced run-to-run different values in lanes 48-63 of the blends
+// (profiles/r01_tp_h_race_bisect.log); tests/test_gpu_repeatable.py guards it.
+#include <hip/hip_fp16.h>
+
+#include "tp_common.h"
+
+namespace neo {
+
+namespace {
+
+using tp::TM;
+using tp::blend4;
+using tp::pe_feature;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define NEO_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+struct HT {   // a swizzled fp16 hi/lo tile
+    _Float16* hi;
+    _Float16* lo;
+};
+
+// 16-B chunk (8 halves) `chunk` of row `row` in a tile with LDH halves per row.  The XOR key uses the
+// row bits that do NOT already select the 256-B bank row, so 16 consecutive rows hit 16 different slots.
+template <int LDH>
+__device__ __forceinline__ int chunk_off(int row, int chunk) {
+    constexpr int KEY_SHIFT = LDH == 128 ? 0 : LDH == 64 ? 1 : 2;
+    constexpr int KEY_MASK = LDH / 8 - 1;
+    return row * LDH + ((chunk ^ ((row >> KEY_SHIFT) & KEY_MASK)) << 3);
+}
+
+__device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+__device__ __forceinline__ void split4(const f32x4 v, h4& vh, h4& vl) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split(v[e], h, l);
+        vh[e] = h;
+        vl[e] = l;
+    }
+}
+
+// ---- packed weight layout (h8 units; one (n_tile, k_step) = hi 64 lanes + lo 64 lanes) -------------
+__host__ __device__ constexpr int pe_ksteps(int pe_c) { return pe_c == 3 ? 4 : 6; }
+__host__ __device__ constexpr int ks_x(int pe_c) { return 32 + 8 + pe_ksteps(pe_c); }
+__host__ __device__ constexpr int hoff_x() { return 0; }
+__host__ __device__ constexpr int hoff_1(int pe_c) { return 8 * ks_x(pe_c) * 128; }
+__host__ __device__ constexpr int hoff_2(int pe_c) { return hoff_1(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_3a(int pe_c) { return hoff_2(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_b(int pe_c) { return hoff_3a(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_v0(int pe_c) { return hoff_b(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_v1(int pe_c) { return hoff_v0(pe_c) + 2 * 10 * 128; }
+__host__ __device__ constexpr int hpack_h8(int pe_c) { return hoff_v1(pe_c) + 2 * 4 * 128; }
+constexpr int B_0 = 0, B_3 = 128, B_1 = 256, B_2 = 384, B_B = 512, B_V0 = 640, B_V1 = 704;
+constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 324;
+
+// acc[nt][mt] += W-stage k-steps [ks0, ks0+n) x tile k-steps [tks0, tks0+n); N-tiles nts[], both M-tiles.
+template <int NTW, int LDH>
+__device__ __forceinline__ void gemm2h(f32x16 (&acc)[NTW][2], const h8* __restrict__ wp, int KS, const int (&nts)[NTW],
+                                       int ks0, int tks0, int n, const HT& tile, const LaneCtx& L) {
+    h8 ah[2][NTW], al[2][NTW];
+    auto load_w = [&](int slot, int ks) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const h8* p = wp + ((nts[nt] * KS + ks) * 2) * 64 + L.lane;
+            ah[slot][nt] = p[0];
+            al[slot][nt] = p[64];
+        }
+    };
+    load_w(0, ks0);
+#pragma unroll 1
+    for (int s = 0; s < n; s += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (s + u < n) {
+                if (s + u + 1 < n) load_w((u + 1) & 1, ks0 + s + u + 1);
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<LDH>(mt * 32 + L.l31, ((tks0 + s + u) << 1) + L.half);
+                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[nt][mt] = NEO_MFMA_H(al[u][nt], bh[mt], acc[nt][mt]);
+                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bl[mt], acc[nt][mt]);
+                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
+                    }
+            }
+        }
+    }
+}
+
+// single accumulator tile (nt, mt): the 64-wide view layers
+template <int LDH>
+__device__ __forceinline__ void gemm1h(f32x16& acc, const h8* __restrict__ wp, int KS, int nt, int mt, int ks0, int n,
+                                       const HT& tile, const LaneCtx& L) {
+#pragma unroll 1
+    for (int s = 0; s < n; ++s) {
+        const h8* p = wp + ((nt * KS + ks0 + s) * 2) * 64 + L.lane;
+        const h8 ah = p[0], al = p[64];
+        const int o = chunk_off<LDH>(mt * 32 + L.l31, (s << 1) + L.half);
+        const h8 bh = *reinterpret_cast<const h8*>(tile.hi + o);
+        const h8 bl = *reinterpret_cast<const h8*>(tile.lo + o);
+        acc = NEO_MFMA_H(al, bh, acc);
+        acc = NEO_MFMA_H(ah, bl, acc);
+        acc = NEO_MFMA_H(ah, bh, acc);
+    }
+}
+
+// D tile (N-tile nt, M-tile mt) -> (ReLU) -> split -> the two planes of a [64][128] activation tile
+template <bool RELU>
+__device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, int nt, int mt, const LaneCtx& L) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = acc[4 * g + e];
+            v[e] = RELU ? fmaxf(x, 0.0f) : x;
+        }
+        h4 vh, vl;
+        split4(v, vh, vl);
+        const int o = chunk_off<128>(mt * 32 + L.l31, nt * 4 + g) + 4 * L.half;
+        *reinterpret_cast<h4*>(act.hi + o) = vh;
+        *reinterpret_cast<h4*>(act.lo + o) = vl;
+    }
+}
+
+template <int PE_C>
+__global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, TpViews views,
+                                                      const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d,
+                                                      const float* __restrict__ viewdirs,
+                                                      const float* __restrict__ tvals,
+                                                      const float* __restrict__ far_arr, int R, int N, int chunk,
+                                                      uint32_t* __restrict__ flags, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* hbase = reinterpret_cast<_Float16*>(smem + tp::OFF_ACT);
+    const HT act{hbase, hbase + TM * 128};                                   // [64][128] x 2 planes (32 KB)
+    auto xbuf = [&](int b) { return HT{hbase + b * (2 * TM * 64), hbase + b * (2 * TM * 64) + TM * 64}; };   // aliases act
+    _Float16* dbase = reinterpret_cast<_Float16*>(smem + tp::OFF_DIR);
+    const HT dsm{dbase, dbase + TM * 32};                                    // [64][32] x 2 planes
+    const tp::Scratch S = tp::carve(smem);
+    int* loc_off = S.loc_off;
+    float* loc_w = S.loc_w;
+    int* pl_off = S.pl_off;
+    float* pl_w = S.pl_w;
+    float* cam_enc = S.cam_enc;
+
+    LaneCtx L;
+    L.init();
+    const int tid = threadIdx.x;
+    const long P = (long)R * N;
+    const long tile0 = (long)blockIdx.x * TM;
+    const h8* wp = reinterpret_cast<const h8*>(m.wpack);
+    constexpr int KSX = ks_x(PE_C);
+    constexpr int NST = PE_C == 3 ? 11 : 12;   // streamed stages of 64 features: 8 local, 2 world, 1-2 pos_enc
+
+    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
+    __syncthreads();
+
+    f32x16 hsum[2], ysum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; ysum[r] = 0.f; }
+    const int nts_x[2] = {L.wv, 4 + L.wv};
+    const int nts_1[1] = {L.wv};
+    const int vnt = L.wv & 1, vmt = L.wv >> 1;
+
+#pragma unroll 1
+    for (int v = 0; v < sc.nv; ++v) {
+        const float* rot = views.rot[v];
+        const float* trn = views.trans[v];
+        tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
+            _Float16 h, l;
+            split(val, h, l);
+            const int o = chunk_off<32>(p, f >> 3) + (f & 7);
+            dsm.hi[o] = h;
+            dsm.lo[o] = l;
+        });
+        __syncthreads();
+
+        // ---- streamed-input GEMM: [L0 | L3 skip half] (256 outputs) over 703 / 724 features ----
+        f32x16 accx[2][2];
+        bias_tile(accx[0][0], m.bias + B_0, L.wv, L);
+        accx[0][1] = accx[0][0];
+        bias_tile(accx[1][0], m.bias + B_3, L.wv, L);
+        accx[1][1] = accx[1][0];
+        {
+            const int col4 = tid & 15, rg = tid >> 4;
+            const f32x4* lat4 = reinterpret_cast<const f32x4*>(sc.latent);
+            f32x4 tap[2][4];
+            auto issue_local = [&](int s, int hf) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tap[i][k] = lat4[(long)loc_off[row * 4 + k] * 128 + 16 * s + col4];
+                }
+            };
+            auto issue_plane = [&](int j, int s2, int hf) {
+                const f32x4* pl4 = reinterpret_cast<const f32x4*>(sc.plane[j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        tap[i][k] = pl4[(long)pl_off[(j * TM + row) * 4 + k] * 32 + 16 * s2 + col4];
+                }
+            };
+            // 4 blended fp32 channels -> hi/lo halves of chunk col4/2 (8-byte stores into both planes)
+            auto write_x = [&](const HT& buf, int row, const f32x4 v) {
+                h4 vh, vl;
+                split4(v, vh, vl);
+                const int o = chunk_off<64>(row, col4 >> 1) + 4 * (col4 & 1);
+                *reinterpret_cast<h4*>(buf.hi + o) = vh;
+                *reinterpret_cast<h4*>(buf.lo + o) = vl;
+            };
+            auto finish_local = [&](const HT& buf, int hf) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+                    write_x(buf, row, blend4(tap[i], *reinterpret_cast<const f32x4*>(loc_w + row * 4)));
+                }
+            };
+            auto finish_planes = [&](const HT& buf, int s2, int hf) {
+                f32x4 sum[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    sum[i] = blend4(tap[i], *reinterpret_cast<const f32x4*>(pl_w + (rg + 16 * (2 * hf + i)) * 4));
+#pragma unroll
+                for (int j = 1; j < 3; ++j) {
+                    issue_plane(j, s2, hf);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        sum[i] = sum[i] + blend4(tap[i], *reinterpret_cast<const f32x4*>(pl_w + (j * TM + rg + 16 * (2 * hf + i)) * 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) write_x(buf, rg + 16 * (2 * hf + i), sum[i]);
+            };
+            // pos_enc of the camera-frame point: half hf of a stage = 32 features = chunks 4hf..4hf+3, one per wave
+            auto finish_pe = [&](const HT& buf, int pstage, int hf) {
+                const int row = tid & 63, q = tid >> 6;
+                const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
+                const int ch = hf * 4 + q;
+                h8 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 h, l;
+                    split(pe_feature<PE_C>(xc, pstage * 64 + ch * 8 + e), h, l);
+                    vh[e] = h;
+                    vl[e] = l;
+                }
+                const int o = chunk_off<64>(row, ch);
+                *reinterpret_cast<h8*>(buf.hi + o) = vh;
+                *reinterpret_cast<h8*>(buf.lo + o) = vl;
+            };
+            // prologue: stage 0
+            issue_local(0, 0);
+            finish_local(xbuf(0), 0);
+            issue_local(0, 1);
+            finish_local(xbuf(0), 1);
+            __syncthreads();
+#pragma unroll 1
+            for (int s = 0; s < NST; ++s) {
+                const HT cur = xbuf(s & 1), nxt = xbuf((s + 1) & 1);
+                const int sn = s + 1;
+                const int nks = (PE_C == 4 && s == NST - 1) ? 2 : 4;     // k-steps in this stage
+#pragma unroll 1
+                for (int hf = 0; hf < 2; ++hf) {
+                    if (sn < 8) issue_local(sn, hf);
+                    else if (sn < 10) issue_plane(0, sn - 8, hf);
+                    if (2 * hf < nks) gemm2h<2, 64>(accx, wp + hoff_x(), KSX, nts_x, s * 4 + 2 * hf, 2 * hf, 2, cur, L);
+                    if (sn < 8) finish_local(nxt, hf);
+                    else if (sn < 10) finish_planes(nxt, sn - 8, hf);
+                    else if (sn < NST) finish_pe(nxt, sn - 10, hf);
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- L0 epilogue, L1, L2 ----
+        f32x16 acc[1][2];
+        store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
+        store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
+        __syncthreads();
+#pragma unroll 1
+        for (int layer = 0; layer < 2; ++layer) {
+            bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : B_2), L.wv, L);
+            acc[0][1] = acc[0][0];
+            gemm2h<1, 128>(acc, wp + (layer == 0 ? hoff_1(PE_C) : hoff_2(PE_C)), 8, nts_1, 0, 0, 8, act, L);
+            __syncthreads();
+            store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
+            store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
+            __syncthreads();
+        }
+        // ---- L3 = skip half (in accx[1]) + W3[:, :128] h2; ReLU; accumulate the view mean ----
+        acc[0][0] = accx[1][0];
+        acc[0][1] = accx[1][1];
+        gemm2h<1, 128>(acc, wp + hoff_3a(PE_C), 8, nts_1, 0, 0, 8, act, L);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
+            hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
+        }
+        store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
+        store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
+        __syncthreads();
+        // ---- per-view bottleneck (no activation) ----
+        bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
+        acc[0][1] = acc[0][0];
+        gemm2h<1, 128>(acc, wp + hoff_b(PE_C), 8, nts_1, 0, 0, 8, act, L);
+        __syncthreads();
+        store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
+        store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
+        __syncthreads();
+        // ---- view layer 0: [bottleneck | dir enc] -> 64, summed over views before the ReLU ----
+        {
+            f32x16 y;
+            bias_tile(y, m.bias + B_V0, vnt, L);
+            gemm1h<128>(y, wp + hoff_v0(PE_C), 10, vnt, vmt, 0, 8, act, L);
+            gemm1h<32>(y, wp + hoff_v0(PE_C), 10, vnt, vmt, 8, 2, dsm, L);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ysum[r] += y[r];
+        }
+        __syncthreads();
+    }
+
+    // ---- view mean of the trunk -> density head ----
+    const float nvf = (float)sc.nv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] / nvf; hsum[1][r] = hsum[1][r] / nvf; }
+    store_tile_h<false>(hsum[0], act, L.wv, 0, L);
+    store_tile_h<false>(hsum[1], act, L.wv, 1, L);
+    __syncthreads();
+    float raw_sigma;
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int chunk_i = part * 4 + ((c + part) & 3);
+            const int o = chunk_off<128>(pt, chunk_i);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += ((float)vh[e] + (float)vl[e]) * m.heads[HD_DW + chunk_i * 8 + e];
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        raw_sigma = s + m.heads[HD_DB];
+    }
+    __syncthreads();
+    // ---- view mean of the view branch -> ReLU -> 64x64 -> ReLU -> rgb head ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ysum[r] = ysum[r] / nvf;
+    store_tile_h<true>(ysum, act, vnt, vmt, L);
+    __syncthreads();
+    {
+        f32x16 y;
+        bias_tile(y, m.bias + B_V1, vnt, L);
+        gemm1h<128>(y, wp + hoff_v1(PE_C), 4, vnt, vmt, 0, 4, act, L);
+        __syncthreads();
+        store_tile_h<true>(y, act, vnt, vmt, L);
+    }
+    __syncthreads();
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const float* wr = m.heads + HD_RW;
+        float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int chunk_i = part * 2 + ((c + part) & 1);
+            const int o = chunk_off<128>(pt, chunk_i);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = (float)vh[e] + (float)vl[e];
+                r += h * wr[chunk_i * 8 + e];
+                g += h * wr[64 + chunk_i * 8 + e];
+                b += h * wr[128 + chunk_i * 8 + e];
+            }
+        }
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+        g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        const long gi = tile0 + pt;
+        if (part == 0 && gi < P) {
+            out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
+                                  colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));
+        }
+    }
+}
+
+// fp16 hi/lo fragments of rows [0, rows) of src into N-tiles [nt0, ...) of a stage with KS 16-deep k-steps;
+// packed k -> source column through up to three segments, zero elsewhere.
+__global__ void k_pack_block_h(const float* __restrict__ src, int ld, int rows, int KS, int nt0, PackSegs sg,
+                               _Float16* __restrict__ dst) {
+    const int total = (rows / 32) * KS * 512;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9;
+        const int ks = blk % KS, ntl = blk / KS;
+        const int n = ntl * 32 + (lane & 31);
+        const int k = ks * 16 + 8 * (lane >> 5) + e;
+        float w = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (k >= sg.k0[q] && k < sg.k0[q] + sg.len[q]) w = src[(long)n * ld + sg.col[q] + (k - sg.k0[q])];
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        const long base = ((long)((nt0 + ntl) * KS + ks) * 2) * 512 + lane * 8 + e;
+        dst[base] = hi;
+        dst[base + 512] = lo;
+    }
+}
+
+void pack_h(const float* src, int ld, int rows, int KS, int nt0, PackSegs sg, _Float16* dst, hipStream_t s) {
+    const int total = (rows / 32) * KS * 512;
+    hipLaunchKernelGGL(k_pack_block_h, dim3((total + 255) / 256), dim3(256), 0, s, src, ld, rows, KS, nt0, sg, dst);
+}
+
+}  // namespace
+
+size_t tp_wpack_h_bytes(int input_ch) { return (size_t)hpack_h8(input_ch) * 16; }
+
+void launch_tp_pack_h(int input_ch, const float* const* w, void* wpack_h, hipStream_t s) {
+    // w order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
+    _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
+    const int pe = input_ch * 21;
+    const int x0w = pe + 512 + 128;
+    const int ksx = ks_x(input_ch);
+    const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    PackSegs sx = {{0, 512, 640}, {512, 128, pe}, {pe, pe + 512, 0}};   // packed [local | world | pe] <- [pe | local | world]
+    pack_h(w[0], x0w, 128, ksx, 0, sx, base + (long)hoff_x() * 8, s);
+    PackSegs sx3 = sx;
+    for (int q = 0; q < 3; ++q) sx3.col[q] += 128;
+    pack_h(w[3], 128 + x0w, 128, ksx, 4, sx3, base + (long)hoff_x() * 8, s);
+    PackSegs p128 = none;
+    p128.len[0] = 128;
+    pack_h(w[1], 128, 128, 8, 0, p128, base + (long)hoff_1(input_ch) * 8, s);
+    pack_h(w[2], 128, 128, 8, 0, p128, base + (long)hoff_2(input_ch) * 8, s);
+    pack_h(w[3], 128 + x0w, 128, 8, 0, p128, base + (long)hoff_3a(input_ch) * 8, s);
+    pack_h(w[6], 128, 128, 8, 0, p128, base + (long)hoff_b(input_ch) * 8, s);
+    PackSegs v0 = none;
+    v0.len[0] = 155;
+    pack_h(w[4], 155, 64, 10, 0, v0, base + (long)hoff_v0(input_ch) * 8, s);
+    PackSegs v1 = none;
+    v1.len[0] = 64;
+    pack_h(w[5], 64, 64, 4, 0, v1, base + (long)hoff_v1(input_ch) * 8, s);
+}
+
+void launch_tp_mlp_h(int input_ch, const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+                     const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
+                     int chunk, uint32_t* flags, float* out, hipStream_t s) {
+    const long P = (long)R * N;
+    if (P <= 0) return;
+    const size_t lds = tp::LDS_WORDS * sizeof(float);
+    const long tiles = (P + TM - 1) / TM;
+    if (input_ch == 3)
+        hipLaunchKernelGGL(k_tp_mlp_h<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(k_tp_mlp_h<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+}
+
+}  // namespace neo

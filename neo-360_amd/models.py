@@ -77,16 +77,17 @@ class _HipModule(nn.Module):
         super().__init__()
         self._ctx_cache = {}
 
-    # MLP GEMM arithmetic (vanilla path): "f16x3" = fp16 matrix cores on hi/lo-split fp32 operands
-    # (fp32-equivalent, ~3x faster), "f32" = exact fp32 MFMA.  None -> $NEO360_PRECISION or "f16x3".
+    # MLP GEMM arithmetic: "f16x3" = fp16 matrix cores on hi/lo-split fp32 operands (fp32-equivalent,
+    # ~3x faster), "f32" = exact fp32 MFMA.  None -> $NEO360_PRECISION or the class default.
     precision = None
+    default_precision = "f16x3"
 
     def _context(self, device):
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         ctx = self._ctx_cache.get(key)
         if ctx is None:
             ctx = self._ctx_cache[key] = new_context(device)
-        want = self.precision or os.environ.get("NEO360_PRECISION", "f16x3")
+        want = self.precision or os.environ.get("NEO360_PRECISION", self.default_precision)
         if getattr(ctx, "_precision", None) != want:
             ctx.set_precision(want)
             ctx._precision = want

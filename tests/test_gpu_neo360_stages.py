@@ -18,11 +18,13 @@ TOL = 1e-4
 R, NC, NF = 192, 128, 256
 
 
-@pytest.fixture(scope="module")
-def setup():
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def setup(request):
+    """Both point-evaluator kernels (split-fp16 matrix cores = default, exact fp32 MFMA) against the oracle."""
     params = synth.nerf_tp_state(0)
     scene = cases.small_scene()
     net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
+    net.precision = request.param
     net.load_state_dict(params)
     net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
                   scene["latent"].to(DEV), scene["image_wh"])
