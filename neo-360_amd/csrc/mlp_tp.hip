@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
 
     LaneCtx L;
     L.init();
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const long P = (long)R * N;
     const long tile0 = (long)blockIdx.x * TM;
     const f32x4* wp = reinterpret_cast<const f32x4*>(m.wpack);
@@ -171,6 +171,13 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
 
 #pragma unroll 1
     for (int v = 0; v < sc.nv; ++v) {
+        // per-lane indices re-derived from an opaque lane id each view: keeps the swizzled LDS addresses of
+        // the loop body from being hoisted and spilled (see mlp_tp_h.hip)
+        asm volatile("" : "+v"(tid));
+        L.lane = tid & 63;
+        L.half = L.lane >> 5;
+        L.l31 = L.lane & 31;
+        L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
         tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) { dsm[swz_index<DIR_LD, 7>(p, f)] = val; });
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
         accx[1][1] = accx[1][0];
         {
             const int col4 = tid & 15, rg = tid >> 4;
-            const f32x4* lat4 = reinterpret_cast<const f32x4*>(sc.latent);
+            const uint32_t lane_b = 16u * col4;      // this lane's 4 channels inside a 64-channel stage slice
             // Each 64-feature stage is produced in two half-tiles (32 rows each) so only 8 taps
             // (32 VGPR) are in flight: issue half A of stage s+1 | MFMA chunks 0-3 of stage s |
             // blend+write A | issue half B | MFMA chunks 4-7 | blend+write B | barrier.
@@ -194,17 +201,16 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
                 for (int i = 0; i < 2; ++i) {
                     const int row = rg + 16 * (2 * hf + i);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) tap[i][k] = lat4[(long)loc_off[row * 4 + k] * 128 + 16 * s + col4];
+                    for (int k = 0; k < 4; ++k) tap[i][k] = tp::load_tap(sc.latent, (uint32_t)loc_off[row * 4 + k] + lane_b + 256u * s);
                 }
             };
             auto issue_plane = [&](int j, int s2, int hf) {
-                const f32x4* pl4 = reinterpret_cast<const f32x4*>(sc.plane[j]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = rg + 16 * (2 * hf + i);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        tap[i][k] = pl4[(long)pl_off[(j * TM + row) * 4 + k] * 32 + 16 * s2 + col4];
+                        tap[i][k] = tp::load_tap(sc.plane[j], (uint32_t)pl_off[(j * TM + row) * 4 + k] + lane_b + 256u * s2);
                 }
             };
             auto write_x = [&](float* buf, int row, const f32x4 v) {

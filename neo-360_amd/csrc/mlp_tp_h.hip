@@ -42,7 +42,7 @@ __device__ __forceinline__ int chunk_off(int row, int chunk) {
 
 __device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
+    lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);      // x - hi, exact; one mixed-precision fma
 }
 
 __device__ __forceinline__ void split4(const f32x4 v, h4& vh, h4& vl) {
@@ -145,6 +145,28 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, i
     }
 }
 
+// this lane's share of w_d . h for its point: point = 16 wave + lane/4, lane%4 picks 32 of the 128 channels
+__device__ __forceinline__ float density_partial(const HT& act, const float* __restrict__ dens_w, const LaneCtx& L) {
+    const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int chunk_i = part * 4 + ((c + part) & 3);
+        const int o = chunk_off<128>(pt, chunk_i);
+        const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+        const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(dens_w + chunk_i * 8);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(dens_w + chunk_i * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float w = e < 4 ? w0[e] : w1[e - 4];
+            s = __builtin_fmaf((float)vh[e], w, s);
+            s = __builtin_fmaf((float)vl[e], w, s);
+        }
+    }
+    return s;
+}
+
 template <int PE_C>
 __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, TpViews views,
                                                       const float* __restrict__ rays_o,
@@ -168,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
 
     LaneCtx L;
     L.init();
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const long P = (long)R * N;
     const long tile0 = (long)blockIdx.x * TM;
     const h8* wp = reinterpret_cast<const h8*>(m.wpack);
@@ -178,15 +200,29 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     __syncthreads();
 
-    f32x16 hsum[2], ysum;
+    // view means: the 64-wide view-branch pre-activation is summed in registers; the density head is linear
+    // in the view mean of the trunk output, so each view adds its own dot product w_d . relu(L3_v) instead of
+    // keeping a 128-wide running sum (32 VGPRs) alive across the whole view loop
+    f32x16 ysum;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; ysum[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) ysum[r] = 0.f;
+    float sig_part = 0.f;
+    float* dens_w = smem + tp::OFF_DENSW;
+    if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
     const int nts_x[2] = {L.wv, 4 + L.wv};
     const int nts_1[1] = {L.wv};
     const int vnt = L.wv & 1, vmt = L.wv >> 1;
 
 #pragma unroll 1
     for (int v = 0; v < sc.nv; ++v) {
+        // Re-derive the per-lane indices inside the loop from an opaque lane id: otherwise every swizzled LDS
+        // address of the loop body is hoisted as a loop invariant and ~40 of them are spilled to scratch
+        // (44 KB of scratch stores per tile x 1.2 M tiles per launch shows up as HBM write traffic).
+        asm volatile("" : "+v"(tid));
+        L.lane = tid & 63;
+        L.half = L.lane >> 5;
+        L.l31 = L.lane & 31;
+        L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
         tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
@@ -206,24 +242,23 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
         accx[1][1] = accx[1][0];
         {
             const int col4 = tid & 15, rg = tid >> 4;
-            const f32x4* lat4 = reinterpret_cast<const f32x4*>(sc.latent);
+            const uint32_t lane_b = 16u * col4;      // this lane's 4 channels inside a 64-channel stage slice
             f32x4 tap[2][4];
             auto issue_local = [&](int s, int hf) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = rg + 16 * (2 * hf + i);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) tap[i][k] = lat4[(long)loc_off[row * 4 + k] * 128 + 16 * s + col4];
+                    for (int k = 0; k < 4; ++k) tap[i][k] = tp::load_tap(sc.latent, (uint32_t)loc_off[row * 4 + k] + lane_b + 256u * s);
                 }
             };
             auto issue_plane = [&](int j, int s2, int hf) {
-                const f32x4* pl4 = reinterpret_cast<const f32x4*>(sc.plane[j]);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = rg + 16 * (2 * hf + i);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        tap[i][k] = pl4[(long)pl_off[(j * TM + row) * 4 + k] * 32 + 16 * s2 + col4];
+                        tap[i][k] = tp::load_tap(sc.plane[j], (uint32_t)pl_off[(j * TM + row) * 4 + k] + lane_b + 256u * s2);
                 }
             };
             // 4 blended fp32 channels -> hi/lo halves of chunk col4/2 (8-byte stores into both planes)
@@ -273,7 +308,43 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
                 *reinterpret_cast<h8*>(buf.hi + o) = vh;
                 *reinterpret_cast<h8*>(buf.lo + o) = vl;
             };
+            // Weights of one half stage (2 k-steps x 2 N-tiles, hi + lo) live in registers.  vmcnt retires in
+            // order, so the schedule per half stage is: gather loads for the NEXT stage, MFMAs on the weights
+            // fetched during the previous half stage, weight loads for the next half stage, then blend the
+            // gathered taps (waits only for the taps: the younger weight loads stay in flight).
+            h8 wh[2][2], wl[2][2];
+            auto load_wx = [&](int h) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const h8* p = wp + hoff_x() + ((nts_x[nt] * KSX + 2 * h + u) * 2) * 64 + L.lane;
+                        wh[u][nt] = p[0];
+                        wl[u][nt] = p[64];
+                    }
+            };
+            auto mma_x = [&](const HT& tile, int tks0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    h8 bh[2], bl[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int o = chunk_off<64>(mt * 32 + L.l31, ((tks0 + u) << 1) + L.half);
+                        bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                        bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            accx[nt][mt] = NEO_MFMA_H(wl[u][nt], bh[mt], accx[nt][mt]);
+                            accx[nt][mt] = NEO_MFMA_H(wh[u][nt], bl[mt], accx[nt][mt]);
+                            accx[nt][mt] = NEO_MFMA_H(wh[u][nt], bh[mt], accx[nt][mt]);
+                        }
+                }
+            };
             // prologue: stage 0
+            load_wx(0);
             issue_local(0, 0);
             finish_local(xbuf(0), 0);
             issue_local(0, 1);
@@ -288,7 +359,13 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
                 for (int hf = 0; hf < 2; ++hf) {
                     if (sn < 8) issue_local(sn, hf);
                     else if (sn < 10) issue_plane(0, sn - 8, hf);
-                    if (2 * hf < nks) gemm2h<2, 64>(accx, wp + hoff_x(), KSX, nts_x, s * 4 + 2 * hf, 2 * hf, 2, cur, L);
+                    if (2 * hf < nks) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_x(cur, 2 * hf);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (2 * (2 * s + hf + 1) < KSX) load_wx(2 * s + hf + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (sn < 8) finish_local(nxt, hf);
                     else if (sn < 10) finish_planes(nxt, sn - 8, hf);
                     else if (sn < NST) finish_pe(nxt, sn - 10, hf);
@@ -317,14 +394,10 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
         acc[0][1] = accx[1][1];
         gemm2h<1, 128>(acc, wp + hoff_3a(PE_C), 8, nts_1, 0, 0, 8, act, L);
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
-            hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
-        }
         store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
         store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
         __syncthreads();
+        sig_part += density_partial(act, dens_w, L);
         // ---- per-view bottleneck (no activation) ----
         bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
         acc[0][1] = acc[0][0];
@@ -345,31 +418,15 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
         __syncthreads();
     }
 
-    // ---- view mean of the trunk -> density head ----
+    // ---- density head: mean over views of the per-view dot products ----
     const float nvf = (float)sc.nv;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] / nvf; hsum[1][r] = hsum[1][r] / nvf; }
-    store_tile_h<false>(hsum[0], act, L.wv, 0, L);
-    store_tile_h<false>(hsum[1], act, L.wv, 1, L);
-    __syncthreads();
     float raw_sigma;
     {
-        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int chunk_i = part * 4 + ((c + part) & 3);
-            const int o = chunk_off<128>(pt, chunk_i);
-            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
-            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += ((float)vh[e] + (float)vl[e]) * m.heads[HD_DW + chunk_i * 8 + e];
-        }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        raw_sigma = s + m.heads[HD_DB];
+        float sg = sig_part;
+        sg += __shfl_xor(sg, 1, 64);
+        sg += __shfl_xor(sg, 2, 64);
+        raw_sigma = sg / nvf + m.heads[HD_DB];
     }
-    __syncthreads();
     // ---- view mean of the view branch -> ReLU -> 64x64 -> ReLU -> rgb head ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) ysum[r] = ysum[r] / nvf;

@@ -23,7 +23,8 @@ constexpr int OFF_CAM = OFF_PL_W + 3 * TM * 4;           // float[64][4]: camera
 constexpr int OFF_PE = OFF_CAM + TM * 4;                 // float[64][4]: world point to encode (+1/r)
 constexpr int OFF_FEAT = OFF_PE + TM * 4;                // float[64][4]: world point for feature lookups
 constexpr int OFF_VDIR = OFF_FEAT + TM * 4;              // float[64][4]: world view direction (Q1-indexed ray)
-constexpr int LDS_WORDS = OFF_VDIR + TM * 4;
+constexpr int OFF_DENSW = OFF_VDIR + TM * 4;             // float[128]: density-head weights (split-fp16 kernel)
+constexpr int LDS_WORDS = OFF_DENSW + 128;
 
 struct Scratch {
     int* loc_off; float* loc_w; int* pl_off; float* pl_w;
@@ -48,7 +49,9 @@ struct TapSet {
 };
 
 // Bilinear taps of F.grid_sample(align_corners=True, padding zeros) at normalised (gx, gy)
-// on a Wd x Hd map; offsets in texels, invalid taps get weight 0 / offset 0.
+// on a Wd x Hd map; offsets in texels, invalid taps get weight 0 / offset 0.  (view_descriptors turns
+// the texel indices into BYTE offsets of the channels-last maps: x2048 for the 512-channel latent,
+// x512 for the 128-channel planes; the largest, 3x240x320x2048 B, fits 32 bits.)
 // Tap order nw, ne, sw, se; weights (x1-x)(y1-y), (x-x0)(y1-y), (x1-x)(y-y0), (x-x0)(y-y0).
 __device__ __forceinline__ TapSet bilinear_taps(float gx, float gy, int Wd, int Hd) {
     const float x = ((gx + 1.0f) / 2.0f) * (float)(Wd - 1);
@@ -69,12 +72,24 @@ __device__ __forceinline__ TapSet bilinear_taps(float gx, float gy, int Wd, int 
 }
 
 __device__ __forceinline__ f32x4 blend4(const f32x4 (&tap)[4], const f32x4 w) {
-    // nw*w0 + ne*w1 + sw*w2 + se*w3, accumulated in that order (separate multiply / add)
-    f32x4 v = tap[0] * w[0];
-    v = v + tap[1] * w[1];
-    v = v + tap[2] * w[2];
-    v = v + tap[3] * w[3];
+    // nw*w0 + ne*w1 + sw*w2 + se*w3, accumulated in that order; fused multiply-adds (one rounding per
+    // tap instead of torch's two: the blends differ from grid_sample's by <= 1 ulp of the feature)
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = tap[0][e] * w[0];
+        a = __builtin_fmaf(tap[1][e], w[1], a);
+        a = __builtin_fmaf(tap[2][e], w[2], a);
+        a = __builtin_fmaf(tap[3][e], w[3], a);
+        v[e] = a;
+    }
     return v;
+}
+
+// 16 B of gathered features at byte offset `off` (32-bit) from a uniform base: the address stays
+// SGPR base + one VGPR offset instead of 64-bit per-lane pointer arithmetic
+__device__ __forceinline__ f32x4 load_tap(const float* __restrict__ base, uint32_t off) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
 }
 
 // feature f of the positional encoding of a C-vector x (C = 3 or 4, 10 octaves): pad -> 0
@@ -179,7 +194,7 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
             TapSet t;
             int* dst_off;
             float* dst_w;
-            int base;
+            int base, texel_bytes;
             if (L.wv == 0) {
                 // pixel-aligned latent (neo360/model.py:239-264, encoder_pn.py:116-150), view 0's intrinsics
                 const float den = cz_ + 1e-9f;
@@ -188,6 +203,7 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 t = bilinear_taps(u * sc.sx - 1.0f, w_ * sc.sy - 1.0f, sc.Wf, sc.Hf);
                 dst_off = loc_off; dst_w = loc_w;
                 base = v * sc.Hf * sc.Wf;
+                texel_bytes = 512 * 4;
                 // camera-frame point that gets encoded (fg: same point; bg: the unit-sphere point)
                 const float ex = pe_world[p * 4], ey = pe_world[p * 4 + 1], ez = pe_world[p * 4 + 2];
                 cam_enc[p * 4 + 0] = (rot[0] * ex + rot[1] * ey + rot[2] * ez) + trn[0];
@@ -202,9 +218,10 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 t = bilinear_taps(ga, gb, sc.Wp, sc.Hp);
                 dst_off = pl_off + (L.wv - 1) * TM * 4; dst_w = pl_w + (L.wv - 1) * TM * 4;
                 base = v * sc.Hp * sc.Wp;
+                texel_bytes = 128 * 4;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { dst_off[p * 4 + k] = base + t.off[k]; dst_w[p * 4 + k] = t.w[k]; }
+            for (int k = 0; k < 4; ++k) { dst_off[p * 4 + k] = (base + t.off[k]) * texel_bytes; dst_w[p * 4 + k] = t.w[k]; }
             // view-direction encoding in this view's camera frame; wave q takes octave q
             const float dx = vdir_world[p * 4], dy = vdir_world[p * 4 + 1], dz = vdir_world[p * 4 + 2];
             const float dc[3] = {rot[0] * dx + rot[1] * dy + rot[2] * dz, rot[3] * dx + rot[4] * dy + rot[5] * dz,

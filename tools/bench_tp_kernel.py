@@ -1,0 +1,44 @@
+"""Micro-benchmark of the NeO-360 point-evaluator kernel alone (env: PREC=f16x3|f32, R, N, SLOT, REPS).
+Same synthetic scene as bench.py --workload neo360 (3 source views, 240x320 latent, 120x160 planes)."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neo360_amd import models, synth, ops
+torch.set_grad_enabled(False)
+dev = torch.device("cuda")
+PREC = os.environ.get("PREC", "f16x3")
+R, N = int(os.environ.get("R", 8192)), int(os.environ.get("N", 385))
+SLOT, REPS = int(os.environ.get("SLOT", 1)), int(os.environ.get("REPS", 3))
+NV = 3
+net = models.NeRF_TP(num_src_views=NV).to(dev)
+net.precision = PREC
+net.load_state_dict(synth.nerf_tp_state(0))
+H, W, focal = 480, 640, 512.0
+g = torch.Generator(device=dev); g.manual_seed(0)
+planes = [torch.randn(NV, 128, 120, 160, device=dev, generator=g) * 0.1 for _ in range(3)]
+latent = torch.randn(NV, 512, 240, 320, device=dev, generator=g) * 0.1
+net.set_scene(planes[0], planes[1], planes[2], latent, (float(W), float(H)))
+c2w = synth.look_at_origin(40.0)
+ro, vd, rd, _ = ops.get_ray_directions_and_rays(H, W, focal, c2w)
+sel = torch.randperm(H * W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))[:R]
+poses, sfocal, centre = synth.source_views(NV, W, H)
+rays = {"rays_o": ro[sel].contiguous(), "rays_d": rd[sel].contiguous(), "viewdirs": vd[sel].contiguous(),
+        "src_poses": poses.to(dev), "src_focal": sfocal.to(dev), "src_c": centre.to(dev)}
+far, _ = ops.intersect_sphere(rays["rays_o"], rays["rays_d"])
+if SLOT < 2:
+    t = torch.linspace(0.02, 0.98, N, device=dev)[None, :] * far.reshape(-1, 1)
+else:
+    t = torch.linspace(0.98, 0.02, N, device=dev)[None, :].expand(R, N).contiguous()
+for _ in range(1):
+    net.eval_mlp(SLOT, rays, t, far=far)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(REPS):
+    out = net.eval_mlp(SLOT, rays, t, far=far)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / REPS
+pe = 63 if SLOT < 2 else 84
+macs = NV * ((pe + 640) * 128 + 2 * 128 * 128 + (pe + 640 + 128) * 128 + 128 * 128 + 155 * 64) + 128 + 64 * 64 + 64 * 3
+print("%s %s slot %d R=%d N=%d  %.2f ms  %.1f algorithmic TFLOP/s  checksum %.6f" % (
+    os.environ.get("TAG", ""), PREC, SLOT, R, N, dt * 1e3, R * N * macs * 2 / dt / 1e12, float(out.double().sum())))
