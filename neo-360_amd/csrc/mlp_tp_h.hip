@@ -11,6 +11,8 @@
 // (profiles/r01_tp_h_race_bisect.log); tests/test_gpu_repeatable.py guards it.
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "tp_common.h"
 
 namespace neo {
@@ -313,15 +315,22 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
             // fetched during the previous half stage, weight loads for the next half stage, then blend the
             // gathered taps (waits only for the taps: the younger weight loads stay in flight).
             h8 wh[2][2], wl[2][2];
+            // byte offsets of this lane's fragments of k-step 0 for the wave's two N-tiles; one half stage is
+            // 4 KB further along each N-tile's stream (2 k-steps x (hi 1 KB + lo 1 KB)): SGPR base + VGPR offset
+            const char* wxb = reinterpret_cast<const char*>(wp + hoff_x());
+            uint32_t wx_off[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wx_off[nt] = (uint32_t)(nts_x[nt] * KSX * 2 * 64 + L.lane) * 16u;
             auto load_wx = [&](int h) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint32_t o = wx_off[nt] + 4096u * h;
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const h8* p = wp + hoff_x() + ((nts_x[nt] * KSX + 2 * h + u) * 2) * 64 + L.lane;
-                        wh[u][nt] = p[0];
-                        wl[u][nt] = p[64];
+                    for (int u = 0; u < 2; ++u) {
+                        wh[u][nt] = *reinterpret_cast<const h8*>(wxb + (o + 2048u * u));
+                        wl[u][nt] = *reinterpret_cast<const h8*>(wxb + (o + 2048u * u + 1024u));
                     }
+                }
             };
             auto mma_x = [&](const HT& tile, int tks0) {
 #pragma unroll
@@ -343,6 +352,25 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
                         }
                 }
             };
+            // One half stage: kind of the NEXT stage's producer is a compile-time constant, so each of the
+            // four loop bodies below is straight-line code (no tap registers carried through branches).
+            constexpr int K_LOCAL = 0, K_PLANE = 1, K_PE = 2, K_NONE = 3;
+            auto half_stage = [&](int s, int hf, auto kind_c) {
+                constexpr int kind = decltype(kind_c)::value;
+                const HT cur = xbuf(s & 1), nxt = xbuf((s + 1) & 1);
+                const int sn = s + 1;
+                if constexpr (kind == K_LOCAL) issue_local(sn, hf);
+                if constexpr (kind == K_PLANE) issue_plane(0, sn - 8, hf);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_x(cur, 2 * hf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (2 * (2 * s + hf + 1) < KSX) load_wx(2 * s + hf + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kind == K_LOCAL) finish_local(nxt, hf);
+                if constexpr (kind == K_PLANE) finish_planes(nxt, sn - 8, hf);
+                if constexpr (kind == K_PE) finish_pe(nxt, sn - 10, hf);
+            };
+            using std::integral_constant;
             // prologue: stage 0
             load_wx(0);
             issue_local(0, 0);
@@ -351,27 +379,26 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
             finish_local(xbuf(0), 1);
             __syncthreads();
 #pragma unroll 1
-            for (int s = 0; s < NST; ++s) {
-                const HT cur = xbuf(s & 1), nxt = xbuf((s + 1) & 1);
-                const int sn = s + 1;
-                const int nks = (PE_C == 4 && s == NST - 1) ? 2 : 4;     // k-steps in this stage
+            for (int s = 0; s < 7; ++s) {            // stages 0..6 multiply while local stages 1..7 are gathered
 #pragma unroll 1
-                for (int hf = 0; hf < 2; ++hf) {
-                    if (sn < 8) issue_local(sn, hf);
-                    else if (sn < 10) issue_plane(0, sn - 8, hf);
-                    if (2 * hf < nks) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        mma_x(cur, 2 * hf);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (2 * (2 * s + hf + 1) < KSX) load_wx(2 * s + hf + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (sn < 8) finish_local(nxt, hf);
-                    else if (sn < 10) finish_planes(nxt, sn - 8, hf);
-                    else if (sn < NST) finish_pe(nxt, sn - 10, hf);
-                }
+                for (int hf = 0; hf < 2; ++hf) half_stage(s, hf, integral_constant<int, K_LOCAL>());
                 __syncthreads();
             }
+#pragma unroll 1
+            for (int s = 7; s < 9; ++s) {            // stages 7, 8: the tri-plane stages 8, 9 are gathered
+#pragma unroll 1
+                for (int hf = 0; hf < 2; ++hf) half_stage(s, hf, integral_constant<int, K_PLANE>());
+                __syncthreads();
+            }
+#pragma unroll 1
+            for (int s = 9; s < NST - 1; ++s) {      // stage 9 (and 10 for the 84-wide encoding): pos_enc stages
+#pragma unroll 1
+                for (int hf = 0; hf < 2; ++hf) half_stage(s, hf, integral_constant<int, K_PE>());
+                __syncthreads();
+            }
+            half_stage(NST - 1, 0, integral_constant<int, K_NONE>());
+            if (PE_C == 3) half_stage(NST - 1, 1, integral_constant<int, K_NONE>());   // (the 84-wide encoding ends with a 2-k-step stage)
+            __syncthreads();
         }
 
         // ---- L0 epilogue, L1, L2 ----
