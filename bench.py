@@ -124,8 +124,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("vanilla", "neo360", "mip360", "mip360_128"), default="vanilla")
     ap.add_argument("--precision", choices=("auto", "f32", "f16x3"), default="auto",
-                    help="vanilla / neo360 MLP arithmetic: exact fp32 MFMA, or fp16 MFMA with hi/lo-split operands "
-                         "(fp32-equivalent); mip360 runs on fp32 MFMA")
+                    help="MLP arithmetic: exact fp32 MFMA, or fp16 MFMA with hi/lo-split operands (fp32-equivalent, "
+                         "the default of every renderer)")
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays in the CPU-baseline sample (0 = skip, -1 = default)")
     args = ap.parse_args()
 
@@ -152,10 +152,9 @@ def main():
     net, state, extra, scene, desc, kw, kernel_name, cpu_default = built
     if args.precision == "auto":
         args.precision = getattr(net, "default_precision", "f32")
-    split = args.workload in ("vanilla", "neo360") and args.precision == "f16x3"
-    if args.workload in ("vanilla", "neo360"):
-        net.precision = args.precision
-        kernel_name = kernel_name + "_h" if split else kernel_name
+    split = args.precision == "f16x3"
+    net.precision = args.precision
+    kernel_name = kernel_name + "_h" if split else kernel_name
     c2w = synth.look_at_origin(40.0)
     R = H * W
     ctx = net._context(dev)

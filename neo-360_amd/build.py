@@ -23,8 +23,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=
 # returned wrong values in lanes 48-63 for ~0.3 % of the points, differently on every launch; one workgroup
 # per CU, or the same code with scalar fp32 VALU ops, is bitwise repeatable.  The fp32-MFMA kernels and the
 # vanilla split kernel are repeatable as built (tests/test_gpu_repeatable.py keeps checking all of them).
+_NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {
-    "mlp_tp_h.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"],
+    "mlp_tp_h.hip": _NO_PK_F32,
+    "mlp_mip_h.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
 }
 
 

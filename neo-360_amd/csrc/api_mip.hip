@@ -14,10 +14,16 @@ int mip_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* ray
                    const float* radii, const float* tdist, int R, int n, float* out, hipStream_t s) {
     const MlpSlot& sl = ctx->mip[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "MipNeRF360 MLP slot %d has no weights", slot);
-    neo::MipMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>()};
     const int* sh = ctx->mip_shape[slot];
     ctx->span_begin(s);
-    const int rc = neo::launch_mip_mlp(sh[0], sh[1], sh[2], m, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
+    int rc;
+    if (ctx->precision == 1) {      // split-fp16 matrix cores (fp32-equivalent), neo_ctx_set_precision
+        neo::MipMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>()};
+        rc = neo::launch_mip_mlp_h(sh[0], sh[1], sh[2], mh, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
+    } else {
+        neo::MipMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>()};
+        rc = neo::launch_mip_mlp(sh[0], sh[1], sh[2], m, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
+    }
     ctx->span_end(s, static_cast<double>(R) * n, mip_flop_per_point(sh[0], sh[2]));
     if (rc) return fail(NEO_ERR_INVALID, "unsupported MipNeRF360 MLP shape");
     return check_launch();
@@ -43,8 +49,10 @@ int neo_mip_upload_mlp(neo_ctx* ctx, int slot, int width, int depth, int rgb, co
     if (sl.heads.reserve(neo::mip_heads_floats(width) * sizeof(float))) return NEO_ERR_NOMEM;
     if (ctx->mip_basis.reserve(63 * sizeof(float))) return NEO_ERR_NOMEM;
     neo::copy_floats(basis, 63, ctx->mip_basis.as<float>(), s);
+    if (sl.wpack_h.reserve(neo::mip_wpack_h_bytes(width, depth, rgb))) return NEO_ERR_NOMEM;
     neo::launch_mip_pack(width, depth, rgb, weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(),
                          sl.heads.as<float>(), s);
+    neo::launch_mip_pack_h(width, depth, rgb, weights, sl.wpack_h.p, s);
     ctx->mip_shape[slot][0] = width;
     ctx->mip_shape[slot][1] = depth;
     ctx->mip_shape[slot][2] = rgb;

@@ -87,6 +87,17 @@ struct MipMlpDev {
     const float* heads;
     const float* basis;   // (3,21) row-major
 };
+struct MipMlpHDev {       // split-fp16 fragments (mlp_mip_h.hip); bias / heads / basis shared with MipMlpDev
+    const void* wpack;
+    const float* bias;
+    const float* heads;
+    const float* basis;
+};
+size_t mip_wpack_h_bytes(int width, int depth, int rgb);
+void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, void* wpack_h, hipStream_t s);
+int launch_mip_mlp_h(int width, int depth, int rgb, const MipMlpHDev& m, const float* rays_o, const float* rays_d,
+                     const float* viewdirs, const float* radii, const float* tdist, int R, int n, float* out,
+                     hipStream_t s);
 size_t mip_wpack_floats(int width, int depth, int rgb);
 size_t mip_bias_floats(int width, int depth, int rgb);
 size_t mip_heads_floats(int width);

@@ -1,0 +1,434 @@
+// Mip-NeRF 360 point evaluator on the fp16 matrix cores with hi/lo-split fp32 operands
+// (models/mipnerf360/model.py:30-176 + helper.py:33-88, 278-370; structure of mlp_mip.hip, arithmetic of
+// split_tile.h): conical frustum -> Gaussian -> contraction -> 21-direction lift -> 504-d integrated
+// positional encoding -> PropMLP 4x256 or NeRFMLP 8x1024 (+ bottleneck / view / rgb branch) -> activations.
+//
+// tile = 32 intervals, workgroup = 8 waves.  The 32 x W activation tile lives in LDS as two fp16 planes
+// (128 KB at W = 1024, same footprint as the fp32 tile of mlp_mip.hip), every wave owns W/8 outputs
+// (4 accumulator tiles at W = 1024).  The encoding is recomputed 64 features at a time into a
+// double-buffered stage tile for layer 0 and for the skip layer.  Weights stream from L2 as split
+// fragments (hi | lo per k-step: the same bytes as fp32); per 16-deep k-step a wave issues 3 MFMAs per
+// accumulator tile.  Compiled without packed-fp32 VALU ops like mlp_tp_h.hip (build.py:EXTRA_FLAGS).
+//
+// Algorithmic work: PropMLP 325,888 MAC, NeRFMLP 8,672,000 MAC per interval.
+#include "split_tile.h"
+
+namespace neo {
+
+namespace {
+
+constexpr int TMR = 32;          // rows (intervals) per tile
+constexpr int NB = 21;           // basis directions
+constexpr float EPS32 = 1.1920929e-07f;
+
+// ---- packed layout (h8 units) / bias layout (floats) ------------------------------------------------
+struct MipLayoutH {
+    int w_layer[8];   // h8 offset of trunk layer i
+    int ks_layer[8];  // 16-deep k-steps of layer i
+    int w_bott, w_view;
+    int b_layer[8], b_bott, b_view;
+    int total_h8, total_b;
+};
+
+__host__ __device__ inline MipLayoutH mip_layout_h(int W, int depth, int rgb) {
+    MipLayoutH L{};
+    int ow = 0, ob = 0;
+    for (int i = 0; i < depth; ++i) {
+        const int ks = i == 0 ? 32 : (W / 16 + ((i == 5) ? 32 : 0));     // 504 -> 512 = 32 k-steps
+        L.w_layer[i] = ow;
+        L.ks_layer[i] = ks;
+        L.b_layer[i] = ob;
+        ow += (W / 32) * ks * 128;
+        ob += W;
+    }
+    if (rgb) {
+        L.w_bott = ow; ow += 8 * (W / 16) * 128;    // 256 outputs
+        L.b_bott = ob; ob += 256;
+        L.w_view = ow; ow += 4 * 18 * 128;          // 128 outputs, K = 256 + 27 -> 288 = 18 k-steps
+        L.b_view = ob; ob += 128;
+    }
+    L.total_h8 = ow;
+    L.total_b = ob;
+    return L;
+}
+// closed forms of the per-layer entries (the kernel indexes layers at run time: no private array in scratch)
+__host__ __device__ constexpr int ks_of(int W, int i) { return i == 0 ? 32 : (W / 16 + (i == 5 ? 32 : 0)); }
+__host__ __device__ constexpr int woff_of(int W, int i) {
+    return i == 0 ? 0 : (W / 32) * 128 * (32 + (i - 1) * (W / 16) + (i > 5 ? 32 : 0));
+}
+// heads (fp32): density w[W] | density b (4) | rgb w[3][128] | rgb b (4)   (same as mlp_mip.hip)
+__host__ __device__ inline int hd_db(int W) { return W; }
+__host__ __device__ inline int hd_rw(int W) { return W + 4; }
+__host__ __device__ inline int hd_rb(int W) { return W + 4 + 384; }
+
+// acc[nt] += W-stage k-steps [ks0, ks0+n) x tile k-steps [tks0, tks0+n); N-tiles nt0..nt0+NTW-1, the one M-tile.
+// wb = byte address of the stage's fragments (uniform); fragments are addressed SGPR base + 32-bit VGPR offset.
+template <int NTW, int LDH>
+__device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW], const char* __restrict__ wb, int KS, int nt0, int ks0,
+                                       int tks0, int n, const HT& tile, const LaneCtx& L) {
+    h8 ah[2][NTW], al[2][NTW];
+    uint32_t off[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) off[nt] = (uint32_t)(((nt0 + nt) * KS + ks0) * 128 + L.lane) * 16u;
+    auto load_w = [&](int slot, int s) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            ah[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s));
+            al[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s + 1024u));
+        }
+    };
+    load_w(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < n; s += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (s + u < n) {
+                if (s + u + 1 < n) load_w((u + 1) & 1, s + u + 1);
+                const int o = chunk_off<LDH>(L.l31, ((tks0 + s + u) << 1) + L.half);
+                const h8 bh = *reinterpret_cast<const h8*>(tile.hi + o);
+                const h8 bl = *reinterpret_cast<const h8*>(tile.lo + o);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    acc[nt] = NEO_MFMA_H(al[u][nt], bh, acc[nt]);
+                    acc[nt] = NEO_MFMA_H(ah[u][nt], bl, acc[nt]);
+                    acc[nt] = NEO_MFMA_H(ah[u][nt], bh, acc[nt]);
+                }
+            }
+        }
+    }
+}
+
+template <int W, int DEPTH, bool RGB>
+__global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHDev m, const float* __restrict__ rays_o,
+                                                                        const float* __restrict__ rays_d,
+                                                                        const float* __restrict__ viewdirs,
+                                                                        const float* __restrict__ radii,
+                                                                        const float* __restrict__ tdist, int R, int n,
+                                                                        float4* __restrict__ out) {
+    constexpr int NTW = W / 256;             // N-tiles per wave for W-wide layers (8 waves x NTW x 32 = W)
+    constexpr int KSW = W / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* hb = reinterpret_cast<_Float16*>(smem);
+    const HT act{hb, hb + TMR * W};                                             // [32][W] x 2 planes
+    _Float16* xb = hb + 2 * TMR * W;
+    auto xbuf = [&](int b) { return HT{xb + b * (2 * TMR * 64), xb + b * (2 * TMR * 64) + TMR * 64}; };   // 2 x [32][64] x 2 planes
+    _Float16* db = xb + 4 * TMR * 64;
+    const HT dsm{db, db + TMR * 32};                                            // [32][32] x 2 planes (rgb branch)
+    float* lift = reinterpret_cast<float*>(db + 2 * TMR * 32);                  // [32][44]: 21 lifted means | 21 variances
+    float* rowz = lift + TMR * 44;                                              // [32][12]: contracted mean | covariance
+    LaneCtx L;
+    L.init();
+    int tid = threadIdx.x;
+    const long P = (long)R * n;
+    const long tile0 = (long)blockIdx.x * TMR;
+    constexpr int W_BOTT = woff_of(W, DEPTH - 1) + (W / 32) * ks_of(W, DEPTH - 1) * 128, W_VIEW = W_BOTT + 8 * (W / 16) * 128;
+    constexpr int B_BOTT = DEPTH * W, B_VIEW = B_BOTT + 256;
+    const char* wbase = reinterpret_cast<const char*>(m.wpack);
+
+    // ---- per-row Gaussian, contraction (identical arithmetic to mlp_mip.hip) ---------------------------
+    if (tid < TMR) {
+        long g = tile0 + tid;
+        if (g >= P) g = P - 1;
+        const int ray = (int)(g / n), i = (int)(g - (long)ray * n);
+        const float t0 = tdist[(long)ray * (n + 1) + i], t1 = tdist[(long)ray * (n + 1) + i + 1];
+        float o[3], d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o[a] = rays_o[ray * 3 + a]; d[a] = rays_d[ray * 3 + a]; }
+        const float rad = radii[ray];
+        // conical_frustum_to_gaussian (helper.py:293-306)
+        const float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
+        const float mu2 = mu * mu, hw2 = hw * hw;
+        const float denom = fmaxf(3.0f * mu2 + hw2, EPS32);
+        const float t_mean = mu + (2.0f * mu * hw2) / denom;
+        const float hw4 = hw2 * hw2;
+        const float t_var = hw2 / 3.0f - (4.0f / 15.0f) * hw4 * (12.0f * mu2 - hw2) / (denom * denom);
+        float r_var = mu2 / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / denom;
+        r_var = r_var * (rad * rad);
+        // lift_gaussian, diag=False (helper.py:320-334)
+        float x[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) x[a] = d[a] * t_mean + o[a];
+        const float dm = fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f);
+        float cov[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float outer = d[a] * d[b];
+                const float null_o = (a == b ? 1.0f : 0.0f) - d[a] * (d[b] / dm);
+                cov[a][b] = t_var * outer + r_var * null_o;
+            }
+        // contract (helper.py:33-66): z, J = dz/dx (closed form of the reference's autograd Jacobian)
+        const float msq = fmaxf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2], 1e-32f);
+        float z[3], J[3][3];
+        if (msq <= 1.0f) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                z[a] = x[a];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) J[a][b] = a == b ? 1.0f : 0.0f;
+            }
+        } else {
+            const float rt = sqrtf(msq);
+            const float sc = (2.0f * rt - 1.0f) / msq;
+            const float coef = 2.0f / (msq * rt) - 2.0f * sc / msq;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                z[a] = sc * x[a];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) J[a][b] = (a == b ? sc : 0.0f) + coef * x[a] * x[b];
+            }
+        }
+        float tmp[3][3], cc[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) tmp[a][b] = J[a][0] * cov[0][b] + J[a][1] * cov[1][b] + J[a][2] * cov[2][b];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) cc[a][b] = tmp[a][0] * J[b][0] + tmp[a][1] * J[b][1] + tmp[a][2] * J[b][2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            rowz[tid * 12 + a] = z[a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) rowz[tid * 12 + 3 + a * 3 + b] = cc[a][b];
+        }
+        if (RGB) {
+            // view-direction encoding, append_identity=True (helper.py:92-99): [d | sin(d 2^k) | sin(d 2^k + pi/2)], k<4
+            auto put = [&](int f, float v) {
+                _Float16 h, l;
+                split(v, h, l);
+                const int o2 = chunk_off<32>(tid, f >> 3) + (f & 7);
+                dsm.hi[o2] = h;
+                dsm.lo[o2] = l;
+            };
+            float vd[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { vd[a] = viewdirs[ray * 3 + a]; put(a, vd[a]); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float sn, cs;
+                    enc_pair(vd[a], k, sn, cs);
+                    put(3 + k * 3 + a, sn);
+                    put(15 + k * 3 + a, cs);
+                }
+#pragma unroll
+            for (int f = 27; f < 32; ++f) put(f, 0.0f);
+        }
+    }
+    __syncthreads();
+    // ---- lift_and_diagonalize (helper.py:70-73): mean_j = z . b_j ; var_j = sum_i b_ij (cov b_j)_i ----
+    for (int idx = tid; idx < TMR * NB; idx += 512) {
+        const int row = idx / NB, j = idx - row * NB;
+        const float b0 = m.basis[j], b1 = m.basis[NB + j], b2 = m.basis[2 * NB + j];
+        const float* rz = rowz + row * 12;
+        const float mj = rz[0] * b0 + rz[1] * b1 + rz[2] * b2;
+        float vj = 0.f;
+        const float bb[3] = {b0, b1, b2};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) vj += bb[a] * (rz[3 + a * 3] * b0 + rz[3 + a * 3 + 1] * b1 + rz[3 + a * 3 + 2] * b2);
+        lift[row * 44 + j] = mj;
+        lift[row * 44 + NB + j] = vj;
+    }
+    __syncthreads();
+
+    // integrated_pos_enc (helper.py:77-88): 64 features of stage s; thread = (row, 4 consecutive features)
+    auto produce = [&](int s, const HT& buf) {
+        const int row = tid & 31, q = tid >> 5;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = s * 64 + q * 4 + e;
+            float val = 0.0f;
+            if (f < 504) {
+                const bool shifted = f >= 252;
+                const int g = shifted ? f - 252 : f;
+                const int k = g / NB, j = g - k * NB;
+                const float mean = lift[row * 44 + j], var = lift[row * 44 + NB + j];
+                const float arg = ldexpf(mean, k);
+                val = expf(-0.5f * ldexpf(var, 2 * k)) * sin_cw(shifted ? arg + HALF_PI_F32 : arg);
+            }
+            v[e] = val;
+        }
+        h4 vh, vl;
+        split4(v, vh, vl);
+        const int o = chunk_off<64>(row, q >> 1) + 4 * (q & 1);
+        *reinterpret_cast<h4*>(buf.hi + o) = vh;
+        *reinterpret_cast<h4*>(buf.lo + o) = vl;
+    };
+    // acc += W_layer[:, ksbase .. ksbase + 32 k-steps] * ipe^T, streamed through the double buffer
+    auto stream_ipe = [&](f32x16 (&acc)[NTW], const char* wl, int KS, int ksbase) {
+        produce(0, xbuf(0));
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) produce(s + 1, xbuf((s + 1) & 1));
+            gemm_h<NTW, 64>(acc, wl, KS, L.wv * NTW, ksbase + s * 4, 0, 4, xbuf(s & 1), L);
+            __syncthreads();
+        }
+    };
+
+    f32x16 acc[NTW];
+    // ---- trunk ----
+#pragma unroll 1
+    for (int layer = 0; layer < DEPTH; ++layer) {
+        // per-lane indices re-derived from an opaque lane id: keeps swizzled LDS addresses out of scratch
+        asm volatile("" : "+v"(tid));
+        L.lane = tid & 63;
+        L.half = L.lane >> 5;
+        L.l31 = L.lane & 31;
+        L.key = L.lane & 15;
+        const char* wl = wbase + (size_t)woff_of(W, layer) * 16;
+        const int KS = ks_of(W, layer);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bias_tile(acc[nt], m.bias + layer * W, L.wv * NTW + nt, L);
+        if (layer == 0) {
+            stream_ipe(acc, wl, KS, 0);
+        } else {
+            gemm_h<NTW, W>(acc, wl, KS, L.wv * NTW, 0, 0, KSW, act, L);
+            if (layer == 5) stream_ipe(acc, wl, KS, KSW);    // skip concat: [h | ipe]
+            __syncthreads();
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) store_tile_h<true, W>(acc[nt], act, L.wv * NTW + nt, 0, L);
+        __syncthreads();
+    }
+    // ---- density head (VALU): 16 lanes per row, W/16 channels each ----
+    float raw_density;
+    {
+        const int row = tid >> 4, part = tid & 15;
+        constexpr int CH = W / 8 / 16;      // 8-half chunks per lane
+        float s = 0.f;
+#pragma unroll 2
+        for (int c = 0; c < CH; ++c) {
+            const int chunk = part * CH + ((c + part) % CH);
+            const int o = chunk_off<W>(row, chunk);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(m.heads + chunk * 8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(m.heads + chunk * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float w = e < 4 ? w0[e] : w1[e - 4];
+                s = __builtin_fmaf((float)vh[e], w, s);
+                s = __builtin_fmaf((float)vl[e], w, s);
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        raw_density = s + m.heads[hd_db(W)];
+    }
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (RGB) {
+        // ---- bottleneck W -> 256 (no activation): one N-tile per wave ----
+        f32x16 ab[1];
+        bias_tile(ab[0], m.bias + B_BOTT, L.wv, L);
+        gemm_h<1, W>(ab, wbase + (size_t)W_BOTT * 16, KSW, L.wv, 0, 0, KSW, act, L);
+        __syncthreads();
+        store_tile_h<false, W>(ab[0], act, L.wv, 0, L);
+        __syncthreads();
+        // ---- view layer [bottleneck 256 | dir enc 27] -> 128, ReLU: waves 0..3 ----
+        if (L.wv < 4) {
+            bias_tile(ab[0], m.bias + B_VIEW, L.wv, L);
+            gemm_h<1, W>(ab, wbase + (size_t)W_VIEW * 16, 18, L.wv, 0, 0, 16, act, L);
+            gemm_h<1, 32>(ab, wbase + (size_t)W_VIEW * 16, 18, L.wv, 16, 0, 2, dsm, L);
+        }
+        __syncthreads();
+        if (L.wv < 4) store_tile_h<true, W>(ab[0], act, L.wv, 0, L);
+        __syncthreads();
+        // ---- rgb head: 16 lanes per row, 8 features each ----
+        const int row = tid >> 4, part = tid & 15;
+        const float* wr = m.heads + hd_rw(W);
+        const int o = chunk_off<W>(row, part);
+        const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+        const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float h = (float)vh[e] + (float)vl[e];
+            r += h * wr[part * 8 + e];
+            g += h * wr[128 + part * 8 + e];
+            b += h * wr[256 + part * 8 + e];
+        }
+#pragma unroll
+        for (int o2 = 1; o2 < 16; o2 <<= 1) {
+            r += __shfl_xor(r, o2, 64);
+            g += __shfl_xor(g, o2, 64);
+            b += __shfl_xor(b, o2, 64);
+        }
+    }
+    {
+        const int row = tid >> 4, part = tid & 15;
+        const long gi = tile0 + row;
+        if (part == 0 && gi < P) {
+            float4 o4;
+            if (RGB) {
+                o4.x = colour_act(r + m.heads[hd_rb(W)]);
+                o4.y = colour_act(g + m.heads[hd_rb(W) + 1]);
+                o4.z = colour_act(b + m.heads[hd_rb(W) + 2]);
+            } else {
+                o4.x = o4.y = o4.z = 0.0f;       // disable_rgb: zeros_like(means) (model.py:131-136)
+            }
+            o4.w = density_act(raw_density);     // softplus(raw + density_bias), density_bias = -1
+            out[gi] = o4;
+        }
+    }
+}
+
+template <int W>
+size_t lds_bytes() {
+    return (size_t)(2 * TMR * W + 4 * TMR * 64 + 2 * TMR * 32) * sizeof(_Float16) + (size_t)(TMR * 44 + TMR * 12) * sizeof(float);
+}
+
+}  // namespace
+
+size_t mip_wpack_h_bytes(int width, int depth, int rgb) { return (size_t)mip_layout_h(width, depth, rgb).total_h8 * 16; }
+
+void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, void* wpack_h, hipStream_t s) {
+    const MipLayoutH lay = mip_layout_h(width, depth, rgb);
+    _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
+    const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < depth; ++i) {
+        PackSegs sg = none;
+        const int kin = i == 0 ? 504 : (i == 5 ? width + 504 : width);
+        sg.len[0] = kin;                      // [h | ipe] are contiguous source columns; zero padded to 16*KS
+        pack_h(w[i], kin, width, lay.ks_layer[i], 0, sg, base + (size_t)lay.w_layer[i] * 8, s);
+    }
+    if (rgb) {
+        PackSegs sb = none;
+        sb.len[0] = width;
+        pack_h(w[depth + 1], width, 256, width / 16, 0, sb, base + (size_t)lay.w_bott * 8, s);
+        PackSegs sv = none;
+        sv.len[0] = 283;
+        pack_h(w[depth + 2], 283, 128, 18, 0, sv, base + (size_t)lay.w_view * 8, s);
+    }
+}
+
+int launch_mip_mlp_h(int width, int depth, int rgb, const MipMlpHDev& m, const float* rays_o, const float* rays_d,
+                     const float* viewdirs, const float* radii, const float* tdist, int R, int n, float* out,
+                     hipStream_t s) {
+    const long P = (long)R * n;
+    if (P <= 0) return 0;
+    const long tiles = (P + TMR - 1) / TMR;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<1024, 8, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<1024>());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<256, 4, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<256>());
+        attr = true;
+    }
+    if (width == 1024 && depth == 8 && rgb)
+        hipLaunchKernelGGL((k_mip_mlp_h<1024, 8, true>), dim3((unsigned)tiles), dim3(512), lds_bytes<1024>(), s, m,
+                           rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));
+    else if (width == 256 && depth == 4 && !rgb)
+        hipLaunchKernelGGL((k_mip_mlp_h<256, 4, false>), dim3((unsigned)tiles), dim3(512), lds_bytes<256>(), s, m,
+                           rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));
+    else
+        return -1;
+    return 0;
+}
+
+}  // namespace neo

@@ -13,6 +13,7 @@
 
 #include <type_traits>
 
+#include "split_tile.h"
 #include "tp_common.h"
 
 namespace neo {
@@ -22,40 +23,6 @@ namespace {
 using tp::TM;
 using tp::blend4;
 using tp::pe_feature;
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-#define NEO_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-
-struct HT {   // a swizzled fp16 hi/lo tile
-    _Float16* hi;
-    _Float16* lo;
-};
-
-// 16-B chunk (8 halves) `chunk` of row `row` in a tile with LDH halves per row.  The XOR key uses the
-// row bits that do NOT already select the 256-B bank row, so 16 consecutive rows hit 16 different slots.
-template <int LDH>
-__device__ __forceinline__ int chunk_off(int row, int chunk) {
-    constexpr int KEY_SHIFT = LDH == 128 ? 0 : LDH == 64 ? 1 : 2;
-    constexpr int KEY_MASK = LDH / 8 - 1;
-    return row * LDH + ((chunk ^ ((row >> KEY_SHIFT) & KEY_MASK)) << 3);
-}
-
-__device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)x;
-    lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);      // x - hi, exact; one mixed-precision fma
-}
-
-__device__ __forceinline__ void split4(const f32x4 v, h4& vh, h4& vl) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        _Float16 h, l;
-        split(v[e], h, l);
-        vh[e] = h;
-        vl[e] = l;
-    }
-}
 
 // ---- packed weight layout (h8 units; one (n_tile, k_step) = hi 64 lanes + lo 64 lanes) -------------
 __host__ __device__ constexpr int pe_ksteps(int pe_c) { return pe_c == 3 ? 4 : 6; }
@@ -125,25 +92,6 @@ __device__ __forceinline__ void gemm1h(f32x16& acc, const h8* __restrict__ wp, i
         acc = NEO_MFMA_H(al, bh, acc);
         acc = NEO_MFMA_H(ah, bl, acc);
         acc = NEO_MFMA_H(ah, bh, acc);
-    }
-}
-
-// D tile (N-tile nt, M-tile mt) -> (ReLU) -> split -> the two planes of a [64][128] activation tile
-template <bool RELU>
-__device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, int nt, int mt, const LaneCtx& L) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float x = acc[4 * g + e];
-            v[e] = RELU ? fmaxf(x, 0.0f) : x;
-        }
-        h4 vh, vl;
-        split4(v, vh, vl);
-        const int o = chunk_off<128>(mt * 32 + L.l31, nt * 4 + g) + 4 * L.half;
-        *reinterpret_cast<h4*>(act.hi + o) = vh;
-        *reinterpret_cast<h4*>(act.lo + o) = vl;
     }
 }
 
@@ -494,33 +442,6 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
                                   colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));
         }
     }
-}
-
-// fp16 hi/lo fragments of rows [0, rows) of src into N-tiles [nt0, ...) of a stage with KS 16-deep k-steps;
-// packed k -> source column through up to three segments, zero elsewhere.
-__global__ void k_pack_block_h(const float* __restrict__ src, int ld, int rows, int KS, int nt0, PackSegs sg,
-                               _Float16* __restrict__ dst) {
-    const int total = (rows / 32) * KS * 512;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int e = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9;
-        const int ks = blk % KS, ntl = blk / KS;
-        const int n = ntl * 32 + (lane & 31);
-        const int k = ks * 16 + 8 * (lane >> 5) + e;
-        float w = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (k >= sg.k0[q] && k < sg.k0[q] + sg.len[q]) w = src[(long)n * ld + sg.col[q] + (k - sg.k0[q])];
-        const _Float16 hi = (_Float16)w;
-        const _Float16 lo = (_Float16)(w - (float)hi);
-        const long base = ((long)((nt0 + ntl) * KS + ks) * 2) * 512 + lane * 8 + e;
-        dst[base] = hi;
-        dst[base + 512] = lo;
-    }
-}
-
-void pack_h(const float* src, int ld, int rows, int KS, int nt0, PackSegs sg, _Float16* dst, hipStream_t s) {
-    const int total = (rows / 32) * KS * 512;
-    hipLaunchKernelGGL(k_pack_block_h, dim3((total + 255) / 256), dim3(256), 0, s, src, ld, rows, KS, nt0, sg, dst);
 }
 
 }  // namespace

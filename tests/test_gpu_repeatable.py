@@ -63,3 +63,27 @@ def test_neo360_evaluators_repeatable(built_lib):
             runs = [h_net.eval_mlp(slot, gb, tt, far=far) for _ in range(3)]
             assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
             assert (runs[0] - ref).abs().max().item() < 5e-6
+
+
+def test_mip360_evaluators_repeatable(built_lib):
+    dev = _dev()
+    R = 512
+    batch = {k: v.to(dev) for k, v in cases.mip_rays(R).items()}
+    state = synth.mip360_state(0, weight_gain=0.5)
+    nets = {}
+    for prec in ("f32", "f16x3"):
+        net = models.MipNeRF360(num_prop_samples=64, num_nerf_samples=32).to(dev)
+        net.precision = prec
+        net.load_state_dict(state)
+        nets[prec] = net
+    with torch.no_grad():
+        for slot, n in ((0, 64), (1, 64), (2, 32)):
+            s_edges = torch.linspace(0.0, 1.0, n + 1, device=dev)
+            tdist = (1.0 / (s_edges / 1e6 + (1.0 - s_edges) / 0.2))[None, :].expand(R, n + 1).contiguous()
+            ref = nets["f32"].eval_mlp(slot, batch, tdist)
+            assert torch.equal(ref, nets["f32"].eval_mlp(slot, batch, tdist))
+            runs = [nets["f16x3"].eval_mlp(slot, batch, tdist) for _ in range(3)]
+            assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+            # colours are in [0,1]; densities reach O(10): compare relative to scale
+            scale = ref.abs().amax().clamp_min(1.0)
+            assert ((runs[0] - ref).abs().max() / scale).item() < 5e-6
