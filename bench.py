@@ -101,20 +101,23 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
     return base, rgb, depth
 
 
-def pmc_traffic(workload):
-    """HBM bytes per dominant-kernel launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_vanilla_pmc_summary.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB, averaged over
-    the launches of a frame.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
+def pmc_traffic(workload, precision):
+    """HBM bytes per dominant-kernel launch from the committed rocprofv3 PMC passes of this same command
+    (tools/pmc_bench.sh -> profiles/r01_pmc_<workload>_<precision>.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB,
+    mean over the launches of a frame.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
     (wide coalesced reads are tallied at half their bytes).  None when no profile is committed."""
-    if workload != "vanilla":
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_vanilla_pmc_summary.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        disp = json.load(f)["dispatches"]
-    per = [(2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for d in disp.values() if "FETCH_SIZE" in d and "WRITE_SIZE" in d]
-    return sum(per) / len(per) if per else None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_%s_%s.json" % (workload, precision))
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)["derived"].get("hbm_bytes_per_launch")
+    if workload == "vanilla" and precision == "f32":
+        path = os.path.join(ROOT, "profiles", "r01_vanilla_pmc_summary.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                disp = json.load(f)["dispatches"]
+            per = [(2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for d in disp.values() if "FETCH_SIZE" in d and "WRITE_SIZE" in d]
+            return sum(per) / len(per) if per else None
+    return None
 
 
 def main():
@@ -193,6 +196,7 @@ def main():
 
     if rank == 0:
         achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        alg_bytes_per_point = 20.0 + (3 * 14336.0 if args.workload == "neo360" else 0.0)
         # split path: every algorithmic product costs three fp16 MFMA products, so the ceiling for
         # ALGORITHMIC flops on the fp16 pipe is peak/3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
@@ -207,18 +211,21 @@ def main():
                                            "(rgb,depth,acc) tiles" if world > 1 else ""),
                        "rays_per_frame": R, "parallelism": "ray-shard x%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": pmc_traffic(args.workload), "kernel": kernel_name,
+                         "frac": achieved / peak, "traffic": pmc_traffic(args.workload, args.precision), "kernel": kernel_name,
                          "launches": launches, "avg_launch_ms": kern_ms / max(launches, 1),
                          "algorithmic_flop_per_launch": flops / max(launches, 1),
                          "points_per_launch": points / max(launches, 1),
-                         "algorithmic_bytes_per_launch": points / max(launches, 1) * 20.0 if args.workload == "vanilla" else None,
+                         "algorithmic_bytes_per_launch": points / max(launches, 1) * alg_bytes_per_point,
                          "peak_definition": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per algorithmic multiply "
                                              "(a_hi*b_hi + a_hi*b_lo + a_lo*b_hi); executed matrix rate = 3 x achieved; "
                                              "the exact-fp32-MFMA kernel (--precision f32) peaks at 157.3")
                          if split else "dense fp32 MFMA peak",
                          "note": "rank 0's launches; algorithmic flops = reference formulation MACs x 2 (SURVEY.md 8d); "
-                                 "traffic = HBM bytes/launch from the committed PMC passes (profiles/), algorithmic "
-                                 "bytes = 4 B t in + 16 B (rgb,sigma) out per point"},
+                                 "traffic = HBM bytes/launch from the committed PMC passes (profiles/); algorithmic "
+                                 "bytes = 4 B t in + 16 B (rgb,sigma) out per point" +
+                                 (" + 3 views x 14,336 B of feature taps per point as the reference gathers them (no "
+                                  "reuse; SURVEY.md 8d upper bound; every texel once would be 560 MB per frame)"
+                                  if args.workload == "neo360" else "")},
         }
         n_cpu = cpu_default if args.cpu_rays < 0 else args.cpu_rays
         if world == 1 and n_cpu > 0:

@@ -66,7 +66,7 @@ __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * LDH 
 
 __device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
+    lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);      // x - hi, exact; one mixed-precision fma
 }
 
 template <int LDH, int KM>
@@ -80,25 +80,38 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 
 // acc[nt][mt] += W[:, ks0*16 .. (ks0+n)*16) x tile^T over n k-steps: 3 fp16 MFMAs per product tile.
 // N-tiles nt0..nt0+NTW-1, M-tiles mt0..mt0+MTW-1.
+#ifndef NEO_VH_PRODUCT_MAJOR
+#define NEO_VH_PRODUCT_MAJOR 1
+#endif
+#ifndef NEO_VH_PREFETCH
+#define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
+#endif
 template <int NTW, int MTW, int LDH, int KM>
 __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __restrict__ wp, int KS, int nt0, int mt0,
                                        int ks0, int n, const HTile& tile, const LaneCtx& L) {
-    h8 ah[2][NTW], al[2][NTW];
-    auto load_w = [&](int slot, int ks) {
+    constexpr int D = NEO_VH_PREFETCH, NB = D + 1;
+    h8 ah[NB][NTW], al[NB][NTW];
+    // SGPR base + 32-bit VGPR byte offset; one k-step = 2 KB (hi 1 KB | lo 1 KB) further along an N-tile's stream
+    const char* wb = reinterpret_cast<const char*>(wp);
+    uint32_t off[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) off[nt] = (uint32_t)(((nt0 + nt) * KS + ks0) * 128 + L.lane) * 16u;
+    auto load_w = [&](int slot, int s) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const h8* p = wp + (((nt0 + nt) * KS + ks) * 2) * 64 + L.lane;
-            ah[slot][nt] = p[0];
-            al[slot][nt] = p[64];
+            ah[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s));
+            al[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s + 1024u));
         }
     };
-    load_w(0, ks0);
-#pragma unroll 1
-    for (int s = 0; s < n; s += 2) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+    for (int d = 0; d < D; ++d)
+        if (d < n) load_w(d, d);
+#pragma unroll 1
+    for (int s = 0; s < n; s += NB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
             if (s + u < n) {
-                if (s + u + 1 < n) load_w((u + 1) & 1, ks0 + s + u + 1);
+                if (s + u + D < n) load_w((u + D) % NB, s + u + D);
                 h8 bh[MTW], bl[MTW];
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
@@ -106,6 +119,22 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
                     bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
                     bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
                 }
+#if NEO_VH_PRODUCT_MAJOR
+                // product-major order: consecutive MFMAs write different accumulators (no back-to-back
+                // dependent issue); per accumulator the summation order is unchanged
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(al[u][nt], bh[mt], acc[nt][mt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bl[mt], acc[nt][mt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
+#else
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -114,6 +143,7 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
                         acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bl[mt], acc[nt][mt]);
                         acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
                     }
+#endif
             }
         }
     }
