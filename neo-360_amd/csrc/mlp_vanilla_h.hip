@@ -80,8 +80,12 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 
 // acc[nt][mt] += W[:, ks0*16 .. (ks0+n)*16) x tile^T over n k-steps: 3 fp16 MFMAs per product tile.
 // N-tiles nt0..nt0+NTW-1, M-tiles mt0..mt0+MTW-1.
-#ifndef NEO_VH_PRODUCT_MAJOR
-#define NEO_VH_PRODUCT_MAJOR 1
+#ifndef NEO_VH_ABLATE
+#define NEO_VH_ABLATE 0        // timing experiments: 1 no weight loads, 2 no LDS fragment reads, 4 a quarter of the epilogue stores, 8 no barriers
+#endif
+#define VH_SYNC() do { if (!(NEO_VH_ABLATE & 8)) __syncthreads(); } while (0)
+#ifndef NEO_VH_BPIPE
+#define NEO_VH_BPIPE 0
 #endif
 #ifndef NEO_VH_PREFETCH
 #define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
@@ -106,22 +110,55 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < n) load_w(d, d);
+#if NEO_VH_BPIPE
+    // activation fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued
+    h8 bh[2][MTW], bl[2][MTW];
+    auto load_b = [&](int slot, int ks) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int o = chunk_off<LDH, KM>((mt0 + mt) * 32 + L.l31, (ks << 1) + L.half);
+            bh[slot][mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+            bl[slot][mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+        }
+    };
+    load_b(0, 0);
+    static_assert(NB % 2 == 0 || NB == 3, "ring size");
+#pragma unroll 1
+    for (int s = 0; s < n; s += 2 * NB) {
+#pragma unroll
+        for (int u = 0; u < 2 * NB; ++u) {
+            if (s + u < n) {
+                if (s + u + D < n) load_w((u + D) % NB, s + u + D);
+                if (s + u + 1 < n) load_b((u + 1) & 1, s + u + 1);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(al[u % NB][nt], bh[u & 1][mt], acc[nt][mt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(ah[u % NB][nt], bl[u & 1][mt], acc[nt][mt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(ah[u % NB][nt], bh[u & 1][mt], acc[nt][mt]);
+            }
+        }
+    }
+#else
 #pragma unroll 1
     for (int s = 0; s < n; s += NB) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             if (s + u < n) {
-                if (s + u + D < n) load_w((u + D) % NB, s + u + D);
+                if (s + u + D < n && !((NEO_VH_ABLATE & 1) && s + u + D >= NB)) load_w((u + D) % NB, s + u + D);
                 h8 bh[MTW], bl[MTW];
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt) {
-                    const int o = chunk_off<LDH, KM>((mt0 + mt) * 32 + L.l31, ((s + u) << 1) + L.half);
+                    const int o = chunk_off<LDH, KM>((mt0 + mt) * 32 + L.l31, (((NEO_VH_ABLATE & 2) ? 0 : (s + u)) << 1) + L.half);
                     bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
                     bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
                 }
-#if NEO_VH_PRODUCT_MAJOR
-                // product-major order: consecutive MFMAs write different accumulators (no back-to-back
-                // dependent issue); per accumulator the summation order is unchanged
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
@@ -134,19 +171,10 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
                 for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
-#else
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) {
-                        acc[nt][mt] = NEO_MFMA_H(al[u][nt], bh[mt], acc[nt][mt]);
-                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bl[mt], acc[nt][mt]);
-                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
-                    }
-#endif
             }
         }
     }
+#endif
 }
 
 template <int NTW, int MTW>
@@ -170,7 +198,7 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][MTW], const H
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < ((NEO_VH_ABLATE & 4) ? 1 : 4); ++g) {
                 h4 vh, vl;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
             put_feat<SIDE_LDH, 7>(side, p, 63, 0.0f);
         }
     }
-    __syncthreads();
+    VH_SYNC();
 
     f32x16 acc[NTW][2];
     const int nt0 = L.wv * NTW;
@@ -246,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
     init_bias<NTW, 2>(acc, m.bias + stage_b_off(0), nt0, L);
     gemm_h<NTW, 2, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 0, 4, side, L);
     store_act<NTW, 2, true>(acc, act, nt0, 0, L);      // the activation planes are idle here
-    __syncthreads();
+    VH_SYNC();
     // ---- L1..L7 (skip concat feeds L5) ----
 #pragma unroll 1
     for (int s = 1; s <= 7; ++s) {
@@ -255,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
         init_bias<NTW, 2>(acc, m.bias + s * 256, nt0, L);
         gemm_h<NTW, 2, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 0, 16, act, L);
         if (s == 5) gemm_h<NTW, 2, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L);
-        __syncthreads();
+        VH_SYNC();
         store_act<NTW, 2, true>(acc, act, nt0, 0, L);
         if (s == 5) {
             // x0 is dead: the side buffer takes the view-direction encoding (wave q < 4: octave q)
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
                 for (int f = 27; f < 32; ++f) put_feat<SIDE_LDH, 7>(side, p, f, 0.0f);
             }
         }
-        __syncthreads();
+        VH_SYNC();
     }
     // ---- density head on h8 (VALU, LP lanes per point; x = hi + lo) ----
     float raw_sigma;
@@ -306,9 +334,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
     // ---- bottleneck: 256 -> 256, no activation ----
     init_bias<NTW, 2>(acc, m.bias + stage_b_off(8), nt0, L);
     gemm_h<NTW, 2, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L);
-    __syncthreads();
+    VH_SYNC();
     store_act<NTW, 2, false>(acc, act, nt0, 0, L);
-    __syncthreads();
+    VH_SYNC();
     // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU (4 N-tiles: split over M as well when NW = 8) ----
     {
         constexpr int MTV = NW == 8 ? 1 : 2;
@@ -317,9 +345,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
         init_bias<1, MTV>(accv, m.bias + stage_b_off(9), ntv, L);
         gemm_h<1, MTV, ACT_LDH, 15>(accv, wp + stage_w_off(9), 18, ntv, mtv, 0, 16, act, L);
         gemm_h<1, MTV, SIDE_LDH, 7>(accv, wp + stage_w_off(9), 18, ntv, mtv, 16, 2, side, L);
-        __syncthreads();
+        VH_SYNC();
         store_act<1, MTV, true>(accv, act, ntv, mtv, L);
-        __syncthreads();
+        VH_SYNC();
     }
     // ---- rgb head (VALU) + activations + store ----
     {
