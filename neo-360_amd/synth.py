@@ -107,6 +107,29 @@ def nerfpp_mlp_state(seed, prefix, sd=None, input_ch=3, local=512, world=128, de
     return sd
 
 
+def pixelnerf_mlp_state(seed, prefix, sd=None, latent=512, density_gain=1.0):
+    """Parameters of one PixelNeRF NeRFMLP (vanilla_nerf/model_pixel.py:35-94): 4x128 trunk on
+    [posenc 63 | latent 512] (the skip never fires at depth 4), bottleneck, 2x128 view branch."""
+    sd = {} if sd is None else sd
+    width = 128
+    _linear(seed, sd, prefix + "pts_linears.0", width, 63 + latent)
+    for i in range(1, 4):
+        _linear(seed, sd, prefix + "pts_linears.%d" % i, width, width)
+    _linear(seed, sd, prefix + "views_linear.0", width, width + 27, xavier=False)
+    _linear(seed, sd, prefix + "views_linear.1", width, width)
+    _linear(seed, sd, prefix + "bottleneck_layer", width, width)
+    _linear(seed, sd, prefix + "density_layer", 1, width, gain=density_gain)
+    _linear(seed, sd, prefix + "rgb_layer", 3, width)
+    return sd
+
+
+def pixelnerf_state(seed=0, density_gain=1.0):
+    sd = {}
+    for name in ("coarse_mlp.", "fine_mlp."):
+        pixelnerf_mlp_state(seed, name, sd, density_gain=density_gain)
+    return sd
+
+
 def nerf_tp_state(seed=0, density_gain=1.0):
     sd = {}
     for name, ch in (("fg_coarse_mlp.", 3), ("fg_fine_mlp.", 3), ("bg_coarse_mlp.", 4), ("bg_fine_mlp.", 4)):

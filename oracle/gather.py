@@ -73,14 +73,16 @@ def latent_scaling(Hf, Wf):
     return s / (s - 1) * 2.0
 
 
-def pixel_aligned_features(pts, latent, c2w, focal, centre, image_wh):
+def pixel_aligned_features(pts, latent, c2w, focal, centre, image_wh, flip_y=True):
     """Project into every source view and bilinearly read the feature map,
     view-major (NV*P, C).  Follows neo360/model.py:239-264 +
     encoder_pn.py:101-152: focal/centre of source view 0 for all views;
-    g = uv * latent_scaling/image_size - 1."""
+    g = uv * latent_scaling/image_size - 1.  flip_y=False is the PixelNeRF baseline's
+    call (vanilla_nerf/model_pixel.py:203-206), which passes (f, f) without the sign flip."""
     cam = world_to_camera(pts.reshape(-1, 3), c2w)
     f = focal[0].unsqueeze(-1).repeat((1, 2)).clone()
-    f[..., 1] *= -1.0
+    if flip_y:
+        f[..., 1] *= -1.0
     uv = project(cam, f, centre[0].unsqueeze(0))
     scale = latent_scaling(latent.shape[-2], latent.shape[-1]) / torch.as_tensor(image_wh, dtype=torch.float32)
     feats = bilinear_zero_pad(latent, uv * scale - 1.0)

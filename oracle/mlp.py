@@ -71,6 +71,27 @@ def nerfpp_mlp(params, prefix, x_enc, cond_rows, world_feat, local_feat, nv, dep
     return _lin(params, prefix + "rgb_layer", y), raw_sigma
 
 
+def pixelnerf_mlp(params, prefix, x_enc, cond_rows, local_feat, nv):
+    """PixelNeRF's late-fusion MLP (vanilla_nerf/model_pixel.py:96-131): input = [enc 63 | latent 512];
+    4 ReLU layers of 128 (skip_layer=4 never fires); after the last one the per-view bottleneck is
+    taken and the trunk averaged over views; density from the mean; view branch
+    [bottleneck | cond 27] -> 128 -> mean over views -> ReLU -> 128 ReLU -> rgb.
+    x_enc (NV,P,63), cond_rows (NV*P,27), local_feat (NV*P,512) -> raw_rgb (P,3), raw_sigma (P,1)."""
+    npts = x_enc.shape[1]
+    h = torch.cat([x_enc.reshape(-1, x_enc.shape[-1]), local_feat], dim=-1)
+    bott = None
+    for i in range(4):
+        h = torch.relu(_lin(params, "%spts_linears.%d" % (prefix, i), h))
+        if i == 3:
+            bott = _lin(params, prefix + "bottleneck_layer", h)
+            h = _view_mean(h, nv, npts)
+    raw_sigma = _lin(params, prefix + "density_layer", h)
+    y = _lin(params, prefix + "views_linear.0", torch.cat([bott, cond_rows], dim=-1))
+    y = torch.relu(_view_mean(y, nv, npts))
+    y = torch.relu(_lin(params, prefix + "views_linear.1", y))
+    return _lin(params, prefix + "rgb_layer", y), raw_sigma
+
+
 def density_activation(raw):
     """softplus(raw - 1).  vanilla_nerf/model.py:203-204, neo360/model.py:380-381."""
     return F.softplus(raw + (-1.0))

@@ -292,6 +292,47 @@ def g6_mip360():
     save("g6_mip360", **out)
 
 
+# ---------------------------------------------------------------------------------
+# G7 PixelNeRF baseline decoder (models/vanilla_nerf/model_pixel.py)
+# ---------------------------------------------------------------------------------
+
+def ref_pixelnerf(state, scene, nv=cases.NV):
+    M = ref.load("models.vanilla_nerf.model_pixel")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = M.PixelNeRF(num_src_views=nv)
+    enc = net.encoder                       # the reference's SpatialEncoder; only its CNN forward is replaced
+    enc.forward = lambda imgs: None         # the image encoder is outside the hot path: latent preset below
+    enc.latent = scene["latent"]
+    Hf, Wf = scene["latent"].shape[-2:]
+    ls = torch.tensor([float(Wf), float(Hf)])
+    enc.latent_scaling = ls / (ls - 1) * 2.0
+    enc.latent_size = 512
+    missing = net.load_state_dict(state, strict=False)
+    assert not [k for k in missing.missing_keys if not k.startswith("encoder")], missing
+    assert not missing.unexpected_keys, missing
+    return net.eval()
+
+
+def g7_pixelnerf():
+    scene = cases.small_scene()
+    per_ray = ("rays_o", "rays_d", "viewdirs")
+    out = {}
+    for tag, n_rays, chunk, gain, white in (("a", 300, 256, 1.0, False), ("sharp", 128, 128, 8.0, False),
+                                             ("white", 96, 96, 1.0, True)):
+        net = ref_pixelnerf(synth.pixelnerf_state(0, density_gain=gain), scene)
+        batch = cases.neo_batch(cases.strided_rays(n_rays))
+        acc = {k: [] for k in ("rgb0", "acc0", "depth0", "rgb1", "acc1", "depth1")}
+        for i in range(0, n_rays, chunk):
+            part = {k: (v[i:i + chunk] if k in per_ray else v) for k, v in batch.items()}
+            res = net(part, False, white, 0.2, 2.5)
+            for lv in (0, 1):
+                acc["rgb%d" % lv].append(res[lv][0]); acc["acc%d" % lv].append(res[lv][1]); acc["depth%d" % lv].append(res[lv][2])
+        out.update({"%s_%s" % (k, tag): torch.cat(v, 0) for k, v in acc.items()})
+    save("g7_pixelnerf", **out)
+
+
 def main(which):
     jobs = {
         "g1": g1_raygen, "g2": g2_aabb, "g3": g3_stages, "g4v": g4_vanilla,
@@ -305,6 +346,7 @@ def main(which):
         "g4n_1500": lambda: g4_neo("1500", 1500, 1024),
         "g4n_sharp": lambda: g4_neo("sharp", 256, 256, 32, 64, gain=8.0),
         "g6": g6_mip360,
+        "g7": g7_pixelnerf,
     }
     for name, fn in jobs.items():
         if not which or name in which:

@@ -217,3 +217,23 @@ def test_g6_mip360_end_to_end(golden, tag, tf, gain, counts):
         assert max_abs(rend[lv]["rgb"], g["rgb%d_%s" % (lv, tag)]) < 5e-6
         assert max_abs(hist[lv]["sdist"], g["sdist%d_%s" % (lv, tag)]) < 5e-5
         assert max_abs(hist[lv]["weights"], g["w%d_%s" % (lv, tag)]) < 5e-5
+
+
+@pytest.mark.parametrize("tag,n_rays,chunk,gain,white", [("a", 300, 256, 1.0, False), ("sharp", 128, 128, 8.0, False),
+                                                         ("white", 96, 96, 1.0, True)])
+def test_g7_pixelnerf_end_to_end(golden, tag, n_rays, chunk, gain, white):
+    """PixelNeRF baseline decoder (vanilla_nerf/model_pixel.py:133-258) vs the reference's own output:
+    two chunks with a short last one (the direction-tiling quirk), a sharp density field, white background."""
+    g = golden("g7_pixelnerf")
+    scene = cases.small_scene()
+    batch = cases.neo_batch(cases.strided_rays(n_rays))
+    state = synth.pixelnerf_state(0, density_gain=gain)
+    lv = {k: [] for k in ("rgb0", "acc0", "depth0", "rgb1", "acc1", "depth1")}
+    for i in range(0, n_rays, chunk):
+        part = {k: (v[i:i + chunk] if k in ("rays_o", "rays_d", "viewdirs") else v) for k, v in batch.items()}
+        res = oracle.pixelnerf.render(state, part, scene, 0.2, 2.5, white_bkgd=white)
+        for l in (0, 1):
+            lv["rgb%d" % l].append(res[l][0]); lv["acc%d" % l].append(res[l][1]); lv["depth%d" % l].append(res[l][2])
+    for k, v in lv.items():
+        tol = 1e-6 if k.endswith("0") else (5e-5 if "depth" in k else 1e-5)   # level 1 passes through the resampler
+        assert max_abs(torch.cat(v), g["%s_%s" % (k, tag)]) < tol, (k, tag)
