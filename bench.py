@@ -65,6 +65,25 @@ def build_neo360(dev):
     return net, state, extra, scene, desc, dict(near=0.0, far=0.0), "k_tp_mlp", 256
 
 
+def build_pixelnerf(dev):
+    from neo360_amd import models, synth
+    nv = 3
+    state = synth.pixelnerf_state(0)
+    net = models.PixelNeRF(num_coarse_samples=64, num_fine_samples=64, num_src_views=nv).to(dev)
+    net.load_state_dict(state)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    scene = {"latent": torch.randn(nv, 512, 240, 320, device=dev, generator=g) * 0.1, "image_wh": (float(W), float(H))}
+    net.set_scene(scene["latent"], scene["image_wh"])
+    poses, focal, centre = synth.source_views(nv, W, H)
+    extra = dict(src_poses=poses.to(dev), src_focal=focal.to(dev), src_c=centre.to(dev),
+                 src_imgs=torch.zeros(nv, 3, H, W, device=dev))
+    desc = ("PixelNeRF baseline decoder 640x480 full frame, 3 source views, 64 coarse + 64 fine samples/ray "
+            "((65+129) MLP points/ray x 3 views), reference chunk 1024, random-init MLPs, synthetic N(0,0.1) "
+            "latents (3x512x240x320)")
+    return net, state, extra, scene, desc, dict(near=0.2, far=3.0), "k_pix_mlp", 1024
+
+
 def build_mip360(dev, n_nerf=32):
     from neo360_amd import models, synth
     state = synth.mip360_state(0, weight_gain=0.5)
@@ -84,6 +103,11 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
     t0 = time.perf_counter()
     if workload == "vanilla":
         rgb, depth = oracle.vanilla.render_chunked(state, sample, kw["near"], kw["far"], chunk=CHUNK)
+    elif workload == "pixelnerf":
+        batch = dict(sample)
+        batch.update({k: v.cpu() for k, v in extra.items()})
+        sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
+        rgb, depth = oracle.pixelnerf.render_chunked(state, batch, sc, kw["near"], kw["far"], chunk=CHUNK)
     elif workload.startswith("mip360"):
         from oracle import mip360
         rend, _ = mip360.render(state, sample, kw["train_frac"], kw["near"], kw["far"], num_prop_samples=64,
@@ -125,7 +149,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("vanilla", "neo360", "mip360", "mip360_128"), default="vanilla")
+    ap.add_argument("--workload", choices=("vanilla", "neo360", "pixelnerf", "mip360", "mip360_128"), default="vanilla")
     ap.add_argument("--precision", choices=("auto", "f32", "f16x3"), default="auto",
                     help="MLP arithmetic: exact fp32 MFMA, or fp16 MFMA with hi/lo-split operands (fp32-equivalent, "
                          "the default of every renderer)")
@@ -150,6 +174,8 @@ def main():
         built = build_vanilla(dev)
     elif args.workload == "neo360":
         built = build_neo360(dev)
+    elif args.workload == "pixelnerf":
+        built = build_pixelnerf(dev)
     else:       # reference defaults (64,64,32), or BASELINE.json's wording "64 proposal + 128 fine"
         built = build_mip360(dev, 128 if args.workload.endswith("128") else 32)
     net, state, extra, scene, desc, kw, kernel_name, cpu_default = built
@@ -196,7 +222,7 @@ def main():
 
     if rank == 0:
         achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        alg_bytes_per_point = 20.0 + (3 * 14336.0 if args.workload == "neo360" else 0.0)
+        alg_bytes_per_point = 20.0 + {"neo360": 3 * 14336.0, "pixelnerf": 3 * 8192.0}.get(args.workload, 0.0)
         # split path: every algorithmic product costs three fp16 MFMA products, so the ceiling for
         # ALGORITHMIC flops on the fp16 pipe is peak/3
         peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
@@ -233,7 +259,7 @@ def main():
             n = min(n_cpu, R)
             rays_cpu = {k: batch[k][:n].cpu() for k in ("rays_o", "viewdirs", "rays_d", "radii") if k in batch}
             base, rgb_c, depth_c = cpu_baseline(args.workload, state, scene, rays_cpu, extra, kw, n)
-            if args.workload == "neo360" and n != CHUNK:
+            if args.workload in ("neo360",) and n != CHUNK:
                 # NeO-360 results depend on chunk membership: render the same rays as their own chunk
                 sub = {k: (v[:n] if k in ("rays_o", "viewdirs", "rays_d") else v) for k, v in batch.items()}
                 got = render.render_rays_test(net, sub, chunk=n, **kw)

@@ -179,6 +179,36 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d,
                   float focal, float cx, float cy, int n_coarse, int n_fine, int white_bkgd,
                   const neo_tp_level_out* level0, const neo_tp_level_out* level1, void* stream);
 
+/* ---- PixelNeRF baseline decoder (models/vanilla_nerf/model_pixel.py) ------------------------ */
+/* Upload one NeRFMLP of model_pixel.py:35-94 (slot 0 = coarse_mlp, 1 = fine_mlp).  weights/biases
+ * [host arrays of 9 device pointers], order: pts_linears.0..3 (128x575, 128x128 x3), views_linear.0
+ * (128x155), views_linear.1 (128x128), bottleneck_layer, density_layer, rgb_layer (3x128).
+ * This evaluator exists in the split-fp16 arithmetic only: neo_ctx_set_precision(ctx, 1). */
+int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights,
+                       const float* const* biases, void* stream);
+
+/* The image encoder's output the reference recomputes per chunk (model_pixel.py:176-178):
+ * latent (NV,512,Hf,Wf) NCHW, re-laid out channels-last into a context-owned buffer. */
+int neo_pix_set_scene(neo_ctx* ctx, const float* latent, int NV, int Cl, int Hf, int Wf,
+                      float image_w, float image_h, void* stream);
+
+/* Per-point outputs at given sample positions (model_pixel.py:198-237): tvals (R,N) along rays_d;
+ * out (R,N,4) = (sigmoid rgb, relu sigma).  chunk / src_poses / focal / cx / cy as for neo_pix_render. */
+int neo_pix_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
+                const float* viewdirs, const float* tvals, int R, int N, int chunk,
+                const float* src_poses, int NV, float focal, float cx, float cy, float* out,
+                void* stream);
+
+/* PixelNeRF.forward decoder half (model_pixel.py:180-256), randomized=False, for R rays processed in
+ * reference-sized chunks (the view-direction tiling of :219-222 makes results depend on chunk
+ * membership).  src_poses [host]: NV*16 floats; focal/cx/cy: source view 0's intrinsics (:203-204;
+ * both image axes use +focal).  Outputs per level (any may be NULL): rgb (R,3), acc (R), depth (R). */
+int neo_pix_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* viewdirs,
+                   int R, int chunk, const float* src_poses, int NV, float focal, float cx,
+                   float cy, float near, float far, int n_coarse, int n_fine, int white_bkgd,
+                   float* rgb0, float* acc0, float* depth0, float* rgb1, float* acc1,
+                   float* depth1, void* stream);
+
 /* ---- Mip-NeRF 360 (models/mipnerf360/model.py) -------------------------------- */
 /* Upload one MipNeRF360MLP (model.py:30-107).  slot 0..2 = mlps.0, mlps.1 (PropMLP: width 256,
  * depth 4, rgb 0) and mlps.2 (NeRFMLP: width 1024, depth 8, rgb 1) — the shapes the kernels are

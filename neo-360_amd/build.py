@@ -26,7 +26,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=
 _NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {
     "mlp_tp_h.hip": _NO_PK_F32,
-    "mlp_mip_h.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
+    "mlp_mip_h.hip": _NO_PK_F32,
+    "mlp_pix_h.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
 }
 
 

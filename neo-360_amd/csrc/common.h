@@ -49,6 +49,9 @@ __device__ __forceinline__ float colour_act(float raw) {
     return s * 1.002f - 0.001f;
 }
 
+// torch.sigmoid (PixelNeRF baseline's rgb activation, vanilla_nerf/model_pixel.py:165, :231)
+__device__ __forceinline__ float sigmoid_act(float raw) { return 1.0f / (1.0f + expf(-raw)); }
+
 // torch.nan_to_num(x, nan): nan -> `nan_value`, +inf -> FLT_MAX, -inf -> -FLT_MAX.
 __device__ __forceinline__ float nan_to_num(float x, float nan_value) {
     if (x != x) return nan_value;

@@ -95,6 +95,7 @@ struct neo_ctx {
     neo_host::MlpSlot vanilla[2];
     neo_host::MlpSlot tp[4];
     neo_host::MlpSlot mip[3];
+    neo_host::MlpSlot pix[2];          // PixelNeRF coarse / fine
     int mip_shape[3][3] = {};          // width, depth, rgb per slot
     neo_host::DevBuf mip_basis;
     std::map<int, neo_host::DevBuf> centre_quantiles;             // n -> linspace(1/2n, 1-1/2n-eps, n)

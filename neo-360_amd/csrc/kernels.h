@@ -60,6 +60,8 @@ struct TpScene {                     // channels-last feature maps owned by the 
     int nv, Hf, Wf, Hp, Wp;
     float focal, cx, cy;            // source view 0's intrinsics (neo360/model.py:242-244)
     float sx, sy;                   // latent_scaling / image_size (encoder_pn.py:121-123, :204-206)
+    float fy_sign = -1.0f;          // v = (-y/z) * (fy_sign * focal) + cy: -1 for NeRF_TP (model.py:243), +1 for the
+                                    // PixelNeRF baseline, which passes (f, f) (vanilla_nerf/model_pixel.py:203-206)
 };
 struct TpViews {                     // world -> camera per source view (neo360/util.py:52-70)
     float rot[TP_MAX_VIEWS][9];     // c2w[:3,:3]^T, row-major
@@ -127,6 +129,16 @@ void launch_tp_pack_h(int input_ch, const float* const* w, void* wpack_h, hipStr
 void launch_tp_mlp_h(int input_ch, const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
                      const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
                      int chunk, uint32_t* flags, float* out, hipStream_t s);
+
+// mlp_pix_h.hip — PixelNeRF baseline decoder evaluator (split-fp16 arithmetic only)
+size_t pix_wpack_h_bytes();
+size_t pix_bias_floats();
+size_t pix_heads_floats();
+void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack_h, float* bias, float* heads,
+                       hipStream_t s);
+void launch_pix_mlp_h(const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+                      const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N,
+                      int chunk, float* out, hipStream_t s);
 
 // sampling.hip — NeO-360 level-0 sample rows and fg/bg merge
 void launch_tp_level0(const float* far, const float* edges, int R, int N, float near, float* fg_t, float* bg_s,

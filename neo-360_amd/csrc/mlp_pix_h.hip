@@ -1,0 +1,338 @@
+// PixelNeRF baseline decoder point evaluator (models/vanilla_nerf/model_pixel.py:35-131, :195-237) on the fp16
+// matrix cores with hi/lo-split fp32 operands (split_tile.h).  Same tile / streaming design as mlp_tp_h.hip
+// (tp_common.h supplies the per-point set-up and the per-view descriptors) for the simpler network:
+//   per 64-point tile, per source view: descriptors -> the 575-wide input [512 pixel-aligned latent | 63 pos_enc of
+//   the camera-frame point] streamed 64 features at a time (9 stages) -> L0..L3 (128, ReLU; the skip never fires at
+//   depth 4) -> per-view bottleneck -> view layer 0 on [bottleneck | 27 camera-frame direction encoding] (128 wide)
+//   -> view means -> density head (ReLU), 128x128 ReLU, rgb head (sigmoid).
+// The view direction of row (view, ray b, sample s) is that of ray (b*N+s) mod B of the reference chunk
+// (model_pixel.py:219-222), as in NeRF_TP.  Compiled without packed-fp32 VALU ops (build.py:EXTRA_FLAGS).
+//
+// Algorithmic work per point-view: 575*128 + 3*128*128 + 128*128 + 155*128 = 158,976 MAC; per point 128 + 128*128
+// + 384 = 16,896 MAC.
+#include <type_traits>
+
+#include "split_tile.h"
+#include "tp_common.h"
+
+namespace neo {
+
+namespace {
+
+using tp::TM;
+using tp::blend4;
+using tp::pe_feature;
+
+// ---- packed weight layout (h8 units) ---------------------------------------------------------------------------
+constexpr int KSX = 36;                                   // 512 latent + 64 (63 pos_enc + pad) = 36 k-steps
+constexpr int PX_X = 0;
+constexpr int PX_1 = 4 * KSX * 128;
+constexpr int PX_2 = PX_1 + 4 * 8 * 128;
+constexpr int PX_3 = PX_2 + 4 * 8 * 128;
+constexpr int PX_B = PX_3 + 4 * 8 * 128;
+constexpr int PX_V0 = PX_B + 4 * 8 * 128;                 // 155 -> 160 = 10 k-steps
+constexpr int PX_V1 = PX_V0 + 4 * 10 * 128;
+constexpr int PX_TOTAL = PX_V1 + 4 * 8 * 128;
+constexpr int B_0 = 0, B_1 = 128, B_2 = 256, B_3 = 384, B_B = 512, B_V0 = 640, B_V1 = 768, BIAS_FLOATS = 896;
+constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 516, HEADS_FLOATS = 520;
+constexpr int NST = 9;                                    // streamed stages: 8 latent, 1 pos_enc
+
+__global__ __launch_bounds__(256, 2) void k_pix_mlp_h(TpMlpHDev m, TpScene sc, TpViews views,
+                                                      const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d,
+                                                      const float* __restrict__ viewdirs,
+                                                      const float* __restrict__ tvals, int t_shared, int R, int N,
+                                                      int chunk, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* hbase = reinterpret_cast<_Float16*>(smem + tp::OFF_ACT);
+    const HT act{hbase, hbase + TM * 128};                                   // [64][128] x 2 planes (32 KB)
+    auto xbuf = [&](int b) { return HT{hbase + b * (2 * TM * 64), hbase + b * (2 * TM * 64) + TM * 64}; };   // aliases act
+    _Float16* dbase = reinterpret_cast<_Float16*>(smem + tp::OFF_DIR);
+    const HT dsm{dbase, dbase + TM * 32};                                    // [64][32] x 2 planes
+    const tp::Scratch S = tp::carve(smem);
+    int* loc_off = S.loc_off;
+    float* loc_w = S.loc_w;
+    float* cam_enc = S.cam_enc;
+
+    LaneCtx L;
+    L.init();
+    int tid = threadIdx.x;
+    const long P = (long)R * N;
+    const long tile0 = (long)blockIdx.x * TM;
+    const h8* wp = reinterpret_cast<const h8*>(m.wpack);
+
+    tp::point_setup<3>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, nullptr, nullptr, t_shared != 0);
+    float* dens_w = smem + tp::OFF_DENSW;
+    if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
+    __syncthreads();
+
+    f32x16 ysum[1][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ysum[0][0][r] = 0.f; ysum[0][1][r] = 0.f; }
+    float sig_part = 0.f;
+    const int nts_1[1] = {L.wv};
+
+#pragma unroll 1
+    for (int v = 0; v < sc.nv; ++v) {
+        // per-lane indices re-derived from an opaque lane id (keeps swizzled LDS addresses out of scratch, mlp_tp_h.hip)
+        asm volatile("" : "+v"(tid));
+        L.lane = tid & 63;
+        L.half = L.lane >> 5;
+        L.l31 = L.lane & 31;
+        L.key = L.lane & 15;
+        const float* rot = views.rot[v];
+        const float* trn = views.trans[v];
+        tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
+            _Float16 h, l;
+            split(val, h, l);
+            const int o = chunk_off<32>(p, f >> 3) + (f & 7);
+            dsm.hi[o] = h;
+            dsm.lo[o] = l;
+        });
+        __syncthreads();
+
+        // ---- streamed-input GEMM: L0 (128 outputs; N-tile = wave) over 575 features ----
+        f32x16 accx[1][2];
+        bias_tile(accx[0][0], m.bias + B_0, L.wv, L);
+        accx[0][1] = accx[0][0];
+        {
+            const int col4 = tid & 15, rg = tid >> 4;
+            const uint32_t lane_b = 16u * col4;
+            f32x4 tap[2][4];
+            auto issue_local = [&](int s, int hf) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tap[i][k] = tp::load_tap(sc.latent, (uint32_t)loc_off[row * 4 + k] + lane_b + 256u * s);
+                }
+            };
+            auto finish_local = [&](const HT& buf, int hf) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+                    const f32x4 v4 = blend4(tap[i], *reinterpret_cast<const f32x4*>(loc_w + row * 4));
+                    h4 vh, vl;
+                    split4(v4, vh, vl);
+                    const int o = chunk_off<64>(row, col4 >> 1) + 4 * (col4 & 1);
+                    *reinterpret_cast<h4*>(buf.hi + o) = vh;
+                    *reinterpret_cast<h4*>(buf.lo + o) = vl;
+                }
+            };
+            // pos_enc of the camera-frame point: half hf of the stage = chunks 4hf..4hf+3, one per wave
+            auto finish_pe = [&](const HT& buf, int hf) {
+                const int row = tid & 63, q = tid >> 6;
+                const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], 0.0f};
+                const int ch = hf * 4 + q;
+                h8 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 h, l;
+                    split(pe_feature<3>(xc, ch * 8 + e), h, l);
+                    vh[e] = h;
+                    vl[e] = l;
+                }
+                const int o = chunk_off<64>(row, ch);
+                *reinterpret_cast<h8*>(buf.hi + o) = vh;
+                *reinterpret_cast<h8*>(buf.lo + o) = vl;
+            };
+            // weights of one half stage (2 k-steps x 1 N-tile, hi + lo): SGPR base + 32-bit VGPR offset, 4 KB per half
+            h8 wh[2], wl[2];
+            const char* wxb = reinterpret_cast<const char*>(wp + PX_X);
+            const uint32_t wx_off = (uint32_t)(L.wv * KSX * 2 * 64 + L.lane) * 16u;
+            auto load_wx = [&](int h) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    wh[u] = *reinterpret_cast<const h8*>(wxb + (wx_off + 4096u * h + 2048u * u));
+                    wl[u] = *reinterpret_cast<const h8*>(wxb + (wx_off + 4096u * h + 2048u * u + 1024u));
+                }
+            };
+            auto mma_x = [&](const HT& tile, int tks0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    h8 bh[2], bl[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int o = chunk_off<64>(mt * 32 + L.l31, ((tks0 + u) << 1) + L.half);
+                        bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                        bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        accx[0][mt] = NEO_MFMA_H(wl[u], bh[mt], accx[0][mt]);
+                        accx[0][mt] = NEO_MFMA_H(wh[u], bl[mt], accx[0][mt]);
+                        accx[0][mt] = NEO_MFMA_H(wh[u], bh[mt], accx[0][mt]);
+                    }
+                }
+            };
+            constexpr int K_LOCAL = 0, K_PE = 2, K_NONE = 3;
+            auto half_stage = [&](int s, int hf, auto kind_c) {
+                constexpr int kind = decltype(kind_c)::value;
+                const HT cur = xbuf(s & 1), nxt = xbuf((s + 1) & 1);
+                if constexpr (kind == K_LOCAL) issue_local(s + 1, hf);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_x(cur, 2 * hf);
+                __builtin_amdgcn_sched_barrier(0);
+                if (2 * (2 * s + hf + 1) < KSX) load_wx(2 * s + hf + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kind == K_LOCAL) finish_local(nxt, hf);
+                if constexpr (kind == K_PE) finish_pe(nxt, hf);
+            };
+            using std::integral_constant;
+            load_wx(0);
+            issue_local(0, 0);
+            finish_local(xbuf(0), 0);
+            issue_local(0, 1);
+            finish_local(xbuf(0), 1);
+            __syncthreads();
+#pragma unroll 1
+            for (int s = 0; s < 7; ++s) {            // stages 0..6 multiply while latent stages 1..7 are gathered
+#pragma unroll 1
+                for (int hf = 0; hf < 2; ++hf) half_stage(s, hf, integral_constant<int, K_LOCAL>());
+                __syncthreads();
+            }
+#pragma unroll 1
+            for (int hf = 0; hf < 2; ++hf) half_stage(7, hf, integral_constant<int, K_PE>());
+            __syncthreads();
+#pragma unroll 1
+            for (int hf = 0; hf < 2; ++hf) half_stage(NST - 1, hf, integral_constant<int, K_NONE>());
+            __syncthreads();
+        }
+
+        // ---- L0 epilogue, L1, L2, L3 ----
+        f32x16 acc[1][2];
+        store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
+        store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
+        __syncthreads();
+#pragma unroll 1
+        for (int layer = 0; layer < 3; ++layer) {
+            bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : layer == 1 ? B_2 : B_3), L.wv, L);
+            acc[0][1] = acc[0][0];
+            gemm2h<1, 128>(acc, wp + (layer == 0 ? PX_1 : layer == 1 ? PX_2 : PX_3), 8, nts_1, 0, 0, 8, act, L);
+            __syncthreads();
+            store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
+            store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
+            __syncthreads();
+        }
+        sig_part += density_partial(act, dens_w, L);       // the density head is linear in the view mean of relu(L3)
+        // ---- per-view bottleneck (no activation) ----
+        bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
+        acc[0][1] = acc[0][0];
+        gemm2h<1, 128>(acc, wp + PX_B, 8, nts_1, 0, 0, 8, act, L);
+        __syncthreads();
+        store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
+        store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
+        __syncthreads();
+        // ---- view layer 0: [bottleneck | dir enc] -> 128, summed over views before the ReLU ----
+        bias_tile(acc[0][0], m.bias + B_V0, L.wv, L);
+        acc[0][1] = acc[0][0];
+        gemm2h<1, 128>(acc, wp + PX_V0, 10, nts_1, 0, 0, 8, act, L);
+        gemm2h<1, 32>(acc, wp + PX_V0, 10, nts_1, 8, 0, 2, dsm, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ysum[0][0][r] += acc[0][0][r]; ysum[0][1][r] += acc[0][1][r]; }
+        __syncthreads();
+    }
+
+    // ---- density head: mean over views of the per-view dot products; ReLU (model_pixel.py:232) ----
+    const float nvf = (float)sc.nv;
+    float sigma;
+    {
+        float sg = sig_part;
+        sg += __shfl_xor(sg, 1, 64);
+        sg += __shfl_xor(sg, 2, 64);
+        sigma = fmaxf(sg / nvf + m.heads[HD_DB], 0.0f);
+    }
+    // ---- view mean -> ReLU -> 128x128 -> ReLU -> rgb head -> sigmoid ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ysum[0][0][r] = ysum[0][0][r] / nvf; ysum[0][1][r] = ysum[0][1][r] / nvf; }
+    store_tile_h<true>(ysum[0][0], act, L.wv, 0, L);
+    store_tile_h<true>(ysum[0][1], act, L.wv, 1, L);
+    __syncthreads();
+    {
+        f32x16 y[1][2];
+        bias_tile(y[0][0], m.bias + B_V1, L.wv, L);
+        y[0][1] = y[0][0];
+        gemm2h<1, 128>(y, wp + PX_V1, 8, nts_1, 0, 0, 8, act, L);
+        __syncthreads();
+        store_tile_h<true>(y[0][0], act, L.wv, 0, L);
+        store_tile_h<true>(y[0][1], act, L.wv, 1, L);
+    }
+    __syncthreads();
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const float* wr = m.heads + HD_RW;
+        float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int chunk_i = part * 4 + ((c + part) & 3);
+            const int o = chunk_off<128>(pt, chunk_i);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = (float)vh[e] + (float)vl[e];
+                r += h * wr[chunk_i * 8 + e];
+                g += h * wr[128 + chunk_i * 8 + e];
+                b += h * wr[256 + chunk_i * 8 + e];
+            }
+        }
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+        g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        const long gi = tile0 + pt;
+        if (part == 0 && gi < P) {
+            out[gi] = make_float4(sigmoid_act(r + m.heads[HD_RB]), sigmoid_act(g + m.heads[HD_RB + 1]),
+                                  sigmoid_act(b + m.heads[HD_RB + 2]), sigma);
+        }
+    }
+}
+
+__global__ void k_copy_n(const float* __restrict__ src, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+}  // namespace
+
+size_t pix_wpack_h_bytes() { return (size_t)PX_TOTAL * 16; }
+size_t pix_bias_floats() { return BIAS_FLOATS; }
+size_t pix_heads_floats() { return HEADS_FLOATS; }
+
+void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack_h, float* bias, float* heads,
+                       hipStream_t s) {
+    // w order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
+    _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
+    const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    PackSegs sx = {{0, 512, 0}, {512, 63, 0}, {63, 0, 0}};      // packed [latent | pos_enc] <- source [pos_enc | latent]
+    pack_h(w[0], 575, 128, KSX, 0, sx, base + (size_t)PX_X * 8, s);
+    PackSegs p128 = none;
+    p128.len[0] = 128;
+    pack_h(w[1], 128, 128, 8, 0, p128, base + (size_t)PX_1 * 8, s);
+    pack_h(w[2], 128, 128, 8, 0, p128, base + (size_t)PX_2 * 8, s);
+    pack_h(w[3], 128, 128, 8, 0, p128, base + (size_t)PX_3 * 8, s);
+    pack_h(w[6], 128, 128, 8, 0, p128, base + (size_t)PX_B * 8, s);
+    PackSegs v0 = none;
+    v0.len[0] = 155;
+    pack_h(w[4], 155, 128, 10, 0, v0, base + (size_t)PX_V0 * 8, s);
+    pack_h(w[5], 128, 128, 8, 0, p128, base + (size_t)PX_V1 * 8, s);
+    auto cp = [&](const float* src, int n, float* dst) {
+        hipLaunchKernelGGL(k_copy_n, dim3((n + 255) / 256), dim3(256), 0, s, src, n, dst);
+    };
+    (void)hipMemsetAsync(heads, 0, HEADS_FLOATS * sizeof(float), s);
+    cp(b[0], 128, bias + B_0); cp(b[1], 128, bias + B_1); cp(b[2], 128, bias + B_2); cp(b[3], 128, bias + B_3);
+    cp(b[6], 128, bias + B_B); cp(b[4], 128, bias + B_V0); cp(b[5], 128, bias + B_V1);
+    cp(w[7], 128, heads + HD_DW); cp(b[7], 1, heads + HD_DB); cp(w[8], 384, heads + HD_RW); cp(b[8], 3, heads + HD_RB);
+}
+
+void launch_pix_mlp_h(const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+                      const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N,
+                      int chunk, float* out, hipStream_t s) {
+    const long P = (long)R * N;
+    if (P <= 0) return;
+    const size_t lds = tp::LDS_WORDS * sizeof(float);
+    const long tiles = (P + TM - 1) / TM;
+    hipLaunchKernelGGL(k_pix_mlp_h, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d, viewdirs,
+                       tvals, t_shared, R, N, chunk, reinterpret_cast<float4*>(out));
+}
+
+}  // namespace neo

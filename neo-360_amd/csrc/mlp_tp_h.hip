@@ -38,85 +38,6 @@ __host__ __device__ constexpr int hpack_h8(int pe_c) { return hoff_v1(pe_c) + 2 
 constexpr int B_0 = 0, B_3 = 128, B_1 = 256, B_2 = 384, B_B = 512, B_V0 = 640, B_V1 = 704;
 constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 324;
 
-// acc[nt][mt] += W-stage k-steps [ks0, ks0+n) x tile k-steps [tks0, tks0+n); N-tiles nts[], both M-tiles.
-template <int NTW, int LDH>
-__device__ __forceinline__ void gemm2h(f32x16 (&acc)[NTW][2], const h8* __restrict__ wp, int KS, const int (&nts)[NTW],
-                                       int ks0, int tks0, int n, const HT& tile, const LaneCtx& L) {
-    h8 ah[2][NTW], al[2][NTW];
-    auto load_w = [&](int slot, int ks) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const h8* p = wp + ((nts[nt] * KS + ks) * 2) * 64 + L.lane;
-            ah[slot][nt] = p[0];
-            al[slot][nt] = p[64];
-        }
-    };
-    load_w(0, ks0);
-#pragma unroll 1
-    for (int s = 0; s < n; s += 2) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (s + u < n) {
-                if (s + u + 1 < n) load_w((u + 1) & 1, ks0 + s + u + 1);
-                h8 bh[2], bl[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int o = chunk_off<LDH>(mt * 32 + L.l31, ((tks0 + s + u) << 1) + L.half);
-                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
-                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
-                }
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[nt][mt] = NEO_MFMA_H(al[u][nt], bh[mt], acc[nt][mt]);
-                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bl[mt], acc[nt][mt]);
-                        acc[nt][mt] = NEO_MFMA_H(ah[u][nt], bh[mt], acc[nt][mt]);
-                    }
-            }
-        }
-    }
-}
-
-// single accumulator tile (nt, mt): the 64-wide view layers
-template <int LDH>
-__device__ __forceinline__ void gemm1h(f32x16& acc, const h8* __restrict__ wp, int KS, int nt, int mt, int ks0, int n,
-                                       const HT& tile, const LaneCtx& L) {
-#pragma unroll 1
-    for (int s = 0; s < n; ++s) {
-        const h8* p = wp + ((nt * KS + ks0 + s) * 2) * 64 + L.lane;
-        const h8 ah = p[0], al = p[64];
-        const int o = chunk_off<LDH>(mt * 32 + L.l31, (s << 1) + L.half);
-        const h8 bh = *reinterpret_cast<const h8*>(tile.hi + o);
-        const h8 bl = *reinterpret_cast<const h8*>(tile.lo + o);
-        acc = NEO_MFMA_H(al, bh, acc);
-        acc = NEO_MFMA_H(ah, bl, acc);
-        acc = NEO_MFMA_H(ah, bh, acc);
-    }
-}
-
-// this lane's share of w_d . h for its point: point = 16 wave + lane/4, lane%4 picks 32 of the 128 channels
-__device__ __forceinline__ float density_partial(const HT& act, const float* __restrict__ dens_w, const LaneCtx& L) {
-    const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int chunk_i = part * 4 + ((c + part) & 3);
-        const int o = chunk_off<128>(pt, chunk_i);
-        const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
-        const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(dens_w + chunk_i * 8);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(dens_w + chunk_i * 8 + 4);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float w = e < 4 ? w0[e] : w1[e - 4];
-            s = __builtin_fmaf((float)vh[e], w, s);
-            s = __builtin_fmaf((float)vl[e], w, s);
-        }
-    }
-    return s;
-}
-
 template <int PE_C>
 __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, TpViews views,
                                                       const float* __restrict__ rays_o,

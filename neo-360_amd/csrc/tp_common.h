@@ -109,7 +109,8 @@ template <int PE_C>
 __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile0, long P, int N, int R, int chunk,
                                             const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                             const float* __restrict__ viewdirs, const float* __restrict__ tvals,
-                                            const float* __restrict__ far_arr, uint32_t* __restrict__ flags) {
+                                            const float* __restrict__ far_arr, uint32_t* __restrict__ flags,
+                                            bool t_shared = false) {
     float* pe_world = S.pe_world;
     float* feat_world = S.feat_world;
     float* vdir_world = S.vdir_world;
@@ -122,7 +123,7 @@ __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile
         const int bc = min(chunk, R - c0);                       // rays in that chunk (last one may be short)
         const int gl = (ray - c0) * N + s;                       // flattened (ray, sample) index inside the chunk
         const int dray = c0 + gl % bc;                           // neo360/model.py:357-360 tiling: direction of ray (b*N+s) mod B
-        const float tv = tvals[g];
+        const float tv = tvals[t_shared ? (long)s : g];        // t_shared: one row of sample positions for all rays
         float o[3], d[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) { o[a] = rays_o[ray * 3 + a]; d[a] = rays_d[ray * 3 + a]; }
@@ -199,7 +200,7 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 // pixel-aligned latent (neo360/model.py:239-264, encoder_pn.py:116-150), view 0's intrinsics
                 const float den = cz_ + 1e-9f;
                 const float u = (-cx_ / den) * sc.focal + sc.cx;
-                const float w_ = (-cy_ / den) * (-sc.focal) + sc.cy;
+                const float w_ = (-cy_ / den) * (sc.fy_sign * sc.focal) + sc.cy;
                 t = bilinear_taps(u * sc.sx - 1.0f, w_ * sc.sy - 1.0f, sc.Wf, sc.Hf);
                 dst_off = loc_off; dst_w = loc_w;
                 base = v * sc.Hf * sc.Wf;

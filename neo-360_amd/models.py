@@ -340,6 +340,143 @@ class NeRF_TP(_HipModule):
         return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]
 
 
+class PixelNeRFMLP(nn.Module):
+    """Parameter container with the layout of vanilla_nerf/model_pixel.py:35-94: pts_linears.0..3 (128 wide;
+    input = 63-d pos_enc + 512 pixel-aligned latent; the skip never fires at depth 4), views_linear.0/.1 (128),
+    bottleneck_layer, density_layer, rgb_layer."""
+
+    def __init__(self, min_deg_point=0, max_deg_point=10, deg_view=4, netdepth=4, netwidth=128,
+                 netdepth_condition=2, netwidth_condition=128, skip_layer=4, input_ch=3, input_ch_view=3,
+                 num_rgb_channels=3, num_density_channels=1, latent_size=512, combine_layer=3, combine_type="average"):
+        super().__init__()
+        if (min_deg_point, max_deg_point, deg_view, netdepth, netwidth, netdepth_condition, netwidth_condition,
+                skip_layer, input_ch, input_ch_view, num_rgb_channels, num_density_channels, latent_size,
+                combine_layer, combine_type) != (0, 10, 4, 4, 128, 2, 128, 4, 3, 3, 3, 1, 512, 3, "average"):
+            raise NotImplementedError("the HIP kernel is specialised for the reference's default PixelNeRF MLP shape")
+        pos = ((max_deg_point - min_deg_point) * 2 + 1) * input_ch + latent_size
+        view = (deg_view * 2 + 1) * input_ch_view
+        self.pts_linears = nn.ModuleList([_xavier_linear(pos, netwidth)] +
+                                         [_xavier_linear(netwidth, netwidth) for _ in range(netdepth - 1)])
+        self.views_linear = nn.ModuleList([_xavier_linear(netwidth + view, netwidth_condition, xavier=False),
+                                           _xavier_linear(netwidth_condition, netwidth_condition)])
+        self.bottleneck_layer = _xavier_linear(netwidth, netwidth)
+        self.density_layer = _xavier_linear(netwidth, num_density_channels)
+        self.rgb_layer = _xavier_linear(netwidth_condition, num_rgb_channels)
+
+    def ordered_layers(self):
+        """Upload order fixed by include/neo360_hip.h (neo_pix_upload_mlp)."""
+        return list(self.pts_linears) + [self.views_linear[0], self.views_linear[1], self.bottleneck_layer,
+                                         self.density_layer, self.rgb_layer]
+
+
+class PixelNeRF(_HipModule):
+    """PixelNeRF baseline decoder renderer (vanilla_nerf/model_pixel.py:133-258).
+
+    `forward(rays, randomized, white_bkgd, near, far)` keeps the reference's signature and returns
+    `[(comp_rgb, acc, depth)] x 2`.  The image encoder (ResNet-34 SpatialEncoder) is outside the accelerated
+    path: provide its latent once per scene with `set_scene(latent, image_wh)`, or attach an `encoder` module with
+    the reference's interface (callable on `src_imgs`, then `.latent`); an attached encoder runs once per
+    distinct `src_imgs` tensor instead of once per chunk.  All rays of a call form ONE reference chunk unless
+    `chunk` is given (the view-direction tiling of model_pixel.py:219-222 depends on chunk membership)."""
+
+    def __init__(self, num_levels=2, min_deg_point=0, max_deg_point=10, deg_view=4, num_coarse_samples=64,
+                 num_fine_samples=64, use_viewdirs=True, noise_std=0.0, lindisp=False, num_src_views=3, encoder=None):
+        super().__init__()
+        if num_levels != 2 or not use_viewdirs or lindisp:
+            raise NotImplementedError("only the reference's default 2-level, view-dependent, linear-depth setup")
+        self.num_levels, self.num_src_views = num_levels, num_src_views
+        self.num_coarse_samples, self.num_fine_samples = num_coarse_samples, num_fine_samples
+        self.noise_std, self.lindisp = noise_std, lindisp
+        if encoder is not None:
+            self.encoder = encoder
+        self.coarse_mlp = PixelNeRFMLP(min_deg_point, max_deg_point, deg_view)
+        self.fine_mlp = PixelNeRFMLP(min_deg_point, max_deg_point, deg_view)
+        self._scene_key = None
+        self._scene_ctx = None
+
+    def _context(self, device):
+        ctx = super()._context(device)
+        if getattr(ctx, "_precision", None) != "f16x3":
+            raise _lib.NeoError("the PixelNeRF evaluator exists in the split-fp16 arithmetic only (precision 'f16x3')")
+        return ctx
+
+    def _sync_weights(self, ctx):
+        for slot, mlp in enumerate((self.coarse_mlp, self.fine_mlp)):
+            layers = mlp.ordered_layers()
+            ws = [f32(l.weight.detach(), "weight") for l in layers]
+            bs = [f32(l.bias.detach(), "bias") for l in layers]
+            fp = _fingerprint(ws + bs)
+            if ctx.uploaded.get(("pix", slot)) == fp:
+                continue
+            _lib.check(ctx.lib.neo_pix_upload_mlp(ctx.handle, slot, _ptr_table(ws), _ptr_table(bs), ctx.stream()))
+            ctx.uploaded[("pix", slot)] = fp
+
+    @torch.no_grad()
+    def set_scene(self, latent, image_wh):
+        """latent (NV,512,Hf,Wf) as the reference's SpatialEncoder leaves it in `.latent`; image_wh = (W,H) of
+        the source images (model_pixel.py:176-177).  Re-laid out channels-last on the device, once."""
+        latent = f32(latent, "latent")
+        ctx = self._context(latent.device)
+        NV, Cl, Hf, Wf = latent.shape
+        _lib.check(ctx.lib.neo_pix_set_scene(ctx.handle, ptr(latent), NV, Cl, Hf, Wf, float(image_wh[0]),
+                                             float(image_wh[1]), ctx.stream()))
+        torch.cuda.current_stream(latent.device).synchronize()   # the caller may free its tensor
+        self._scene_ctx = ctx
+
+    def _ensure_scene(self, rays):
+        enc = getattr(self, "encoder", None)
+        if enc is None:
+            if self._scene_ctx is None:
+                raise _lib.NeoError("no scene latent: call set_scene(...) or attach an encoder module")
+            return
+        src = rays["src_imgs"]
+        key = (src.data_ptr(), src._version, tuple(src.shape))
+        if key == self._scene_key and self._scene_ctx is not None:
+            return
+        enc(src)
+        self.set_scene(enc.latent, (src.shape[-1], src.shape[-2]))
+        self._scene_key = key
+
+    _camera_args = staticmethod(NeRF_TP._camera_args)
+
+    @torch.no_grad()
+    def eval_mlp(self, slot, rays, tvals, chunk=None):
+        """Stage-level access for parity tests: latent lookups + pos_enc + MLP + activations at sample
+        positions tvals (B,N) along rays_d.  Returns (B,N,4) = (sigmoid rgb, relu sigma)."""
+        rays_o, rays_d, viewdirs = f32(rays["rays_o"]), f32(rays["rays_d"]), f32(rays["viewdirs"])
+        tvals = f32(tvals, "tvals")
+        ctx = self._context(rays_o.device)
+        self._ensure_scene(rays)
+        self._sync_weights(ctx)
+        B, N = tvals.shape
+        host_poses, NV, focal, cx, cy = self._camera_args(rays)
+        out = torch.empty(B, N, 4, device=rays_o.device)
+        _lib.check(ctx.lib.neo_pix_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(tvals), B, N,
+                                       int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy, ptr(out), ctx.stream()))
+        return out
+
+    @torch.no_grad()
+    def forward(self, rays, randomized, white_bkgd, near, far, chunk=None):
+        self._check_mode(randomized)
+        rays_o = f32(rays["rays_o"], "rays_o")
+        rays_d = f32(rays["rays_d"], "rays_d")
+        viewdirs = f32(rays["viewdirs"], "viewdirs")
+        dev = rays_o.device
+        ctx = self._context(dev)
+        self._ensure_scene(rays)
+        if self._scene_ctx is not ctx:
+            raise _lib.NeoError("the scene latent was uploaded on a different device")
+        self._sync_weights(ctx)
+        B = rays_o.shape[0]
+        host_poses, NV, focal, cx, cy = self._camera_args(rays)
+        lv = [(torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)) for _ in range(2)]
+        _lib.check(ctx.lib.neo_pix_render(
+            ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
+            float(near), float(far), self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
+            ptr(lv[0][0]), ptr(lv[0][1]), ptr(lv[0][2]), ptr(lv[1][0]), ptr(lv[1][1]), ptr(lv[1][2]), ctx.stream()))
+        return lv
+
+
 class MipNeRF360MLP(nn.Module):
     """Parameter container with the layout of mipnerf360/model.py:30-107: pts_linear.0..depth-1
     (input = 504-d integrated positional encoding over the 21-direction geodesic basis, skip concat

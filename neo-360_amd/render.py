@@ -35,6 +35,9 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
     if isinstance(model, models.NeRF_TP):
         res = model(batch, False, white_bkgd, near, far, out_depth=True, chunk=chunk)
         out = dict(rgb=res[1][0], depth=res[1][5], fg_rgb=res[1][1], bg_rgb=res[1][2], acc=res[1][3])
+    elif isinstance(model, models.PixelNeRF):
+        res = model(batch, False, white_bkgd, near, far, chunk=chunk)      # vanilla_nerf/model_pixel.py:356-383
+        out = dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
     elif isinstance(model, models.MipNeRF360):
         # mipnerf360/model.py:471-505: train_frac = global_step / max_steps of the trainer; near/far as given
         rend, hist = model(batch, train_frac, False, False, near, far)
