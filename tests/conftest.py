@@ -51,4 +51,6 @@ def built_lib():
 
 
 def max_abs(a, b):
+    a = torch.as_tensor(a).detach().cpu() if not isinstance(a, torch.Tensor) else a.detach().cpu()
+    b = torch.as_tensor(b).detach().cpu() if not isinstance(b, torch.Tensor) else b.detach().cpu()
     return float((a.double() - b.double()).abs().max())

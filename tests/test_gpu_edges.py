@@ -1,0 +1,63 @@
+"""GPU: edge cases of the render entry points — empty batches, a single ray, and the largest supported
+sample counts (n_coarse + 1 + n_fine = 1024: the 1024-wide in-LDS sort of the resampler)."""
+import pytest
+import torch
+
+import cases
+import oracle
+from conftest import max_abs
+from neo360_amd import models, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PER_RAY = ("rays_o", "rays_d", "viewdirs")
+
+
+def _take(batch, n):
+    return {k: (v[:n] if k in PER_RAY else v) for k, v in batch.items()}
+
+
+def test_neo360_single_ray_and_empty():
+    scene = cases.small_scene()
+    net = models.NeRF_TP(num_coarse_samples=32, num_fine_samples=64, num_src_views=cases.NV).to(DEV)
+    params = synth.nerf_tp_state(0)
+    net.load_state_dict(params)
+    net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
+                  scene["latent"].to(DEV), scene["image_wh"])
+    batch = cases.neo_batch(cases.strided_rays(4))
+    one = _take(batch, 1)
+    got = net({k: v.to(DEV) for k, v in one.items()}, False, False, 0.0, 0.0, out_depth=True)
+    want = oracle.neo360.render(params, one, scene, 32, 64)
+    assert max_abs(got[1][0], want[1][0]) < 1e-4 and max_abs(got[1][5], want[1][5]) < 1e-4
+    none = net({k: v.to(DEV) for k, v in _take(batch, 0).items()}, False, False, 0.0, 0.0, out_depth=True)
+    assert none[1][0].shape == (0, 3) and none[1][5].shape == (0,)
+
+
+def test_pixelnerf_single_ray_and_empty():
+    scene = cases.small_scene()
+    net = models.PixelNeRF(num_src_views=cases.NV).to(DEV)
+    params = synth.pixelnerf_state(0)
+    net.load_state_dict(params)
+    net.set_scene(scene["latent"].to(DEV), scene["image_wh"])
+    batch = cases.neo_batch(cases.strided_rays(4))
+    one = _take(batch, 1)
+    got = net({k: v.to(DEV) for k, v in one.items()}, False, False, 0.2, 2.5)
+    want = oracle.pixelnerf.render(params, one, scene, 0.2, 2.5)
+    assert max_abs(got[1][0], want[1][0]) < 1e-4 and max_abs(got[1][2], want[1][2]) < 1e-4
+    none = net({k: v.to(DEV) for k, v in _take(batch, 0).items()}, False, False, 0.2, 2.5)
+    assert none[1][0].shape == (0, 3) and none[1][2].shape == (0,)
+
+
+def test_vanilla_largest_sample_counts():
+    """256 coarse + 767 fine = 1024 fine-level samples per ray."""
+    net = models.NeRF(num_coarse_samples=256, num_fine_samples=767).to(DEV)
+    params = synth.vanilla_state(0)
+    net.load_state_dict(params)
+    rays = cases.strided_rays(6)
+    got = net({k: v.to(DEV) for k, v in rays.items()}, False, False, 0.2, 3.0)
+    want = oracle.vanilla.render(params, rays, 0.2, 3.0, 256, 767)
+    assert max_abs(got[0][0], want[0][0]) < 1e-5
+    assert max_abs(got[1][0], want[1][0]) < 1e-4 and max_abs(got[1][2], want[1][2]) < 2e-4
+    with pytest.raises(Exception):
+        models.NeRF(num_coarse_samples=256, num_fine_samples=768).to(DEV)({k: v.to(DEV) for k, v in rays.items()},
+                                                                         False, False, 0.2, 3.0)
