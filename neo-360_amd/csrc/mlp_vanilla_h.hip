@@ -84,9 +84,6 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 #define NEO_VH_ABLATE 0        // timing experiments: 1 no weight loads, 2 no LDS fragment reads, 4 a quarter of the epilogue stores, 8 no barriers
 #endif
 #define VH_SYNC() do { if (!(NEO_VH_ABLATE & 8)) __syncthreads(); } while (0)
-#ifndef NEO_VH_BPIPE
-#define NEO_VH_BPIPE 0
-#endif
 #ifndef NEO_VH_PREFETCH
 #define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
 #endif
@@ -110,42 +107,6 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < n) load_w(d, d);
-#if NEO_VH_BPIPE
-    // activation fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued
-    h8 bh[2][MTW], bl[2][MTW];
-    auto load_b = [&](int slot, int ks) {
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-            const int o = chunk_off<LDH, KM>((mt0 + mt) * 32 + L.l31, (ks << 1) + L.half);
-            bh[slot][mt] = *reinterpret_cast<const h8*>(tile.hi + o);
-            bl[slot][mt] = *reinterpret_cast<const h8*>(tile.lo + o);
-        }
-    };
-    load_b(0, 0);
-    static_assert(NB % 2 == 0 || NB == 3, "ring size");
-#pragma unroll 1
-    for (int s = 0; s < n; s += 2 * NB) {
-#pragma unroll
-        for (int u = 0; u < 2 * NB; ++u) {
-            if (s + u < n) {
-                if (s + u + D < n) load_w((u + D) % NB, s + u + D);
-                if (s + u + 1 < n) load_b((u + 1) & 1, s + u + 1);
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(al[u % NB][nt], bh[u & 1][mt], acc[nt][mt]);
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(ah[u % NB][nt], bl[u & 1][mt], acc[nt][mt]);
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt) acc[nt][mt] = NEO_MFMA_H(ah[u % NB][nt], bh[u & 1][mt], acc[nt][mt]);
-            }
-        }
-    }
-#else
 #pragma unroll 1
     for (int s = 0; s < n; s += NB) {
 #pragma unroll
@@ -174,7 +135,6 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
             }
         }
     }
-#endif
 }
 
 template <int NTW, int MTW>
