@@ -27,7 +27,8 @@ _NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {
     "mlp_tp_h.hip": _NO_PK_F32,
     "mlp_mip_h.hip": _NO_PK_F32,
-    "mlp_pix_h.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
+    "mlp_pix_h.hip": _NO_PK_F32,
+    "mlp_tp_hv.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
 }
 
 

@@ -1,5 +1,7 @@
 // NeO-360 (NeRF_TP) entry points of the C ABI: weight / scene upload and the
 // two-level, two-region render (neo360/model.py:266-581).
+#include <cstdlib>
+
 #include "ctx.h"
 
 using namespace neo_host;
@@ -35,7 +37,14 @@ void tp_launch(neo_ctx* ctx, const MlpSlot& sl, const neo::TpScene& sc, const ne
     ctx->span_begin(s);
     if (ctx->precision == 1) {
         neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>()};
-        neo::launch_tp_mlp_h(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+        // $NEO_TP_BATCHED=1 selects the three-views-resident kernel (mlp_tp_hv.hip: one weight fetch per tile, one
+        // workgroup per CU); measured 5-10 % slower than the view-loop kernel on MI355X, bit-identical results
+        const char* sel = getenv("NEO_TP_BATCHED");
+        const bool batched = sel && sel[0] == '1';
+        if (batched && neo::tp_views_batched_supported(sc.nv))
+            neo::launch_tp_mlp_hv(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+        else
+            neo::launch_tp_mlp_h(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
     } else {
         neo::TpMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
         neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);

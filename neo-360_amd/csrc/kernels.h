@@ -130,6 +130,12 @@ void launch_tp_mlp_h(int input_ch, const TpMlpHDev& m, const TpScene& sc, const 
                      const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
                      int chunk, uint32_t* flags, float* out, hipStream_t s);
 
+// mlp_tp_hv.hip — the same evaluator with all three source views resident per tile (NV == 3)
+bool tp_views_batched_supported(int nv);
+void launch_tp_mlp_hv(int input_ch, const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+                      const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
+                      int chunk, uint32_t* flags, float* out, hipStream_t s);
+
 // mlp_pix_h.hip — PixelNeRF baseline decoder evaluator (split-fp16 arithmetic only)
 size_t pix_wpack_h_bytes();
 size_t pix_bias_floats();

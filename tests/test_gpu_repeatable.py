@@ -57,12 +57,19 @@ def test_neo360_evaluators_repeatable(built_lib):
         t_fg = torch.linspace(0.05, 0.95, NC, device=dev)[None, :] * far.reshape(-1, 1)
         t_bg = torch.linspace(0.98, 0.02, NC, device=dev)[None, :].expand(R, NC).contiguous()
         ref_net, h_net = mk("f32"), mk("f16x3")
+        import os
         for slot, tt in ((0, t_fg), (1, t_fg), (2, t_bg), (3, t_bg)):
             ref = ref_net.eval_mlp(slot, gb, tt, far=far)
             assert torch.equal(ref, ref_net.eval_mlp(slot, gb, tt, far=far))
             runs = [h_net.eval_mlp(slot, gb, tt, far=far) for _ in range(3)]
             assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
             assert (runs[0] - ref).abs().max().item() < 5e-6
+            os.environ["NEO_TP_BATCHED"] = "1"                     # three-views-resident kernel (opt-in): same bits
+            try:
+                loop = [h_net.eval_mlp(slot, gb, tt, far=far) for _ in range(2)]
+            finally:
+                del os.environ["NEO_TP_BATCHED"]
+            assert torch.equal(loop[0], loop[1]) and torch.equal(loop[0], runs[0])
 
 
 def test_mip360_evaluators_repeatable(built_lib):
