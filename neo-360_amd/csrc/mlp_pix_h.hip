@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256, 2) void k_pix_mlp_h(TpMlpHDev m, TpScene sc, T
     L.init();
     int tid = threadIdx.x;
     const long P = (long)R * N;
-    const long tile0 = (long)blockIdx.x * TM;
+    const long tile0 = tp::xcd_tile(blockIdx.x, (P + TM - 1) / TM) * TM;      // contiguous tile range per XCD (tp_common.h)
+    if (tile0 >= P) return;       // surplus workgroup of the rounded-up grid (uniform exit before any barrier)
     const h8* wp = reinterpret_cast<const h8*>(m.wpack);
 
     tp::point_setup<3>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, nullptr, nullptr, t_shared != 0);
@@ -330,7 +331,7 @@ void launch_pix_mlp_h(const TpMlpHDev& m, const TpScene& sc, const TpViews& view
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = tp::LDS_WORDS * sizeof(float);
-    const long tiles = (P + TM - 1) / TM;
+    const long tiles = tp::xcd_grid((P + TM - 1) / TM);
     hipLaunchKernelGGL(k_pix_mlp_h, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d, viewdirs,
                        tvals, t_shared, R, N, chunk, reinterpret_cast<float4*>(out));
 }

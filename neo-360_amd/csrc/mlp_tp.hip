@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
     L.init();
     int tid = threadIdx.x;
     const long P = (long)R * N;
-    const long tile0 = (long)blockIdx.x * TM;
+    const long tile0 = tp::xcd_tile(blockIdx.x, (P + TM - 1) / TM) * TM;      // contiguous tile range per XCD (tp_common.h)
+    if (tile0 >= P) return;       // surplus workgroup of the rounded-up grid (uniform exit before any barrier)
     const f32x4* wp = reinterpret_cast<const f32x4*>(m.wpack);
     constexpr int KCX = kc_x(PE_C);
     constexpr int NST = PE_C == 3 ? 11 : 12;   // streamed-input stages: 8 local, 2 world, 1-2 pos_enc
@@ -486,7 +487,7 @@ void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpV
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = LDS_FLOATS * sizeof(float);
-    const long tiles = (P + TM - 1) / TM;
+    const long tiles = tp::xcd_grid((P + TM - 1) / TM);
     if (input_ch == 3)
         hipLaunchKernelGGL(k_tp_mlp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
                            viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));

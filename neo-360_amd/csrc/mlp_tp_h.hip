@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp_h(TpMlpHDev m, TpScene sc, Tp
     L.init();
     int tid = threadIdx.x;
     const long P = (long)R * N;
-    const long tile0 = (long)blockIdx.x * TM;
+    const long tile0 = tp::xcd_tile(blockIdx.x, (P + TM - 1) / TM) * TM;
+    if (tile0 >= P) return;       // surplus workgroup of the rounded-up grid (uniform exit before any barrier)
     const h8* wp = reinterpret_cast<const h8*>(m.wpack);
     constexpr int KSX = ks_x(PE_C);
     constexpr int NST = PE_C == 3 ? 11 : 12;   // streamed stages of 64 features: 8 local, 2 world, 1-2 pos_enc
@@ -401,7 +402,7 @@ void launch_tp_mlp_h(int input_ch, const TpMlpHDev& m, const TpScene& sc, const 
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = tp::LDS_WORDS * sizeof(float);
-    const long tiles = (P + TM - 1) / TM;
+    const long tiles = tp::xcd_grid((P + TM - 1) / TM);
     if (input_ch == 3)
         hipLaunchKernelGGL(k_tp_mlp_h<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
                            viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));

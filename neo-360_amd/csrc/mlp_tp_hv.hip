@@ -119,7 +119,8 @@ __global__ __launch_bounds__(512, 2) void k_tp_mlp_hv(TpMlpHDev m, TpScene sc, T
     L.init();
     const int tid = threadIdx.x;
     const long P = (long)R * N;
-    const long tile0 = (long)blockIdx.x * TM;
+    const long tile0 = tp::xcd_tile(blockIdx.x, (P + TM - 1) / TM) * TM;      // contiguous tile range per XCD (tp_common.h)
+    if (tile0 >= P) return;       // surplus workgroup of the rounded-up grid (uniform exit before any barrier)
     const char* wb = reinterpret_cast<const char*>(m.wpack);
     constexpr int KSX = ks_x(PE_C);
     constexpr int NST = PE_C == 3 ? 11 : 12;
@@ -430,7 +431,7 @@ void launch_tp_mlp_hv(int input_ch, const TpMlpHDev& m, const TpScene& sc, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hv<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr = true;
     }
-    const long tiles = (P + TM - 1) / TM;
+    const long tiles = tp::xcd_grid((P + TM - 1) / TM);
     if (input_ch == 3)
         hipLaunchKernelGGL(k_tp_mlp_hv<3>, dim3((unsigned)tiles), dim3(512), LDS_BYTES, s, m, sc, views, rays_o, rays_d,
                            viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));

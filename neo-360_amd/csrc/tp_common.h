@@ -26,6 +26,20 @@ constexpr int OFF_VDIR = OFF_FEAT + TM * 4;              // float[64][4]: world 
 constexpr int OFF_DENSW = OFF_VDIR + TM * 4;             // float[128]: density-head weights (split-fp16 kernel)
 constexpr int LDS_WORDS = OFF_DENSW + 128;
 
+// Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2).  Consecutive tiles hold neighbouring
+// samples that share feature texels, so each XCD is given a CONTIGUOUS range of tiles: workgroup b works on tile
+// (b % 8) * ceil(T / 8) + b / 8.  The launch rounds the grid up to a multiple of 8; surplus workgroups exit.
+constexpr int XCDS = 8;
+__device__ __forceinline__ long xcd_tile(unsigned bid, long tiles) {
+#ifdef NEO_NO_XCD_REMAP
+    return bid;
+#else
+    const long per = (tiles + XCDS - 1) / XCDS;
+    return (long)(bid % XCDS) * per + bid / XCDS;
+#endif
+}
+inline long xcd_grid(long tiles) { return ((tiles + XCDS - 1) / XCDS) * XCDS; }
+
 struct Scratch {
     int* loc_off; float* loc_w; int* pl_off; float* pl_w;
     float* cam_enc; float* pe_world; float* feat_world; float* vdir_world;
