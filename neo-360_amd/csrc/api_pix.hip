@@ -66,7 +66,7 @@ int neo_pix_set_scene(neo_ctx* ctx, const float* latent, int NV, int Cl, int Hf,
     REQUIRE(NV >= 1 && NV <= neo::TP_MAX_VIEWS, "1..8 source views supported");
     REQUIRE(Cl == 512, "the latent width is fixed by the reference MLP (512)");
     REQUIRE(Hf >= 2 && Wf >= 2, "feature maps must be at least 2x2");
-    REQUIRE(static_cast<long>(NV) * Hf * Wf * 128 < 2147483647L / 16, "latent too large for 32-bit byte offsets");
+    REQUIRE(static_cast<long>(NV) * Hf * Wf * 2048 <= 4294967295L, "latent too large for 32-bit byte offsets (NV*Hf*Wf < 2^21 texels)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ctx->latent.reserve(static_cast<size_t>(NV) * Cl * Hf * Wf * 4)) return NEO_ERR_NOMEM;
     neo::launch_channels_last(latent, NV, Cl, Hf, Wf, ctx->latent.as<float>(), s);

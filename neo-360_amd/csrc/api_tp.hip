@@ -84,7 +84,8 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
     REQUIRE(NV >= 1 && NV <= neo::TP_MAX_VIEWS, "1..8 source views supported");
     REQUIRE(Cw == 128 && Cl == 512, "feature widths are fixed by the reference MLP (128 world, 512 local)");
     REQUIRE(Hp >= 2 && Wp >= 2 && Hf >= 2 && Wf >= 2, "feature maps must be at least 2x2");
-    REQUIRE(static_cast<long>(NV) * Hf * Wf * 128 < 2147483647L, "latent too large for 32-bit texel offsets");
+    REQUIRE(static_cast<long>(NV) * Hf * Wf * 2048 <= 4294967295L && static_cast<long>(NV) * Hp * Wp * 512 <= 4294967295L,
+            "feature maps too large for 32-bit byte offsets (NV*Hf*Wf < 2^21 texels)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float* planes[3] = {plane_xz, plane_xy, plane_yz};
     for (int j = 0; j < 3; ++j) {

@@ -236,7 +236,10 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 texel_bytes = 128 * 4;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { dst_off[p * 4 + k] = (base + t.off[k]) * texel_bytes; dst_w[p * 4 + k] = t.w[k]; }
+            for (int k = 0; k < 4; ++k) {
+                dst_off[p * 4 + k] = (int)((uint32_t)(base + t.off[k]) * (uint32_t)texel_bytes);   // byte offset mod 2^32
+                dst_w[p * 4 + k] = t.w[k];
+            }
             // view-direction encoding in this view's camera frame; wave q takes octave q
             const float dx = vdir_world[p * 4], dy = vdir_world[p * 4 + 1], dz = vdir_world[p * 4 + 2];
             const float dc[3] = {rot[0] * dx + rot[1] * dy + rot[2] * dz, rot[3] * dx + rot[4] * dy + rot[5] * dz,
