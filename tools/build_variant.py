@@ -1,6 +1,6 @@
 """Link a variant of the library with one translation unit recompiled with extra flags.
 usage: build_variant.py <name> <source.hip> [extra hipcc flags...]  ->  tools/build/libneo_<name>.so
-(select it with NEO360_HIP_LIB=<path>; kernel experiments only)"""
+(select it with NEO360_HIP_LIB=<path>; kernel experiments only; NEO_VARIANT_NO_EXTRA=1 drops build.py's per-file flags)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "neo-360_amd"))
@@ -10,7 +10,7 @@ name, src, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
 out = os.path.join(ROOT, "tools", "build")
 os.makedirs(out, exist_ok=True)
 obj = os.path.join(out, "%s_%s.o" % (src[:-4], name))
-subprocess.check_call([B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + extra + ["-c", os.path.join(B.CSRC, src), "-o", obj],
+subprocess.check_call([B._hipcc()] + B.FLAGS + ([] if os.environ.get("NEO_VARIANT_NO_EXTRA") else B.EXTRA_FLAGS.get(src, [])) + extra + ["-c", os.path.join(B.CSRC, src), "-o", obj],
                       stderr=subprocess.DEVNULL)
 objs = [os.path.join(B.OUT_DIR, s[:-4] + ".o") for s in B.sources() if s != src] + [obj]
 lib = os.path.join(out, "libneo_%s.so" % name)

@@ -67,3 +67,17 @@ for name, slot, tt in (("neo fg0", 0, tv), ("neo fg1", 1, tv), ("neo bg0", 2, tb
     runs = [h_net.eval_mlp(slot, gb, tt, far=far_g).cpu() for _ in range(RUNS)]
     report(name, ref, runs)
     print("   fp32 kernel repeatable:", torch.equal(ref, again))
+
+# ---- pixelnerf ----
+R, NC = int(os.environ.get("RP", "2048")), 129
+pnet = models.PixelNeRF(num_src_views=cases.NV).to(DEV)
+pnet.load_state_dict(synth.pixelnerf_state(0))
+pnet.set_scene(scene["latent"].to(DEV), scene["image_wh"])
+batch = cases.neo_batch(cases.strided_rays(R))
+gb = {k: v.to(DEV) for k, v in batch.items()}
+tt = torch.linspace(0.2, 2.5, NC, device=DEV)[None, :].expand(R, NC).contiguous()
+for slot in (0, 1):
+    runs = [pnet.eval_mlp(slot, gb, tt).cpu() for _ in range(RUNS)]
+    same = all(torch.equal(runs[0], r) for r in runs[1:])
+    d = max((runs[0] - r).abs().max().item() for r in runs[1:])
+    print("pixelnerf slot %d points %8d  bitwise-repeatable %s  max run-to-run diff %.2e" % (slot, R * NC, same, d))
