@@ -15,6 +15,12 @@
 #include "split_tile.h"
 #include "tp_common.h"
 
+#ifndef NEO_GATHER_WAVES_PER_SIMD
+// 3 workgroups per CU (53.8 KB LDS each): caps the kernel at 168 VGPRs; the 16-register view-branch sum is then
+// spilled once per view, and the third wave per SIMD still buys 4-6 % (tools/bench_tp_kernel.py: 17.40 -> 16.63 ms)
+#define NEO_GATHER_WAVES_PER_SIMD 3
+#endif
+
 namespace neo {
 
 namespace {
@@ -37,7 +43,7 @@ constexpr int B_0 = 0, B_1 = 128, B_2 = 256, B_3 = 384, B_B = 512, B_V0 = 640, B
 constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 516, HEADS_FLOATS = 520;
 constexpr int NST = 9;                                    // streamed stages: 8 latent, 1 pos_enc
 
-__global__ __launch_bounds__(256, 2) void k_pix_mlp_h(TpMlpHDev m, TpScene sc, TpViews views,
+__global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(TpMlpHDev m, TpScene sc, TpViews views,
                                                       const float* __restrict__ rays_o,
                                                       const float* __restrict__ rays_d,
                                                       const float* __restrict__ viewdirs,
