@@ -13,6 +13,10 @@
 // Algorithmic work: PropMLP 325,888 MAC, NeRFMLP 8,672,000 MAC per interval.
 #include "split_tile.h"
 
+#ifndef NEO_MIP_H_WAVES
+#define NEO_MIP_H_WAVES 16      // waves per workgroup of the 1024-wide evaluator: 16 (4 per SIMD) measured +3-4 % over 8
+#endif
+
 namespace neo {
 
 namespace {
@@ -98,14 +102,17 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW], const char* __restric
     }
 }
 
-template <int W, int DEPTH, bool RGB>
-__global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHDev m, const float* __restrict__ rays_o,
+// NWV waves per workgroup (8, or 16 for the 1024-wide MLP: 4 waves per SIMD, 128 VGPRs, two accumulator tiles each)
+template <int W, int DEPTH, bool RGB, int NWV>
+__global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) void k_mip_mlp_h(MipMlpHDev m, const float* __restrict__ rays_o,
                                                                         const float* __restrict__ rays_d,
                                                                         const float* __restrict__ viewdirs,
                                                                         const float* __restrict__ radii,
                                                                         const float* __restrict__ tdist, int R, int n,
                                                                         float4* __restrict__ out) {
-    constexpr int NTW = W / 256;             // N-tiles per wave for W-wide layers (8 waves x NTW x 32 = W)
+    constexpr int NTW = W / (32 * NWV);      // N-tiles per wave for W-wide layers (NWV waves x NTW x 32 = W)
+    constexpr int NT = NWV * 64;             // threads
+    constexpr int FPT = 2048 / NT;           // encoding features per thread and stage (32 rows x 64 features)
     constexpr int KSW = W / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* hb = reinterpret_cast<_Float16*>(smem);
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHD
     }
     __syncthreads();
     // ---- lift_and_diagonalize (helper.py:70-73): mean_j = z . b_j ; var_j = sum_i b_ij (cov b_j)_i ----
-    for (int idx = tid; idx < TMR * NB; idx += 512) {
+    for (int idx = tid; idx < TMR * NB; idx += NT) {
         const int row = idx / NB, j = idx - row * NB;
         const float b0 = m.basis[j], b1 = m.basis[NB + j], b2 = m.basis[2 * NB + j];
         const float* rz = rowz + row * 12;
@@ -237,11 +244,11 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHD
 
     // integrated_pos_enc (helper.py:77-88): 64 features of stage s; thread = (row, 4 consecutive features)
     auto produce = [&](int s, const HT& buf) {
-        const int row = tid & 31, q = tid >> 5;
-        f32x4 v;
+        const int row = tid & 31, q = tid >> 5;              // q: group of FPT consecutive features
+        _Float16 vh[FPT], vl[FPT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int f = s * 64 + q * 4 + e;
+        for (int e = 0; e < FPT; ++e) {
+            const int f = s * 64 + q * FPT + e;
             float val = 0.0f;
             if (f < 504) {
                 const bool shifted = f >= 252;
@@ -251,13 +258,11 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHD
                 const float arg = ldexpf(mean, k);
                 val = expf(-0.5f * ldexpf(var, 2 * k)) * sin_cw(shifted ? arg + HALF_PI_F32 : arg);
             }
-            v[e] = val;
+            split(val, vh[e], vl[e]);
         }
-        h4 vh, vl;
-        split4(v, vh, vl);
-        const int o = chunk_off<64>(row, q >> 1) + 4 * (q & 1);
-        *reinterpret_cast<h4*>(buf.hi + o) = vh;
-        *reinterpret_cast<h4*>(buf.lo + o) = vl;
+        const int o = chunk_off<64>(row, (q * FPT) >> 3) + ((q * FPT) & 7);
+#pragma unroll
+        for (int e = 0; e < FPT; ++e) { buf.hi[o + e] = vh[e]; buf.lo[o + e] = vl[e]; }
     };
     // acc += W_layer[:, ksbase .. ksbase + 32 k-steps] * ipe^T, streamed through the double buffer
     auto stream_ipe = [&](f32x16 (&acc)[NTW], const char* wl, int KS, int ksbase) {
@@ -297,8 +302,8 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHD
         __syncthreads();
     }
     // ---- density head (VALU): 16 lanes per row, W/16 channels each ----
-    float raw_density;
-    {
+    float raw_density = 0.f;
+    if (tid < 512) {
         const int row = tid >> 4, part = tid & 15;
         constexpr int CH = W / 8 / 16;      // 8-half chunks per lane
         float s = 0.f;
@@ -325,10 +330,12 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHD
     if (RGB) {
         // ---- bottleneck W -> 256 (no activation): one N-tile per wave ----
         f32x16 ab[1];
-        bias_tile(ab[0], m.bias + B_BOTT, L.wv, L);
-        gemm_h<1, W>(ab, wbase + (size_t)W_BOTT * 16, KSW, L.wv, 0, 0, KSW, act, L);
+        if (L.wv < 8) {
+            bias_tile(ab[0], m.bias + B_BOTT, L.wv, L);
+            gemm_h<1, W>(ab, wbase + (size_t)W_BOTT * 16, KSW, L.wv, 0, 0, KSW, act, L);
+        }
         __syncthreads();
-        store_tile_h<false, W>(ab[0], act, L.wv, 0, L);
+        if (L.wv < 8) store_tile_h<false, W>(ab[0], act, L.wv, 0, L);
         __syncthreads();
         // ---- view layer [bottleneck 256 | dir enc 27] -> 128, ReLU: waves 0..3 ----
         if (L.wv < 4) {
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHD
         if (L.wv < 4) store_tile_h<true, W>(ab[0], act, L.wv, 0, L);
         __syncthreads();
         // ---- rgb head: 16 lanes per row, 8 features each ----
-        const int row = tid >> 4, part = tid & 15;
+        const int row = (tid >> 4) & 31, part = tid & 15;     // (threads >= 512 repeat rows; only tid < 512 writes)
         const float* wr = m.heads + hd_rw(W);
         const int o = chunk_off<W>(row, part);
         const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(512, (W == 1024 ? 2 : 4)) void k_mip_mlp_h(MipMlpHD
     {
         const int row = tid >> 4, part = tid & 15;
         const long gi = tile0 + row;
-        if (part == 0 && gi < P) {
+        if (tid < 512 && part == 0 && gi < P) {
             float4 o4;
             if (RGB) {
                 o4.x = colour_act(r + m.heads[hd_rb(W)]);
@@ -414,17 +421,17 @@ int launch_mip_mlp_h(int width, int depth, int rgb, const MipMlpHDev& m, const f
     const long tiles = (P + TMR - 1) / TMR;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<1024, 8, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<1024, 8, true, NEO_MIP_H_WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<1024>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<256, 4, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<256, 4, false, 8>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<256>());
         attr = true;
     }
     if (width == 1024 && depth == 8 && rgb)
-        hipLaunchKernelGGL((k_mip_mlp_h<1024, 8, true>), dim3((unsigned)tiles), dim3(512), lds_bytes<1024>(), s, m,
+        hipLaunchKernelGGL((k_mip_mlp_h<1024, 8, true, NEO_MIP_H_WAVES>), dim3((unsigned)tiles), dim3(NEO_MIP_H_WAVES * 64), lds_bytes<1024>(), s, m,
                            rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));
     else if (width == 256 && depth == 4 && !rgb)
-        hipLaunchKernelGGL((k_mip_mlp_h<256, 4, false>), dim3((unsigned)tiles), dim3(512), lds_bytes<256>(), s, m,
+        hipLaunchKernelGGL((k_mip_mlp_h<256, 4, false, 8>), dim3((unsigned)tiles), dim3(512), lds_bytes<256>(), s, m,
                            rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));
     else
         return -1;
