@@ -84,6 +84,9 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 #define NEO_VH_ABLATE 0        // timing experiments: 1 no weight loads, 2 no LDS fragment reads, 4 a quarter of the epilogue stores, 8 no barriers
 #endif
 #define VH_SYNC() do { if (!(NEO_VH_ABLATE & 8)) __syncthreads(); } while (0)
+#ifndef NEO_VH_SETPRIO
+#define NEO_VH_SETPRIO 3      // s_setprio during the matrix phase: +0.5-0.7 % (tools/bench_kernel.py)
+#endif
 #ifndef NEO_VH_PREFETCH
 #define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
 #endif
@@ -107,6 +110,9 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (d < n) load_w(d, d);
+#if NEO_VH_SETPRIO
+    __builtin_amdgcn_s_setprio(NEO_VH_SETPRIO);      // matrix phase: issue ahead of the co-resident wave's epilogue VALU work
+#endif
 #pragma unroll 1
     for (int s = 0; s < n; s += NB) {
 #pragma unroll
@@ -135,6 +141,9 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
             }
         }
     }
+#if NEO_VH_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 template <int NTW, int MTW>
