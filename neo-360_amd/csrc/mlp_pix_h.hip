@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
     __syncthreads();
 
-    f32x16 ysum[1][2];
+    // View means by linearity (see mlp_tp_h.hip): the loop accumulates hsum = sum_v relu(L3_v) and the direction
+    // encodings; density head, bottleneck and view layer 0 run once per tile on the view means.
+    f32x16 hsum[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ysum[0][0][r] = 0.f; ysum[0][1][r] = 0.f; }
-    float sig_part = 0.f;
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; }
+    float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
     const int nts_1[1] = {L.wv};
 
 #pragma unroll 1
@@ -90,11 +92,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
         tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
-            _Float16 h, l;
-            split(val, h, l);
-            const int o = chunk_off<32>(p, f >> 3) + (f & 7);
-            dsm.hi[o] = h;
-            dsm.lo[o] = l;
+            dsum[p * 32 + f] = v == 0 ? val : dsum[p * 32 + f] + val;      // (p, f) is owned by one thread in every view
         });
         __syncthreads();
 
@@ -217,12 +215,53 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
             acc[0][1] = acc[0][0];
             gemm2h<1, 128>(acc, wp + (layer == 0 ? PX_1 : layer == 1 ? PX_2 : PX_3), 8, nts_1, 0, 0, 8, act, L);
             __syncthreads();
-            store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
-            store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
-            __syncthreads();
+            if (layer < 2) {
+                store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
+                store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
+                __syncthreads();
+            }
         }
-        sig_part += density_partial(act, dens_w, L);       // the density head is linear in the view mean of relu(L3)
-        // ---- per-view bottleneck (no activation) ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {         // relu(L3_v) joins the view sum; it is not written back per view
+            hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
+            hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
+        }
+    }
+
+    // ---- view mean of the trunk -> density head (ReLU, model_pixel.py:232) ----
+    const float nvf = (float)sc.nv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] / nvf; hsum[1][r] = hsum[1][r] / nvf; }
+    store_tile_h<false>(hsum[0], act, L.wv, 0, L);
+    store_tile_h<false>(hsum[1], act, L.wv, 1, L);
+    float dmean[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dmean[j] = dsum[tid * 8 + j] / nvf;
+    __syncthreads();
+    {
+        h8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 h, l;
+            split(dmean[j], h, l);
+            vh[j] = h;
+            vl[j] = l;
+        }
+        const int o = chunk_off<32>(tid >> 2, tid & 3);
+        *reinterpret_cast<h8*>(dsm.hi + o) = vh;
+        *reinterpret_cast<h8*>(dsm.lo + o) = vl;
+    }
+    float sigma;
+    {
+        float sg = density_partial(act, dens_w, L);
+        sg += __shfl_xor(sg, 1, 64);
+        sg += __shfl_xor(sg, 2, 64);
+        sigma = fmaxf(sg + m.heads[HD_DB], 0.0f);
+    }
+    // ---- bottleneck of the view mean (no activation), view layer 0 on [mean bottleneck | mean dir enc] -> 128 ----
+    f32x16 ysum[1][2];
+    {
+        f32x16 acc[1][2];
         bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
         acc[0][1] = acc[0][0];
         gemm2h<1, 128>(acc, wp + PX_B, 8, nts_1, 0, 0, 8, act, L);
@@ -230,28 +269,13 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
         store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
         __syncthreads();
-        // ---- view layer 0: [bottleneck | dir enc] -> 128, summed over views before the ReLU ----
-        bias_tile(acc[0][0], m.bias + B_V0, L.wv, L);
-        acc[0][1] = acc[0][0];
-        gemm2h<1, 128>(acc, wp + PX_V0, 10, nts_1, 0, 0, 8, act, L);
-        gemm2h<1, 32>(acc, wp + PX_V0, 10, nts_1, 8, 0, 2, dsm, L);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { ysum[0][0][r] += acc[0][0][r]; ysum[0][1][r] += acc[0][1][r]; }
+        bias_tile(ysum[0][0], m.bias + B_V0, L.wv, L);
+        ysum[0][1] = ysum[0][0];
+        gemm2h<1, 128>(ysum, wp + PX_V0, 10, nts_1, 0, 0, 8, act, L);
+        gemm2h<1, 32>(ysum, wp + PX_V0, 10, nts_1, 8, 0, 2, dsm, L);
         __syncthreads();
     }
-
-    // ---- density head: mean over views of the per-view dot products; ReLU (model_pixel.py:232) ----
-    const float nvf = (float)sc.nv;
-    float sigma;
-    {
-        float sg = sig_part;
-        sg += __shfl_xor(sg, 1, 64);
-        sg += __shfl_xor(sg, 2, 64);
-        sigma = fmaxf(sg / nvf + m.heads[HD_DB], 0.0f);
-    }
-    // ---- view mean -> ReLU -> 128x128 -> ReLU -> rgb head -> sigmoid ----
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ysum[0][0][r] = ysum[0][0][r] / nvf; ysum[0][1][r] = ysum[0][1][r] / nvf; }
+    // ---- ReLU -> 128x128 -> ReLU -> rgb head -> sigmoid ----
     store_tile_h<true>(ysum[0][0], act, L.wv, 0, L);
     store_tile_h<true>(ysum[0][1], act, L.wv, 1, L);
     __syncthreads();

@@ -78,15 +78,18 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     __syncthreads();
 
-    // view means: the 64-wide view-branch pre-activation is summed in registers; the density head is linear
-    // in the view mean of the trunk output, so each view adds its own dot product w_d . relu(L3_v) instead of
-    // keeping a 128-wide running sum (32 VGPRs) alive across the whole view loop
-    f32x16 ysum;
+    // View means by linearity.  Everything after relu(L3_v) is linear up to the view mean: the density head acts on
+    // mean_v relu(L3_v); the bottleneck is linear, and so is view layer 0 on [bottleneck_v | dir_enc_v], whose view
+    // mean is then V0 [mean_v bottleneck_v | mean_v dir_enc_v] + b.  So the view loop only accumulates
+    // hsum = sum_v relu(L3_v) (two accumulator tiles per wave) and the 27 direction features (fp32 in LDS), and the
+    // bottleneck / view-layer GEMMs run ONCE per tile instead of once per view (10 % of the MFMA work, two
+    // epilogues and three barriers per view).
+    f32x16 hsum[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ysum[r] = 0.f;
-    float sig_part = 0.f;
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; }
     float* dens_w = smem + tp::OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
+    float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
     const int nts_x[2] = {L.wv, 4 + L.wv};
     const int nts_1[1] = {L.wv};
     const int vnt = L.wv & 1, vmt = L.wv >> 1;
@@ -104,11 +107,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
         tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
-            _Float16 h, l;
-            split(val, h, l);
-            const int o = chunk_off<32>(p, f >> 3) + (f & 7);
-            dsm.hi[o] = h;
-            dsm.lo[o] = l;
+            dsum[p * 32 + f] = v == 0 ? val : dsum[p * 32 + f] + val;      // (p, f) is owned by one thread in every view
         });
         __syncthreads();
 
@@ -292,16 +291,52 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
             store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
             __syncthreads();
         }
-        // ---- L3 = skip half (in accx[1]) + W3[:, :128] h2; ReLU; accumulate the view mean ----
+        // ---- L3 = skip half (in accx[1]) + W3[:, :128] h2; ReLU; accumulate over the views ----
         acc[0][0] = accx[1][0];
         acc[0][1] = accx[1][1];
         gemm2h<1, 128>(acc, wp + hoff_3a(PE_C), 8, nts_1, 0, 0, 8, act, L);
-        __syncthreads();
-        store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
-        store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
-        __syncthreads();
-        sig_part += density_partial(act, dens_w, L);
-        // ---- per-view bottleneck (no activation) ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
+            hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
+        }
+        __syncthreads();           // every wave is done reading this view's tiles
+    }
+
+    // ---- view mean of the trunk -> density head ----
+    const float nvf = (float)sc.nv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] / nvf; hsum[1][r] = hsum[1][r] / nvf; }
+    store_tile_h<false>(hsum[0], act, L.wv, 0, L);
+    store_tile_h<false>(hsum[1], act, L.wv, 1, L);
+    // view mean of the direction encoding: fp32 sums -> hi/lo planes in place (read all, barrier, write)
+    float dmean[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dmean[j] = dsum[tid * 8 + j] / nvf;
+    __syncthreads();
+    {
+        h8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 h, l;
+            split(dmean[j], h, l);
+            vh[j] = h;
+            vl[j] = l;
+        }
+        const int o = chunk_off<32>(tid >> 2, tid & 3);
+        *reinterpret_cast<h8*>(dsm.hi + o) = vh;
+        *reinterpret_cast<h8*>(dsm.lo + o) = vl;
+    }
+    float raw_sigma;
+    {
+        float sg = density_partial(act, dens_w, L);
+        sg += __shfl_xor(sg, 1, 64);
+        sg += __shfl_xor(sg, 2, 64);
+        raw_sigma = sg + m.heads[HD_DB];
+    }
+    // ---- bottleneck of the view mean (no activation) ----
+    {
+        f32x16 acc[1][2];
         bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
         acc[0][1] = acc[0][0];
         gemm2h<1, 128>(acc, wp + hoff_b(PE_C), 8, nts_1, 0, 0, 8, act, L);
@@ -309,30 +344,14 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
         store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
         store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
         __syncthreads();
-        // ---- view layer 0: [bottleneck | dir enc] -> 64, summed over views before the ReLU ----
-        {
-            f32x16 y;
-            bias_tile(y, m.bias + B_V0, vnt, L);
-            gemm1h<128>(y, wp + hoff_v0(PE_C), 10, vnt, vmt, 0, 8, act, L);
-            gemm1h<32>(y, wp + hoff_v0(PE_C), 10, vnt, vmt, 8, 2, dsm, L);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ysum[r] += y[r];
-        }
-        __syncthreads();
     }
-
-    // ---- density head: mean over views of the per-view dot products ----
-    const float nvf = (float)sc.nv;
-    float raw_sigma;
-    {
-        float sg = sig_part;
-        sg += __shfl_xor(sg, 1, 64);
-        sg += __shfl_xor(sg, 2, 64);
-        raw_sigma = sg / nvf + m.heads[HD_DB];
-    }
-    // ---- view mean of the view branch -> ReLU -> 64x64 -> ReLU -> rgb head ----
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ysum[r] = ysum[r] / nvf;
+    // ---- view layer 0 on [mean bottleneck | mean dir enc] -> 64 ----
+    f32x16 ysum;
+    bias_tile(ysum, m.bias + B_V0, vnt, L);
+    gemm1h<128>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 0, 8, act, L);
+    gemm1h<32>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 8, 2, dsm, L);
+    __syncthreads();
+    // ---- ReLU -> 64x64 -> ReLU -> rgb head ----
     store_tile_h<true>(ysum, act, vnt, vmt, L);
     __syncthreads();
     {

@@ -64,12 +64,13 @@ def test_neo360_evaluators_repeatable(built_lib):
             runs = [h_net.eval_mlp(slot, gb, tt, far=far) for _ in range(3)]
             assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
             assert (runs[0] - ref).abs().max().item() < 5e-6
-            os.environ["NEO_TP_BATCHED"] = "1"                     # three-views-resident kernel (opt-in): same bits
+            os.environ["NEO_TP_BATCHED"] = "1"                     # three-views-resident kernel (opt-in)
             try:
                 loop = [h_net.eval_mlp(slot, gb, tt, far=far) for _ in range(2)]
             finally:
                 del os.environ["NEO_TP_BATCHED"]
-            assert torch.equal(loop[0], loop[1]) and torch.equal(loop[0], runs[0])
+            # (it sums the view branch per view, the default kernel applies it to the view means: same to fp32 rounding)
+            assert torch.equal(loop[0], loop[1]) and (loop[0] - runs[0]).abs().max().item() < 2e-6
 
 
 def test_mip360_evaluators_repeatable(built_lib):
