@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
         tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
-            dsum[p * 32 + f] = v == 0 ? val : dsum[p * 32 + f] + val;      // (p, f) is owned by one thread in every view
+            const int di = p * 32 + (f ^ (p & 31));     // lane = p: XOR keeps the 64 lanes on distinct banks
+            dsum[di] = v == 0 ? val : dsum[di] + val;   // (p, f) is owned by one thread in every view
         });
         __syncthreads();
 
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
     store_tile_h<false>(hsum[1], act, L.wv, 1, L);
     float dmean[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dmean[j] = dsum[tid * 8 + j] / nvf;
+    for (int j = 0; j < 8; ++j) dmean[j] = dsum[(tid >> 2) * 32 + ((((tid & 3) << 3) + j) ^ ((tid >> 2) & 31))] / nvf;
     __syncthreads();
     {
         h8 vh, vl;
