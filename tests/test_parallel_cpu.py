@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from neo360_amd import parallel
+from neo360_amd import models, parallel
 
 
 @pytest.mark.parametrize("n,world,unit", [(307200, 8, 1024), (307200, 1, 1024), (1500, 2, 1024), (1500, 4, 1024),
@@ -65,3 +65,49 @@ def test_psnr_formula():
     assert abs(render.psnr(b, a) - 20.0) < 1e-4     # mse = 0.01 -> 20 dB
     # inputs are clipped to [0,1] before the mse, as the reference does
     assert render.psnr(torch.full((2, 3), 2.0), torch.full((2, 3), 1.0)) == float("inf")
+
+
+class _FakePixelNeRF(models.PixelNeRF):
+    """Stands in for the HIP renderer on CPU: per-ray outputs that depend on the ray, on its position inside its
+    reference chunk (as the real direction-tiling quirk does) and on the whole-tensor keys (src_poses)."""
+
+    def forward(self, rays, randomized, white_bkgd, near, far, chunk=None):
+        o = rays["rays_o"]
+        B = o.shape[0]
+        chunk = int(chunk or max(B, 1))
+        pos = (torch.arange(B) % chunk).float()[:, None]                      # position inside the reference chunk
+        bias = rays["src_poses"].sum()                                        # whole-tensor key must arrive unsliced
+        rgb = o * 2.0 + pos * 1e-3 + bias
+        depth = o.sum(-1) + float(near)
+        acc = o[:, 0] * 0.5 + float(far)
+        return [(rgb * 0, acc * 0, depth * 0), (rgb, acc, depth)]
+
+
+def _sharded_worker(rank, world, port, n, chunk, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from neo360_amd import render
+        g = torch.Generator().manual_seed(11)
+        batch = dict(rays_o=torch.randn(n, 3, generator=g), rays_d=torch.randn(n, 3, generator=g),
+                     viewdirs=torch.randn(n, 3, generator=g), src_poses=torch.randn(3, 4, 4, generator=g),
+                     src_focal=torch.ones(3), src_c=torch.zeros(3, 2), src_imgs=torch.zeros(3, 3, 4, 4))
+        net = _FakePixelNeRF()
+        whole = render.render_rays_test(net, batch, chunk=chunk, near=0.2, far=2.5)
+        want = torch.cat([whole["rgb"], whole["depth"][:, None], whole["acc"][:, None]], dim=1)
+        got = render.render_frame_sharded(net, batch, world, rank, chunk=chunk, near=0.2, far=2.5)
+        ret[rank] = bool(torch.equal(got, want))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,chunk", [(1500, 2, 256), (1000, 3, 128)])
+def test_sharded_frame_equals_whole_frame_gloo(n, world, chunk):
+    """Shards are whole reference chunks, per-ray keys are sliced, src_* keys are passed whole, and the gathered
+    (rgb, depth, acc) frame equals the single-process frame bit for bit — on every rank."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sharded_worker, args=(world, port, n, chunk, ret), nprocs=world, join=True)
+        assert all(ret.get(r) for r in range(world)), dict(ret)
