@@ -119,58 +119,47 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
         bias_tile(accx[1][0], m.bias + B_3, L.wv, L);
         accx[1][1] = accx[1][0];
         {
+            // Quarter-stage schedule: one row per thread and one k-step per pass (4 passes per 64-feature stage):
+            // 16 tap registers + 16 weight registers (a half-stage schedule needs 32 + 32), so the 168-VGPR build
+            // (three workgroups per CU) spills 14 registers instead of 42: 16.0 -> 15.7 ms fg, 14.3 -> 13.4 ms bg.
+            // Per pass: gathers of one row of the NEXT stage | 12 MFMAs of this stage's k-step | next k-step's
+            // weights | blend + split + store of the gathered row.
             const int col4 = tid & 15, rg = tid >> 4;
-            const uint32_t lane_b = 16u * col4;      // this lane's 4 channels inside a 64-channel stage slice
-            f32x4 tap[2][4];
-            auto issue_local = [&](int s, int hf) {
+            const uint32_t lane_b = 16u * col4;
+            f32x4 tap[4];
+            auto issue_local = [&](int s, int q) __attribute__((always_inline)) {
+                const int row = rg + 16 * q;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = rg + 16 * (2 * hf + i);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) tap[i][k] = tp::load_tap(sc.latent, (uint32_t)loc_off[row * 4 + k] + lane_b + 256u * s);
-                }
+                for (int k = 0; k < 4; ++k) tap[k] = tp::load_tap(sc.latent, (uint32_t)loc_off[row * 4 + k] + lane_b + 256u * s);
             };
-            auto issue_plane = [&](int j, int s2, int hf) {
+            auto issue_plane = [&](int j, int s2, int q) __attribute__((always_inline)) {
+                const int row = rg + 16 * q;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = rg + 16 * (2 * hf + i);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        tap[i][k] = tp::load_tap(sc.plane[j], (uint32_t)pl_off[(j * TM + row) * 4 + k] + lane_b + 256u * s2);
-                }
+                for (int k = 0; k < 4; ++k) tap[k] = tp::load_tap(sc.plane[j], (uint32_t)pl_off[(j * TM + row) * 4 + k] + lane_b + 256u * s2);
             };
-            // 4 blended fp32 channels -> hi/lo halves of chunk col4/2 (8-byte stores into both planes)
-            auto write_x = [&](const HT& buf, int row, const f32x4 v) {
+            auto write_x = [&](const HT& buf, int row, const f32x4 v) __attribute__((always_inline)) {
                 h4 vh, vl;
                 split4(v, vh, vl);
                 const int o = chunk_off<64>(row, col4 >> 1) + 4 * (col4 & 1);
                 *reinterpret_cast<h4*>(buf.hi + o) = vh;
                 *reinterpret_cast<h4*>(buf.lo + o) = vl;
             };
-            auto finish_local = [&](const HT& buf, int hf) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = rg + 16 * (2 * hf + i);
-                    write_x(buf, row, blend4(tap[i], *reinterpret_cast<const f32x4*>(loc_w + row * 4)));
-                }
+            auto finish_local = [&](const HT& buf, int q) __attribute__((always_inline)) {
+                const int row = rg + 16 * q;
+                write_x(buf, row, blend4(tap, *reinterpret_cast<const f32x4*>(loc_w + row * 4)));
             };
-            auto finish_planes = [&](const HT& buf, int s2, int hf) {
-                f32x4 sum[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    sum[i] = blend4(tap[i], *reinterpret_cast<const f32x4*>(pl_w + (rg + 16 * (2 * hf + i)) * 4));
+            auto finish_planes = [&](const HT& buf, int s2, int q) __attribute__((always_inline)) {
+                const int row = rg + 16 * q;
+                f32x4 sum = blend4(tap, *reinterpret_cast<const f32x4*>(pl_w + row * 4));
 #pragma unroll
                 for (int j = 1; j < 3; ++j) {
-                    issue_plane(j, s2, hf);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        sum[i] = sum[i] + blend4(tap[i], *reinterpret_cast<const f32x4*>(pl_w + (j * TM + rg + 16 * (2 * hf + i)) * 4));
+                    issue_plane(j, s2, q);
+                    sum = sum + blend4(tap, *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4));
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) write_x(buf, rg + 16 * (2 * hf + i), sum[i]);
+                write_x(buf, row, sum);
             };
-            // pos_enc of the camera-frame point: half hf of a stage = 32 features = chunks 4hf..4hf+3, one per wave
-            auto finish_pe = [&](const HT& buf, int pstage, int hf) {
+            // pos_enc: half hf of a stage = chunks 4hf..4hf+3, one per wave (run in the odd quarters)
+            auto finish_pe = [&](const HT& buf, int pstage, int hf) __attribute__((always_inline)) {
                 const int row = tid & 63, q = tid >> 6;
                 const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
                 const int ch = hf * 4 + q;
@@ -186,97 +175,79 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
                 *reinterpret_cast<h8*>(buf.hi + o) = vh;
                 *reinterpret_cast<h8*>(buf.lo + o) = vl;
             };
-            // Weights of one half stage (2 k-steps x 2 N-tiles, hi + lo) live in registers.  vmcnt retires in
-            // order, so the schedule per half stage is: gather loads for the NEXT stage, MFMAs on the weights
-            // fetched during the previous half stage, weight loads for the next half stage, then blend the
-            // gathered taps (waits only for the taps: the younger weight loads stay in flight).
-            h8 wh[2][2], wl[2][2];
-            // byte offsets of this lane's fragments of k-step 0 for the wave's two N-tiles; one half stage is
-            // 4 KB further along each N-tile's stream (2 k-steps x (hi 1 KB + lo 1 KB)): SGPR base + VGPR offset
+            h8 wh[2], wl[2];                                   // one k-step x 2 N-tiles, hi + lo
             const char* wxb = reinterpret_cast<const char*>(wp + hoff_x());
             uint32_t wx_off[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) wx_off[nt] = (uint32_t)(nts_x[nt] * KSX * 2 * 64 + L.lane) * 16u;
-            auto load_wx = [&](int h) {
+            auto load_wq = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const uint32_t o = wx_off[nt] + 4096u * h;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        wh[u][nt] = *reinterpret_cast<const h8*>(wxb + (o + 2048u * u));
-                        wl[u][nt] = *reinterpret_cast<const h8*>(wxb + (o + 2048u * u + 1024u));
-                    }
+                    wh[nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks));
+                    wl[nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks + 1024u));
                 }
             };
-            auto mma_x = [&](const HT& tile, int tks0) {
+            auto mma_q = [&](const HT& tile, int tks) __attribute__((always_inline)) {
+                h8 bh[2], bl[2];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    h8 bh[2], bl[2];
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<64>(mt * 32 + L.l31, (tks << 1) + L.half);
+                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        const int o = chunk_off<64>(mt * 32 + L.l31, ((tks0 + u) << 1) + L.half);
-                        bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
-                        bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                        accx[nt][mt] = NEO_MFMA_H(wl[nt], bh[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[nt], bl[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[nt], bh[mt], accx[nt][mt]);
                     }
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            accx[nt][mt] = NEO_MFMA_H(wl[u][nt], bh[mt], accx[nt][mt]);
-                            accx[nt][mt] = NEO_MFMA_H(wh[u][nt], bl[mt], accx[nt][mt]);
-                            accx[nt][mt] = NEO_MFMA_H(wh[u][nt], bh[mt], accx[nt][mt]);
-                        }
-                }
             };
-            // One half stage: kind of the NEXT stage's producer is a compile-time constant, so each of the
-            // four loop bodies below is straight-line code (no tap registers carried through branches).
             constexpr int K_LOCAL = 0, K_PLANE = 1, K_PE = 2, K_NONE = 3;
-            auto half_stage = [&](int s, int hf, auto kind_c) {
+            auto quarter = [&](int s, int q, auto kind_c) __attribute__((always_inline)) {
                 constexpr int kind = decltype(kind_c)::value;
                 const HT cur = xbuf(s & 1), nxt = xbuf((s + 1) & 1);
                 const int sn = s + 1;
-                if constexpr (kind == K_LOCAL) issue_local(sn, hf);
-                if constexpr (kind == K_PLANE) issue_plane(0, sn - 8, hf);
+                if constexpr (kind == K_LOCAL) issue_local(sn, q);
+                if constexpr (kind == K_PLANE) issue_plane(0, sn - 8, q);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_x(cur, 2 * hf);
+                mma_q(cur, q);
                 __builtin_amdgcn_sched_barrier(0);
-                if (2 * (2 * s + hf + 1) < KSX) load_wx(2 * s + hf + 1);
+                if (4 * s + q + 1 < KSX) load_wq(4 * s + q + 1);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (kind == K_LOCAL) finish_local(nxt, hf);
-                if constexpr (kind == K_PLANE) finish_planes(nxt, sn - 8, hf);
-                if constexpr (kind == K_PE) finish_pe(nxt, sn - 10, hf);
+                if constexpr (kind == K_LOCAL) finish_local(nxt, q);
+                if constexpr (kind == K_PLANE) finish_planes(nxt, sn - 8, q);
+                if constexpr (kind == K_PE) { if (q & 1) finish_pe(nxt, sn - 10, q >> 1); }
             };
             using std::integral_constant;
             // prologue: stage 0
-            load_wx(0);
-            issue_local(0, 0);
-            finish_local(xbuf(0), 0);
-            issue_local(0, 1);
-            finish_local(xbuf(0), 1);
+            load_wq(0);
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) { issue_local(0, q); finish_local(xbuf(0), q); }
             __syncthreads();
 #pragma unroll 1
-            for (int s = 0; s < 7; ++s) {            // stages 0..6 multiply while local stages 1..7 are gathered
+            for (int s = 0; s < 7; ++s) {
 #pragma unroll 1
-                for (int hf = 0; hf < 2; ++hf) half_stage(s, hf, integral_constant<int, K_LOCAL>());
+                for (int q = 0; q < 4; ++q) quarter(s, q, integral_constant<int, K_LOCAL>());
                 __syncthreads();
             }
 #pragma unroll 1
-            for (int s = 7; s < 9; ++s) {            // stages 7, 8: the tri-plane stages 8, 9 are gathered
+            for (int s = 7; s < 9; ++s) {
 #pragma unroll 1
-                for (int hf = 0; hf < 2; ++hf) half_stage(s, hf, integral_constant<int, K_PLANE>());
+                for (int q = 0; q < 4; ++q) quarter(s, q, integral_constant<int, K_PLANE>());
                 __syncthreads();
             }
 #pragma unroll 1
-            for (int s = 9; s < NST - 1; ++s) {      // stage 9 (and 10 for the 84-wide encoding): pos_enc stages
+            for (int s = 9; s < NST - 1; ++s) {
 #pragma unroll 1
-                for (int hf = 0; hf < 2; ++hf) half_stage(s, hf, integral_constant<int, K_PE>());
+                for (int q = 0; q < 4; ++q) quarter(s, q, integral_constant<int, K_PE>());
                 __syncthreads();
             }
-            half_stage(NST - 1, 0, integral_constant<int, K_NONE>());
-            if (PE_C == 3) half_stage(NST - 1, 1, integral_constant<int, K_NONE>());   // (the 84-wide encoding ends with a 2-k-step stage)
+#pragma unroll 1
+            for (int q = 0; q < (PE_C == 3 ? 4 : 2); ++q) quarter(NST - 1, q, integral_constant<int, K_NONE>());
             __syncthreads();
         }
-
         // ---- L0 epilogue, L1, L2 ----
         f32x16 acc[1][2];
         store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
