@@ -1,0 +1,97 @@
+"""CPU, build container only: the oracle against the reference itself, imported LIVE under the import stubs of
+tests/golden/_ref_loader.py (the committed fixtures hold outputs of exactly these calls).  Skipped wherever
+/root/reference is absent — nothing here runs on the GPU box."""
+import contextlib
+import io
+import os
+import sys
+
+import pytest
+import torch
+
+import cases
+import oracle
+from conftest import max_abs
+from neo360_amd import synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import _ref_loader as ref  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref.reference_available(), reason="reference tree not present")
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_vanilla_forward_live():
+    M = ref.load("models.vanilla_nerf.model")
+    net = _quiet(M.NeRF)
+    state = synth.vanilla_state(0)
+    net.load_state_dict(state)
+    rays = cases.strided_rays(64)
+    with torch.no_grad():
+        want = net.eval()(rays, False, False, 0.2, 3.0)
+    got = oracle.vanilla.render(state, rays, 0.2, 3.0)
+    assert max_abs(got[0][0], want[0][0]) < 1e-6 and max_abs(got[1][0], want[1][0]) < 5e-6
+    assert max_abs(got[1][2], want[1][2]) < 5e-5
+
+
+def test_pixelnerf_mlp_stage_live():
+    """The PixelNeRF late-fusion MLP (vanilla_nerf/model_pixel.py:96-131) on synthetic encodings / latents."""
+    M = ref.load("models.vanilla_nerf.model_pixel")
+    for nv in (1, 3):
+        mlp = _quiet(M.NeRFMLP, 0, 10, 4)
+        sd = synth.pixelnerf_mlp_state(61 + nv, "")
+        mlp.load_state_dict(sd)
+        P = 40
+        x = synth.uniform(63, "pix_x%d" % nv, (nv, P, 63), -1, 1)
+        cond = synth.uniform(63, "pix_c%d" % nv, (nv * P, 27), -1, 1)
+        latent = synth.normal(63, "pix_l%d" % nv, (nv * P, 512), 0.3)
+        with torch.no_grad():
+            r, s = mlp.eval()(x, cond, latent, combine_inner_dims=(nv, P))
+        rr, ss = oracle.mlp.pixelnerf_mlp(sd, "", x, cond, latent, nv)
+        assert max_abs(rr, r.reshape(-1, 3)) < 1e-6 and max_abs(ss, s.reshape(-1, 1)) < 1e-6
+
+
+def test_pixelnerf_forward_live():
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden
+    scene = cases.small_scene()
+    state = synth.pixelnerf_state(0)
+    net = make_golden.ref_pixelnerf(state, scene)
+    batch = cases.neo_batch(cases.strided_rays(48))
+    with torch.no_grad():
+        want = net(batch, False, False, 0.2, 2.5)
+    got = oracle.pixelnerf.render(state, batch, scene, 0.2, 2.5)
+    assert max_abs(got[0][0], want[0][0]) < 1e-6
+    assert max_abs(got[1][0], want[1][0]) < 1e-5 and max_abs(got[1][2], want[1][2]) < 5e-5
+
+
+def test_neo360_forward_live():
+    import make_golden
+    scene = cases.small_scene()
+    state = synth.nerf_tp_state(0)
+    net = make_golden.ref_nerf_tp(state, scene)
+    net.num_coarse_samples, net.num_fine_samples = 24, 40
+    batch = cases.neo_batch(cases.strided_rays(40))
+    with torch.no_grad():
+        want = net(batch, False, False, 0.0, 0.0, out_depth=True)
+    got = oracle.neo360.render(state, batch, scene, 24, 40)
+    assert max_abs(got[0][0], want[0][0]) < 5e-6 and max_abs(got[1][0], want[1][0]) < 5e-6
+    assert max_abs(got[1][5], want[1][5]) < 5e-5 and max_abs(got[1][4], want[1][4]) < 5e-6
+
+
+def test_mip360_forward_live():
+    M = ref.load("models.mipnerf360.model")
+    net = M.MipNeRF360(num_prop_samples=32, num_nerf_samples=16)
+    state = synth.mip360_state(0, weight_gain=0.5)
+    net.load_state_dict(state, strict=True)
+    rays = cases.mip_rays(24)
+    with torch.enable_grad():
+        rend, hist = net(rays, 1.0, False, False, 0.2, 3.0)
+    from oracle import mip360
+    got, ghist = mip360.render(state, rays, 1.0, 0.2, 3.0, num_prop_samples=32, num_nerf_samples=16)
+    assert max_abs(got[-1]["rgb"], rend[-1]["rgb"].detach()) < 5e-6
+    assert max_abs(ghist[-1]["sdist"], hist[-1]["sdist"].detach()) < 5e-6
