@@ -1,22 +1,25 @@
 """Headline benchmark: rays/s of the full-frame render path on synthetic 640x480
 frames (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus 1] [--steps K] [--warmup W] [--workload vanilla|neo360]
+    python bench.py [--gpus 1] [--steps K] [--warmup W] [--workload neo360|vanilla|mip360|mip360_128|pixelnerf]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Default workload = BASELINE.json configs[1] (the configuration the metric is quoted on):
-vanilla NeRF, 640x480, 64 coarse + 128 fine samples/ray, random-init MLP.
-`--workload neo360` = configs[2]/[3]: the NeO-360 tri-planar decoder, 3 source views,
-128 coarse + 256 fine samples, inside + outside sphere, reference chunk 1024.
+Default workload = the north-star path, BASELINE.json configs[2] (and [3] when N > 1): the NeO-360
+tri-planar decoder, 3 source views, 640x480, 128 coarse + 256 fine samples per ray, inside + outside
+sphere, reference chunk 1024.  `--workload vanilla` = configs[1], `mip360` / `mip360_128` = configs[4]
+(reference default 64/64/32 and BASELINE's wording 64 + 128).  At N = 1 the JSON line also carries
+one-step numbers of the vanilla and mip360 configurations (`other_workloads`).
 
-A step = ray generation for one frame + coarse and fine render of this rank's contiguous
-range of whole 1024-ray chunks (+ ONE RCCL all-gather of the packed (rgb,depth,acc) tiles
-when N > 1).  The frame is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
+A step = ray generation for this rank's range of the frame + coarse and fine render of its
+contiguous range of whole 1024-ray chunks (+ ONE RCCL all-gather of the packed (rgb,depth,acc)
+tiles when N > 1).  The frame is fixed, so scaling is "strong".  Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -29,7 +32,9 @@ H, W = 480, 640
 CHUNK = 1024
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector peak)
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+PEAK_HBM_BYTES = 8.0e12               # MI355X_MICROARCH.md: HBM3E spec peak
 CPU_THREADS = 32                      # fastest of an 8..256 sweep on the GPU box (profiles/cpu_threads_r01.log)
+CPU_REPS = 3                          # >= 3 repetitions of the CPU sample
 
 
 def build_vanilla(dev):
@@ -37,10 +42,9 @@ def build_vanilla(dev):
     state = synth.vanilla_state(0)
     net = models.NeRF(num_coarse_samples=64, num_fine_samples=128).to(dev)
     net.load_state_dict(state)
-    extra = {}
     desc = ("vanilla_nerf 640x480 full frame, 64 coarse + 128 fine samples/ray (65+193 = 258 MLP points/ray), "
             "random-init 8x256 MLP, raygen + both levels")
-    return net, state, extra, None, desc, dict(near=0.2, far=3.0), "k_vanilla_mlp", 8192
+    return net, state, {}, None, desc, dict(near=0.2, far=3.0), "k_vanilla_mlp", 4096
 
 
 def build_neo360(dev):
@@ -62,7 +66,7 @@ def build_neo360(dev):
     desc = ("neo360 tri-planar decoder 640x480 full frame, 3 source views, 128 coarse + 256 fine samples/ray, "
             "inside + outside sphere ((129+385)x2 = 1028 MLP points/ray x 3 views), reference chunk 1024, "
             "random-init MLPs, synthetic N(0,0.1) tri-planes (3x128x120x160) + latents (3x512x240x320)")
-    return net, state, extra, scene, desc, dict(near=0.0, far=0.0), "k_tp_mlp", 256
+    return net, state, extra, scene, desc, dict(near=0.0, far=0.0), "k_tp_mlp", 128
 
 
 def build_pixelnerf(dev):
@@ -81,7 +85,7 @@ def build_pixelnerf(dev):
     desc = ("PixelNeRF baseline decoder 640x480 full frame, 3 source views, 64 coarse + 64 fine samples/ray "
             "((65+129) MLP points/ray x 3 views), reference chunk 1024, random-init MLPs, synthetic N(0,0.1) "
             "latents (3x512x240x320)")
-    return net, state, extra, scene, desc, dict(near=0.2, far=3.0), "k_pix_mlp", 1024
+    return net, state, extra, scene, desc, dict(near=0.2, far=3.0), "k_pix_mlp", 512
 
 
 def build_mip360(dev, n_nerf=32):
@@ -91,69 +95,167 @@ def build_mip360(dev, n_nerf=32):
     net.load_state_dict(state)
     desc = ("mipnerf360 640x480 full frame, 2 proposal levels x 64 samples (PropMLP 4x256) + %d NeRF samples "
             "(NeRFMLP 8x1024), cone casting + contraction + 504-d IPE, random-init MLPs (kaiming x0.5)" % n_nerf)
-    return net, state, {}, None, desc, dict(near=0.2, far=3.0, train_frac=1.0), "k_mip_mlp", (4096 if n_nerf == 128 else 8192)
+    return net, state, {}, None, desc, dict(near=0.2, far=3.0, train_frac=1.0), "k_mip_mlp", (2048 if n_nerf == 128 else 4096)
+
+
+BUILDERS = {"vanilla": build_vanilla, "neo360": build_neo360, "pixelnerf": build_pixelnerf,
+            "mip360": build_mip360, "mip360_128": lambda dev: build_mip360(dev, 128)}
 
 
 def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
-    """The oracle (CPU restatement of the reference: kind 'port') timed on a bounded sample
-    of the same frame on the host cores."""
+    """The oracle (CPU restatement of the reference: kind 'port'; oracle == reference is pinned by tests/golden and
+    tests/test_oracle_vs_reference.py) timed CPU_REPS times on a bounded sample of the same frame on the host cores."""
     import oracle
     torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
     sample = {k: v[:n] for k, v in rays_cpu.items()}
-    t0 = time.perf_counter()
-    if workload == "vanilla":
-        rgb, depth = oracle.vanilla.render_chunked(state, sample, kw["near"], kw["far"], chunk=CHUNK)
-    elif workload == "pixelnerf":
-        batch = dict(sample)
-        batch.update({k: v.cpu() for k, v in extra.items()})
-        sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
-        rgb, depth = oracle.pixelnerf.render_chunked(state, batch, sc, kw["near"], kw["far"], chunk=CHUNK)
-    elif workload.startswith("mip360"):
-        from oracle import mip360
-        rend, _ = mip360.render(state, sample, kw["train_frac"], kw["near"], kw["far"], num_prop_samples=64,
-                                num_nerf_samples=128 if workload.endswith("128") else 32)
-        rgb, depth = rend[-1]["rgb"], torch.zeros(n)
-    else:
-        batch = dict(sample)
-        batch.update({k: v.cpu() for k, v in extra.items()})
-        sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
-        rgb, depth = oracle.neo360.render_chunked(state, batch, sc, chunk=n)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(CPU_REPS):
+        t0 = time.perf_counter()
+        if workload == "vanilla":
+            rgb, depth = oracle.vanilla.render_chunked(state, sample, kw["near"], kw["far"], chunk=CHUNK)
+        elif workload == "pixelnerf":
+            batch = dict(sample)
+            batch.update({k: v.cpu() for k, v in extra.items()})
+            sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
+            rgb, depth = oracle.pixelnerf.render_chunked(state, batch, sc, kw["near"], kw["far"], chunk=CHUNK)
+        elif workload.startswith("mip360"):
+            from oracle import mip360
+            rend, _ = mip360.render(state, sample, kw["train_frac"], kw["near"], kw["far"], num_prop_samples=64,
+                                    num_nerf_samples=128 if workload.endswith("128") else 32)
+            rgb, depth = rend[-1]["rgb"], torch.zeros(n)
+        else:
+            batch = dict(sample)
+            batch.update({k: v.cpu() for k, v in extra.items()})
+            sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
+            rgb, depth = oracle.neo360.render_chunked(state, batch, sc, chunk=n)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     base = dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
                 sample="first %d rays of the same 640x480 frame as one%s reference chunk%s, same weights / features, "
-                       "torch fp32 CPU oracle, %.1f s" % (n, "" if n <= CHUNK else " run of", "" if n <= CHUNK else "s", dt))
+                       "torch fp32 CPU oracle (validated equal to the reference: tests/golden, "
+                       "tests/test_oracle_vs_reference.py); median of %d repetitions, %s s"
+                       % (n, "" if n <= CHUNK else " run of", "" if n <= CHUNK else "s", CPU_REPS,
+                          "/".join("%.1f" % t for t in times)))
     return base, rgb, depth
 
 
-def pmc_traffic(workload, precision):
-    """HBM bytes per dominant-kernel launch from the committed rocprofv3 PMC passes of this same command
-    (tools/pmc_bench.sh -> profiles/r01_pmc_<workload>_<precision>.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB,
-    mean over the launches of a frame.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
-    (wide coalesced reads are tallied at half their bytes).  None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_%s_%s.json" % (workload, precision))
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f)["derived"].get("hbm_bytes_per_launch")
-    if workload == "vanilla" and precision == "f32":
-        path = os.path.join(ROOT, "profiles", "r01_vanilla_pmc_summary.json")
-        if os.path.exists(path):
-            with open(path) as f:
-                disp = json.load(f)["dispatches"]
-            per = [(2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 for d in disp.values() if "FETCH_SIZE" in d and "WRITE_SIZE" in d]
-            return sum(per) / len(per) if per else None
-    return None
+def pmc_profile(workload, precision):
+    """Summary of the committed rocprofv3 PMC passes of this same command (tools/pmc_bench.sh ->
+    profiles/rNN_pmc_<workload>_<precision>.json; newest round wins): HBM bytes per dominant-kernel launch =
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of a frame (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950), MFMA-busy fraction, effective clock.  {} when none is committed."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s_%s.json" % (workload, precision))))
+    if not paths:
+        return {}
+    with open(paths[-1]) as f:
+        d = json.load(f).get("derived", {})
+    d["source"] = os.path.relpath(paths[-1], ROOT)
+    return d
+
+
+class Runner:
+    """One workload on this rank: builds the renderer, generates only this rank's ray range, renders, gathers."""
+
+    def __init__(self, workload, precision, dev, world, rank, dist):
+        from neo360_amd import ops, render, synth
+        from neo360_amd.parallel import shard_bounds
+        self.ops, self.render, self.dist = ops, render, dist
+        self.workload, self.world, self.rank, self.dev = workload, world, rank, dev
+        (self.net, self.state, self.extra, self.scene, self.desc, self.kw, kernel, self.cpu_default) = BUILDERS[workload](dev)
+        if precision == "auto":
+            precision = getattr(self.net, "default_precision", "f32")
+        self.precision = precision
+        self.split = precision == "f16x3"
+        self.net.precision = precision
+        self.kernel_name = kernel + ("_h" if self.split else "")
+        if workload == "neo360" and self.split and getattr(self.net, "preproject", False):
+            self.kernel_name = "k_tp_mlp_hp"
+        self.c2w = synth.look_at_origin(40.0)
+        self.R = H * W
+        self.lo, self.hi = shard_bounds(self.R, world, rank, unit=CHUNK)
+        self.ctx = self.net._context(dev)
+        self._rays = None
+
+    def shard_rays(self):
+        # only this rank's rays are generated, into the previous frame's tensors
+        self._rays = self.ops.get_ray_directions_and_rays(H, W, 0.8 * W, self.c2w, ctx=self.ctx,
+                                                          ray_range=(self.lo, self.hi), out=self._rays)
+        ro, vd, rd, radii = self._rays
+        batch = dict(rays_o=ro, viewdirs=vd, rays_d=rd)
+        if self.workload.startswith("mip360"):
+            batch["radii"] = radii[:, None]
+        batch.update(self.extra)
+        return batch
+
+    def step(self):
+        return self.render.render_frame_sharded(self.net, self.shard_rays(), self.world, self.rank, chunk=CHUNK,
+                                                n_rays=self.R, **self.kw)
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup):
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        self.ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frame = self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        kern = self.ctx.read_timing()
+        self.ctx.set_timing(False)
+        if self.world > 1:
+            tmax = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, kern, frame
+
+    def roofline(self, kern):
+        kern_ms, launches, points, flops = kern
+        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+        alg_bytes_per_point = 20.0 + {"neo360": 3 * 14336.0, "pixelnerf": 3 * 8192.0}.get(self.workload, 0.0)
+        # split path: every algorithmic product costs three fp16 MFMA products, so the ceiling for
+        # ALGORITHMIC flops on the fp16 pipe is peak/3
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if self.split else PEAK_F32_MFMA_TFLOPS
+        pmc = pmc_profile(self.workload, self.precision)
+        avg_ms = kern_ms / max(launches, 1)
+        traffic = pmc.get("hbm_bytes_per_launch")
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": traffic, "kernel": self.kernel_name, "launches": launches, "avg_launch_ms": avg_ms,
+                "algorithmic_flop_per_launch": flops / max(launches, 1), "points_per_launch": points / max(launches, 1),
+                "algorithmic_bytes_per_launch": points / max(launches, 1) * alg_bytes_per_point,
+                # HBM side of the roofline (north_star): PMC bytes of the profiled run / this run's launch time
+                "hbm_frac": (traffic / (avg_ms * 1e-3) / PEAK_HBM_BYTES) if traffic and avg_ms > 0 else None,
+                "mfma_busy": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"),
+                "peak_definition": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per algorithmic multiply "
+                                    "(a_hi*b_hi + a_hi*b_lo + a_lo*b_hi); executed matrix rate = 3 x achieved x (executed / "
+                                    "algorithmic MACs); the exact-fp32-MFMA kernel (--precision f32) peaks at 157.3")
+                if self.split else "dense fp32 MFMA peak",
+                "note": "rank 0's launches, HIP events on the kernel's stream; algorithmic flops = reference formulation "
+                        "MACs x 2 (SURVEY.md 8d) whatever the kernel executes; traffic / hbm_frac / mfma_busy from the "
+                        "committed PMC passes (profiles/); algorithmic bytes = 4 B t in + 16 B (rgb,sigma) out per point" +
+                        (" + 3 views x 14,336 B of feature taps per point as the reference gathers them (no reuse; "
+                         "SURVEY.md 8d upper bound; every texel once would be 560 MB per frame); k_tp_mlp_hp gathers "
+                         "the latent pre-projected through the first-layer weights (8,192 -> 4,096 B per point-view, "
+                         "131,072 of 255,424 MACs per point-view not executed)" if self.workload == "neo360" else "")}
+        return roof
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("vanilla", "neo360", "pixelnerf", "mip360", "mip360_128"), default="vanilla")
+    ap.add_argument("--workload", choices=tuple(BUILDERS), default="neo360")
     ap.add_argument("--precision", choices=("auto", "f32", "f16x3"), default="auto",
                     help="MLP arithmetic: exact fp32 MFMA, or fp16 MFMA with hi/lo-split operands (fp32-equivalent, "
                          "the default of every renderer)")
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays in the CPU-baseline sample (0 = skip, -1 = default)")
+    ap.add_argument("--others", type=int, default=-1, help="1/0: also time one step of the other BASELINE configs (default: N == 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,101 +270,35 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from neo360_amd import ops, render, synth
+    from neo360_amd import render
 
-    if args.workload == "vanilla":
-        built = build_vanilla(dev)
-    elif args.workload == "neo360":
-        built = build_neo360(dev)
-    elif args.workload == "pixelnerf":
-        built = build_pixelnerf(dev)
-    else:       # reference defaults (64,64,32), or BASELINE.json's wording "64 proposal + 128 fine"
-        built = build_mip360(dev, 128 if args.workload.endswith("128") else 32)
-    net, state, extra, scene, desc, kw, kernel_name, cpu_default = built
-    if args.precision == "auto":
-        args.precision = getattr(net, "default_precision", "f32")
-    split = args.precision == "f16x3"
-    net.precision = args.precision
-    kernel_name = kernel_name + "_h" if split else kernel_name
-    c2w = synth.look_at_origin(40.0)
-    R = H * W
-    ctx = net._context(dev)
-
-    def frame_rays():
-        ro, vd, rd, radii = ops.get_ray_directions_and_rays(H, W, 0.8 * W, c2w, ctx=ctx)
-        batch = dict(rays_o=ro, viewdirs=vd, rays_d=rd)
-        if args.workload.startswith("mip360"):
-            batch["radii"] = radii[:, None]
-        batch.update(extra)
-        return batch
-
-    def step():
-        return render.render_frame_sharded(net, frame_rays(), world, rank, chunk=CHUNK, **kw)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.set_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame = step()
-    fence()
-    dt = time.perf_counter() - t0
-    kern_ms, launches, points, flops = ctx.read_timing()
-    ctx.set_timing(False)
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    run = Runner(args.workload, args.precision, dev, world, rank, dist)
+    dt, kern, frame = run.timed(args.steps, args.warmup)
+    R = run.R
 
     if rank == 0:
-        achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-        alg_bytes_per_point = 20.0 + {"neo360": 3 * 14336.0, "pixelnerf": 3 * 8192.0}.get(args.workload, 0.0)
-        # split path: every algorithmic product costs three fp16 MFMA products, so the ceiling for
-        # ALGORITHMIC flops on the fp16 pipe is peak/3
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
         out = {
             "metric": "rays/sec (128 samples/ray) + PSNR vs ref, 640x480",
             "value": R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (fp16-MFMA products of hi/lo-split fp32 operands, fp32 accumulate)" if split else "f32",
+            "dtype": "f32 (fp16-MFMA products of hi/lo-split fp32 operands, fp32 accumulate)" if run.split else "f32",
             "data": "synthetic",
-            "config": {"workload": desc + (", rays sharded by whole 1024-ray chunks + one RCCL all-gather of "
-                                           "(rgb,depth,acc) tiles" if world > 1 else ""),
+            "config": {"workload": run.desc + (", rays sharded by whole 1024-ray chunks + one RCCL all-gather of "
+                                               "(rgb,depth,acc) tiles" if world > 1 else ""),
                        "rays_per_frame": R, "parallelism": "ray-shard x%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": pmc_traffic(args.workload, args.precision), "kernel": kernel_name,
-                         "launches": launches, "avg_launch_ms": kern_ms / max(launches, 1),
-                         "algorithmic_flop_per_launch": flops / max(launches, 1),
-                         "points_per_launch": points / max(launches, 1),
-                         "algorithmic_bytes_per_launch": points / max(launches, 1) * alg_bytes_per_point,
-                         "peak_definition": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per algorithmic multiply "
-                                             "(a_hi*b_hi + a_hi*b_lo + a_lo*b_hi); executed matrix rate = 3 x achieved; "
-                                             "the exact-fp32-MFMA kernel (--precision f32) peaks at 157.3")
-                         if split else "dense fp32 MFMA peak",
-                         "note": "rank 0's launches; algorithmic flops = reference formulation MACs x 2 (SURVEY.md 8d); "
-                                 "traffic = HBM bytes/launch from the committed PMC passes (profiles/); algorithmic "
-                                 "bytes = 4 B t in + 16 B (rgb,sigma) out per point" +
-                                 (" + 3 views x 14,336 B of feature taps per point as the reference gathers them (no "
-                                  "reuse; SURVEY.md 8d upper bound; every texel once would be 560 MB per frame)"
-                                  if args.workload == "neo360" else "")},
+            "roofline": run.roofline(kern),
         }
-        n_cpu = cpu_default if args.cpu_rays < 0 else args.cpu_rays
+        n_cpu = run.cpu_default if args.cpu_rays < 0 else args.cpu_rays
         if world == 1 and n_cpu > 0:
-            batch = frame_rays()
+            batch = run.shard_rays()
             n = min(n_cpu, R)
             rays_cpu = {k: batch[k][:n].cpu() for k in ("rays_o", "viewdirs", "rays_d", "radii") if k in batch}
-            base, rgb_c, depth_c = cpu_baseline(args.workload, state, scene, rays_cpu, extra, kw, n)
-            if args.workload in ("neo360",) and n != CHUNK:
+            base, rgb_c, depth_c = cpu_baseline(args.workload, run.state, run.scene, rays_cpu, run.extra, run.kw, n)
+            if args.workload == "neo360" and n != CHUNK:
                 # NeO-360 results depend on chunk membership: render the same rays as their own chunk
                 sub = {k: (v[:n] if k in ("rays_o", "viewdirs", "rays_d") else v) for k, v in batch.items()}
-                got = render.render_rays_test(net, sub, chunk=n, **kw)
+                got = render.render_rays_test(run.net, sub, chunk=n, **run.kw)
                 rgb_g, depth_g = got["rgb"].cpu(), got["depth"].cpu()
             else:
                 rgb_g, depth_g = frame[:n, :3].cpu(), frame[:n, 3].cpu()
@@ -272,6 +308,24 @@ def main():
                                     "max_abs_depth": float((depth_g - depth_c).abs().max()),
                                     "psnr_db": render.psnr(rgb_g, rgb_c), "rays": n}
             out["speedup_vs_cpu"] = out["value"] / base["value"]
+        others = (world == 1) if args.others < 0 else bool(args.others)
+        if others and world == 1:
+            # the other BASELINE.json single-GPU configurations, 1 warm-up + 2 timed frames each, same code path
+            del run, frame
+            torch.cuda.empty_cache()
+            out["other_workloads"] = {}
+            for wl in ("vanilla", "mip360", "mip360_128"):
+                if wl == args.workload:
+                    continue
+                r2 = Runner(wl, "auto", dev, 1, 0, None)
+                dt2, kern2, f2 = r2.timed(2, 1)
+                roof = r2.roofline(kern2)
+                out["other_workloads"][wl] = {"value": R * 2 / dt2, "unit": "rays/s", "ms_per_step": dt2 / 2 * 1e3, "steps": 2,
+                                              "kernel": roof["kernel"], "achieved_tflops": roof["achieved"],
+                                              "roofline_frac": roof["frac"], "workload": r2.desc}
+                r2.net.close()
+                del r2, f2
+                torch.cuda.empty_cache()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -51,10 +51,13 @@ int neo_ctx_destroy(neo_ctx* ctx);
  * Synchronises `stream`.  [flags: host out] */
 int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream);
 
-/* Arithmetic of the vanilla per-point MLP GEMMs.  0 (default): exact fp32 MFMA
- * (v_mfma_f32_32x32x2_f32).  1: fp16 MFMA with every fp32 operand split into hi+lo fp16 and
- * three products per term (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulate) — fp32-class
- * error at a 5.3x higher matrix-pipe ceiling.  Both meet the 1e-4 parity contract. */
+/* Arithmetic of the per-point MLP GEMMs of every renderer (vanilla, NeRF_TP, Mip-NeRF 360, PixelNeRF).
+ * 1 (the context default, and the default of the Python modules, "f16x3"): fp16 MFMA with every fp32
+ * operand split into hi+lo fp16 and three products per term (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32
+ * accumulate) - fp32-class error at a 5.3x higher matrix-pipe ceiling; operands must stay below the fp16
+ * range (|x| < 65504: checked, see NEO_FLAG_SPLIT_RANGE).  0 ("f32"): exact fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), no range limit (not available for the PixelNeRF evaluator).  Both meet the
+ * 1e-4 parity contract. */
 int neo_ctx_set_precision(neo_ctx* ctx, int mode);
 
 /* torch.linspace(start, end, steps) for fp32 on the host (symmetric fill,
@@ -78,6 +81,22 @@ int neo_raygen(neo_ctx* ctx, int H, int W, float focal, const float* c2w,
 int neo_aabb_intersect(neo_ctx* ctx, const double* bounds, const double* rays_o,
                        const double* rays_d, int R, uint8_t* hit, double* tmin,
                        double* tmax, void* stream);
+
+/* The same for rays [ray0, ray0 + n_rays) of the row-major H x W frame, written to rows [0, n_rays) of the
+ * outputs: a rank of a ray-sharded render (models/interface.py:30-50 gathers the pieces) generates only its range. */
+int neo_raygen_range(neo_ctx* ctx, int H, int W, float focal, const float* c2w, int ray0, int n_rays,
+                     float* rays_o, float* viewdirs, float* rays_d, float* radii, void* stream);
+
+/* models/neo360/helper.py:359-373 sample_rays_in_bbox over n_boxes oriented boxes: per box the rays are moved to
+ * the box frame in float64 (:325-331; world_to_box [host]: n_boxes x 16 doubles, the row-major 4x4
+ * np.linalg.inv([R|T]) the caller computes as get_object_rays_in_bbox does, :348-357), slab-tested (:275-323;
+ * bounds [host]: n_boxes x 6 doubles, min xyz then max xyz), tmin/tmax rounded to float32, and merged by the
+ * running minimum that treats 0 as "no hit".  rays_o / rays_d: (R,3) float64.  Outputs (any may be NULL):
+ * hit_per_box (n_boxes,R) uint8, near (R) / far (R) float32 merged, mask (R) uint8 = near != 0 && far != 0
+ * (bit-exact contract). */
+int neo_aabb_multi(neo_ctx* ctx, int n_boxes, const double* world_to_box, const double* bounds,
+                   const double* rays_o, const double* rays_d, int R, uint8_t* hit_per_box, float* near,
+                   float* far, uint8_t* mask, void* stream);
 
 /* models/neo360/helper.py:253-273 intersect_sphere.  far (R); ok (R) uint8 =
  * (1-|p|^2 >= 0), may be NULL; a miss also raises flag bit0. */
@@ -152,6 +171,13 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
                      const float* plane_yz, int NV, int Cw, int Hp, int Wp,
                      const float* latent, int Cl, int Hf, int Wf, float image_w,
                      float image_h, void* stream);
+
+/* Split-fp16 arithmetic only.  enable != 0 (default): the 512-channel latent is pre-projected once per
+ * (scene, MLP slot) through the local columns of pts_linears.0 and of pts_linears.3's skip half
+ * (W . bilerp(F) = bilerp(W . F): neo360/model.py:110-158 is linear in the latent up to the first ReLU), and
+ * the evaluator gathers the 256-channel result; costs 1 KB per latent texel and slot of context memory.
+ * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order). */
+int neo_tp_set_preproject(neo_ctx* ctx, int enable);
 
 /* `predict` + the feature lookups for one region at given sample positions
  * (neo360/model.py:343-464): slot 0/1 inside the sphere (tvals = t, ascending),

@@ -35,6 +35,9 @@ SIGNATURES = {
     "neo_ctx_set_precision": (_i, [_vp, _i]),
     "neo_linspace_host": (None, [_f, _f, _i, c_float_p]),
     "neo_raygen": (_i, [_vp, _i, _i, _f, c_float_p, _vp, _vp, _vp, _vp, _vp]),
+    "neo_raygen_range": (_i, [_vp, _i, _i, _f, c_float_p, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "neo_aabb_multi": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _vp, _vp, _i,
+                            _vp, _vp, _vp, _vp, _vp]),
     "neo_aabb_intersect": (_i, [_vp, ctypes.POINTER(ctypes.c_double), _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "neo_intersect_sphere": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "neo_pos_enc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -45,6 +48,7 @@ SIGNATURES = {
     "neo_vanilla_render": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "neo_tp_upload_mlp": (_i, [_vp, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "neo_tp_set_scene": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _f, _f, _vp]),
+    "neo_tp_set_preproject": (_i, [_vp, _i]),
     "neo_tp_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i,
                            ctypes.POINTER(TpLevelOut), ctypes.POINTER(TpLevelOut), _vp]),

@@ -28,7 +28,7 @@ EXTRA_FLAGS = {
     "mlp_tp_h.hip": _NO_PK_F32,
     "mlp_mip_h.hip": _NO_PK_F32,
     "mlp_pix_h.hip": _NO_PK_F32,
-    "mlp_tp_hv.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
+    "mlp_tp_hp.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
 }
 
 

@@ -1,5 +1,6 @@
 """Per-device library context and tensor marshalling helpers."""
 import ctypes
+import weakref
 
 import torch
 
@@ -52,6 +53,16 @@ class Context:
         _lib.check(self.lib.neo_ctx_create(self.index, ctypes.byref(h)))
         self.handle = h
         self.uploaded = {}   # slot key -> fingerprint of the parameters packed on the device
+        # the context owns device memory (packed weights, scene features, grow-only workspaces: ~5 GB after a 640x480
+        # NeO-360 frame): release it when this object is collected, not at interpreter exit
+        self._finalizer = weakref.finalize(self, Context._destroy, self.lib, h)
+
+    @staticmethod
+    def _destroy(lib, handle):
+        try:
+            lib.neo_ctx_destroy(handle)
+        except Exception:       # interpreter shutdown: the driver frees everything anyway
+            pass
 
     def stream(self):
         return stream_of(self.device)
@@ -77,6 +88,7 @@ class Context:
 
     def close(self):
         if self.handle:
+            self._finalizer.detach()
             self.lib.neo_ctx_destroy(self.handle)
             self.handle = None
 

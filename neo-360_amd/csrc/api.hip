@@ -137,6 +137,9 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     for (auto& kv : ctx->edges) kv.second.release();
     for (auto& b : ctx->ws) b.release();
     for (auto& sl : ctx->tp) sl.release();
+    for (auto& sl : ctx->pix) sl.release();
+    ctx->pix_latent.release();
+    ctx->boxes.release();
     ctx->latent.release();
     for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
@@ -193,7 +196,38 @@ int neo_raygen(neo_ctx* ctx, int H, int W, float focal, const float* c2w, float*
     ENTER(ctx);
     REQUIRE(H >= 3 && W >= 1, "image must be at least 3 rows (the radii rule reads row H-3)");
     REQUIRE(c2w && rays_o && viewdirs && rays_d, "null pointer");
-    neo::launch_raygen(H, W, focal, c2w, rays_o, viewdirs, rays_d, radii, static_cast<hipStream_t>(stream));
+    neo::launch_raygen(H, W, focal, c2w, 0, H * W, rays_o, viewdirs, rays_d, radii, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_raygen_range(neo_ctx* ctx, int H, int W, float focal, const float* c2w, int ray0, int n_rays, float* rays_o,
+                     float* viewdirs, float* rays_d, float* radii, void* stream) {
+    ENTER(ctx);
+    REQUIRE(H >= 3 && W >= 1, "image must be at least 3 rows (the radii rule reads row H-3)");
+    REQUIRE(ray0 >= 0 && n_rays >= 0 && static_cast<long>(ray0) + n_rays <= static_cast<long>(H) * W, "ray range outside the frame");
+    if (n_rays == 0) return NEO_OK;
+    REQUIRE(c2w && rays_o && viewdirs && rays_d, "null pointer");
+    neo::launch_raygen(H, W, focal, c2w, ray0, n_rays, rays_o, viewdirs, rays_d, radii, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_aabb_multi(neo_ctx* ctx, int n_boxes, const double* world_to_box, const double* bounds, const double* rays_o,
+                   const double* rays_d, int R, uint8_t* hit_per_box, float* near, float* far, uint8_t* mask,
+                   void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && n_boxes >= 1 && n_boxes <= 4096, "bad ray / box count");
+    if (R == 0) return NEO_OK;
+    REQUIRE(world_to_box && bounds && rays_o && rays_d, "null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<neo::BoxFrame> h(n_boxes);
+    for (int b = 0; b < n_boxes; ++b) {
+        for (int i = 0; i < 12; ++i) h[b].m[i] = world_to_box[b * 16 + i];
+        for (int a = 0; a < 3; ++a) { h[b].lo[a] = bounds[b * 6 + a]; h[b].hi[a] = bounds[b * 6 + 3 + a]; }
+    }
+    if (ctx->boxes.reserve(h.size() * sizeof(neo::BoxFrame))) return NEO_ERR_NOMEM;
+    HIP_TRY(hipMemcpyAsync(ctx->boxes.p, h.data(), h.size() * sizeof(neo::BoxFrame), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));          // `h` is pageable host memory about to go out of scope
+    neo::launch_aabb_multi(ctx->boxes.as<neo::BoxFrame>(), n_boxes, rays_o, rays_d, R, hit_per_box, near, far, mask, s);
     return check_launch();
 }
 
@@ -270,17 +304,19 @@ int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, 
     neo::launch_vanilla_pack(weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
                              static_cast<hipStream_t>(stream));
     neo::launch_vanilla_pack_h(weights, sl.wpack_h.p, static_cast<hipStream_t>(stream));
+    sl.weights_epoch += 1;
     sl.ready = true;
     return check_launch();
 }
 
 static int vanilla_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* dirs, const float* t,
                               int t_row_stride, int R, int N, float* out, hipStream_t s) {
-    const MlpSlot& sl = ctx->vanilla[slot];
+    MlpSlot& sl = ctx->vanilla[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "vanilla MLP slot %d has no weights", slot);
+    if (ctx->precision == 1) guard_split_weights(sl, sl.wpack_h.p, neo::vanilla_wpack_h_bytes(), ctx->flags, s);
     ctx->span_begin(s);
     if (ctx->precision == 1) {
-        neo::VanillaMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>()};
+        neo::VanillaMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
         neo::launch_vanilla_mlp_h(mh, rays_o, dirs, t, t_row_stride, R, N, out, s);
     } else {
         neo::VanillaMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};

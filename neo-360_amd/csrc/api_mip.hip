@@ -12,13 +12,14 @@ double mip_flop_per_point(int width, int rgb) { return 2.0 * (width == 1024 && r
 
 int mip_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d, const float* viewdirs,
                    const float* radii, const float* tdist, int R, int n, float* out, hipStream_t s) {
-    const MlpSlot& sl = ctx->mip[slot];
+    MlpSlot& sl = ctx->mip[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "MipNeRF360 MLP slot %d has no weights", slot);
     const int* sh = ctx->mip_shape[slot];
+    if (ctx->precision == 1) guard_split_weights(sl, sl.wpack_h.p, neo::mip_wpack_h_bytes(sh[0], sh[1], sh[2]), ctx->flags, s);
     ctx->span_begin(s);
     int rc;
     if (ctx->precision == 1) {      // split-fp16 matrix cores (fp32-equivalent), neo_ctx_set_precision
-        neo::MipMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>()};
+        neo::MipMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>(), ctx->flags};
         rc = neo::launch_mip_mlp_h(sh[0], sh[1], sh[2], mh, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
     } else {
         neo::MipMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>()};
@@ -56,6 +57,7 @@ int neo_mip_upload_mlp(neo_ctx* ctx, int slot, int width, int depth, int rgb, co
     ctx->mip_shape[slot][0] = width;
     ctx->mip_shape[slot][1] = depth;
     ctx->mip_shape[slot][2] = rgb;
+    sl.weights_epoch += 1;
     sl.ready = true;
     return check_launch();
 }

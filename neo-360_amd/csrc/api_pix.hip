@@ -27,11 +27,16 @@ void fill_views(const float* poses, int nv, neo::TpViews& v) {
 int pix_launch(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
                const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N, int chunk,
                float* out, hipStream_t s) {
-    const MlpSlot& sl = ctx->pix[slot];
+    MlpSlot& sl = ctx->pix[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "PixelNeRF MLP slot %d has no weights", slot);
     if (ctx->precision != 1)
         return fail(NEO_ERR_STATE, "the PixelNeRF evaluator exists in the split-fp16 arithmetic only (neo_ctx_set_precision(ctx, 1))");
-    neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>()};
+    guard_split_weights(sl, sl.wpack_h.p, neo::pix_wpack_h_bytes(), ctx->flags, s);
+    if (!ctx->pix_latent_checked) {
+        neo::launch_f32_range_check(sc.latent, static_cast<size_t>(sc.nv) * sc.Hf * sc.Wf * 512, 65504.0f, ctx->flags, s);
+        ctx->pix_latent_checked = true;
+    }
+    neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
     ctx->span_begin(s);
     neo::launch_pix_mlp_h(mh, sc, views, rays_o, rays_d, viewdirs, tvals, t_shared, R, N, chunk, out, s);
     ctx->span_end(s, static_cast<double>(R) * N, pix_flop_per_point(sc.nv));
@@ -55,6 +60,7 @@ int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, cons
     neo::launch_pix_pack_h(weights, biases, sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(),
                            static_cast<hipStream_t>(stream));
     sl.input_ch = 3;
+    sl.weights_epoch += 1;
     sl.ready = true;
     return check_launch();
 }
@@ -68,18 +74,19 @@ int neo_pix_set_scene(neo_ctx* ctx, const float* latent, int NV, int Cl, int Hf,
     REQUIRE(Hf >= 2 && Wf >= 2, "feature maps must be at least 2x2");
     REQUIRE(static_cast<long>(NV) * Hf * Wf * 2048 <= 4294967295L, "latent too large for 32-bit byte offsets (NV*Hf*Wf < 2^21 texels)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ctx->latent.reserve(static_cast<size_t>(NV) * Cl * Hf * Wf * 4)) return NEO_ERR_NOMEM;
-    neo::launch_channels_last(latent, NV, Cl, Hf, Wf, ctx->latent.as<float>(), s);
-    ctx->scene.latent = ctx->latent.as<float>();
-    for (int j = 0; j < 3; ++j) ctx->scene.plane[j] = nullptr;     // no tri-planes in this decoder
-    ctx->scene.nv = NV;
-    ctx->scene.Hf = Hf; ctx->scene.Wf = Wf; ctx->scene.Hp = 2; ctx->scene.Wp = 2;
+    if (ctx->pix_latent.reserve(static_cast<size_t>(NV) * Cl * Hf * Wf * 4)) return NEO_ERR_NOMEM;
+    neo::launch_channels_last(latent, NV, Cl, Hf, Wf, ctx->pix_latent.as<float>(), s);
+    ctx->pix_scene.latent = ctx->pix_latent.as<float>();
+    for (int j = 0; j < 3; ++j) ctx->pix_scene.plane[j] = nullptr;     // no tri-planes in this decoder
+    ctx->pix_scene.nv = NV;
+    ctx->pix_scene.Hf = Hf; ctx->pix_scene.Wf = Wf; ctx->pix_scene.Hp = 2; ctx->pix_scene.Wp = 2;
     // latent_scaling = [Wf,Hf]/([Wf,Hf]-1)*2 ; scale = latent_scaling/image_size (vanilla_nerf/encoder.py index())
     const float wf = static_cast<float>(Wf), hf = static_cast<float>(Hf);
-    ctx->scene.sx = ((wf / (wf - 1.0f)) * 2.0f) / image_w;
-    ctx->scene.sy = ((hf / (hf - 1.0f)) * 2.0f) / image_h;
-    ctx->scene.fy_sign = 1.0f;                                     // model_pixel.py:203 passes (f, f)
-    ctx->scene_ready = true;
+    ctx->pix_scene.sx = ((wf / (wf - 1.0f)) * 2.0f) / image_w;
+    ctx->pix_scene.sy = ((hf / (hf - 1.0f)) * 2.0f) / image_h;
+    ctx->pix_scene.fy_sign = 1.0f;                                     // model_pixel.py:203 passes (f, f)
+    ctx->pix_scene_ready = true;
+    ctx->pix_latent_checked = false;
     return check_launch();
 }
 
@@ -91,12 +98,12 @@ int neo_pix_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d
     REQUIRE(R >= 0 && N >= 1 && chunk >= 1, "bad shape");
     if (R == 0) return NEO_OK;
     REQUIRE(rays_o && rays_d && viewdirs && tvals && src_poses && out, "null pointer");
-    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene latent not set (neo_pix_set_scene)");
-    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    if (!ctx->pix_scene_ready) return fail(NEO_ERR_STATE, "scene latent not set (neo_pix_set_scene)");
+    REQUIRE(NV == ctx->pix_scene.nv, "NV differs from the uploaded scene");
     hipStream_t s = static_cast<hipStream_t>(stream);
     neo::TpViews views{};
     fill_views(src_poses, NV, views);
-    neo::TpScene sc = ctx->scene;
+    neo::TpScene sc = ctx->pix_scene;
     sc.focal = focal; sc.cx = cx; sc.cy = cy;
     const int rc = pix_launch(ctx, slot, sc, views, rays_o, rays_d, viewdirs, tvals, 0, R, N, chunk, out, s);
     if (rc) return rc;
@@ -112,12 +119,12 @@ int neo_pix_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const
     REQUIRE(n_coarse >= 3 && n_coarse <= 256 && n_fine >= 1 && n_coarse + 1 + n_fine <= 1024, "unsupported sample counts");
     if (R == 0) return NEO_OK;
     REQUIRE(rays_o && rays_d && viewdirs && src_poses, "null pointer");
-    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene latent not set (neo_pix_set_scene)");
-    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    if (!ctx->pix_scene_ready) return fail(NEO_ERR_STATE, "scene latent not set (neo_pix_set_scene)");
+    REQUIRE(NV == ctx->pix_scene.nv, "NV differs from the uploaded scene");
     hipStream_t s = static_cast<hipStream_t>(stream);
     neo::TpViews views{};
     fill_views(src_poses, NV, views);
-    neo::TpScene sc = ctx->scene;
+    neo::TpScene sc = ctx->pix_scene;
     sc.focal = focal; sc.cx = cx; sc.cy = cy;
     const int N0 = n_coarse + 1, N1 = N0 + n_fine;
     const float* t0 = ctx->get_edges(n_coarse, near, far, s);

@@ -1,7 +1,5 @@
 // NeO-360 (NeRF_TP) entry points of the C ABI: weight / scene upload and the
 // two-level, two-region render (neo360/model.py:266-581).
-#include <cstdlib>
-
 #include "ctx.h"
 
 using namespace neo_host;
@@ -31,25 +29,49 @@ void fill_views(const float* poses, int nv, neo::TpViews& v) {
 }
 
 // one region's evaluator launch in the context's arithmetic mode
-void tp_launch(neo_ctx* ctx, const MlpSlot& sl, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
-               const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N, int chunk,
-               float* out, hipStream_t s) {
-    ctx->span_begin(s);
+int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
+              const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N, int chunk,
+              float* out, hipStream_t s) {
     if (ctx->precision == 1) {
-        neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>()};
-        // $NEO_TP_BATCHED=1 selects the three-views-resident kernel (mlp_tp_hv.hip: one weight fetch per tile, one
-        // workgroup per CU); measured 5-10 % slower than the view-loop kernel on MI355X, bit-identical results
-        const char* sel = getenv("NEO_TP_BATCHED");
-        const bool batched = sel && sel[0] == '1';
-        if (batched && neo::tp_views_batched_supported(sc.nv))
-            neo::launch_tp_mlp_hv(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
-        else
+        // range guard of the split arithmetic: tri-planes are summed over three maps before they are split
+        if (ctx->planes_checked != ctx->scene_epoch) {
+            const size_t n = static_cast<size_t>(sc.nv) * sc.Hp * sc.Wp * 128;
+            for (int j = 0; j < 3; ++j) neo::launch_f32_range_check(sc.plane[j], n, 65504.0f / 3.0f, ctx->flags, s);
+            ctx->planes_checked = ctx->scene_epoch;
+        }
+        if (ctx->preproject) {
+            // latent pre-projected through this slot's [W0_loc | W3_loc]: recomputed (exact fp32 MFMA, ~1 ms) only
+            // when the scene or the slot's weights changed since the last launch
+            if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->scene_epoch) {
+                const long texels = static_cast<long>(sc.nv) * sc.Hf * sc.Wf;
+                if (sl.proj.reserve(neo::tp_proj_bytes(texels))) return NEO_ERR_NOMEM;
+                neo::launch_tp_preproject(sc.latent, texels, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch),
+                                          sl.proj.as<float>(), s);
+                sl.proj_weights = sl.weights_epoch;
+                sl.proj_scene = ctx->scene_epoch;
+            }
+            guard_split_weights(sl, sl.wpack_hp.p, neo::tp_wpack_hp_bytes(sl.input_ch), ctx->flags, s);
+            neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
+            ctx->span_begin(s);
+            neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
+                                  chunk, ctx->flags, out, s);
+        } else {
+            guard_split_weights(sl, sl.wpack_h.p, neo::tp_wpack_h_bytes(sl.input_ch), ctx->flags, s);
+            if (ctx->latent_checked != ctx->scene_epoch) {
+                neo::launch_f32_range_check(sc.latent, static_cast<size_t>(sc.nv) * sc.Hf * sc.Wf * 512, 65504.0f, ctx->flags, s);
+                ctx->latent_checked = ctx->scene_epoch;
+            }
+            neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
+            ctx->span_begin(s);
             neo::launch_tp_mlp_h(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+        }
     } else {
         neo::TpMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
+        ctx->span_begin(s);
         neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
     }
     ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(sl.input_ch, sc.nv));
+    return NEO_OK;
 }
 
 }  // namespace
@@ -68,9 +90,12 @@ int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* 
     if (sl.bias.reserve(neo::tp_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.heads.reserve(neo::tp_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.wpack_h.reserve(neo::tp_wpack_h_bytes(input_ch))) return NEO_ERR_NOMEM;
+    if (sl.wpack_hp.reserve(neo::tp_wpack_hp_bytes(input_ch))) return NEO_ERR_NOMEM;
     neo::launch_tp_pack(input_ch, weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
                         static_cast<hipStream_t>(stream));
     neo::launch_tp_pack_h(input_ch, weights, sl.wpack_h.p, static_cast<hipStream_t>(stream));
+    neo::launch_tp_pack_hp(input_ch, weights, sl.wpack_hp.p, static_cast<hipStream_t>(stream));
+    sl.weights_epoch += 1;
     sl.input_ch = input_ch;
     sl.ready = true;
     return check_launch();
@@ -103,8 +128,19 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
     const float lsx = (wf / (wf - 1.0f)) * 2.0f, lsy = (hf / (hf - 1.0f)) * 2.0f;
     ctx->scene.sx = lsx / image_w;
     ctx->scene.sy = lsy / image_h;
+    ctx->scene.fy_sign = -1.0f;                                       // NeRF_TP projects with (f, -f) (model.py:243)
+    ctx->scene_epoch += 1;
     ctx->scene_ready = true;
     return check_launch();
+}
+
+int neo_tp_set_preproject(neo_ctx* ctx, int enable) {
+    ENTER(ctx);
+    ctx->preproject = enable != 0;
+    for (auto& sl : ctx->tp) sl.range_checked = 0;       // the other fragment set is checked at its first launch
+    if (!ctx->preproject)
+        for (auto& sl : ctx->tp) { sl.proj.release(); sl.proj_weights = sl.proj_scene = 0; }
+    return NEO_OK;
 }
 
 int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -117,7 +153,7 @@ int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
     REQUIRE(rays_o && rays_d && viewdirs && tvals && src_poses && out, "null pointer");
     if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
     REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
-    const MlpSlot& sl = ctx->tp[slot];
+    MlpSlot& sl = ctx->tp[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "NeRF_TP MLP slot %d has no weights", slot);
     REQUIRE(sl.input_ch == (slot < 2 ? 3 : 4), "slots 0,1 must hold fg weights, 2,3 bg weights");
     REQUIRE(slot < 2 || far, "far required for the outside-sphere slots");
@@ -126,7 +162,7 @@ int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
     fill_views(src_poses, NV, views);
     neo::TpScene sc = ctx->scene;
     sc.focal = focal; sc.cx = cx; sc.cy = cy;
-    tp_launch(ctx, sl, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, out, s);
+    if (int rc = tp_launch(ctx, sl, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, out, s)) return rc;
     return check_launch();
 }
 
@@ -189,10 +225,10 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const 
     for (int level = 0; level < 2; ++level) {
         const int N = level == 0 ? N0 : N1;
         const neo_tp_level_out* lo = level == 0 ? level0 : level1;
-        const MlpSlot& fg = ctx->tp[level];
-        const MlpSlot& bg = ctx->tp[2 + level];
-        tp_launch(ctx, fg, sc, views, rays_o, rays_d, viewdirs, fg_t, nullptr, R, N, chunk, fg_out, s);
-        tp_launch(ctx, bg, sc, views, rays_o, rays_d, viewdirs, bg_s, far, R, N, chunk, bg_out, s);
+        MlpSlot& fg = ctx->tp[level];
+        MlpSlot& bg = ctx->tp[2 + level];
+        if (int rc = tp_launch(ctx, fg, sc, views, rays_o, rays_d, viewdirs, fg_t, nullptr, R, N, chunk, fg_out, s)) return rc;
+        if (int rc = tp_launch(ctx, bg, sc, views, rays_o, rays_d, viewdirs, bg_s, far, R, N, chunk, bg_out, s)) return rc;
         float* fg_rgb = (lo && lo->fg_rgb) ? lo->fg_rgb : s_fg_rgb;
         float* bg_rgb = (lo && lo->bg_rgb) ? lo->bg_rgb : s_bg_rgb;
         float* fg_acc = (lo && lo->fg_acc) ? lo->fg_acc : s_fg_acc;

@@ -55,10 +55,19 @@ struct DevBuf {
 
 struct MlpSlot {
     DevBuf wpack, bias, heads;
-    DevBuf wpack_h;      // fp16 hi/lo split fragments (vanilla path, precision mode 1)
+    DevBuf wpack_h;      // fp16 hi/lo split fragments (precision mode 1)
+    DevBuf wpack_hp;     // NeRF_TP: split fragments of the pre-projected evaluator (no local-latent k-steps)
+    DevBuf proj;         // NeRF_TP: latent pre-projected through this slot's [W0_loc | W3_loc] (256 ch / texel)
+    uint64_t weights_epoch = 0;             // bumped by every upload
+    uint64_t range_checked = 0;             // weights_epoch whose split fragments passed through the range check
+    uint64_t proj_weights = 0, proj_scene = 0;   // (weights_epoch, scene_epoch) `proj` was computed for; 0 = never
     int input_ch = 0;
     bool ready = false;
-    void release() { wpack.release(); bias.release(); heads.release(); wpack_h.release(); ready = false; }
+    void release() {
+        wpack.release(); bias.release(); heads.release(); wpack_h.release(); wpack_hp.release(); proj.release();
+        proj_weights = proj_scene = 0;
+        ready = false;
+    }
 };
 
 struct DeviceGuard {
@@ -78,6 +87,14 @@ struct DeviceGuard {
     REQUIRE((ctx) != nullptr, "null context");                                      \
     neo_host::DeviceGuard guard_((ctx)->device);                                    \
     if (!guard_.ok) return neo_host::fail(NEO_ERR_HIP, "hipSetDevice failed")
+
+// Split-fp16 range guard, weight side: the first split launch after an upload scans the packed hi/lo fragments for
+// fp16 inf / NaN (|w| >= 65520 or a non-finite weight) and raises FLAG_SPLIT_RANGE in the context's flag word.
+inline void guard_split_weights(MlpSlot& sl, const void* halves, size_t bytes, uint32_t* flags, hipStream_t s) {
+    if (sl.range_checked == sl.weights_epoch) return;
+    neo::launch_half_range_check(halves, bytes / 2, flags, s);
+    sl.range_checked = sl.weights_epoch;
+}
 
 inline int check_launch() {
     hipError_t e = hipGetLastError();
@@ -103,10 +120,19 @@ struct neo_ctx {
     neo_host::DevBuf latent, plane[3];
     neo::TpScene scene{};
     bool scene_ready = false;
+    uint64_t scene_epoch = 0;          // bumped by every neo_tp_set_scene
+    uint64_t planes_checked = 0, latent_checked = 0;   // scene_epoch whose maps passed the split range check
+    int preproject = 1;                // split path: gather the latent pre-projected through the first-layer weights
+    // PixelNeRF scene latent: its own buffer / descriptor / ready flag (a context may hold both decoders)
+    neo_host::DevBuf pix_latent;
+    neo::TpScene pix_scene{};
+    bool pix_scene_ready = false;
+    bool pix_latent_checked = false;
     std::map<int, neo_host::DevBuf> quantiles;                    // n_new -> linspace(0, fl32(1-2^-32), n_new)
     std::map<std::pair<int, uint64_t>, neo_host::DevBuf> edges;   // (n, near/far bits) -> level-0 t row
     neo_host::DevBuf ws[12];                                      // render workspaces (grow-only)
-    int precision = 0;   // 0: fp32 MFMA, 1: fp16 MFMA with hi/lo-split operands (fp32-equivalent)
+    neo_host::DevBuf boxes;                                       // neo_aabb_multi: box frames + bounds
+    int precision = 1;   // 1 (default): fp16 MFMA with hi/lo-split operands (fp32-equivalent); 0: exact fp32 MFMA
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
     double timed_points = 0.0, timed_flops = 0.0;

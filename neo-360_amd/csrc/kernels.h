@@ -6,8 +6,15 @@
 namespace neo {
 
 // rays.hip
-void launch_raygen(int H, int W, float focal, const float* c2w, float* rays_o, float* viewdirs, float* rays_d,
-                   float* radii, hipStream_t s);
+// rays [ray0, ray0 + n) of the H x W frame -> rows [0, n) of the outputs
+void launch_raygen(int H, int W, float focal, const float* c2w, int ray0, int n, float* rays_o, float* viewdirs,
+                   float* rays_d, float* radii, hipStream_t s);
+struct BoxFrame {        // one oriented box: world -> box frame (row-major 3x4 of a 4x4, float64) and its bounds
+    double m[12];
+    double lo[3], hi[3];
+};
+void launch_aabb_multi(const BoxFrame* boxes_dev, int n_boxes, const double* rays_o, const double* rays_d, int R,
+                       uint8_t* hit_per_box, float* near, float* far, uint8_t* mask, hipStream_t s);
 void launch_aabb(const double* bounds, const double* rays_o, const double* rays_d, int R, uint8_t* hit,
                  double* tmin, double* tmax, hipStream_t s);
 void launch_sphere(const float* rays_o, const float* rays_d, int R, float* far, uint8_t* ok, uint32_t* flags,
@@ -39,6 +46,7 @@ struct VanillaMlpHDev {
     const void* wpack;    // fp16 hi/lo fragments
     const float* bias;    // shared with the fp32 path
     const float* heads;
+    uint32_t* flags;      // context assertion word (bit 1: split range guard)
 };
 size_t vanilla_wpack_h_bytes();
 void launch_vanilla_pack_h(const float* const* weights, void* wpack_h, hipStream_t s);
@@ -94,6 +102,7 @@ struct MipMlpHDev {       // split-fp16 fragments (mlp_mip_h.hip); bias / heads 
     const float* bias;
     const float* heads;
     const float* basis;
+    uint32_t* flags;      // context assertion word (bit 1: split range guard)
 };
 size_t mip_wpack_h_bytes(int width, int depth, int rgb);
 void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, void* wpack_h, hipStream_t s);
@@ -123,18 +132,29 @@ struct TpMlpHDev {
     const void* wpack;    // fp16 hi/lo fragments
     const float* bias;    // shared with the fp32 path
     const float* heads;
+    uint32_t* flags;      // context assertion word (bit 0: unit-sphere miss, bit 1: split range guard)
 };
+// Range checks backing the split-fp16 guard (pack_h.hip): any fp16 inf / NaN among n packed halves (a weight
+// >= 65520 in magnitude, or non-finite), any fp32 value with |x| >= limit or non-finite -> flags |= 2.
+void launch_half_range_check(const void* halves, size_t n, uint32_t* flags, hipStream_t s);
+void launch_f32_range_check(const float* x, size_t n, float limit, uint32_t* flags, hipStream_t s);
 size_t tp_wpack_h_bytes(int input_ch);
 void launch_tp_pack_h(int input_ch, const float* const* w, void* wpack_h, hipStream_t s);
 void launch_tp_mlp_h(int input_ch, const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
                      const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
                      int chunk, uint32_t* flags, float* out, hipStream_t s);
 
-// mlp_tp_hv.hip — the same evaluator with all three source views resident per tile (NV == 3)
-bool tp_views_batched_supported(int nv);
-void launch_tp_mlp_hv(int input_ch, const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
-                      const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
-                      int chunk, uint32_t* flags, float* out, hipStream_t s);
+// mlp_tp_hp.hip — the split-fp16 evaluator on the latent pre-projected through [W0_loc | W3_loc] (default)
+int tp_kc_x(int input_ch);            // k-chunks per N-tile of stage X in the fp32 fragment pack (mlp_tp.hip)
+size_t tp_wpack_hp_bytes(int input_ch);
+size_t tp_proj_bytes(long texels);    // pre-projected map: 256 fp32 channels per latent texel
+void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipStream_t s);
+// G (texels, 256) = latent_cl (texels, 512) . [W0_loc | W3_loc]^T from the fp32 fragment pack's stage X
+void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
+                          hipStream_t s);
+void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
+                      const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
+                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s);
 
 // mlp_pix_h.hip — PixelNeRF baseline decoder evaluator (split-fp16 arithmetic only)
 size_t pix_wpack_h_bytes();

@@ -18,7 +18,11 @@ namespace neo {
 
 struct LaneCtx {
     int lane, wv, half, l31, key;
+    // split-fp16 kernels: running max |x| over everything this thread split into hi/lo fp16 planes (the range guard,
+    // see split_tile.h:range_commit); unused by the fp32-MFMA kernels
+    mutable float amax;
     __device__ __forceinline__ void init() {
+        amax = 0.0f;
         lane = threadIdx.x & 63;
         wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         half = lane >> 5;

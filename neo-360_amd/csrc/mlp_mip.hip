@@ -384,14 +384,11 @@ int launch_mip_mlp(int width, int depth, int rgb, const MipMlpDev& m, const floa
     const long P = (long)R * n;
     if (P <= 0) return 0;
     const long tiles = (P + TMR - 1) / TMR;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp<1024, 8, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<1024>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp<256, 4, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<256>());
-        attr = true;
-    }
+    // per-device attribute: set on every launch (a host-side table write), not once per process
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp<1024, 8, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<1024>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp<256, 4, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<256>());
     if (width == 1024 && depth == 8 && rgb)
         hipLaunchKernelGGL((k_mip_mlp<1024, 8, true>), dim3((unsigned)tiles), dim3(512), lds_bytes<1024>(), s, m, rays_o,
                            rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));

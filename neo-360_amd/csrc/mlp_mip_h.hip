@@ -366,6 +366,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
             b += __shfl_xor(b, o2, 64);
         }
     }
+    range_commit(L, m.flags);        // split range guard (split_tile.h): IPE features are bounded by 1, activations are not
     {
         const int row = tid >> 4, part = tid & 15;
         const long gi = tile0 + row;
@@ -419,14 +420,11 @@ int launch_mip_mlp_h(int width, int depth, int rgb, const MipMlpHDev& m, const f
     const long P = (long)R * n;
     if (P <= 0) return 0;
     const long tiles = (P + TMR - 1) / TMR;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<1024, 8, true, NEO_MIP_H_WAVES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<1024>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<256, 4, false, 8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<256>());
-        attr = true;
-    }
+    // the attribute is per device: set it on every launch (a host-side table write) rather than once per process
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<1024, 8, true, NEO_MIP_H_WAVES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<1024>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_mlp_h<256, 4, false, 8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<256>());
     if (width == 1024 && depth == 8 && rgb)
         hipLaunchKernelGGL((k_mip_mlp_h<1024, 8, true, NEO_MIP_H_WAVES>), dim3((unsigned)tiles), dim3(NEO_MIP_H_WAVES * 64), lds_bytes<1024>(), s, m,
                            rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));

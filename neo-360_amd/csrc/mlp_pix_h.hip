@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
             auto finish_pe = [&](const HT& buf, int hf) {
                 const int row = tid & 63, q = tid >> 6;
                 const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], 0.0f};
+                range_see(L, xc[0]); range_see(L, xc[1]); range_see(L, xc[2]);     // identity features (the rest are sines)
                 const int ch = hf * 4 + q;
                 h8 vh, vl;
 #pragma unroll
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
         g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
         b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        range_commit(L, m.flags);
         const long gi = tile0 + pt;
         if (part == 0 && gi < P) {
             out[gi] = make_float4(sigmoid_act(r + m.heads[HD_RB]), sigmoid_act(g + m.heads[HD_RB + 1]),

@@ -437,6 +437,7 @@ void copy_floats(const float* src, int n, float* dst, hipStream_t s) {
 }
 
 size_t tp_wpack_floats(int input_ch) { return wpack_floats(input_ch); }
+int tp_kc_x(int input_ch) { return kc_x(input_ch); }
 size_t tp_bias_floats() { return BIAS_FLOATS; }
 size_t tp_heads_floats() { return HEADS_FLOATS; }
 

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
                 for (int k = 0; k < 4; ++k) tap[k] = tp::load_tap(sc.plane[j], (uint32_t)pl_off[(j * TM + row) * 4 + k] + lane_b + 256u * s2);
             };
             auto write_x = [&](const HT& buf, int row, const f32x4 v) __attribute__((always_inline)) {
+                range_see4(L, v);
                 h4 vh, vl;
                 split4(v, vh, vl);
                 const int o = chunk_off<64>(row, col4 >> 1) + 4 * (col4 & 1);
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
             auto finish_pe = [&](const HT& buf, int pstage, int hf) __attribute__((always_inline)) {
                 const int row = tid & 63, q = tid >> 6;
                 const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
+                range_see(L, xc[0]); range_see(L, xc[1]); range_see(L, xc[2]);     // identity features (the rest are sines)
                 const int ch = hf * 4 + q;
                 h8 vh, vl;
 #pragma unroll
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
         r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
         g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
         b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        range_commit(L, m.flags);
         const long gi = tile0 + pt;
         if (part == 0 && gi < P) {
             out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),

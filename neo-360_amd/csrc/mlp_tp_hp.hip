@@ -1,0 +1,529 @@
+// NeO-360 decoder point evaluator, split-fp16 arithmetic, with the pixel-aligned latent PRE-PROJECTED
+// through the first-layer weights once per (scene, MLP).
+//
+// NeRFPPMLP (neo360/model.py:110-158) feeds the 512-channel latent only through two linear maps: the local
+// columns of pts_linears.0 and of the skip half of pts_linears.3.  Bilinear interpolation is linear, so
+//        W_loc . bilerp(F; taps) = bilerp(W_loc . F; taps)
+// and G = F . [W0_loc | W3_loc]^T  (256 channels per texel, k_tp_preproject below, exact fp32 MFMA) can be
+// gathered instead of F: 1 KB per tap instead of 2 KB, and 131,072 of the 255,424 MACs per point-view
+// (32 of 44 k-steps of the streamed GEMM, their weight fragments, hi/lo splits and LDS writes) disappear from
+// the per-point path.  The reassociation moves the pre-activations by ~4e-7.  Algorithmic
+// flops in the roofline stay those of the reference formulation.
+//
+// Per 64-point tile and source view the kernel runs ONE flat software pipeline over 40 gather items
+// (16 = 4 chunks x 4 row groups of the pre-projected latent, 24 = 2 stages x 4 row groups x 3 planes),
+// a ring of NEO_TP_RING tap register sets deep: item i+RING-1 is requested before item i is blended, and
+// loads stay in flight across the stage barriers.  Pre-projected chunks travel through a 16 KB fp32 LDS
+// tile (gather layout = one row per 16 lanes, coalesced 256-B runs; accumulator layout = MFMA D fragments)
+// and are ADDED to the L0 / L3-skip accumulators; tri-plane and pos_enc stages are split into hi/lo fp16
+// planes and multiplied on the matrix cores while the next stage is gathered.  The rest (L1, L2, L3, view-mean
+// linearity, heads) is the structure of mlp_tp_h.hip.
+#include <hip/hip_fp16.h>
+
+#include <type_traits>
+
+#include "split_tile.h"
+#include "tp_common.h"
+
+#ifndef NEO_TP_WPS
+#define NEO_TP_WPS 2          // workgroups per CU = waves per SIMD the register allocation is capped for
+#endif
+#ifndef NEO_TP_RING
+#define NEO_TP_RING 3         // tap register sets (16 VGPRs each); prefetch distance = RING - 1 items
+#endif
+
+namespace neo {
+
+namespace {
+
+using tp::TM;
+using tp::blend4;
+using tp::pe_feature;
+
+// ---- packed weight layout (h8 units; one (n_tile, k_step) = hi 64 lanes + lo 64 lanes) -------------
+// streamed stage: packed k = [world 128 | pos_enc 63/84 -> 64/96]
+__host__ __device__ constexpr int pe_ksteps(int pe_c) { return pe_c == 3 ? 4 : 6; }
+__host__ __device__ constexpr int ks_x(int pe_c) { return 8 + pe_ksteps(pe_c); }
+__host__ __device__ constexpr int hoff_x() { return 0; }
+__host__ __device__ constexpr int hoff_1(int pe_c) { return 8 * ks_x(pe_c) * 128; }
+__host__ __device__ constexpr int hoff_2(int pe_c) { return hoff_1(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_3a(int pe_c) { return hoff_2(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_b(int pe_c) { return hoff_3a(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_v0(int pe_c) { return hoff_b(pe_c) + 4 * 8 * 128; }
+__host__ __device__ constexpr int hoff_v1(int pe_c) { return hoff_v0(pe_c) + 2 * 10 * 128; }
+__host__ __device__ constexpr int hpack_h8(int pe_c) { return hoff_v1(pe_c) + 2 * 4 * 128; }
+constexpr int B_0 = 0, B_3 = 128, B_1 = 256, B_2 = 384, B_B = 512, B_V0 = 640, B_V1 = 704;
+constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 324;
+
+constexpr int PROJ_TEXEL_BYTES = 1024;     // 256 fp32 channels per texel of the pre-projected map
+constexpr int RING = NEO_TP_RING;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Channel order of the pre-projected map.  Output o in [0, 256) of [L0 | L3 skip]: N-tile nt = o / 32 (0..3 L0,
+// 4..7 L3), r = o % 32.  Stored in 4 chunks of 64 channels; chunk c = (nt / 4) * 2 + r / 16 holds, for every
+// wave w = nt % 4, the 16 outputs r % 16 = 8 gg + 4 half + e of its N-tile: position = w * 16 + r % 16.
+// A wave's D fragment of N-tile nt (registers 4g+e <-> outputs 8g + 4 half + e) is then two 16-B pieces per chunk.
+__host__ __device__ constexpr int proj_index(int o) {
+    const int nt = o >> 5, r = o & 31;
+    return ((nt >> 2) * 2 + (r >> 4)) * 64 + (nt & 3) * 16 + (r & 15);
+}
+
+template <int PE_C>
+__global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, const float* __restrict__ proj, TpScene sc,
+                                                             TpViews views, const float* __restrict__ rays_o,
+                                                             const float* __restrict__ rays_d,
+                                                             const float* __restrict__ viewdirs,
+                                                             const float* __restrict__ tvals,
+                                                             const float* __restrict__ far_arr, int R, int N, int chunk,
+                                                             uint32_t* __restrict__ flags, float4* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* hbase = reinterpret_cast<_Float16*>(smem + tp::OFF_ACT);
+    const HT act{hbase, hbase + TM * 128};                                   // [64][128] x 2 planes (32 KB)
+    auto xbuf = [&](int b) { return HT{hbase + b * (2 * TM * 64), hbase + b * (2 * TM * 64) + TM * 64}; };   // aliases act
+    auto fbuf = [&](int b) { return smem + tp::OFF_ACT + b * (TM * 64); };   // the same 16 KB halves as fp32 [64][64]
+    _Float16* dbase = reinterpret_cast<_Float16*>(smem + tp::OFF_DIR);
+    const HT dsm{dbase, dbase + TM * 32};                                    // [64][32] x 2 planes
+    const tp::Scratch S = tp::carve(smem);
+    int* loc_off = S.loc_off;
+    float* loc_w = S.loc_w;
+    int* pl_off = S.pl_off;
+    float* pl_w = S.pl_w;
+    float* cam_enc = S.cam_enc;
+
+    LaneCtx L;
+    L.init();
+    int tid = threadIdx.x;
+    const long P = (long)R * N;
+    const long tile0 = tp::xcd_tile(blockIdx.x, (P + TM - 1) / TM) * TM;
+    if (tile0 >= P) return;       // surplus workgroup of the rounded-up grid (uniform exit before any barrier)
+    const h8* wp = reinterpret_cast<const h8*>(m.wpack);
+    constexpr int KSX = ks_x(PE_C);
+    constexpr int NPE = PE_C == 3 ? 1 : 2;     // pos_enc stages of 64 features
+
+    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
+    __syncthreads();
+
+    // view means by linearity (see mlp_tp_h.hip): only sum_v relu(L3_v) and sum_v dir_enc_v are accumulated per view
+    f32x16 hsum[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; }
+    float* dens_w = smem + tp::OFF_DENSW;
+    if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
+    float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum[tid + 256 * j] = 0.0f;    // each thread later owns (p = lane, f): a barrier follows
+    const int nts_1[1] = {L.wv};
+    const int vnt = L.wv & 1, vmt = L.wv >> 1;
+
+#pragma unroll 1
+    for (int v = 0; v < sc.nv; ++v) {
+        // per-lane indices re-derived from an opaque lane id inside the loop: keeps the swizzled LDS addresses of the
+        // loop body from being hoisted (and spilled) as loop invariants
+        asm volatile("" : "+v"(tid));
+        L.lane = tid & 63;
+        L.half = L.lane >> 5;
+        L.l31 = L.lane & 31;
+        L.key = L.lane & 15;
+        const float* rot = views.rot[v];
+        const float* trn = views.trans[v];
+        tp::view_descriptors<PROJ_TEXEL_BYTES>(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
+            const int di = p * 32 + (f ^ (p & 31));     // lane = p: XOR keeps the 64 lanes on distinct banks
+            dsum[di] += val;                            // (p, f) is owned by one thread in every view; zeroed before the loop
+        });
+        __syncthreads();
+
+        // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
+        f32x16 accx[2][2];
+        bias_tile(accx[0][0], m.bias + B_0, L.wv, L);
+        accx[0][1] = accx[0][0];
+        bias_tile(accx[1][0], m.bias + B_3, L.wv, L);
+        accx[1][1] = accx[1][0];
+        {
+            const int col4 = tid & 15, rg = tid >> 4;
+            const uint32_t lane_b = 16u * col4;
+            f32x4 taps[RING][4];
+            f32x4 wsum;                                    // running sum over the three planes of one row group
+            // item i: 0..15 = pre-projected latent (chunk i / 4, row group i % 4); 16..39 = tri-planes
+            // (stage (i - 16) / 12, row group ((i - 16) % 12) / 3, plane (i - 16) % 3)
+            constexpr int NI = 40;
+            auto issue = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 16) {
+                    constexpr int c = i / 4, q = i % 4;
+                    const int row = rg + 16 * q;
+                    const int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
+                    taps[i % RING][0] = tp::load_tap(proj, (uint32_t)off.x + lane_b + 256u * c);
+                    taps[i % RING][1] = tp::load_tap(proj, (uint32_t)off.y + lane_b + 256u * c);
+                    taps[i % RING][2] = tp::load_tap(proj, (uint32_t)off.z + lane_b + 256u * c);
+                    taps[i % RING][3] = tp::load_tap(proj, (uint32_t)off.w + lane_b + 256u * c);
+                } else if constexpr (i < NI) {
+                    constexpr int w = i - 16, s2 = w / 12, q = (w % 12) / 3, j = w % 3;
+                    const int row = rg + 16 * q;
+                    const int4 off = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
+                    taps[i % RING][0] = tp::load_tap(sc.plane[j], (uint32_t)off.x + lane_b + 256u * s2);
+                    taps[i % RING][1] = tp::load_tap(sc.plane[j], (uint32_t)off.y + lane_b + 256u * s2);
+                    taps[i % RING][2] = tp::load_tap(sc.plane[j], (uint32_t)off.z + lane_b + 256u * s2);
+                    taps[i % RING][3] = tp::load_tap(sc.plane[j], (uint32_t)off.w + lane_b + 256u * s2);
+                }
+            };
+            auto write_x = [&](const HT& buf, int row, const f32x4 val) __attribute__((always_inline)) {
+                range_see4(L, val);
+                h4 vh, vl;
+                split4(val, vh, vl);
+                const int o = chunk_off<64>(row, col4 >> 1) + 4 * (col4 & 1);
+                *reinterpret_cast<h4*>(buf.hi + o) = vh;
+                *reinterpret_cast<h4*>(buf.lo + o) = vl;
+            };
+            auto finish = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 16) {
+                    constexpr int c = i / 4, q = i % 4;
+                    const int row = rg + 16 * q;
+                    const f32x4 val = blend4(taps[i % RING], *reinterpret_cast<const f32x4*>(loc_w + row * 4));
+                    *reinterpret_cast<f32x4*>(fbuf(c & 1) + row * 64 + ((col4 ^ (row & 15)) << 2)) = val;
+                } else {
+                    constexpr int w = i - 16, s2 = w / 12, q = (w % 12) / 3, j = w % 3;
+                    const int row = rg + 16 * q;
+                    const f32x4 val = blend4(taps[i % RING], *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4));
+                    if constexpr (j == 0) wsum = val; else wsum = wsum + val;
+                    if constexpr (j == 2) write_x(xbuf(s2), row, wsum);
+                }
+            };
+            // chunk c of the pre-projected latent -> accumulators (this wave's pieces: 2 per M-tile)
+            auto consume_chunk = [&](auto cc) __attribute__((always_inline)) {
+                constexpr int c = decltype(cc)::value;
+                const float* buf = fbuf(c & 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int row = mt * 32 + L.l31;
+                        const int piece = L.wv * 4 + gg * 2 + L.half;
+                        const f32x4 val = *reinterpret_cast<const f32x4*>(buf + row * 64 + ((piece ^ (row & 15)) << 2));
+                        constexpr int g0 = 2 * (c & 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += val[e];
+                    }
+            };
+            // pos_enc: half hf of a stage = chunks 4hf..4hf+3, one per wave
+            auto finish_pe = [&](const HT& buf, int pstage, int hf) __attribute__((always_inline)) {
+                const int row = tid & 63, q = tid >> 6;
+                const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
+                range_see(L, xc[0]); range_see(L, xc[1]); range_see(L, xc[2]);     // identity features (the rest are sines)
+                const int ch = hf * 4 + q;
+                h8 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 h, l;
+                    split(pe_feature<PE_C>(xc, pstage * 64 + ch * 8 + e), h, l);
+                    vh[e] = h;
+                    vl[e] = l;
+                }
+                const int o = chunk_off<64>(row, ch);
+                *reinterpret_cast<h8*>(buf.hi + o) = vh;
+                *reinterpret_cast<h8*>(buf.lo + o) = vl;
+            };
+            h8 wh[2], wl[2];                                   // one k-step x 2 N-tiles, hi + lo
+            const char* wxb = reinterpret_cast<const char*>(wp + hoff_x());
+            uint32_t wx_off[2];
+            wx_off[0] = (uint32_t)(L.wv * KSX * 2 * 64 + L.lane) * 16u;
+            wx_off[1] = (uint32_t)((4 + L.wv) * KSX * 2 * 64 + L.lane) * 16u;
+            auto load_wq = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    wh[nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks));
+                    wl[nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks + 1024u));
+                }
+            };
+            auto mma_q = [&](const HT& tile, int tks) __attribute__((always_inline)) {
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<64>(mt * 32 + L.l31, (tks << 1) + L.half);
+                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        accx[nt][mt] = NEO_MFMA_H(wl[nt], bh[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[nt], bl[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[nt], bh[mt], accx[nt][mt]);
+                    }
+            };
+
+            // ---- the flat gather pipeline ----
+            static_for<0, RING - 1>([&](auto ic) { issue(ic); });
+            static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                issue(std::integral_constant<int, i + RING - 1>());
+                if constexpr (i == 4 || i == 8 || i == 12 || i == 16) consume_chunk(std::integral_constant<int, i / 4 - 1>());
+                if constexpr (i == 16) load_wq(0);
+                if constexpr (i >= 28 && (i - 28) % 3 == 0) {          // world stage 1 is gathered: multiply stage 0
+                    constexpr int q = (i - 28) / 3;
+                    mma_q(xbuf(0), q);
+                    load_wq(q + 1);
+                }
+                finish(ic);
+                __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
+                if constexpr (i == 3 || i == 7 || i == 11 || i == 15 || i == 27 || i == 39) __syncthreads();
+            });
+            // ---- world stage 1 is multiplied while the first pos_enc stage is computed ----
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                mma_q(xbuf(1), q);
+                load_wq(4 + q + 1);
+                if (q & 1) finish_pe(xbuf(0), 0, q >> 1);
+            }
+            __syncthreads();
+            // ---- pos_enc stage(s) ----
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                mma_q(xbuf(0), q);
+                if (8 + q + 1 < KSX) load_wq(8 + q + 1);
+                if constexpr (NPE == 2) { if (q == 1) finish_pe(xbuf(1), 1, 0); }   // features 64..95 (84..95 are padding)
+            }
+            __syncthreads();
+            if constexpr (NPE == 2) {
+#pragma unroll 1
+                for (int q = 0; q < 2; ++q) {
+                    mma_q(xbuf(1), q);
+                    if (12 + q + 1 < KSX) load_wq(12 + q + 1);
+                }
+                __syncthreads();
+            }
+        }
+        // ---- L0 epilogue, L1, L2 ----
+        f32x16 acc[1][2];
+        store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
+        store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
+        __syncthreads();
+#pragma unroll 1
+        for (int layer = 0; layer < 2; ++layer) {
+            bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : B_2), L.wv, L);
+            acc[0][1] = acc[0][0];
+            gemm2h<1, 128>(acc, wp + (layer == 0 ? hoff_1(PE_C) : hoff_2(PE_C)), 8, nts_1, 0, 0, 8, act, L);
+            __syncthreads();
+            store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
+            store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
+            __syncthreads();
+        }
+        // ---- L3 = skip half (in accx[1]) + W3[:, :128] h2; ReLU; accumulate over the views ----
+        acc[0][0] = accx[1][0];
+        acc[0][1] = accx[1][1];
+        gemm2h<1, 128>(acc, wp + hoff_3a(PE_C), 8, nts_1, 0, 0, 8, act, L);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
+            hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
+        }
+        __syncthreads();           // every wave is done reading this view's tiles
+    }
+
+    // ---- view mean of the trunk -> density head ----
+    const float nvf = (float)sc.nv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] / nvf; hsum[1][r] = hsum[1][r] / nvf; }
+    store_tile_h<false>(hsum[0], act, L.wv, 0, L);
+    store_tile_h<false>(hsum[1], act, L.wv, 1, L);
+    // view mean of the direction encoding: fp32 sums -> hi/lo planes in place (read all, barrier, write)
+    float dmean[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dmean[j] = dsum[(tid >> 2) * 32 + ((((tid & 3) << 3) + j) ^ ((tid >> 2) & 31))] / nvf;
+    __syncthreads();
+    {
+        h8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 h, l;
+            split(dmean[j], h, l);
+            vh[j] = h;
+            vl[j] = l;
+        }
+        const int o = chunk_off<32>(tid >> 2, tid & 3);
+        *reinterpret_cast<h8*>(dsm.hi + o) = vh;
+        *reinterpret_cast<h8*>(dsm.lo + o) = vl;
+    }
+    float raw_sigma;
+    {
+        float sg = density_partial(act, dens_w, L);
+        sg += __shfl_xor(sg, 1, 64);
+        sg += __shfl_xor(sg, 2, 64);
+        raw_sigma = sg + m.heads[HD_DB];
+    }
+    // ---- bottleneck of the view mean (no activation) ----
+    {
+        f32x16 acc[1][2];
+        bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
+        acc[0][1] = acc[0][0];
+        gemm2h<1, 128>(acc, wp + hoff_b(PE_C), 8, nts_1, 0, 0, 8, act, L);
+        __syncthreads();
+        store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
+        store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
+        __syncthreads();
+    }
+    // ---- view layer 0 on [mean bottleneck | mean dir enc] -> 64 ----
+    f32x16 ysum;
+    bias_tile(ysum, m.bias + B_V0, vnt, L);
+    gemm1h<128>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 0, 8, act, L);
+    gemm1h<32>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 8, 2, dsm, L);
+    __syncthreads();
+    // ---- ReLU -> 64x64 -> ReLU -> rgb head ----
+    store_tile_h<true>(ysum, act, vnt, vmt, L);
+    __syncthreads();
+    {
+        f32x16 y;
+        bias_tile(y, m.bias + B_V1, vnt, L);
+        gemm1h<128>(y, wp + hoff_v1(PE_C), 4, vnt, vmt, 0, 4, act, L);
+        __syncthreads();
+        store_tile_h<true>(y, act, vnt, vmt, L);
+    }
+    __syncthreads();
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const float* wr = m.heads + HD_RW;
+        float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int chunk_i = part * 2 + ((c + part) & 1);
+            const int o = chunk_off<128>(pt, chunk_i);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = (float)vh[e] + (float)vl[e];
+                r += h * wr[chunk_i * 8 + e];
+                g += h * wr[64 + chunk_i * 8 + e];
+                b += h * wr[128 + chunk_i * 8 + e];
+            }
+        }
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+        g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        range_commit(L, m.flags);
+        const long gi = tile0 + pt;
+        if (part == 0 && gi < P) {
+            out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
+                                  colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));
+        }
+    }
+}
+
+// ---- G = F . [W0_loc | W3_loc]^T: exact fp32 MFMA, once per (scene, MLP) ----------------------------------
+// F: channels-last latent (T texels, 512); wx: the fp32 fragment stream of stage X of mlp_tp.hip's pack
+// (8 N-tiles x KC chunks of 8, packed k = [local 512 | world | pe]): its chunks 0..63 are exactly [W0_loc; W3_loc].
+// One workgroup = 64 texels (2 M-tiles), wave w = N-tiles 2w, 2w+1.  B fragments come straight from global memory
+// (16 B per lane at a 2 KB row pitch: every line is consumed over four consecutive chunks); the kernel is bound by
+// the 64-cycle fp32 MFMA (60 GFLOP per MLP at 640x480 sources: ~1 ms).
+__global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restrict__ F, const f32x4* __restrict__ wx, int KC,
+                                                           long T, float* __restrict__ G) {
+    LaneCtx L;
+    L.init();
+    const long t0 = (long)blockIdx.x * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const float* frow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        long t = t0 + mt * 32 + L.l31;
+        if (t >= T) t = T - 1;
+        frow[mt] = F + t * 512 + 4 * L.half;
+    }
+#pragma unroll 2
+    for (int c = 0; c < 64; ++c) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) a[nt] = wx[((2 * L.wv + nt) * KC + c) * 64 + L.lane];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) b[mt] = *reinterpret_cast<const f32x4*>(frow[mt] + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = NEO_MFMA(a[nt][e], b[mt][e], acc[nt][mt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const long t = t0 + mt * 32 + L.l31;
+            if (t >= T) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o = (2 * L.wv + nt) * 32 + 8 * g + 4 * L.half;
+                f32x4 val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = acc[nt][mt][4 * g + e];
+                *reinterpret_cast<f32x4*>(G + t * 256 + proj_index(o)) = val;
+            }
+        }
+}
+
+}  // namespace
+
+size_t tp_wpack_hp_bytes(int input_ch) { return (size_t)hpack_h8(input_ch) * 16; }
+size_t tp_proj_bytes(long texels) { return (size_t)texels * PROJ_TEXEL_BYTES; }
+
+void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipStream_t s) {
+    // w order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
+    _Float16* base = reinterpret_cast<_Float16*>(wpack_hp);
+    const int pe = input_ch * 21;
+    const int x0w = pe + 512 + 128;
+    const int ksx = ks_x(input_ch);
+    const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    PackSegs sx = {{0, 128, 0}, {128, pe, 0}, {pe + 512, 0, 0}};   // packed [world | pe] <- x0 columns [pe | local | world]
+    pack_h(w[0], x0w, 128, ksx, 0, sx, base + (long)hoff_x() * 8, s);
+    PackSegs sx3 = sx;
+    for (int q = 0; q < 2; ++q) sx3.col[q] += 128;                 // L3 input = [h(128) | x0]
+    pack_h(w[3], 128 + x0w, 128, ksx, 4, sx3, base + (long)hoff_x() * 8, s);
+    PackSegs p128 = none;
+    p128.len[0] = 128;
+    pack_h(w[1], 128, 128, 8, 0, p128, base + (long)hoff_1(input_ch) * 8, s);
+    pack_h(w[2], 128, 128, 8, 0, p128, base + (long)hoff_2(input_ch) * 8, s);
+    pack_h(w[3], 128 + x0w, 128, 8, 0, p128, base + (long)hoff_3a(input_ch) * 8, s);
+    pack_h(w[6], 128, 128, 8, 0, p128, base + (long)hoff_b(input_ch) * 8, s);
+    PackSegs v0 = none;
+    v0.len[0] = 155;
+    pack_h(w[4], 155, 64, 10, 0, v0, base + (long)hoff_v0(input_ch) * 8, s);
+    PackSegs v1 = none;
+    v1.len[0] = 64;
+    pack_h(w[5], 64, 64, 4, 0, v1, base + (long)hoff_v1(input_ch) * 8, s);
+}
+
+void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
+                          hipStream_t s) {
+    if (texels <= 0) return;
+    hipLaunchKernelGGL(k_tp_preproject, dim3((unsigned)((texels + 63) / 64)), dim3(256), 0, s, latent_cl,
+                       reinterpret_cast<const f32x4*>(wpack_f32_stage_x), kc_x, texels, proj);
+}
+
+void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
+                      const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
+                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s) {
+    const long P = (long)R * N;
+    if (P <= 0) return;
+    const size_t lds = tp::LDS_WORDS * sizeof(float);
+    const long tiles = tp::xcd_grid((P + TM - 1) / TM);
+    if (input_ch == 3)
+        hipLaunchKernelGGL(k_tp_mlp_hp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(k_tp_mlp_hp<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+}
+
+}  // namespace neo

@@ -379,12 +379,8 @@ void launch_vanilla_mlp(const VanillaMlpDev& m, const float* rays_o, const float
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = (TM * ACT_LD + TM * DIR_LD) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-        attr_set = true;
-    }
+    // per-device attribute: set on every launch (a host-side table write), not once per process
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long tiles = (P + TM - 1) / TM;
     hipLaunchKernelGGL(k_vanilla_mlp, dim3((unsigned)tiles), dim3(256), lds, s, m, rays_o, dirs, t, t_row_stride, P,
                        N, reinterpret_cast<float4*>(out));

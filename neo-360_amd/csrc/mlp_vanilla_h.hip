@@ -169,10 +169,12 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][MTW], const H
 #pragma unroll
             for (int g = 0; g < ((NEO_VH_ABLATE & 4) ? 1 : 4); ++g) {
                 h4 vh, vl;
+                float xprev = 0.0f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = acc[nt][mt][4 * g + e];
                     if (RELU) x = fmaxf(x, 0.0f);
+                    if (e & 1) L.amax = fmaxf(fmaxf(L.amax, fabsf(x)), fabsf(xprev)); else xprev = x;   // range guard (split_tile.h)
                     _Float16 h, l;
                     split(x, h, l);
                     vh[e] = h;
@@ -218,7 +220,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
         const float tt = t[(long)ray * t_row_stride + s];
         float x[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) x[a] = rays_o[ray * 3 + a] + tt * dirs[ray * 3 + a];   // mul then add (helper.py:20-21)
+        for (int a = 0; a < 3; ++a) {
+            x[a] = rays_o[ray * 3 + a] + tt * dirs[ray * 3 + a];   // mul then add (helper.py:20-21)
+            L.amax = fmaxf(L.amax, fabsf(x[a]));
+        }
 #pragma unroll 1
         for (int k = L.wv; k < 10; k += NW) {
 #pragma unroll
@@ -344,6 +349,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
             g += __shfl_xor(g, o, 64);
             b += __shfl_xor(b, o, 64);
         }
+        if (!(L.amax < 65504.0f)) atomicOr(m.flags, 2u);       // split range guard: an operand left the fp16 range
         const long gi = tile0 + pt;
         if (part == 0 && gi < P) {
             out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
@@ -392,11 +398,10 @@ void launch_vanilla_mlp_h(const VanillaMlpHDev& m, const float* rays_o, const fl
     if (nw == 0) {
         nw = 4;   // measured: 4 waves 396 TFLOP/s, 8 waves 381 (profiles/r01_vanilla_h_variants.log)
         if (const char* e = getenv("NEO_VANILLA_H_WAVES")) nw = atoi(e) == 8 ? 8 : 4;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
+    // per-device attribute: set on every launch (a host-side table write), not once per process
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const long tiles = (P + TM - 1) / TM;
     if (nw == 8)
         hipLaunchKernelGGL(k_vanilla_mlp_h<8>, dim3((unsigned)tiles), dim3(512), lds, s, m, rays_o, dirs, t, t_row_stride,

@@ -27,7 +27,39 @@ __global__ void k_pack_block_h(const float* __restrict__ src, int ld, int rows, 
     }
 }
 
+// any fp16 inf / NaN (exponent all ones) among n halves -> flags |= FLAG_SPLIT_RANGE
+__global__ void k_half_range_check(const uint16_t* __restrict__ h, size_t n, uint32_t* __restrict__ flags) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        bad |= (h[i] & 0x7c00u) == 0x7c00u;
+    if (bad) atomicOr(flags, FLAG_SPLIT_RANGE);
+}
+
+__global__ void k_f32_range_check(const float* __restrict__ x, size_t n4, size_t n, float limit, uint32_t* __restrict__ flags) {
+    bool bad = false;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = x4[i];
+        bad = bad || !(fabsf(v[0]) < limit) || !(fabsf(v[1]) < limit) || !(fabsf(v[2]) < limit) || !(fabsf(v[3]) < limit);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(fabsf(x[n4 * 4 + threadIdx.x]) < limit);
+    if (bad) atomicOr(flags, FLAG_SPLIT_RANGE);
+}
+
 }  // namespace
+
+void launch_half_range_check(const void* halves, size_t n, uint32_t* flags, hipStream_t s) {
+    if (n == 0) return;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_half_range_check, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, s,
+                       reinterpret_cast<const uint16_t*>(halves), n, flags);
+}
+
+void launch_f32_range_check(const float* x, size_t n, float limit, uint32_t* flags, hipStream_t s) {
+    if (n == 0) return;
+    const size_t n4 = n / 4, blocks = (n4 + 255) / 256 + 1;
+    hipLaunchKernelGGL(k_f32_range_check, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, x, n4, n, limit, flags);
+}
 
 void pack_h(const float* src, int ld, int rows, int KS, int nt0, PackSegs sg, _Float16* dst, hipStream_t s) {
     const int total = (rows / 32) * KS * 512;

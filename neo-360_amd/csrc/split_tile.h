@@ -33,6 +33,23 @@ __device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);      // x - hi, exact; one mixed-precision fma
 }
 
+// ---- range guard -------------------------------------------------------------------------------------------
+// hi = fp16(x) overflows to inf for |x| >= 65520 and lo = x - hi then poisons the products; ReLU would turn the
+// resulting NaN back into a plausible 0.  Every value a split kernel turns into hi/lo planes is therefore folded into
+// a per-thread running max (v_max3_f32 with |.| modifiers: half an instruction per element), and a thread that saw
+// |x| >= 65504 (or inf / NaN accumulators) raises NEO_FLAG_SPLIT_RANGE once, at the end of the kernel.  Weights
+// are checked when they are packed, feature maps when they are uploaded (api*.hip).
+constexpr uint32_t FLAG_SPHERE_MISS = 1u, FLAG_SPLIT_RANGE = 2u;
+constexpr float SPLIT_LIMIT = 65504.0f;
+__device__ __forceinline__ void range_see4(const LaneCtx& L, const f32x4 v) {
+    L.amax = fmaxf(fmaxf(L.amax, fabsf(v[0])), fabsf(v[1]));
+    L.amax = fmaxf(fmaxf(L.amax, fabsf(v[2])), fabsf(v[3]));
+}
+__device__ __forceinline__ void range_see(const LaneCtx& L, float v) { L.amax = fmaxf(L.amax, fabsf(v)); }
+__device__ __forceinline__ void range_commit(const LaneCtx& L, uint32_t* __restrict__ flags) {
+    if (!(L.amax < SPLIT_LIMIT)) atomicOr(flags, FLAG_SPLIT_RANGE);
+}
+
 __device__ __forceinline__ void split4(const f32x4 v, h4& vh, h4& vl) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -54,6 +71,7 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, i
             const float x = acc[4 * g + e];
             v[e] = RELU ? fmaxf(x, 0.0f) : x;
         }
+        range_see4(L, v);
         h4 vh, vl;
         split4(v, vh, vl);
         const int o = chunk_off<LDH>(mt * 32 + L.l31, nt * 4 + g) + 4 * L.half;

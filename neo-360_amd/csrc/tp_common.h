@@ -193,7 +193,9 @@ __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile
 
 // ---- per-view descriptors (all 4 waves; lane = row) ---------------------------------------------------
 // put_dir(row, feature, value) stores one feature of the 27(+5 pad)-wide view-direction encoding.
-template <class PutDir>
+// LOC_TEXEL_BYTES: bytes per latent texel the local taps address (512 fp32 channels, or 256 for the
+// pre-projected map of mlp_tp_hp.hip).
+template <int LOC_TEXEL_BYTES = 2048, class PutDir>
 __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx& L, const TpScene& sc,
                                                  const float* rot, const float* trn, int v, PutDir put_dir) {
     int* loc_off = S.loc_off; float* loc_w = S.loc_w; int* pl_off = S.pl_off; float* pl_w = S.pl_w;
@@ -218,7 +220,7 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 t = bilinear_taps(u * sc.sx - 1.0f, w_ * sc.sy - 1.0f, sc.Wf, sc.Hf);
                 dst_off = loc_off; dst_w = loc_w;
                 base = v * sc.Hf * sc.Wf;
-                texel_bytes = 512 * 4;
+                texel_bytes = LOC_TEXEL_BYTES;
                 // camera-frame point that gets encoded (fg: same point; bg: the unit-sphere point)
                 const float ex = pe_world[p * 4], ey = pe_world[p * 4 + 1], ez = pe_world[p * 4 + 2];
                 cam_enc[p * 4 + 0] = (rot[0] * ex + rot[1] * ey + rot[2] * ez) + trn[0];

@@ -32,6 +32,30 @@ def _fingerprint(tensors):
     return tuple((t.data_ptr(), t._version, t.device) for t in tensors)
 
 
+class _SceneKey:
+    """Identity of the inputs an attached encoder was last run on.  Holds STRONG references to the source tensors
+    (so the allocator cannot hand their addresses to a later batch) and compares them with `is` + `_version`,
+    plus a fingerprint of the encoder's parameters / buffers and its training flag: a new `src_imgs` tensor, an
+    in-place edit, `load_state_dict`, an optimizer step or `.train()` all force a re-encode."""
+
+    def __init__(self, tensors, encoder):
+        self.tensors = tuple(tensors)
+        self.versions = tuple(t._version for t in self.tensors)
+        self.enc = self._enc_fp(encoder)
+
+    @staticmethod
+    def _enc_fp(encoder):
+        if not isinstance(encoder, nn.Module):
+            return None
+        items = list(encoder.parameters()) + list(encoder.buffers())
+        return (encoder.training, tuple((id(t), t.data_ptr(), t._version) for t in items))
+
+    def matches(self, tensors, encoder):
+        tensors = tuple(tensors)
+        return (len(tensors) == len(self.tensors) and all(a is b for a, b in zip(tensors, self.tensors))
+                and tuple(t._version for t in tensors) == self.versions and self._enc_fp(encoder) == self.enc)
+
+
 def _ptr_table(tensors):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -81,17 +105,41 @@ class _HipModule(nn.Module):
     # ~3x faster), "f32" = exact fp32 MFMA.  None -> $NEO360_PRECISION or the class default.
     precision = None
     default_precision = "f16x3"
+    # Read the device assertion word after every call (one stream sync): the unit-sphere assertion of NeRF_TP and the
+    # range guard of the split-fp16 arithmetic.  False skips the sync on NeRF / MipNeRF360 / PixelNeRF calls (no
+    # assertion in the reference there); `check_flags()` then reads it on demand.
+    poll_flags = True
+
+    def check_flags(self):
+        for ctx in self._ctx_cache.values():
+            self._raise_flags(ctx.poll_flags())
 
     def _context(self, device):
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         ctx = self._ctx_cache.get(key)
         if ctx is None:
-            ctx = self._ctx_cache[key] = new_context(device)
+            ctx = self._ctx_cache[key] = new_context(device)     # freed by Context's finalizer with the module
         want = self.precision or os.environ.get("NEO360_PRECISION", self.default_precision)
         if getattr(ctx, "_precision", None) != want:
             ctx.set_precision(want)
             ctx._precision = want
         return ctx
+
+    def close(self):
+        """Release the library contexts (packed weights, scene features, workspaces) now."""
+        for ctx in self._ctx_cache.values():
+            ctx.close()
+        self._ctx_cache.clear()
+
+    @staticmethod
+    def _raise_flags(flags):
+        """Device assertion word -> the reference's AssertionError / a NeoError for the split-fp16 range guard."""
+        if flags & 1:
+            raise AssertionError("1.0 - p_norm_sq should be greater than 0")
+        if flags & 2:
+            raise _lib.NeoError(
+                "split-fp16 arithmetic (precision 'f16x3') met an operand outside the fp16 range (|x| >= 65504 or "
+                "non-finite weights / features / activations): results of this call are invalid; use precision 'f32'")
 
     @staticmethod
     def _check_mode(randomized):
@@ -144,6 +192,8 @@ class NeRF(_HipModule):
             self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
             ptr(outs[0][0]), ptr(outs[0][1]), ptr(outs[0][2]), ptr(outs[1][0]), ptr(outs[1][1]), ptr(outs[1][2]),
             ctx.stream()))
+        if self.poll_flags:
+            self._raise_flags(ctx.poll_flags())
         return outs
 
     @torch.no_grad()
@@ -157,6 +207,8 @@ class NeRF(_HipModule):
         out = torch.empty(B, N, 4, device=rays_o.device)
         _lib.check(ctx.lib.neo_vanilla_mlp(ctx.handle, level, ptr(rays_o), ptr(dirs), ptr(t), N, B, N, ptr(out),
                                            ctx.stream()))
+        if self.poll_flags:
+            self._raise_flags(ctx.poll_flags())
         return out
 
 
@@ -227,6 +279,16 @@ class NeRF_TP(_HipModule):
         self.chunk = 1024            # rays per reference forward call (opt.py:195-200)
         self._scene_key = None
         self._scene_ctx = None
+        # split path: gather the latent pre-projected through each MLP's first-layer weights (256 instead of 512
+        # channels per tap, 51 % fewer MACs per point-view; see csrc/mlp_tp_hp.hip).  False: the reference's order.
+        self.preproject = os.environ.get("NEO360_TP_PREPROJECT", "1") != "0"
+
+    def _context(self, device):
+        ctx = super()._context(device)
+        if getattr(ctx, "_preproject", None) != bool(self.preproject):
+            _lib.check(ctx.lib.neo_tp_set_preproject(ctx.handle, int(bool(self.preproject))))
+            ctx._preproject = bool(self.preproject)
+        return ctx
 
     def _mlps(self):
         return (self.fg_coarse_mlp, self.fg_fine_mlp, self.bg_coarse_mlp, self.bg_fine_mlp)
@@ -244,10 +306,13 @@ class NeRF_TP(_HipModule):
             ctx.uploaded[("tp", slot)] = fp
 
     @torch.no_grad()
-    def set_scene(self, plane_xz, plane_xy, plane_yz, latent, image_wh):
+    def set_scene(self, plane_xz, plane_xy, plane_yz, latent, image_wh, preproject=None):
         """Scene features in the reference's layout: planes (NV,128,Hp,Wp), latent
         (NV,512,Hf,Wf), image_wh = (W,H) of the source images the latent was encoded from
-        (neo360/model.py:267-269).  Re-laid out channels-last on the device, once."""
+        (neo360/model.py:267-269).  Re-laid out channels-last on the device, once.
+        preproject (None = keep `self.preproject`): see that attribute."""
+        if preproject is not None:
+            self.preproject = bool(preproject)
         planes = [f32(p, "plane") for p in (plane_xz, plane_xy, plane_yz)]
         latent = f32(latent, "latent")
         ctx = self._context(latent.device)
@@ -266,22 +331,31 @@ class NeRF_TP(_HipModule):
                 raise _lib.NeoError("no scene features: call set_scene(...) or attach an encoder module")
             return
         src = rays["src_imgs"]
-        key = (src.data_ptr(), src._version, tuple(src.shape), rays["src_poses"].data_ptr())
-        if key == self._scene_key and self._scene_ctx is not None:
+        inputs = (src, rays["src_poses"], rays["src_focal"], rays["src_c"])
+        if self._scene_key is not None and self._scene_ctx is not None and self._scene_key.matches(inputs, enc):
             return
-        planes = enc(rays["src_imgs"], rays["src_poses"], rays["src_focal"], rays["src_c"])
+        planes = enc(*inputs)
         self.set_scene(planes[0], planes[1], planes[2], enc.spatial_encoder.latent,
                        (src.shape[-1], src.shape[-2]))
-        self._scene_key = key
+        self._scene_key = _SceneKey(inputs, enc)
+        self.encoder_runs = getattr(self, "encoder_runs", 0) + 1
 
-    @staticmethod
-    def _camera_args(rays):
-        poses = rays["src_poses"].detach().float().cpu().contiguous()
+    def _camera_args(self, rays):
+        """Host copies of the source cameras (kernel arguments).  Cached on the identity + version of the three
+        tensors: the reference's chunk loop passes the same src_* tensors with every chunk, so only the first call of
+        a frame reads them back from the device."""
+        src = (rays["src_poses"], rays["src_focal"], rays["src_c"])
+        cache = getattr(self, "_cam_cache", None)
+        if cache is not None and all(a is b for a, b in zip(src, cache[0])) and tuple(t._version for t in src) == cache[1]:
+            return cache[2]
+        poses = src[0].detach().float().cpu().contiguous()
         NV = poses.shape[0]
         host_poses = (ctypes.c_float * (16 * NV))(*poses.reshape(-1).tolist())
-        focal = float(rays["src_focal"][0])                 # view 0's intrinsics for every view (model.py:242-244)
-        cx, cy = (float(x) for x in rays["src_c"][0])
-        return host_poses, NV, focal, cx, cy
+        focal = float(src[1][0])                            # view 0's intrinsics for every view (model.py:242-244)
+        cx, cy = (float(x) for x in src[2][0])
+        args = (host_poses, NV, focal, cx, cy)
+        self._cam_cache = (src, tuple(t._version for t in src), args)
+        return args
 
     @torch.no_grad()
     def eval_mlp(self, slot, rays, tvals, far=None, chunk=None):
@@ -301,6 +375,7 @@ class NeRF_TP(_HipModule):
         _lib.check(ctx.lib.neo_tp_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(tvals), ptr(far),
                                       B, N, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy, ptr(out),
                                       ctx.stream()))
+        self._raise_flags(ctx.poll_flags())       # also clears the word: a miss here must not fail a later forward()
         return out
 
     @torch.no_grad()
@@ -335,8 +410,7 @@ class NeRF_TP(_HipModule):
             ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
             self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
             ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
-        if ctx.poll_flags() & 1:
-            raise AssertionError("1.0 - p_norm_sq should be greater than 0")
+        self._raise_flags(ctx.poll_flags())
         return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]
 
 
@@ -430,14 +504,14 @@ class PixelNeRF(_HipModule):
                 raise _lib.NeoError("no scene latent: call set_scene(...) or attach an encoder module")
             return
         src = rays["src_imgs"]
-        key = (src.data_ptr(), src._version, tuple(src.shape))
-        if key == self._scene_key and self._scene_ctx is not None:
+        if self._scene_key is not None and self._scene_ctx is not None and self._scene_key.matches((src,), enc):
             return
         enc(src)
         self.set_scene(enc.latent, (src.shape[-1], src.shape[-2]))
-        self._scene_key = key
+        self._scene_key = _SceneKey((src,), enc)
+        self.encoder_runs = getattr(self, "encoder_runs", 0) + 1
 
-    _camera_args = staticmethod(NeRF_TP._camera_args)
+    _camera_args = NeRF_TP._camera_args
 
     @torch.no_grad()
     def eval_mlp(self, slot, rays, tvals, chunk=None):
@@ -453,6 +527,8 @@ class PixelNeRF(_HipModule):
         out = torch.empty(B, N, 4, device=rays_o.device)
         _lib.check(ctx.lib.neo_pix_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(tvals), B, N,
                                        int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy, ptr(out), ctx.stream()))
+        if self.poll_flags:
+            self._raise_flags(ctx.poll_flags())
         return out
 
     @torch.no_grad()
@@ -474,6 +550,8 @@ class PixelNeRF(_HipModule):
             ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
             float(near), float(far), self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
             ptr(lv[0][0]), ptr(lv[0][1]), ptr(lv[0][2]), ptr(lv[1][0]), ptr(lv[1][1]), ptr(lv[1][2]), ctx.stream()))
+        if self.poll_flags:
+            self._raise_flags(ctx.poll_flags())
         return lv
 
 
@@ -565,6 +643,8 @@ class MipNeRF360(_HipModule):
         _lib.check(ctx.lib.neo_mip_render(ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), B,
                                           float(train_frac), float(near), float(far), self.num_prop_samples,
                                           self.num_nerf_samples, arr, ctx.stream()))
+        if self.poll_flags:
+            self._raise_flags(ctx.poll_flags())
         renderings = [{"rgb": b["rgb"]} for b in bufs]
         history = [dict(density=b["rgbdens"][..., 3], rgb=b["rgbdens"][..., :3], sdist=b["sdist"], weights=b["weights"])
                    for b in bufs]
@@ -581,4 +661,6 @@ class MipNeRF360(_HipModule):
         out = torch.empty(B, n1 - 1, 4, device=rays_o.device)
         _lib.check(ctx.lib.neo_mip_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), ptr(tdist),
                                        B, n1 - 1, ptr(out), ctx.stream()))
+        if self.poll_flags:
+            self._raise_flags(ctx.poll_flags())
         return out

@@ -13,20 +13,26 @@ def _ctx(t, ctx):
     return ctx if ctx is not None else get_context(t.device)
 
 
-def get_ray_directions_and_rays(H, W, focal, c2w, ctx=None, device="cuda"):
+def get_ray_directions_and_rays(H, W, focal, c2w, ctx=None, device="cuda", ray_range=None, out=None):
     """datasets/ray_utils.py:84-104 + :133-176 in one kernel.
-    c2w: (3,4) or (4,4) array-like (host).  Returns rays_o, viewdirs, rays_d (HW,3), radii (HW,)."""
+    c2w: (3,4) or (4,4) array-like (host).  Returns rays_o, viewdirs, rays_d (n,3), radii (n,) for the whole frame
+    (n = H W) or for rays [lo, hi) of it when ray_range = (lo, hi) (a rank's shard).  `out`: tensors to write into
+    (e.g. the previous frame's, so a render loop allocates nothing)."""
     ctx = ctx if ctx is not None else get_context(device)
     dev = ctx.device
     pose = torch.as_tensor(c2w, dtype=torch.float32, device="cpu")[:3, :4].contiguous()
     host = (ctypes.c_float * 12)(*pose.reshape(-1).tolist())
-    n = H * W
-    rays_o = torch.empty(n, 3, device=dev)
-    viewdirs = torch.empty(n, 3, device=dev)
-    rays_d = torch.empty(n, 3, device=dev)
-    radii = torch.empty(n, device=dev)
-    _lib.check(ctx.lib.neo_raygen(ctx.handle, H, W, float(focal), host, ptr(rays_o), ptr(viewdirs), ptr(rays_d),
-                                  ptr(radii), ctx.stream()))
+    lo, hi = ray_range if ray_range is not None else (0, H * W)
+    n = hi - lo
+    if out is not None and out[0].shape[0] == n:
+        rays_o, viewdirs, rays_d, radii = out
+    else:
+        rays_o = torch.empty(n, 3, device=dev)
+        viewdirs = torch.empty(n, 3, device=dev)
+        rays_d = torch.empty(n, 3, device=dev)
+        radii = torch.empty(n, device=dev)
+    _lib.check(ctx.lib.neo_raygen_range(ctx.handle, H, W, float(focal), host, int(lo), int(n), ptr(rays_o), ptr(viewdirs),
+                                        ptr(rays_d), ptr(radii), ctx.stream()))
     return rays_o, viewdirs, rays_d, radii
 
 
@@ -44,6 +50,38 @@ def bbox_intersection_batch(bounds, rays_o, rays_d, ctx=None):
     _lib.check(ctx.lib.neo_aabb_intersect(ctx.handle, host, ptr(rays_o), ptr(rays_d), R, ptr(hit), ptr(tmin),
                                           ptr(tmax), ctx.stream()))
     return hit, tmin, tmax
+
+
+def sample_rays_in_bbox(RTs, rays_o, view_dirs, ctx=None, return_per_box=False):
+    """models/neo360/helper.py:359-373 (with get_object_rays_in_bbox :348-357 and get_rays_in_bbox :333-346 inside):
+    RTs = dict(R=[3x3 or 9], T=[3], s=[(2,3) bounds]) per object; rays are moved into every box frame in float64,
+    slab-tested, and merged with 0 as the "no hit" sentinel.  rays_o / view_dirs: (R,3) device tensors (any float
+    dtype; the reference's NumPy arrays are promoted to float64 the same way).  Returns all_near (R,1), all_far (R,1)
+    float32 and bbox_mask (R,1) bool, as the reference; with return_per_box also the per-box hit masks (n,R)."""
+    import numpy as np
+    rays_o, view_dirs = f64(rays_o, "rays_o"), f64(view_dirs, "view_dirs")
+    ctx = _ctx(rays_o, ctx)
+    R = rays_o.shape[0]
+    mats, bounds = [], []
+    for rot, tran, sca in zip(RTs["R"], RTs["T"], RTs["s"]):
+        box = np.eye(4)                                         # helper.py:352-356, verbatim order of operations
+        box[:3, :3] = np.reshape(np.array(rot), (3, 3))
+        box[:3, -1] = np.array(tran)
+        mats.append(np.linalg.inv(box))
+        bounds.append(np.asarray(sca, dtype=np.float64).reshape(6))
+    n = len(mats)
+    hm = (ctypes.c_double * (16 * n))(*np.stack(mats).astype(np.float64).reshape(-1).tolist())
+    hb = (ctypes.c_double * (6 * n))(*np.stack(bounds).reshape(-1).tolist())
+    dev = rays_o.device
+    near = torch.empty(R, 1, device=dev)
+    far = torch.empty(R, 1, device=dev)
+    mask = torch.empty(R, 1, dtype=torch.uint8, device=dev)
+    per_box = torch.empty(n, R, dtype=torch.uint8, device=dev) if return_per_box else None
+    _lib.check(ctx.lib.neo_aabb_multi(ctx.handle, n, hm, hb, ptr(rays_o), ptr(view_dirs), R, ptr(per_box), ptr(near),
+                                      ptr(far), ptr(mask), ctx.stream()))
+    if return_per_box:
+        return near, far, mask.bool(), per_box
+    return near, far, mask.bool()
 
 
 def intersect_sphere(rays_o, rays_d, ctx=None, check=True):

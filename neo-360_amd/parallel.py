@@ -28,19 +28,38 @@ def shard_bounds(n_rays, world, rank, unit=1024):
     return lo, lo + counts[rank]
 
 
+_buffers = {}
+
+
+def _buffer(tag, shape, like):
+    """Grow-never, reuse-always scratch tensors: a steady-state frame loop allocates nothing for the exchange."""
+    key = (tag, tuple(shape), like.device, like.dtype)
+    buf = _buffers.get(key)
+    if buf is None:
+        buf = _buffers[key] = torch.zeros(*shape, device=like.device, dtype=like.dtype)
+    return buf
+
+
 def gather_tiles(tile, n_rays, world, unit=1024, group=None):
     """All ranks' (r_i, C) tiles -> the full (n_rays, C) frame on every rank.
-    Unequal shards are padded to the largest so one all_gather_into_tensor suffices."""
+    Unequal shards are padded to the largest so one all_gather_into_tensor suffices.  The padded send tile, the
+    receive buffer and (for unequal shards) the compacted frame are cached per shape: the returned tensor is
+    overwritten by the next call with the same shapes."""
     import torch.distributed as dist
     counts = shard_counts(n_rays, world, unit)
     biggest = max(counts)
     C = tile.shape[1]
-    if tile.shape[0] != biggest:
-        pad = torch.zeros(biggest, C, device=tile.device, dtype=tile.dtype)
-        pad[: tile.shape[0]] = tile
+    if tile.shape[0] != biggest or not tile.is_contiguous():
+        pad = _buffer("send", (biggest, C), tile)
+        pad[: tile.shape[0]].copy_(tile)
         tile = pad
-    out = torch.empty(world * biggest, C, device=tile.device, dtype=tile.dtype)
-    dist.all_gather_into_tensor(out, tile.contiguous(), group=group)
+    out = _buffer("recv", (world * biggest, C), tile)
+    dist.all_gather_into_tensor(out, tile, group=group)
     if all(c == biggest for c in counts):
         return out
-    return torch.cat([out[r * biggest: r * biggest + counts[r]] for r in range(world)], dim=0)
+    frame = _buffer("frame", (n_rays, C), tile)
+    lo = 0
+    for r in range(world):
+        frame[lo: lo + counts[r]].copy_(out[r * biggest: r * biggest + counts[r]])
+        lo += counts[r]
+    return frame

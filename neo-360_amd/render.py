@@ -56,12 +56,21 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
 
 @torch.no_grad()
 def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False, near=0.2, far=3.0, group=None,
-                         gather=True, train_frac=1.0):
+                         gather=True, train_frac=1.0, n_rays=None):
     """This rank renders its contiguous range of whole chunks; `gather=True` reassembles
-    the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather."""
-    R = batch["rays_o"].shape[0]
-    lo, hi = shard_bounds(R, world, rank, unit=chunk)
-    part = render_rays_test(model, _slice(batch, lo, hi), chunk, white_bkgd, near, far, train_frac)
+    the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather.
+    `batch` holds the whole frame's rays, or - with n_rays = R given - only this rank's shard
+    (rays [shard_bounds(R, world, rank)), e.g. from ops.get_ray_directions_and_rays(ray_range=...))."""
+    if n_rays is None:
+        R = batch["rays_o"].shape[0]
+        lo, hi = shard_bounds(R, world, rank, unit=chunk)
+        mine = _slice(batch, lo, hi)
+    else:
+        R = int(n_rays)
+        lo, hi = shard_bounds(R, world, rank, unit=chunk)
+        assert batch["rays_o"].shape[0] == hi - lo, "batch must hold exactly this rank's shard"
+        mine = batch
+    part = render_rays_test(model, mine, chunk, white_bkgd, near, far, train_frac)
     tile = torch.cat([part["rgb"], part["depth"][:, None], part["acc"][:, None]], dim=1)
     if world == 1 or not gather:
         return tile

@@ -111,6 +111,23 @@ def merge_boxes(nears, fars):
     return all_near, all_far, (all_near != 0) & (all_far != 0)
 
 
+def sample_rays_in_bbox(RTs, rays_o, view_dirs):
+    """models/neo360/helper.py:348-373: per object, box frame = inverse([R|T]) (get_object_rays_in_bbox :348-357),
+    rays_in_box, running merge.  rays_o / view_dirs: NumPy (R,3).  Returns all_near, all_far (R,1) float32,
+    bbox_mask (R,1) bool and the list of per-box hit masks."""
+    nears, fars, hits = [], [], []
+    for rot, tran, sca in zip(RTs["R"], RTs["T"], RTs["s"]):
+        box = np.eye(4)
+        box[:3, :3] = np.reshape(np.array(rot), (3, 3))
+        box[:3, -1] = np.array(tran)
+        hit, near, far = rays_in_box(rays_o, view_dirs, np.array(sca), np.linalg.inv(box))
+        hits.append(hit)
+        nears.append(near)
+        fars.append(far)
+    all_near, all_far, mask = merge_boxes(nears, fars)
+    return all_near, all_far, mask, hits
+
+
 def sphere_exit_depth(rays_o, rays_d):
     """Depth at which each ray leaves the unit sphere, (B,1).
 

@@ -38,17 +38,17 @@ def take(rays, idx):
     return {k: v[idx].contiguous() for k, v in rays.items()}
 
 
-def neo_batch(rays):
+def neo_batch(rays, nv=NV):
     """Adds the src_* keys of the reference's batch dict (datasets/nerds360_ae.py)."""
-    poses, focal, centre = synth.source_views(NV, IMG_WH[0], IMG_WH[1])
+    poses, focal, centre = synth.source_views(nv, IMG_WH[0], IMG_WH[1])
     out = dict(rays)
     out.update(src_poses=poses, src_focal=focal, src_c=centre,
-               src_imgs=torch.zeros(NV, 3, IMG_WH[1], IMG_WH[0]))
+               src_imgs=torch.zeros(nv, 3, IMG_WH[1], IMG_WH[0]))
     return out
 
 
-def small_scene(seed=7):
-    sc = synth.scene_features(seed, NV, 128, PLANE_HW, 512, LATENT_HW, std=0.5)
+def small_scene(seed=7, nv=NV):
+    sc = synth.scene_features(seed, nv, 128, PLANE_HW, 512, LATENT_HW, std=0.5)
     sc["image_wh"] = (float(IMG_WH[0]), float(IMG_WH[1]))
     return sc
 
@@ -79,6 +79,31 @@ def aabb_cases(seed=3, n=4096):
         [[0.2, 0.2, 0.2], [1.5, 0.4, 1.2]],
     ])
     return boxes, u, d
+
+
+def oriented_box_cases(seed=4, n=3000):
+    """World-frame rays (float32, as the dataset holds them) and four ORIENTED boxes in the reference's RTs format
+    (datasets/nerds360_ae.py: R (3,3), T (3,), s (2,3) bounds in the box frame): rotated + translated boxes, one
+    axis-aligned, exact-zero direction components, origins inside boxes, rays that miss everything."""
+    o = (synth.uniform01(seed, "ob_o", n * 3).reshape(n, 3) * 3.0 - 1.5).astype(np.float32)
+    aim = (synth.uniform01(seed, "ob_aim", n * 3).reshape(n, 3) * 1.2 - 0.6).astype(np.float32)
+    d = aim - o
+    d[::9] = (synth.uniform01(seed, "ob_d", n * 3).reshape(n, 3) * 2.0 - 1.0).astype(np.float32)[::9]
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d[::23, 1] = 0.0
+    d[7::31, 0] = 0.0
+    o[5::19] *= 0.05                                             # origins inside the central boxes
+
+    def rot(ax, ang):
+        c, s = math.cos(ang), math.sin(ang)
+        m = {"x": [[1, 0, 0], [0, c, -s], [0, s, c]], "y": [[c, 0, s], [0, 1, 0], [-s, 0, c]], "z": [[c, -s, 0], [s, c, 0], [0, 0, 1]]}[ax]
+        return np.array(m, dtype=np.float64)
+
+    Rs = [rot("z", 0.4) @ rot("x", -0.3), np.eye(3), rot("y", 1.1), rot("x", 0.7) @ rot("z", 2.0)]
+    Ts = [np.array([0.1, -0.05, 0.0]), np.array([-0.4, 0.3, 0.1]), np.array([0.5, 0.5, -0.2]), np.array([0.0, -0.6, 0.3])]
+    ss = [np.array([[-0.3, -0.2, -0.25], [0.3, 0.2, 0.25]]), np.array([[-0.2, -0.2, -0.2], [0.2, 0.2, 0.2]]),
+          np.array([[-0.15, -0.4, -0.1], [0.15, 0.4, 0.1]]), np.array([[-0.25, -0.1, -0.3], [0.25, 0.1, 0.3]])]
+    return dict(R=Rs, T=Ts, s=ss), o, d
 
 
 def pdf_cases(seed=5, R=96, nb=64):

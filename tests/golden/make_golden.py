@@ -131,6 +131,14 @@ def g2_aabb():
         all_near = torch.where((all_near == 0) | (near == 0), torch.maximum(near, all_near), torch.minimum(near, all_near))
         all_far = torch.where((all_far == 0) | (far == 0), torch.maximum(far, all_far), torch.minimum(far, all_far))
     out["merged_mask"] = ((all_near != 0) & (all_far != 0)).numpy().astype(np.uint8)
+    # oriented boxes through the reference's own sample_rays_in_bbox / get_object_rays_in_bbox (helper.py:348-373)
+    RTs, wo, wd = cases.oriented_box_cases()
+    near, far, mask = H.sample_rays_in_bbox(RTs, wo.copy(), wd.copy())
+    out.update(ob_near=near, ob_far=far, ob_mask=mask.numpy().astype(np.uint8))
+    for bi in range(len(RTs["R"])):
+        single = {"R": RTs["R"][bi], "T": RTs["T"][bi], "s": RTs["s"][bi]}
+        hit, _, _ = H.get_object_rays_in_bbox(wo.copy(), wd.copy(), single)
+        out["ob_hit%d" % bi] = hit.numpy().astype(np.uint8)
     save("g2_aabb", **out)
 
 
@@ -235,11 +243,11 @@ def g4_vanilla():
     save("g4_vanilla", **out)
 
 
-def g4_neo(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0):
-    scene = cases.small_scene()
-    net = ref_nerf_tp(synth.nerf_tp_state(0, density_gain=gain), scene)
+def g4_neo(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, nv=cases.NV):
+    scene = cases.small_scene(nv=nv)
+    net = ref_nerf_tp(synth.nerf_tp_state(0, density_gain=gain), scene, nv=nv)
     net.num_coarse_samples, net.num_fine_samples = n_coarse, n_fine
-    batch = cases.neo_batch(cases.strided_rays(n_rays))
+    batch = cases.neo_batch(cases.strided_rays(n_rays), nv=nv)
     per_ray = ("rays_o", "rays_d", "viewdirs")
     acc = {k: [] for k in ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")}
     for i in range(0, n_rays, chunk):
@@ -249,6 +257,51 @@ def g4_neo(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0):
         acc["rgb1"].append(res[1][0]); acc["fg1"].append(res[1][1]); acc["bg1"].append(res[1][2])
         acc["fgacc1"].append(res[1][3]); acc["lam1"].append(res[1][4]); acc["depth1"].append(res[1][5])
     save("g4_neo_" + tag, **{k: torch.cat(v, 0) for k, v in acc.items()})
+
+
+def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0):
+    """The reference's OWN rounding noise on the rays of fixture g4_neo_<tag>: the same call evaluated by the
+    reference in fp32 and by its fp64 twin (module.double(), fp64 rays / latent; the tri-planes stay fp32 because
+    index_grid casts its coordinates with .float(), encoder_tp_fusion_conv.py:128-130).  Stored per ray:
+    |ref32 - ref64| (max over channels) for every output of the fixture, plus the fp64 values themselves.
+    tests/test_gpu_neo360.py uses it to separate well-conditioned rays (contract: 1e-4 on every one) from rays on
+    which the reference disagrees with itself."""
+    scene = cases.small_scene()
+    state = synth.nerf_tp_state(0, density_gain=gain)
+    batch = cases.neo_batch(cases.strided_rays(n_rays))
+    per_ray = ("rays_o", "rays_d", "viewdirs")
+    keys = ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")
+
+    def run(net, b):
+        acc = {k: [] for k in keys}
+        for i in range(0, n_rays, chunk):
+            part = {k: (v[i:i + chunk] if k in per_ray else v) for k, v in b.items()}
+            res = net(part, False, False, 0.0, 0.0, out_depth=True)
+            acc["rgb0"].append(res[0][0]); acc["depth0"].append(res[0][5])
+            acc["rgb1"].append(res[1][0]); acc["fg1"].append(res[1][1]); acc["bg1"].append(res[1][2])
+            acc["fgacc1"].append(res[1][3]); acc["lam1"].append(res[1][4]); acc["depth1"].append(res[1][5])
+        return {k: torch.cat(v, 0) for k, v in acc.items()}
+
+    net32 = ref_nerf_tp(state, scene)
+    net32.num_coarse_samples, net32.num_fine_samples = n_coarse, n_fine
+    r32 = run(net32, batch)
+    scene64 = dict(scene)
+    scene64["latent"] = scene["latent"].double()
+    net64 = ref_nerf_tp(state, scene64).double()
+    net64.num_coarse_samples, net64.num_fine_samples = n_coarse, n_fine
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    r64 = run(net64, b64)
+    out = {}
+    for k in keys:
+        assert r64[k].dtype == torch.float64, (k, r64[k].dtype)
+        d = (r32[k].double() - r64[k]).abs()
+        out["noise_" + k] = (d.amax(dim=-1) if d.dim() == 2 and d.shape[-1] == 3 else d.reshape(n_rays)).float()
+        out["ref64_" + k] = r64[k]
+    # the fp32 run here must be the committed fixture (same code, same inputs)
+    fx = np.load(os.path.join(HERE, "g4_neo_%s.npz" % tag))
+    for k in keys:
+        out["refit_" + k] = np.float32(np.abs(fx[k] - r32[k].numpy()).max())
+    save("g4_neo_%s_noise" % tag, **out)
 
 
 # ---------------------------------------------------------------------------------
@@ -345,6 +398,14 @@ def main(which):
         "g4n_1024": lambda: g4_neo("1024", 1024, 1024),
         "g4n_1500": lambda: g4_neo("1500", 1500, 1024),
         "g4n_sharp": lambda: g4_neo("sharp", 256, 256, 32, 64, gain=8.0),
+        # other source-view counts (the reference builds NeRF_TP(num_src_views=int(render_name[0])), model.py:606-616)
+        "g4n_nv1": lambda: g4_neo("nv1", 96, 96, 32, 64, nv=1),
+        "g4n_nv2": lambda: g4_neo("nv2", 96, 96, 32, 64, nv=2),
+        "g4n_nv5": lambda: g4_neo("nv5", 96, 96, 32, 64, nv=5),
+        # the reference's own fp32-vs-fp64 disagreement on the same rays (conditioning of the fine-level resampling)
+        "g4n_1024_noise": lambda: g4_neo_noise("1024", 1024, 1024),
+        "g4n_1500_noise": lambda: g4_neo_noise("1500", 1500, 1024),
+        "g4n_sharp_noise": lambda: g4_neo_noise("sharp", 256, 256, 32, 64, gain=8.0),
         "g6": g6_mip360,
         "g7": g7_pixelnerf,
     }

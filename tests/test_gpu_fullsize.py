@@ -1,0 +1,108 @@
+"""GPU: the BASELINE.json configurations at their FULL sizes inside the -m gpu suite (round 1 only ran them from
+bench.py): NeO-360 640x480 with 3 x 128 x 120 x 160 tri-planes and 3 x 512 x 240 x 320 latents (C3), Mip-NeRF 360
+640x480 (C5).  Whole frames are checked through size-independent properties (finite, ranges, partition of
+opacity, row-order independence, chunk structure); a strip of rays is compared with the CPU oracle on the same
+full-size features."""
+import pytest
+import torch
+
+import oracle
+from conftest import max_abs
+from neo360_amd import models, ops, render, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+H, W = 480, 640
+NV = 3
+
+
+@pytest.fixture(scope="module")
+def neo_full():
+    state = synth.nerf_tp_state(0)
+    net = models.NeRF_TP(num_coarse_samples=128, num_fine_samples=256, num_src_views=NV).to(DEV)
+    net.load_state_dict(state)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(0)
+    scene = {k: torch.randn(NV, 128, 120, 160, device=DEV, generator=g) * 0.1 for k in ("plane_xz", "plane_xy", "plane_yz")}
+    scene["latent"] = torch.randn(NV, 512, 240, 320, device=DEV, generator=g) * 0.1
+    scene["image_wh"] = (float(W), float(H))
+    net.set_scene(scene["plane_xz"], scene["plane_xy"], scene["plane_yz"], scene["latent"], scene["image_wh"])
+    poses, focal, centre = synth.source_views(NV, W, H)
+    ro, vd, rd, radii = ops.get_ray_directions_and_rays(H, W, 0.8 * W, synth.look_at_origin(40.0))
+    batch = dict(rays_o=ro, rays_d=rd, viewdirs=vd, src_poses=poses.to(DEV), src_focal=focal.to(DEV),
+                 src_c=centre.to(DEV), src_imgs=torch.zeros(NV, 3, H, W, device=DEV))
+    return state, net, scene, batch
+
+
+def test_neo360_full_frame_properties(neo_full):
+    state, net, scene, batch = neo_full
+    res = net(batch, False, False, 0.0, 0.0, out_depth=True, chunk=1024)
+    R = H * W
+    for lv in (0, 1):
+        rgb, fg, bg, acc, lam, depth = res[lv]
+        assert rgb.shape == (R, 3) and acc.shape == (R,) and lam.shape == (R, 1) and depth.shape == (R,)
+        for x in (rgb, fg, bg, acc, lam, depth):
+            assert bool(torch.isfinite(x).all())
+        # colours are convex combinations of sigmoid outputs in [-0.001, 1.001]
+        assert float(rgb.min()) >= -2e-3 and float(rgb.max()) <= 1.002 + 1e-3
+        assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+        assert float(lam.min()) >= 0.0 and float(lam.max()) <= 1.0 + 1e-5
+        # opacity inside the sphere + transmittance behind it partition 1 (helper.py:150-160: acc = 1 - T_last up to 1e-10 terms)
+        assert max_abs(acc + lam.squeeze(-1), torch.ones(R)) < 1e-4
+        assert max_abs(rgb, fg + lam * bg) < 1e-6
+        assert float(depth.min()) >= 0.0
+    # chunk structure: rendering rows 100..107 (whole 1024-ray chunks 62..67 + 68th partially? no: 8 rows = 5 chunks) alone
+    lo, hi = 100 * W, 108 * W                                   # 5120 rays = exactly 5 reference chunks
+    sub = {k: (v if k.startswith("src_") else v[lo:hi]) for k, v in batch.items()}
+    part = net(sub, False, False, 0.0, 0.0, out_depth=True, chunk=1024)
+    assert torch.equal(part[1][0], res[1][0][lo:hi]) and torch.equal(part[1][5], res[1][5][lo:hi])
+    # whole-frame API == the module call
+    out = render.render_rays_test(net, batch, chunk=1024)
+    assert torch.equal(out["rgb"], res[1][0]) and torch.equal(out["depth"], res[1][5])
+
+
+def test_neo360_full_size_strip_vs_oracle(neo_full):
+    """256 rays of the 640x480 frame (a strided strip through the image centre), full-size features, default sample
+    counts, as ONE reference chunk on both sides."""
+    state, net, scene, batch = neo_full
+    idx = (torch.arange(256, device=DEV) * 601 + 230 * W) % (H * W)
+    sub = {k: (v if k.startswith("src_") else v[idx].contiguous()) for k, v in batch.items()}
+    got = net(sub, False, False, 0.0, 0.0, out_depth=True)
+    csub = {k: v.cpu() for k, v in sub.items()}
+    cscene = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
+    torch.set_num_threads(32)
+    want = oracle.neo360.render(state, csub, cscene, 128, 256)
+    for lv in (0, 1):
+        err_rgb = (got[lv][0].cpu() - want[lv][0]).abs().amax(-1)
+        err_depth = (got[lv][5].cpu() - want[lv][5]).abs()
+        print("level", lv, "rgb max %.2e p99 %.2e  depth max %.2e" % (float(err_rgb.max()), float(err_rgb.quantile(0.99)), float(err_depth.max())))
+    assert max_abs(got[0][0], want[0][0]) < 1e-4 and max_abs(got[0][5], want[0][5]) < 1e-4      # coarse level: every ray
+    # fine level: the 1e-4 contract on every ray but the (reference-side) ill-conditioned ones, see test_gpu_neo360.py;
+    # with random-init densities at this size those are < 1 % of the rays and stay below 1e-3
+    err = (got[1][0].cpu() - want[1][0]).abs().amax(-1)
+    assert float(err.quantile(0.99)) < 1e-4 and float(err.max()) < 1e-3
+    assert float((got[1][5].cpu() - want[1][5]).abs().quantile(0.99)) < 1e-4
+
+
+def test_mip360_full_frame_and_strip():
+    state = synth.mip360_state(0, weight_gain=0.5)
+    net = models.MipNeRF360(num_prop_samples=64, num_nerf_samples=32).to(DEV)
+    net.load_state_dict(state)
+    ro, vd, rd, radii = ops.get_ray_directions_and_rays(H, W, 0.8 * W, synth.look_at_origin(40.0))
+    batch = dict(rays_o=ro, rays_d=rd, viewdirs=vd, radii=radii[:, None])
+    rend, hist = net(batch, 1.0, False, False, 0.2, 3.0)
+    R = H * W
+    for lv, n in enumerate((64, 64, 32)):
+        rgb, w, sd = rend[lv]["rgb"], hist[lv]["weights"], hist[lv]["sdist"]
+        assert rgb.shape == (R, 3) and w.shape == (R, n) and sd.shape == (R, n + 1)
+        assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(w).all())
+        assert float(rgb.min()) >= -2e-3 and float(rgb.max()) <= 1.0 + 2e-3
+        assert float(w.min()) >= 0.0 and max_abs(w.sum(-1), torch.ones(R)) < 1e-4      # opaque background: weights sum to 1
+        assert bool((sd[:, 1:] >= sd[:, :-1]).all()) and float(sd.min()) >= 0.0 and float(sd.max()) <= 1.0
+    idx = (torch.arange(128, device=DEV) * 1201 + 200 * W) % R
+    sub = {k: v[idx].contiguous() for k, v in batch.items()}
+    got, _ = net(sub, 1.0, False, False, 0.2, 3.0)
+    torch.set_num_threads(32)
+    want, _ = oracle.mip360.render(state, {k: v.cpu() for k, v in sub.items()}, 1.0, 0.2, 3.0, num_prop_samples=64, num_nerf_samples=32)
+    assert torch.equal(got[-1]["rgb"], rend[-1]["rgb"][idx])                            # rays are independent
+    assert max_abs(got[-1]["rgb"], want[-1]["rgb"]) < 1e-4

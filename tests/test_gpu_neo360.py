@@ -12,26 +12,26 @@ DEV = "cuda"
 TOL = 1e-4
 
 
-def _net(n_coarse, n_fine, gain=1.0):
-    net = models.NeRF_TP(num_coarse_samples=n_coarse, num_fine_samples=n_fine, num_src_views=cases.NV).to(DEV)
+def _net(n_coarse, n_fine, gain=1.0, nv=cases.NV, preproject=True):
+    net = models.NeRF_TP(num_coarse_samples=n_coarse, num_fine_samples=n_fine, num_src_views=nv).to(DEV)
     net.load_state_dict(synth.nerf_tp_state(0, density_gain=gain))
-    sc = cases.small_scene()
+    sc = cases.small_scene(nv=nv)
     net.set_scene(sc["plane_xz"].to(DEV), sc["plane_xy"].to(DEV), sc["plane_yz"].to(DEV), sc["latent"].to(DEV),
-                  sc["image_wh"])
+                  sc["image_wh"], preproject=preproject)
     return net
 
 
-def _batch(n):
-    b = cases.neo_batch(cases.strided_rays(n))
+def _batch(n, nv=cases.NV):
+    b = cases.neo_batch(cases.strided_rays(n), nv=nv)
     return {k: v.to(DEV) for k, v in b.items()}
 
 
-def _render(net, n, chunk):
-    batch = _batch(n)
+def _render(net, n, chunk, nv=cases.NV, white=False):
+    batch = _batch(n, nv)
     outs = []
     for i in range(0, n, chunk):
         part = {k: (v if k.startswith("src_") else v[i:i + chunk]) for k, v in batch.items()}
-        outs.append(net(part, False, False, 0.0, 0.0, out_depth=True))
+        outs.append(net(part, False, white, 0.0, 0.0, out_depth=True))
     cat = lambda lv, j: torch.cat([o[lv][j] for o in outs]).cpu()
     return dict(rgb0=cat(0, 0), depth0=cat(0, 5), rgb1=cat(1, 0), fg1=cat(1, 1), bg1=cat(1, 2), fgacc1=cat(1, 3),
                 lam1=cat(1, 4), depth1=cat(1, 5))
@@ -62,46 +62,180 @@ def test_internal_chunking_equals_callers(golden):
     assert max_abs(res[1][0].cpu(), g["rgb1"]) < TOL and max_abs(res[1][5].cpu(), g["depth1"]) < TOL
 
 
-def test_sharp_density(golden):
-    """Density head x8 (trained-like, peaky weights).  Hierarchical resampling is ill-conditioned
-    there: the REFERENCE's own fp32-vs-fp64 noise on depth exceeds 1e-4 with sharp weights
-    (SURVEY.md §7, "chaotic resampling"), so depth gets the reference's noise floor as tolerance;
-    rgb, acc and lambda still meet 1e-4."""
-    _check(_render(_net(32, 64, gain=8.0), 256, 256), golden("g4_neo_sharp"), depth_tol=1e-3)
+KEYS = ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")
 
 
-def _check_e2e_default_counts(got, g):
-    """End to end at the reference's default 128+256 samples.
+def _per_ray(x):
+    return x.abs().amax(dim=-1) if x.dim() == 2 and x.shape[-1] == 3 else x.abs().reshape(x.shape[0])
 
-    Everything up to and including the fine-level SAMPLE PLACEMENT inputs is strict (1e-4
-    on every ray).  The fine level's background branch inverts a cdf whose bins DEscend
-    (neo360/model.py:319-331): every new sample is interpolated across the WHOLE [0,1]
-    range with t=(u-cdf0)/(cdf1-cdf0), so where a bin carries ~no weight an ulp of the
-    fp32 cdf moves a sample anywhere along the ray.  The reference is that sensitive to
-    its own rounding (fp32 vs fp64 of the reference differ the same way; its CPU sum
-    order even depends on the host's vector width), so bit-level agreement on those rays
-    is not defined.  Measured on MI355X vs the fixtures: p99 of |rgb err| 3.6e-6, ~0.2% of
-    rays above 1e-4 (max 2.3e-4), all through bg_rgb; fg, acc, lambda, depth stay < 2e-5.
-    test_gpu_neo360_stages.py closes the gap: with identical sample positions on both
-    sides every ray meets 1e-4."""
-    for k in ("rgb0", "depth0", "fg1", "fgacc1", "lam1", "depth1"):
-        assert max_abs(got[k], g[k]) < TOL, k
-    for k in ("rgb1", "bg1"):
-        err = (got[k] - g[k]).abs().amax(dim=-1)
-        assert float(err.quantile(0.99)) < 2e-5, k
-        assert float((err > TOL).float().mean()) < 0.01, k
-        assert float(err.max()) < 2e-3, k
+
+def _check_vs_reference_noise(got, g, noise, label):
+    """End-to-end contract, separated by how well the REFERENCE determines each ray.
+
+    The fixture g4_neo_<tag>_noise holds, per ray and output, |ref32 - ref64|: the reference's decoder run in fp32
+    (= the fixture) and by its own fp64 twin (tests/golden/make_golden.py:g4_neo_noise).  At the default 128+256
+    samples that self-disagreement is < 1e-5 on 99.4-99.6 % of the rays and reaches 2.2e-4 (rgb1) / 3.4e-4 (bg1) on
+    the rest: the background fine level inverts a cdf over DEscending bins (neo360/model.py:319-331), where one ulp
+    of the fp32 cdf moves a sample along the whole ray.
+      * every ray the reference determines to better than 1e-5 must meet the 1e-4 contract - no exceptions;
+      * a ray where the reference disagrees with itself by n >= 1e-5 must land within 1e-4 + 3 n of the fp32
+        reference (i.e. GPU outliers are the reference's own outliers, with comparable magnitude)."""
+    worst = {}
+    for k in KEYS:
+        err = _per_ray(got[k] - g[k])
+        n = noise["noise_" + k]
+        well = n < 1e-5
+        assert float(err[well].max()) < TOL, (label, k, "well-conditioned ray above 1e-4", float(err[well].max()))
+        ill = ~well
+        if bool(ill.any()):
+            excess = err[ill] - (TOL + 3.0 * n[ill])
+            assert float(excess.max()) <= 0.0, (label, k, "ill-conditioned ray beyond the reference's own noise",
+                                                float(err[ill].max()), float(n[ill].max()))
+        worst[k] = (float(err.max()), int(ill.sum()))
+    print(label, {k: "%.2e (%d ill)" % v for k, v in worst.items()})
     mse = float(((got["rgb1"].clamp(0, 1) - g["rgb1"].clamp(0, 1)) ** 2).mean())
     assert mse < 1e-10       # PSNR vs the reference frame > 100 dB
 
 
-def test_reference_sample_counts_1024(golden):
-    """One reference-sized chunk: 1024 rays, 128 coarse + 256 fine, fg + bg, 3 views."""
-    _check_e2e_default_counts(_render(_net(128, 256), 1024, 1024), golden("g4_neo_1024"))
+def test_sharp_density(golden):
+    """Density head x8 (trained-like, peaky weights): hierarchical resampling is ill-conditioned there in the
+    reference itself (fixture g4_neo_sharp_noise: depth1 differs by up to 4.4e-4 between its fp32 and fp64 runs)."""
+    _check_vs_reference_noise(_render(_net(32, 64, gain=8.0), 256, 256), golden("g4_neo_sharp"),
+                              golden("g4_neo_sharp_noise"), "sharp")
+
+
+@pytest.mark.parametrize("preproject", [True, False])
+def test_reference_sample_counts_1024(golden, preproject):
+    """One reference-sized chunk: 1024 rays, 128 coarse + 256 fine, fg + bg, 3 views; both split evaluators
+    (latent pre-projected through the first-layer weights = default, and the reference's operation order)."""
+    _check_vs_reference_noise(_render(_net(128, 256, preproject=preproject), 1024, 1024), golden("g4_neo_1024"),
+                              golden("g4_neo_1024_noise"), "1024 preproject=%s" % preproject)
 
 
 def test_reference_sample_counts_1500_two_chunks(golden):
-    _check_e2e_default_counts(_render(_net(128, 256), 1500, 1024), golden("g4_neo_1500"))
+    _check_vs_reference_noise(_render(_net(128, 256), 1500, 1024), golden("g4_neo_1500"),
+                              golden("g4_neo_1500_noise"), "1500")
+
+
+def test_preprojection_is_a_reassociation(golden):
+    """Per-point outputs of the pre-projected evaluator vs the evaluator that gathers the 512-channel latent and
+    multiplies it per point: identical up to fp32 reassociation (W.bilerp(F) = bilerp(W.F)), on every slot."""
+    from neo360_amd import ops
+    a, b = _net(32, 64, preproject=True), _net(32, 64, preproject=False)
+    batch = _batch(256)
+    far, _ = ops.intersect_sphere(batch["rays_o"], batch["rays_d"])
+    t_fg = torch.linspace(0.03, 0.97, 65, device=DEV)[None, :] * far.reshape(-1, 1)
+    t_bg = torch.linspace(0.99, 0.01, 65, device=DEV)[None, :].expand(256, 65).contiguous()
+    for slot, tv in ((0, t_fg), (1, t_fg), (2, t_bg), (3, t_bg)):
+        ya, yb = a.eval_mlp(slot, batch, tv, far=far), b.eval_mlp(slot, batch, tv, far=far)
+        assert max_abs(ya[..., :3], yb[..., :3]) < 5e-6, slot
+        assert max_abs(ya[..., 3], yb[..., 3]) < 2e-5, slot          # softplus densities reach O(10)
+    # new weights invalidate the projection
+    sd = synth.nerf_tp_state(3)
+    a.load_state_dict(sd); b.load_state_dict(sd)
+    ya, yb = a.eval_mlp(1, batch, t_fg, far=far), b.eval_mlp(1, batch, t_fg, far=far)
+    assert max_abs(ya, yb) < 2e-5
+    # and so does a new scene
+    sc = cases.small_scene(seed=11)
+    for net in (a, b):
+        net.set_scene(sc["plane_xz"].to(DEV), sc["plane_xy"].to(DEV), sc["plane_yz"].to(DEV), sc["latent"].to(DEV), sc["image_wh"])
+    ya, yb = a.eval_mlp(3, batch, t_bg, far=far), b.eval_mlp(3, batch, t_bg, far=far)
+    assert max_abs(ya, yb) < 2e-5
+
+
+@pytest.mark.parametrize("nv", [1, 2, 5])
+def test_other_view_counts(golden, nv):
+    """NeRF_TP(num_src_views=1|2|5) against fixtures generated by the reference with that many source views."""
+    got = _render(_net(32, 64, nv=nv), 96, 96, nv=nv)
+    _check(got, golden("g4_neo_nv%d" % nv))
+
+
+def test_white_bkgd_is_ignored_with_out_depth(golden):
+    """The evaluation call (out_depth=True) composites with white_bkgd=False whatever the caller passes
+    (neo360/model.py:487-517): results must not change."""
+    net = _net(32, 64)
+    a, b = _render(net, 300, 256, white=False), _render(net, 300, 256, white=True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    _check(b, golden("g4_neo_small"))
+
+
+def test_out_of_range_lookups():
+    """Sample positions far outside the feature volumes / image frusta: every tap that falls off a map contributes
+    zero (grid_sample padding_mode='zeros'), per-point outputs still match the oracle."""
+    import oracle
+    net = _net(32, 64)
+    params, scene = synth.nerf_tp_state(0), cases.small_scene()
+    cb = cases.neo_batch(cases.strided_rays(64))
+    gb = {k: v.to(DEV) for k, v in cb.items()}
+    far_c, _ = oracle.rays.sphere_exit_depth(cb["rays_o"], cb["rays_d"])
+    tv = torch.linspace(0.0, 6.0, 48)[None, :].repeat(64, 1)           # up to 6 units along the ray: far off every map
+    got = net.eval_mlp(0, gb, tv.to(DEV), far=far_c.to(DEV)).cpu()
+    rgb, sigma = oracle.neo360.region_eval(params, "fg_coarse_mlp.", cb, scene, tv, True, far_c)
+    assert max_abs(got[..., :3], rgb) < 2e-5 and max_abs(got[..., 3:], sigma) < 2e-5
+    # behind / beside the source cameras as well: rays shot away from the scene
+    cb2 = dict(cb)
+    cb2["rays_d"] = -cb["rays_d"]
+    cb2["viewdirs"] = -cb["viewdirs"]
+    gb2 = {k: v.to(DEV) for k, v in cb2.items()}
+    got = net.eval_mlp(1, gb2, tv.to(DEV), far=far_c.to(DEV)).cpu()
+    rgb, sigma = oracle.neo360.region_eval(params, "fg_fine_mlp.", cb2, scene, tv, True, far_c)
+    assert max_abs(got[..., :3], rgb) < 2e-5 and max_abs(got[..., 3:], sigma) < 2e-5
+
+
+class _StubEncoder(torch.nn.Module):
+    """Stands in for GridEncoder: deterministic features that depend on the source images, so a stale cache shows."""
+
+    class _Spatial:
+        latent = None
+
+    def __init__(self):
+        super().__init__()
+        self.gain = torch.nn.Parameter(torch.ones(()))
+        self.spatial_encoder = self._Spatial()
+        self.calls = 0
+
+    def forward(self, src_imgs, src_poses, src_focal, src_c):
+        self.calls += 1
+        sc = cases.small_scene()
+        k = float(src_imgs.mean()) + 1.0
+        self.spatial_encoder.latent = (sc["latent"].to(src_imgs.device) * k * self.gain).contiguous()
+        return tuple((sc[n].to(src_imgs.device) * k * self.gain).contiguous() for n in ("plane_xz", "plane_xy", "plane_yz"))
+
+
+def test_attached_encoder_runs_once_per_scene():
+    """INTEGRATION.md's 'no edits' mode: an attached encoder is run once per distinct src_imgs, re-run for a new
+    tensor (even one the allocator places at the old address), an in-place edit, or new encoder weights."""
+    enc = _StubEncoder().to(DEV)
+    net = models.NeRF_TP(num_coarse_samples=32, num_fine_samples=64, num_src_views=cases.NV, encoder=enc).to(DEV)
+    net.load_state_dict(synth.nerf_tp_state(0), strict=False)
+    batch = _batch(64)
+    chunks = [{k: (v if k.startswith("src_") else v[i:i + 32]) for k, v in batch.items()} for i in (0, 32)]
+    a = [net(c, False, False, 0.0, 0.0, out_depth=True)[1][0] for c in chunks]
+    assert enc.calls == 1                                        # two chunks of one frame: encoded once
+    ref = _net(32, 64)(batch, False, False, 0.0, 0.0, out_depth=True, chunk=32)[1][0]
+    assert max_abs(torch.cat(a), ref) < 1e-6                     # src_imgs = 0 -> k = 1: the plain small scene
+    # a new scene in a NEW tensor at (very likely) the same address
+    shape = batch["src_imgs"].shape
+    del batch["src_imgs"]
+    for c in chunks:
+        del c["src_imgs"]
+    torch.cuda.synchronize()
+    batch["src_imgs"] = torch.full(shape, 0.5, device=DEV)
+    b = net(batch, False, False, 0.0, 0.0, out_depth=True, chunk=32)[1][0]
+    assert enc.calls == 2 and max_abs(b, ref) > 1e-3             # really rendered from the new features
+    # in-place edit of the same tensor
+    batch["src_imgs"].fill_(0.0)
+    c = net(batch, False, False, 0.0, 0.0, out_depth=True, chunk=32)[1][0]
+    assert enc.calls == 3 and max_abs(c, ref) < 1e-6
+    # unchanged inputs: cached
+    net(batch, False, False, 0.0, 0.0, out_depth=True, chunk=32)
+    assert enc.calls == 3
+    # encoder weights change (fine-tuning / load_state_dict)
+    with torch.no_grad():
+        enc.gain.mul_(1.5)
+    d = net(batch, False, False, 0.0, 0.0, out_depth=True, chunk=32)[1][0]
+    assert enc.calls == 4 and max_abs(d, ref) > 1e-3
 
 
 def test_sphere_miss_raises():

@@ -18,16 +18,17 @@ TOL = 1e-4
 R, NC, NF = 192, 128, 256
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f32"])
 def setup(request):
-    """Both point-evaluator kernels (split-fp16 matrix cores = default, exact fp32 MFMA) against the oracle."""
+    """All three point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent
+    (default), split-fp16 in the reference's operation order, exact fp32 MFMA."""
     params = synth.nerf_tp_state(0)
     scene = cases.small_scene()
     net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
-    net.precision = request.param
+    net.precision = request.param.split("-")[0]
     net.load_state_dict(params)
     net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
-                  scene["latent"].to(DEV), scene["image_wh"])
+                  scene["latent"].to(DEV), scene["image_wh"], preproject=not request.param.endswith("noproj"))
     batch = cases.neo_batch(cases.strided_rays(R))
     return params, scene, net, batch, {k: v.to(DEV) for k, v in batch.items()}
 

@@ -56,21 +56,15 @@ def test_neo360_evaluators_repeatable(built_lib):
         far, _ = ops.intersect_sphere(gb["rays_o"], gb["rays_d"])
         t_fg = torch.linspace(0.05, 0.95, NC, device=dev)[None, :] * far.reshape(-1, 1)
         t_bg = torch.linspace(0.98, 0.02, NC, device=dev)[None, :].expand(R, NC).contiguous()
-        ref_net, h_net = mk("f32"), mk("f16x3")
-        import os
+        ref_net, h_net, n_net = mk("f32"), mk("f16x3"), mk("f16x3")
+        n_net.preproject = False                        # the split evaluator that gathers the 512-channel latent
         for slot, tt in ((0, t_fg), (1, t_fg), (2, t_bg), (3, t_bg)):
             ref = ref_net.eval_mlp(slot, gb, tt, far=far)
             assert torch.equal(ref, ref_net.eval_mlp(slot, gb, tt, far=far))
-            runs = [h_net.eval_mlp(slot, gb, tt, far=far) for _ in range(3)]
-            assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
-            assert (runs[0] - ref).abs().max().item() < 5e-6
-            os.environ["NEO_TP_BATCHED"] = "1"                     # three-views-resident kernel (opt-in)
-            try:
-                loop = [h_net.eval_mlp(slot, gb, tt, far=far) for _ in range(2)]
-            finally:
-                del os.environ["NEO_TP_BATCHED"]
-            # (it sums the view branch per view, the default kernel applies it to the view means: same to fp32 rounding)
-            assert torch.equal(loop[0], loop[1]) and (loop[0] - runs[0]).abs().max().item() < 2e-6
+            for net in (h_net, n_net):
+                runs = [net.eval_mlp(slot, gb, tt, far=far) for _ in range(3)]
+                assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+                assert (runs[0] - ref).abs().max().item() < 5e-6
 
 
 def test_mip360_evaluators_repeatable(built_lib):

@@ -40,6 +40,41 @@ def test_aabb_hit_mask_bit_exact(golden):
         assert np.array_equal(tmax.cpu().numpy(), g["tmax%d" % bi].numpy())
 
 
+def test_oriented_boxes_bit_exact(golden):
+    """neo_aabb_multi = sample_rays_in_bbox (box-frame transform in float64, slab test, float32 rounding, 0-sentinel
+    merge) against outputs of the reference's own function: integer masks and the merged near / far, bit for bit."""
+    g = golden("g2_aabb")
+    RTs, o, d = cases.oriented_box_cases()
+    near, far, mask, per_box = ops.sample_rays_in_bbox(RTs, torch.from_numpy(o).to(DEV), torch.from_numpy(d).to(DEV),
+                                                       return_per_box=True)
+    for bi in range(len(RTs["R"])):
+        assert torch.equal(per_box[bi].cpu(), g["ob_hit%d" % bi]), bi
+    assert torch.equal(mask.cpu().to(torch.uint8), g["ob_mask"])
+    assert torch.equal(near.cpu(), g["ob_near"]) and torch.equal(far.cpu(), g["ob_far"])
+    # one box == the single-box entry point on pre-transformed rays
+    single = {k: v[:1] for k, v in RTs.items()}
+    n1, f1, m1 = ops.sample_rays_in_bbox(single, torch.from_numpy(o).to(DEV), torch.from_numpy(d).to(DEV))
+    assert torch.equal(m1.cpu().squeeze(-1).to(torch.uint8), g["ob_hit0"])
+    # empty ray set
+    e = torch.zeros(0, 3, device=DEV)
+    n0, f0, m0 = ops.sample_rays_in_bbox(RTs, e, e)
+    assert n0.shape == (0, 1) and m0.shape == (0, 1)
+
+
+def test_raygen_range_equals_full_frame():
+    """A rank's shard: rays [lo, hi) generated alone are the rows [lo, hi) of the full frame, bit for bit (radii too)."""
+    from neo360_amd import synth
+    c2w = synth.look_at_origin(40.0)
+    full = ops.get_ray_directions_and_rays(48, 64, 51.2, c2w)
+    for lo, hi in ((0, 1024), (1024, 2048), (2048, 3072), (3000, 3072), (64 * 47 - 5, 64 * 48)):
+        part = ops.get_ray_directions_and_rays(48, 64, 51.2, c2w, ray_range=(lo, hi))
+        for a, b in zip(part, full):
+            assert torch.equal(a, b[lo:hi])
+    buf = ops.get_ray_directions_and_rays(48, 64, 51.2, c2w, ray_range=(100, 200))
+    again = ops.get_ray_directions_and_rays(48, 64, 51.2, c2w, ray_range=(300, 400), out=buf)
+    assert again[0].data_ptr() == buf[0].data_ptr() and torch.equal(again[3], full[3][300:400])
+
+
 def test_aabb_empty_and_single():
     b = [[-1, -1, -1], [1, 1, 1]]
     hit, _, _ = ops.bbox_intersection_batch(b, torch.zeros(0, 3, dtype=torch.float64, device=DEV),

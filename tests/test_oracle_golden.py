@@ -44,6 +44,19 @@ def test_g2_aabb_bit_exact(golden):
     assert torch.equal(mask.to(torch.uint8), g["merged_mask"])
 
 
+def test_g2_oriented_boxes_bit_exact(golden):
+    """sample_rays_in_bbox / get_object_rays_in_bbox (neo360/helper.py:348-373) called on the reference itself:
+    per-box masks, merged near / far (float32) and the merged mask, bit for bit."""
+    g = golden("g2_aabb")
+    RTs, o, d = cases.oriented_box_cases()
+    near, far, mask, hits = oracle.rays.sample_rays_in_bbox(RTs, o, d)
+    for bi, h in enumerate(hits):
+        assert torch.equal(h.to(torch.uint8), g["ob_hit%d" % bi])
+    assert torch.equal(near, g["ob_near"]) and torch.equal(far, g["ob_far"])
+    assert torch.equal(mask.to(torch.uint8), g["ob_mask"])
+    assert 0.2 < float(g["ob_mask"].float().mean()) < 0.8
+
+
 def test_g3_encoding_and_samplers(golden):
     g = golden("g3_stages")
     x3 = synth.uniform(11, "pe3", (257, 3), -1.7, 1.7)
