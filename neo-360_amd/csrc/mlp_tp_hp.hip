@@ -20,6 +20,7 @@
 // linearity, heads) is the structure of mlp_tp_h.hip.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "split_tile.h"
@@ -31,6 +32,16 @@
 #ifndef NEO_TP_RING
 #define NEO_TP_RING 3         // tap register sets (16 VGPRs each); prefetch distance = RING - 1 items
 #endif
+#ifndef NEO_TP_STAGGER_DEFAULT
+#define NEO_TP_STAGGER_DEFAULT 0      // x 64 cycles; $NEO_TP_STAGGER overrides (see k_tp_mlp_hp)
+#endif
+#ifndef NEO_TP_ABLATE
+// timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
+// tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
+// 64 no barriers inside the view loop, 128 no layer-epilogue stores
+#define NEO_TP_ABLATE 0
+#endif
+#define TP_SYNC() do { if (!(NEO_TP_ABLATE & 64)) __syncthreads(); } while (0)
 
 namespace neo {
 
@@ -82,8 +93,14 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                                                              const float* __restrict__ viewdirs,
                                                              const float* __restrict__ tvals,
                                                              const float* __restrict__ far_arr, int R, int N, int chunk,
-                                                             uint32_t* __restrict__ flags, float4* __restrict__ out) {
+                                                             uint32_t* __restrict__ flags, float4* __restrict__ out, int stagger) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // Two workgroups share a CU.  Launched together they run their phases (gather-bound, matrix-bound) in lockstep and
+    // contend for the same pipe all the time; the second generation of resident workgroups (blocks 256..511 on this
+    // 256-CU part) therefore starts `stagger` x 64 cycles late, once: later workgroups start whenever a slot frees and
+    // inherit the offset.  Placement-independent: a wrong guess about which blocks co-reside only costs the delay.
+    if (stagger > 0 && blockIdx.x >= 256u && blockIdx.x < 512u)
+        for (int i = 0; i < stagger; i += 100) __builtin_amdgcn_s_sleep(100);
     _Float16* hbase = reinterpret_cast<_Float16*>(smem + tp::OFF_ACT);
     const HT act{hbase, hbase + TM * 128};                                   // [64][128] x 2 planes (32 KB)
     auto xbuf = [&](int b) { return HT{hbase + b * (2 * TM * 64), hbase + b * (2 * TM * 64) + TM * 64}; };   // aliases act
@@ -108,17 +125,17 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     constexpr int NPE = PE_C == 3 ? 1 : 2;     // pos_enc stages of 64 features
 
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
+    float* dens_w = smem + tp::OFF_DENSW;
+    if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
+    float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum[tid + 256 * j] = 0.0f;    // (p, f) is accumulated by another thread: zero BEFORE the barrier
     __syncthreads();
 
     // view means by linearity (see mlp_tp_h.hip): only sum_v relu(L3_v) and sum_v dir_enc_v are accumulated per view
     f32x16 hsum[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; }
-    float* dens_w = smem + tp::OFF_DENSW;
-    if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
-    float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dsum[tid + 256 * j] = 0.0f;    // each thread later owns (p = lane, f): a barrier follows
     const int nts_1[1] = {L.wv};
     const int vnt = L.wv & 1, vmt = L.wv >> 1;
 
@@ -133,11 +150,12 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
+        if (!(NEO_TP_ABLATE & 32) || v == 0)
         tp::view_descriptors<PROJ_TEXEL_BYTES>(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
             const int di = p * 32 + (f ^ (p & 31));     // lane = p: XOR keeps the 64 lanes on distinct banks
             dsum[di] += val;                            // (p, f) is owned by one thread in every view; zeroed before the loop
         });
-        __syncthreads();
+        TP_SYNC();
 
         // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
         f32x16 accx[2][2];
@@ -155,7 +173,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             constexpr int NI = 40;
             auto issue = [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i < 16) {
+                if constexpr ((i < 16 && (NEO_TP_ABLATE & 1)) || (i >= 16 && (NEO_TP_ABLATE & 2))) {
+                } else if constexpr (i < 16) {
                     constexpr int c = i / 4, q = i % 4;
                     const int row = rg + 16 * q;
                     const int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
@@ -183,7 +202,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             };
             auto finish = [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i < 16) {
+                if constexpr ((i < 16 && (NEO_TP_ABLATE & 1)) || (i >= 16 && (NEO_TP_ABLATE & 2))) {
+                } else if constexpr (i < 16) {
                     constexpr int c = i / 4, q = i % 4;
                     const int row = rg + 16 * q;
                     const f32x4 val = blend4(taps[i % RING], *reinterpret_cast<const f32x4*>(loc_w + row * 4));
@@ -199,6 +219,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             // chunk c of the pre-projected latent -> accumulators (this wave's pieces: 2 per M-tile)
             auto consume_chunk = [&](auto cc) __attribute__((always_inline)) {
                 constexpr int c = decltype(cc)::value;
+                if constexpr ((NEO_TP_ABLATE & 1) != 0) return;
                 const float* buf = fbuf(c & 1);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -214,6 +235,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             };
             // pos_enc: half hf of a stage = chunks 4hf..4hf+3, one per wave
             auto finish_pe = [&](const HT& buf, int pstage, int hf) __attribute__((always_inline)) {
+                if constexpr ((NEO_TP_ABLATE & 4) != 0) return;
                 const int row = tid & 63, q = tid >> 6;
                 const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
                 range_see(L, xc[0]); range_see(L, xc[1]); range_see(L, xc[2]);     // identity features (the rest are sines)
@@ -236,6 +258,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             wx_off[0] = (uint32_t)(L.wv * KSX * 2 * 64 + L.lane) * 16u;
             wx_off[1] = (uint32_t)((4 + L.wv) * KSX * 2 * 64 + L.lane) * 16u;
             auto load_wq = [&](int ks) __attribute__((always_inline)) {
+                if constexpr ((NEO_TP_ABLATE & 8) != 0) return;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     wh[nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks));
@@ -243,6 +266,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 }
             };
             auto mma_q = [&](const HT& tile, int tks) __attribute__((always_inline)) {
+                if constexpr ((NEO_TP_ABLATE & 8) != 0) return;
                 h8 bh[2], bl[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -274,7 +298,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 }
                 finish(ic);
                 __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
-                if constexpr (i == 3 || i == 7 || i == 11 || i == 15 || i == 27 || i == 39) __syncthreads();
+                if constexpr (i == 3 || i == 7 || i == 11 || i == 15 || i == 27 || i == 39) TP_SYNC();
             });
             // ---- world stage 1 is multiplied while the first pos_enc stage is computed ----
 #pragma unroll 1
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 load_wq(4 + q + 1);
                 if (q & 1) finish_pe(xbuf(0), 0, q >> 1);
             }
-            __syncthreads();
+            TP_SYNC();
             // ---- pos_enc stage(s) ----
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
@@ -291,41 +315,45 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 if (8 + q + 1 < KSX) load_wq(8 + q + 1);
                 if constexpr (NPE == 2) { if (q == 1) finish_pe(xbuf(1), 1, 0); }   // features 64..95 (84..95 are padding)
             }
-            __syncthreads();
+            TP_SYNC();
             if constexpr (NPE == 2) {
 #pragma unroll 1
                 for (int q = 0; q < 2; ++q) {
                     mma_q(xbuf(1), q);
                     if (12 + q + 1 < KSX) load_wq(12 + q + 1);
                 }
-                __syncthreads();
+                TP_SYNC();
             }
         }
         // ---- L0 epilogue, L1, L2 ----
         f32x16 acc[1][2];
-        store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
-        store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
-        __syncthreads();
+        if (!(NEO_TP_ABLATE & 128)) {
+            store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
+            store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
+        }
+        TP_SYNC();
 #pragma unroll 1
         for (int layer = 0; layer < 2; ++layer) {
             bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : B_2), L.wv, L);
             acc[0][1] = acc[0][0];
-            gemm2h<1, 128>(acc, wp + (layer == 0 ? hoff_1(PE_C) : hoff_2(PE_C)), 8, nts_1, 0, 0, 8, act, L);
-            __syncthreads();
-            store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
-            store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
-            __syncthreads();
+            if (!(NEO_TP_ABLATE & 16)) gemm2h<1, 128>(acc, wp + (layer == 0 ? hoff_1(PE_C) : hoff_2(PE_C)), 8, nts_1, 0, 0, 8, act, L);
+            TP_SYNC();
+            if (!(NEO_TP_ABLATE & 128)) {
+                store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
+                store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
+            }
+            TP_SYNC();
         }
         // ---- L3 = skip half (in accx[1]) + W3[:, :128] h2; ReLU; accumulate over the views ----
         acc[0][0] = accx[1][0];
         acc[0][1] = accx[1][1];
-        gemm2h<1, 128>(acc, wp + hoff_3a(PE_C), 8, nts_1, 0, 0, 8, act, L);
+        if (!(NEO_TP_ABLATE & 16)) gemm2h<1, 128>(acc, wp + hoff_3a(PE_C), 8, nts_1, 0, 0, 8, act, L);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
             hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
         }
-        __syncthreads();           // every wave is done reading this view's tiles
+        TP_SYNC();           // every wave is done reading this view's tiles
     }
 
     // ---- view mean of the trunk -> density head ----
@@ -516,14 +544,28 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
                       const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s) {
     const long P = (long)R * N;
     if (P <= 0) return;
-    const size_t lds = tp::LDS_WORDS * sizeof(float);
+    static int stagger = -1;
+    if (stagger < 0) {
+        const char* e = getenv("NEO_TP_STAGGER");
+        stagger = e ? atoi(e) : NEO_TP_STAGGER_DEFAULT;
+    }
+    static size_t lds_pad = ~size_t(0);
+    if (lds_pad == ~size_t(0)) {          // occupancy experiments: $NEO_TP_LDS_PAD extra bytes of dynamic LDS per workgroup
+        const char* e = getenv("NEO_TP_LDS_PAD");
+        lds_pad = e ? (size_t)atol(e) : 0;
+    }
+    const size_t lds = tp::LDS_WORDS * sizeof(float) + lds_pad;
+    if (lds > 65536) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     const long tiles = tp::xcd_grid((P + TM - 1) / TM);
     if (input_ch == 3)
         hipLaunchKernelGGL(k_tp_mlp_hp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
-                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), stagger);
     else
         hipLaunchKernelGGL(k_tp_mlp_hp<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
-                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), stagger);
 }
 
 }  // namespace neo

@@ -51,8 +51,8 @@ def test_neo360_full_frame_properties(neo_full):
         assert max_abs(acc + lam.squeeze(-1), torch.ones(R)) < 1e-4
         assert max_abs(rgb, fg + lam * bg) < 1e-6
         assert float(depth.min()) >= 0.0
-    # chunk structure: rendering rows 100..107 (whole 1024-ray chunks 62..67 + 68th partially? no: 8 rows = 5 chunks) alone
-    lo, hi = 100 * W, 108 * W                                   # 5120 rays = exactly 5 reference chunks
+    # chunk structure: reference chunks 64..68 of the frame (rays 65536..70655) rendered alone give the same pixels
+    lo, hi = 64 * 1024, 69 * 1024
     sub = {k: (v if k.startswith("src_") else v[lo:hi]) for k, v in batch.items()}
     part = net(sub, False, False, 0.0, 0.0, out_depth=True, chunk=1024)
     assert torch.equal(part[1][0], res[1][0][lo:hi]) and torch.equal(part[1][5], res[1][5][lo:hi])

@@ -59,6 +59,12 @@ def test_neo360_scaled_features_parity_or_flag(scale):
     far_c, _ = oracle.rays.sphere_exit_depth(cb["rays_o"], cb["rays_d"])
     tv = torch.linspace(0.05, 0.95, 40)[None, :] * far_c
     rgb, sigma = oracle.neo360.region_eval(params, "fg_fine_mlp.", cb, scene, tv, True, far_c)
+    # truth: the oracle in float64.  At x1e3 the fp32 reference arithmetic itself is only good to ~1e-3 relative on the
+    # densities (512-term dot products of O(500) features), so the bound is relative to the fp32 oracle's own error.
+    dbl = lambda d: {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in d.items()}
+    rgb64, sigma64 = oracle.neo360.region_eval(dbl(params), "fg_fine_mlp.", dbl(cb), dbl(scene), tv.double(), True, far_c.double())
+    rel = lambda a: float(((a.double() - sigma64).abs() / sigma64.abs().clamp_min(1.0)).max())
+    cpu_rgb, cpu_sig = float((rgb.double() - rgb64).abs().max()), rel(sigma)
     for preproject in (True, False):
         net = models.NeRF_TP(num_coarse_samples=32, num_fine_samples=64, num_src_views=cases.NV).to(DEV)
         net.load_state_dict(params)
@@ -68,9 +74,11 @@ def test_neo360_scaled_features_parity_or_flag(scale):
             got = net.eval_mlp(1, gb, tv.to(DEV), far=far_c.to(DEV)).cpu()
         except _lib.NeoError:
             continue                                                   # flagged: acceptable, never silent
-        assert max_abs(got[..., :3], rgb) < 1e-4
-        rel = ((got[..., 3:] - sigma).abs() / sigma.abs().clamp_min(1.0)).max()
-        assert float(rel) < 2e-5, (preproject, float(rel))
+        gpu_rgb, gpu_sig = float((got[..., :3].double() - rgb64).abs().max()), rel(got[..., 3:])
+        print("scale %g preproject %s: |rgb - fp64| gpu %.2e cpu32 %.2e; rel sigma gpu %.2e cpu32 %.2e" %
+              (scale, preproject, gpu_rgb, cpu_rgb, gpu_sig, cpu_sig))
+        assert gpu_rgb < max(1e-4, 2.0 * cpu_rgb)
+        assert gpu_sig < 2.0 * cpu_sig + 2e-5, (preproject, gpu_sig, cpu_sig)
 
 
 def test_neo360_features_beyond_range_raise():
