@@ -205,6 +205,61 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d,
                   float focal, float cx, float cy, int n_coarse, int n_fine, int white_bkgd,
                   const neo_tp_level_out* level0, const neo_tp_level_out* level1, void* stream);
 
+/* ---- training-side operators ----------------------------------------------------------- */
+/* Counter-based uniforms in [0,1): out[r][c] = (Philox4x32-10(key = seed, counter = (r, c, stream_id, 0))[0] >> 8) 2^-24
+ * - the generator behind every randomized=True sampler here (the reference draws torch.rand: helper.py:49, :196). */
+int neo_rand_uniform(neo_ctx* ctx, uint64_t seed, uint32_t stream_id, int rows, int cols, float* out, void* stream);
+
+/* neo360/helper.py:24-75 sample_along_rays for both regions: far (R) from neo_intersect_sphere, near = 1e-4.
+ * u_fg / u_bg (R, n_coarse+1) uniforms = randomized=True (stratified jitter, :44-51); both NULL = randomized=False.
+ * fg_t (R, n_coarse+1) ascending t; bg_s (R, n_coarse+1) descending inverse radius. */
+int neo_tp_sample_level0(neo_ctx* ctx, const float* far, int R, int n_coarse, const float* u_fg, const float* u_bg,
+                         float* fg_t, float* bg_s, void* stream);
+
+/* neo_resample with one row of quantiles per ray, u (R, n_new) in [0,1): sorted_piecewise_constant_pdf with
+ * randomized=True (neo360/helper.py:195-196; the draws need not be sorted). */
+int neo_resample_u(neo_ctx* ctx, const float* t_prev, const float* weights, const float* u, int R, int n_prev,
+                   int n_new, int descending, float* t_out, void* stream);
+
+/* Backward of neo_composite (same mode / inputs): upstream gradients g_rgb (R,3), g_acc (R), g_depth (R),
+ * g_weights (R,N), g_lambda (R) (any may be NULL = zero) -> g_rgbsigma (R,N,4) = dL/d(rgb, sigma) per sample.
+ * The sample positions carry no gradient (the reference detaches them, helper.py:224). */
+int neo_composite_backward(neo_ctx* ctx, int mode, const float* rgbsigma, const float* t, const float* rays_d,
+                           const float* t_far, int R, int N, int white_bkgd, const float* g_rgb,
+                           const float* g_acc, const float* g_depth, const float* g_weights,
+                           const float* g_lambda, float* g_rgbsigma, void* stream);
+
+/* torch_efficient_distloss.eff_distloss(w, m, interval) (requirements.txt:29; call site neo360/model.py:1246-1260):
+ * per ray interval/3 sum w^2 + 2 sum_{i>j} w_i w_j (m_i - m_j) evaluated with prefix sums.  loss_rays (R) = per-ray
+ * loss (the reference returns their mean), grad_w (R,N) = d loss_ray / d w; either may be NULL. */
+int neo_distloss(neo_ctx* ctx, const float* w, const float* m, int R, int N, float interval, float* loss_rays,
+                 float* grad_w, void* stream);
+
+/* Stand-alone feature lookups of the scene set with neo_tp_set_scene, view-major rows (row = v P + p):
+ * world (NV*P,128) = index_grid (encoder_tp_fusion_conv.py:122-209: three planes summed), local (NV*P,512) =
+ * get_local_feats / SpatialEncoder.index (neo360/model.py:239-264).  pts (P,3) world points. */
+int neo_tp_gather(neo_ctx* ctx, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+                  float cy, float* world, float* local, void* stream);
+/* Its backward: g_world / g_local scattered (atomic adds) into CHANNELS-LAST gradient maps the caller zeroed:
+ * g_plane_* (NV,Hp,Wp,128), g_latent (NV,Hf,Wf,512).  Points carry no gradient. */
+int neo_tp_gather_backward(neo_ctx* ctx, const float* pts, long P, const float* src_poses, int NV, float focal,
+                           float cx, float cy, const float* g_world, const float* g_local, float* g_plane_xz,
+                           float* g_plane_xy, float* g_plane_yz, float* g_latent, void* stream);
+
+/* NeRF_TP.forward in its TRAINING form (neo360/model.py:531-579, out_depth=False): white_bkgd honoured, per level
+ * rgb (R,3), fg_weights / bg_weights (R,N), the sample rows fg_tvals / bg_tvals (R,N) the caller derives sdist from
+ * (:564-571), bg_acc (R), and optionally the per-sample (rgb, sigma) of both regions (inputs of
+ * neo_composite_backward).  seed != 0 = randomized=True: stratified level-0 jitter and uniform level-1 quantiles
+ * from neo_rand_uniform streams 0..3; seed == 0 = randomized=False.  Any output pointer may be NULL. */
+typedef struct {
+    float* rgb; float* fg_weights; float* bg_weights; float* fg_tvals; float* bg_tvals; float* bg_acc;
+    float* fg_rgbsigma; float* bg_rgbsigma;
+} neo_tp_train_out;
+int neo_tp_render_train(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* viewdirs, int R,
+                        int chunk, const float* src_poses, int NV, float focal, float cx, float cy, int n_coarse,
+                        int n_fine, int white_bkgd, uint64_t seed, const neo_tp_train_out* level0,
+                        const neo_tp_train_out* level1, void* stream);
+
 /* ---- PixelNeRF baseline decoder (models/vanilla_nerf/model_pixel.py) ------------------------ */
 /* Upload one NeRFMLP of model_pixel.py:35-94 (slot 0 = coarse_mlp, 1 = fine_mlp).  weights/biases
  * [host arrays of 9 device pointers], order: pts_linears.0..3 (128x575, 128x128 x3), views_linear.0

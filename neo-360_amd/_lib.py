@@ -21,6 +21,11 @@ class MipLevelOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("rgb", "sdist", "weights", "rgbdens")]
 
 
+class TpTrainOut(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("rgb", "fg_weights", "bg_weights", "fg_tvals", "bg_tvals", "bg_acc",
+                                               "fg_rgbsigma", "bg_rgbsigma")]
+
+
 class TpLevelOut(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth")]
 
@@ -52,6 +57,15 @@ SIGNATURES = {
     "neo_tp_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i,
                            ctypes.POINTER(TpLevelOut), ctypes.POINTER(TpLevelOut), _vp]),
+    "neo_rand_uniform": (_i, [_vp, ctypes.c_uint64, ctypes.c_uint32, _i, _i, _vp, _vp]),
+    "neo_tp_sample_level0": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "neo_resample_u": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "neo_composite_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "neo_distloss": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "neo_tp_gather": (_i, [_vp, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "neo_tp_gather_backward": (_i, [_vp, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "neo_tp_render_train": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i, ctypes.c_uint64,
+                                 ctypes.POINTER(TpTrainOut), ctypes.POINTER(TpTrainOut), _vp]),
     "neo_pix_upload_mlp": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "neo_pix_set_scene": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "neo_pix_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, c_float_p, _i, _f, _f, _f, _vp, _vp]),

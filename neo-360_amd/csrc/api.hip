@@ -270,7 +270,7 @@ int neo_resample(neo_ctx* ctx, const float* t_prev, const float* weights, int R,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float* u = ctx->get_quantiles(n_new, s);
     if (!u) return fail(NEO_ERR_HIP, "quantile table upload failed");
-    if (neo::launch_resample(t_prev, n_prev, weights, u, R, n_prev, n_new, descending, t_out, s))
+    if (neo::launch_resample(t_prev, n_prev, weights, u, 0, R, n_prev, n_new, descending, t_out, s))
         return fail(NEO_ERR_INVALID, "unsupported sample counts");
     return check_launch();
 }
@@ -364,7 +364,7 @@ int neo_vanilla_render(neo_ctx* ctx, const float* rays_o, const float* viewdirs,
     if (rc) return rc;
     neo::launch_composite(0, out0, t0, 0, rays_d, nullptr, R, N0, white_bkgd, rgb0, acc0, depth0, w0, nullptr, s);
     // level 1: bins = mids(t0), weights[1:-1] (model.py:171-181); sort-merge
-    if (neo::launch_resample(t0, 0, w0, u, R, N0, n_fine, 0, t1, s)) return fail(NEO_ERR_INVALID, "unsupported sample counts");
+    if (neo::launch_resample(t0, 0, w0, u, 0, R, N0, n_fine, 0, t1, s)) return fail(NEO_ERR_INVALID, "unsupported sample counts");
     rc = vanilla_mlp_launch(ctx, 1, rays_o, viewdirs, t1, N1, R, N1, out1, s);
     if (rc) return rc;
     neo::launch_composite(0, out1, t1, N1, rays_d, nullptr, R, N1, white_bkgd, rgb1, acc1, depth1, nullptr, nullptr, s);

@@ -143,7 +143,7 @@ int neo_pix_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const
     if (rc) return rc;
     neo::launch_composite(0, out0, t0, 0, rays_d, nullptr, R, N0, white_bkgd, rgb0, acc0, depth0, w0, nullptr, s);
     // level 1: bins = mids(t0), weights[1:-1] (model_pixel.py:195-206); sort-merge
-    if (neo::launch_resample(t0, 0, w0, u, R, N0, n_fine, 0, t1, s)) return fail(NEO_ERR_INVALID, "unsupported sample counts");
+    if (neo::launch_resample(t0, 0, w0, u, 0, R, N0, n_fine, 0, t1, s)) return fail(NEO_ERR_INVALID, "unsupported sample counts");
     rc = pix_launch(ctx, 1, sc, views, rays_o, rays_d, viewdirs, t1, 0, R, N1, chunk, out1, s);
     if (rc) return rc;
     neo::launch_composite(0, out1, t1, N1, rays_d, nullptr, R, N1, white_bkgd, rgb1, acc1, depth1, nullptr, nullptr, s);

@@ -76,6 +76,15 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
 
 }  // namespace
 
+// one region's evaluator launch for other translation units (api_train.hip)
+int neo_tp_eval_region(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
+                       const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
+                       int chunk, float* out, hipStream_t s) {
+    MlpSlot& sl = ctx->tp[slot];
+    if (!sl.ready) return fail(NEO_ERR_STATE, "NeRF_TP MLP slot %d has no weights", slot);
+    return tp_launch(ctx, sl, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, out, s);
+}
+
 extern "C" {
 
 int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* weights,
@@ -241,8 +250,8 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const 
             neo::launch_tp_merge(fg_rgb, s_fg_depth, lam, bg_rgb, s_bg_depth, R, lo->rgb, lo->depth, s);
         if (level == 0) {
             // hierarchical resampling (model.py:306-332): fg ascending; bg on the descending inverse radius
-            if (neo::launch_resample(fg_t0, N0, fg_w0, u, R, N0, n_fine, 0, fg_t1, s) ||
-                neo::launch_resample(bg_s0, N0, bg_w0, u, R, N0, n_fine, 1, bg_s1, s))
+            if (neo::launch_resample(fg_t0, N0, fg_w0, u, 0, R, N0, n_fine, 0, fg_t1, s) ||
+                neo::launch_resample(bg_s0, N0, bg_w0, u, 0, R, N0, n_fine, 1, bg_s1, s))
                 return fail(NEO_ERR_INVALID, "unsupported sample counts");
             fg_t = fg_t1;
             bg_s = bg_s1;

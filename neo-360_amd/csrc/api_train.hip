@@ -1,0 +1,217 @@
+// Training-side entry points of the C ABI: counter-based uniforms, stratified samplers, the
+// backward of the compositing, stand-alone feature lookups with their backward, the distortion loss, and the
+// training-mode forward of NeRF_TP (out_depth=False tuple, randomized sampling, white background honoured).
+#include "ctx.h"
+
+using namespace neo_host;
+
+namespace {
+
+void fill_views(const float* poses, int nv, neo::TpViews& v) {       // as api_tp.hip (neo360/util.py:64-66)
+    for (int i = 0; i < nv; ++i) {
+        const float* m = poses + i * 16;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) v.rot[i][r * 3 + c] = m[c * 4 + r];
+        for (int r = 0; r < 3; ++r) {
+            float acc = v.rot[i][r * 3 + 0] * m[0 * 4 + 3];
+            acc = acc + v.rot[i][r * 3 + 1] * m[1 * 4 + 3];
+            acc = acc + v.rot[i][r * 3 + 2] * m[2 * 4 + 3];
+            v.trans[i][r] = -acc;
+        }
+    }
+}
+
+}  // namespace
+
+int neo_tp_eval_region(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
+                       const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
+                       int chunk, float* out, hipStream_t s);     // api_tp.hip
+
+extern "C" {
+
+int neo_rand_uniform(neo_ctx* ctx, uint64_t seed, uint32_t stream_id, int rows, int cols, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    if (rows == 0 || cols == 0) return NEO_OK;
+    REQUIRE(out != nullptr, "null pointer");
+    neo::launch_uniform(seed, stream_id, rows, cols, out, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_sample_level0(neo_ctx* ctx, const float* far, int R, int n_coarse, const float* u_fg, const float* u_bg,
+                         float* fg_t, float* bg_s, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && n_coarse >= 3 && n_coarse <= 1023, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(far && fg_t && bg_s, "null pointer");
+    REQUIRE((u_fg == nullptr) == (u_bg == nullptr), "pass both uniform arrays (randomized) or neither");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* edges = ctx->get_edges(n_coarse, 0.0f, 1.0f, s);
+    if (!edges) return fail(NEO_ERR_HIP, "constant table upload failed");
+    if (u_fg) neo::launch_tp_level0_rand(far, edges, R, n_coarse + 1, 1e-4f, u_fg, u_bg, fg_t, bg_s, s);
+    else neo::launch_tp_level0(far, edges, R, n_coarse + 1, 1e-4f, fg_t, bg_s, s);
+    return check_launch();
+}
+
+int neo_resample_u(neo_ctx* ctx, const float* t_prev, const float* weights, const float* u, int R, int n_prev, int n_new,
+                   int descending, float* t_out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && n_new >= 1, "bad shape");
+    REQUIRE(n_prev >= 4 && n_prev <= 257 && n_prev + n_new <= 1024, "unsupported sample counts");
+    if (R == 0) return NEO_OK;
+    REQUIRE(t_prev && weights && u && t_out, "null pointer");
+    if (neo::launch_resample(t_prev, n_prev, weights, u, n_new, R, n_prev, n_new, descending, t_out, static_cast<hipStream_t>(stream)))
+        return fail(NEO_ERR_INVALID, "unsupported sample counts");
+    return check_launch();
+}
+
+int neo_composite_backward(neo_ctx* ctx, int mode, const float* rgbsigma, const float* t, const float* rays_d,
+                           const float* t_far, int R, int N, int white_bkgd, const float* g_rgb, const float* g_acc,
+                           const float* g_depth, const float* g_weights, const float* g_lambda, float* g_rgbsigma,
+                           void* stream) {
+    ENTER(ctx);
+    REQUIRE(mode >= 0 && mode <= 2, "mode must be 0, 1 or 2");
+    REQUIRE(R >= 0 && N >= 1 && N <= 1024, "bad shape (N <= 1024)");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rgbsigma && t && g_rgbsigma, "null pointer");
+    REQUIRE(mode == 2 || rays_d, "rays_d required");
+    REQUIRE(mode != 1 || t_far, "t_far required for mode 1");
+    if (neo::launch_composite_bwd(mode, rgbsigma, t, N, rays_d, t_far, R, N, white_bkgd, g_rgb, g_acc, g_depth, g_weights,
+                                  g_lambda, g_rgbsigma, static_cast<hipStream_t>(stream)))
+        return fail(NEO_ERR_INVALID, "unsupported sample count");
+    return check_launch();
+}
+
+int neo_distloss(neo_ctx* ctx, const float* w, const float* m, int R, int N, float interval, float* loss_rays,
+                 float* grad_w, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && N >= 1, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(w && m && (loss_rays || grad_w), "null pointer");
+    neo::launch_distloss(w, m, R, N, interval, loss_rays, grad_w, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_gather(neo_ctx* ctx, const float* pts, long P, const float* src_poses, int NV, float focal, float cx, float cy,
+                  float* world, float* local, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0, "negative point count");
+    if (P == 0) return NEO_OK;
+    REQUIRE(pts && src_poses && world && local, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_gather(sc, views, pts, P, world, local, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_gather_backward(neo_ctx* ctx, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+                           float cy, const float* g_world, const float* g_local, float* g_plane_xz, float* g_plane_xy,
+                           float* g_plane_yz, float* g_latent, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0, "negative point count");
+    if (P == 0) return NEO_OK;
+    REQUIRE(pts && src_poses && g_world && g_local && g_plane_xz && g_plane_xy && g_plane_yz && g_latent, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_gather_bwd(sc, views, pts, P, g_world, g_local, g_plane_xz, g_plane_xy, g_plane_yz, g_latent,
+                           static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_render_train(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* viewdirs, int R, int chunk,
+                        const float* src_poses, int NV, float focal, float cx, float cy, int n_coarse, int n_fine,
+                        int white_bkgd, uint64_t seed, const neo_tp_train_out* level0, const neo_tp_train_out* level1,
+                        void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && chunk >= 1, "bad ray count / chunk");
+    REQUIRE(n_coarse >= 3 && n_coarse <= 256 && n_fine >= 1 && n_coarse + 1 + n_fine <= 1024, "unsupported sample counts");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && rays_d && viewdirs && src_poses, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    const int N0 = n_coarse + 1, N1 = N0 + n_fine;
+    const float* edges = ctx->get_edges(n_coarse, 0.0f, 1.0f, s);
+    const float* u_det = ctx->get_quantiles(n_fine, s);
+    if (!edges || !u_det) return fail(NEO_ERR_HIP, "constant table upload failed");
+    auto& W = ctx->ws;
+    const size_t r = static_cast<size_t>(R);
+    const size_t nu = seed ? r * (N0 > n_fine ? N0 : n_fine) * 4 : 4;
+    if (W[0].reserve(r * 4) || W[1].reserve(r * N0 * 4) || W[2].reserve(r * N0 * 4) || W[3].reserve(r * N1 * 16) ||
+        W[4].reserve(r * N1 * 16) || W[5].reserve(r * N1 * 4) || W[6].reserve(r * N1 * 4) || W[7].reserve(r * N1 * 4) ||
+        W[8].reserve(r * N1 * 4) || W[9].reserve(r * 16 * 4) || W[10].reserve(nu) || W[11].reserve(nu))
+        return NEO_ERR_NOMEM;
+    float* far = W[0].as<float>();
+    float* fg_t0 = W[1].as<float>();
+    float* bg_s0 = W[2].as<float>();
+    float* fg_out = W[3].as<float>();
+    float* bg_out = W[4].as<float>();
+    float* fg_w_ws = W[5].as<float>();
+    float* bg_w_ws = W[6].as<float>();
+    float* fg_t1 = W[7].as<float>();
+    float* bg_s1 = W[8].as<float>();
+    float* scratch = W[9].as<float>();
+    float* ua = W[10].as<float>();
+    float* ub = W[11].as<float>();
+    neo::launch_sphere(rays_o, rays_d, R, far, nullptr, ctx->flags, s);
+    // randomized=True (seed != 0): Philox streams 0/1 = level-0 jitter fg/bg, 2/3 = level-1 quantiles fg/bg
+    if (seed) {
+        neo::launch_uniform(seed, 0, R, N0, ua, s);
+        neo::launch_uniform(seed, 1, R, N0, ub, s);
+        neo::launch_tp_level0_rand(far, edges, R, N0, 1e-4f, ua, ub, fg_t0, bg_s0, s);
+    } else {
+        neo::launch_tp_level0(far, edges, R, N0, 1e-4f, fg_t0, bg_s0, s);
+    }
+    const float* fg_t = fg_t0;
+    const float* bg_s = bg_s0;
+    for (int level = 0; level < 2; ++level) {
+        const int N = level == 0 ? N0 : N1;
+        const neo_tp_train_out* lo = level == 0 ? level0 : level1;
+        if (int rc = neo_tp_eval_region(ctx, level, sc, views, rays_o, rays_d, viewdirs, fg_t, nullptr, R, N, chunk, fg_out, s)) return rc;
+        if (int rc = neo_tp_eval_region(ctx, 2 + level, sc, views, rays_o, rays_d, viewdirs, bg_s, far, R, N, chunk, bg_out, s)) return rc;
+        float* fg_w = (lo && lo->fg_weights) ? lo->fg_weights : fg_w_ws;
+        float* bg_w = (lo && lo->bg_weights) ? lo->bg_weights : bg_w_ws;
+        float* fg_rgb = scratch;
+        float* lam = scratch + r * 3;
+        float* bg_rgb = scratch + r * 4;
+        // training tuple (neo360/model.py:531-579): white_bkgd is honoured in both regions
+        neo::launch_composite(1, fg_out, fg_t, N, rays_d, far, R, N, white_bkgd, fg_rgb, nullptr, nullptr, fg_w, lam, s);
+        neo::launch_composite(2, bg_out, bg_s, N, nullptr, nullptr, R, N, white_bkgd, bg_rgb, lo ? lo->bg_acc : nullptr, nullptr, bg_w,
+                              nullptr, s);
+        if (lo && lo->rgb) neo::launch_tp_merge(fg_rgb, nullptr, lam, bg_rgb, nullptr, R, lo->rgb, nullptr, s);
+        if (lo && lo->fg_tvals) HIP_TRY(hipMemcpyAsync(lo->fg_tvals, fg_t, r * N * 4, hipMemcpyDeviceToDevice, s));
+        if (lo && lo->bg_tvals) HIP_TRY(hipMemcpyAsync(lo->bg_tvals, bg_s, r * N * 4, hipMemcpyDeviceToDevice, s));
+        if (lo && lo->fg_rgbsigma) HIP_TRY(hipMemcpyAsync(lo->fg_rgbsigma, fg_out, r * N * 16, hipMemcpyDeviceToDevice, s));
+        if (lo && lo->bg_rgbsigma) HIP_TRY(hipMemcpyAsync(lo->bg_rgbsigma, bg_out, r * N * 16, hipMemcpyDeviceToDevice, s));
+        if (level == 0) {
+            const float* u_fg = u_det;
+            const float* u_bg = u_det;
+            int ustride = 0;
+            if (seed) {
+                neo::launch_uniform(seed, 2, R, n_fine, ua, s);
+                neo::launch_uniform(seed, 3, R, n_fine, ub, s);
+                u_fg = ua; u_bg = ub; ustride = n_fine;
+            }
+            if (neo::launch_resample(fg_t0, N0, fg_w, u_fg, ustride, R, N0, n_fine, 0, fg_t1, s) ||
+                neo::launch_resample(bg_s0, N0, bg_w, u_bg, ustride, R, N0, n_fine, 1, bg_s1, s))
+                return fail(NEO_ERR_INVALID, "unsupported sample counts");
+            fg_t = fg_t1;
+            bg_s = bg_s1;
+        }
+    }
+    return check_launch();
+}
+
+}  // extern "C"

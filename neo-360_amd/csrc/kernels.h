@@ -26,9 +26,27 @@ void launch_pos_enc(const float* x, int n, int C, int min_deg, int max_deg, floa
 void launch_composite(int mode, const float* rgbsigma, const float* t, int t_row_stride, const float* rays_d,
                       const float* t_far, int R, int N, int white_bkgd, float* rgb, float* acc, float* depth, float* weights,
                       float* lambda, hipStream_t s);
-// u: n_new quantiles (device), see Ctx::quantiles.
-int launch_resample(const float* t_prev, int t_prev_stride, const float* weights, const float* u, int R, int n_prev, int n_new,
-                    int descending, float* t_out, hipStream_t s);
+// u: n_new quantiles (device), see Ctx::quantiles; u_row_stride 0 = one row shared by all rays (randomized=False),
+// n_new = one row per ray (randomized=True: uniform draws)
+int launch_resample(const float* t_prev, int t_prev_stride, const float* weights, const float* u, int u_row_stride, int R,
+                    int n_prev, int n_new, int descending, float* t_out, hipStream_t s);
+
+// training.hip — training-side operators
+void launch_uniform(uint64_t seed, uint32_t stream, int rows, int cols, float* out, hipStream_t s);
+void launch_tp_level0_rand(const float* far, const float* edges, int R, int N, float near, const float* u_fg,
+                           const float* u_bg, float* fg_t, float* bg_s, hipStream_t s);
+int launch_composite_bwd(int mode, const float* rgbsigma, const float* t, int t_row_stride, const float* rays_d,
+                         const float* t_far, int R, int N, int white_bkgd, const float* g_rgb, const float* g_acc,
+                         const float* g_depth, const float* g_w, const float* g_lam, float* g_rgbsigma, hipStream_t s);
+void launch_distloss(const float* w, const float* m, int R, int N, float interval, float* loss_rays, float* grad_w,
+                     hipStream_t s);
+struct TpScene;
+struct TpViews;
+void launch_gather(const TpScene& sc, const TpViews& views, const float* pts, long P, float* world, float* local,
+                   hipStream_t s);
+void launch_gather_bwd(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* g_world,
+                       const float* g_local, float* g_plane_xz, float* g_plane_xy, float* g_plane_yz, float* g_latent,
+                       hipStream_t s);
 
 // mlp_vanilla.hip
 struct VanillaMlpDev {

@@ -151,8 +151,8 @@ void launch_composite(int mode, const float* rgbsigma, const float* t, int t_row
 template <int MAXB, int SORT_N>
 __global__ __launch_bounds__(256) void k_resample(const float* __restrict__ t_prev, int t_prev_stride,
                                                   const float* __restrict__ weights,
-                                                  const float* __restrict__ u_arr, int R, int n_prev, int n_new,
-                                                  int descending, float* __restrict__ t_out) {
+                                                  const float* __restrict__ u_arr, int u_row_stride, int R, int n_prev,
+                                                  int n_new, int descending, float* __restrict__ t_out) {
     __shared__ float s_bins[RAYS_PER_BLOCK][MAXB];
     __shared__ float s_pmax[RAYS_PER_BLOCK][MAXB];
     __shared__ float s_smin[RAYS_PER_BLOCK][MAXB];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_resample(const float* __restrict__ t_pr
         for (int i = lane; i < SORT_N; i += 64) srt[i] = i < n_prev ? tp[i] : __builtin_inff();
         // new samples
         for (int m = lane; m < n_new; m += 64) {
-            const float u = u_arr[m];
+            const float u = u_arr[(long)ray * u_row_stride + m];     // stride 0: one shared row of quantiles
             int lo = 0, hi = nb;  // first index with cdf > u
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -252,17 +252,17 @@ __global__ __launch_bounds__(256) void k_resample(const float* __restrict__ t_pr
     }
 }
 
-int launch_resample(const float* t_prev, int t_prev_stride, const float* weights, const float* u, int R, int n_prev, int n_new,
-                    int descending, float* t_out, hipStream_t s) {
+int launch_resample(const float* t_prev, int t_prev_stride, const float* weights, const float* u, int u_row_stride, int R,
+                    int n_prev, int n_new, int descending, float* t_out, hipStream_t s) {
     const int n_out = n_prev + n_new;
     const dim3 grid((R + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK), block(256);
     if (n_prev < 4 || n_prev - 1 > 256) return -1;
     if (n_out <= 256)
-        hipLaunchKernelGGL((k_resample<256, 256>), grid, block, 0, s, t_prev, t_prev_stride, weights, u, R, n_prev, n_new, descending, t_out);
+        hipLaunchKernelGGL((k_resample<256, 256>), grid, block, 0, s, t_prev, t_prev_stride, weights, u, u_row_stride, R, n_prev, n_new, descending, t_out);
     else if (n_out <= 512)
-        hipLaunchKernelGGL((k_resample<256, 512>), grid, block, 0, s, t_prev, t_prev_stride, weights, u, R, n_prev, n_new, descending, t_out);
+        hipLaunchKernelGGL((k_resample<256, 512>), grid, block, 0, s, t_prev, t_prev_stride, weights, u, u_row_stride, R, n_prev, n_new, descending, t_out);
     else if (n_out <= 1024)
-        hipLaunchKernelGGL((k_resample<256, 1024>), grid, block, 0, s, t_prev, t_prev_stride, weights, u, R, n_prev, n_new, descending, t_out);
+        hipLaunchKernelGGL((k_resample<256, 1024>), grid, block, 0, s, t_prev, t_prev_stride, weights, u, u_row_stride, R, n_prev, n_new, descending, t_out);
     else
         return -1;
     return 0;

@@ -379,15 +379,59 @@ class NeRF_TP(_HipModule):
         return out
 
     @torch.no_grad()
-    def forward(self, rays, randomized, white_bkgd, near, far, out_depth=False, chunk=None):
-        """Per level: (comp_rgb, fg_rgb, bg_rgb, fg_acc, bg_lambda, comp_depth) — the
-        reference's out_depth=True tuple (neo360/model.py:521-527).  `near`/`far` are
-        ignored exactly as in the reference (:277-278).  All rays of the call form ONE
-        reference chunk unless `chunk` is given (whole-frame rendering, see render.py)."""
-        self._check_mode(randomized)
+    def _forward_train(self, rays, randomized, white_bkgd, chunk=None, seed=None):
+        """out_depth=False: per level (comp_rgb, fg_weights, bg_weights, fg_sdist, bg_sdist, bg_acc)
+        (neo360/model.py:531-579), forward values only.  randomized=True draws the stratified level-0 jitter and the
+        level-1 quantiles from the library's counter-based generator (`seed`, default: one fresh seed per call from
+        torch's CPU generator, so torch.manual_seed makes runs repeatable)."""
+        if self.density_noise != 0.0 and randomized:
+            raise NotImplementedError("density_noise (neo360/model.py:381-384) is not part of the accelerated path")
+        rays_o, rays_d, viewdirs = f32(rays["rays_o"], "rays_o"), f32(rays["rays_d"], "rays_d"), f32(rays["viewdirs"], "viewdirs")
+        dev = rays_o.device
+        ctx = self._context(dev)
+        self._ensure_scene(rays, dev)
+        if self._scene_ctx is not ctx:
+            raise _lib.NeoError("scene features were uploaded on a different device")
+        self._sync_weights(ctx)
+        B = rays_o.shape[0]
+        host_poses, NV, focal, cx, cy = self._camera_args(rays)
+        if randomized:
+            seed = int(seed) if seed is not None else int(torch.randint(1, 2 ** 62, (1,)).item())
+            seed = seed or 1
+        else:
+            seed = 0
+        n0, n1 = self.num_coarse_samples + 1, self.num_coarse_samples + 1 + self.num_fine_samples
+        levels, structs = [], []
+        for n in (n0, n1):
+            t = dict(rgb=torch.empty(B, 3, device=dev), fg_w=torch.empty(B, n, device=dev), bg_w=torch.empty(B, n, device=dev),
+                     fg_t=torch.empty(B, n, device=dev), bg_t=torch.empty(B, n, device=dev), bg_acc=torch.empty(B, device=dev))
+            levels.append(t)
+            structs.append(_lib.TpTrainOut(t["rgb"].data_ptr(), t["fg_w"].data_ptr(), t["bg_w"].data_ptr(), t["fg_t"].data_ptr(),
+                                           t["bg_t"].data_ptr(), t["bg_acc"].data_ptr(), None, None))
+        _lib.check(ctx.lib.neo_tp_render_train(
+            ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
+            self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)), seed,
+            ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
+        self._raise_flags(ctx.poll_flags())
+        out = []
+        for t in levels:
+            fg_t, bg_t = t["fg_t"], t["bg_t"]
+            fg_sd = 0.5 * (fg_t[..., 1:] + fg_t[..., :-1])                                   # model.py:564-571
+            fg_sd = torch.cat([fg_sd, (fg_sd[:, -1] + (fg_sd[:, -1] - fg_sd[:, -2])).unsqueeze(-1)], dim=-1)
+            bg_sd = torch.cat([0.5 * (bg_t[..., 1:] + bg_t[..., :-1]), bg_t[..., -1:]], dim=-1)
+            out.append((t["rgb"], t["fg_w"], t["bg_w"], fg_sd, bg_sd, t["bg_acc"]))
+        return out
+
+    @torch.no_grad()
+    def forward(self, rays, randomized, white_bkgd, near, far, out_depth=False, chunk=None, seed=None):
+        """out_depth=True (evaluation, neo360/model.py:521-527): per level (comp_rgb, fg_rgb, bg_rgb, fg_acc, bg_lambda,
+        comp_depth), randomized=False.  out_depth=False (the training call, :531-579): per level (comp_rgb, fg_weights,
+        bg_weights, fg_sdist, bg_sdist, bg_acc), randomized as asked (`_forward_train`).  `near`/`far` are ignored
+        exactly as in the reference (:277-278).  All rays of the call form ONE reference chunk unless `chunk` is given
+        (whole-frame rendering, see render.py)."""
         if not out_depth:
-            raise NotImplementedError("out_depth=False returns training-only tensors (weights / sdist); "
-                                      "the accelerated path implements the evaluation call (out_depth=True)")
+            return self._forward_train(rays, randomized, white_bkgd, chunk, seed)
+        self._check_mode(randomized)
         rays_o = f32(rays["rays_o"], "rays_o")
         rays_d = f32(rays["rays_d"], "rays_d")
         viewdirs = f32(rays["viewdirs"], "viewdirs")

@@ -1,0 +1,162 @@
+"""Training-side operators as PyTorch autograd functions over the C ABI:
+
+  composite(...)        volumetric_rendering with a HIP backward (neo360/helper.py:128-171, vanilla :521-559)
+  gather_features(...)  index_grid + get_local_feats as one op, backward = scatter-add into the feature maps
+  eff_distloss(w, m, interval)   torch_efficient_distloss.eff_distloss (call site neo360/model.py:1246-1260)
+  rand_uniform / sample_level0 / resample_u   the randomized=True samplers on a counter-based generator
+
+The fused MLP evaluators are inference kernels: these ops cover the parts of the training step around them
+(sampling, lookups, compositing, regulariser); `models.NeRF_TP(...)(rays, randomized, white_bkgd, near, far)` returns
+the reference's training tuple (forward values) through `neo_tp_render_train`.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .context import f32, get_context, ptr
+
+
+def _ctx(t, ctx):
+    return ctx if ctx is not None else get_context(t.device)
+
+
+def rand_uniform(seed, stream_id, rows, cols, device="cuda", ctx=None):
+    """(rows, cols) uniforms in [0,1): Philox4x32-10 keyed by `seed`, counter (row, col, stream_id, 0), 24 bits."""
+    ctx = ctx if ctx is not None else get_context(device)
+    out = torch.empty(rows, cols, device=ctx.device)
+    _lib.check(ctx.lib.neo_rand_uniform(ctx.handle, int(seed), int(stream_id), rows, cols, ptr(out), ctx.stream()))
+    return out
+
+
+def sample_level0(far, n_coarse, u_fg=None, u_bg=None, ctx=None):
+    """neo360/helper.py:24-75 for both regions.  far (R,1) or (R,); u_* (R, n_coarse+1) uniforms = randomized=True.
+    Returns fg_t (ascending t) and bg_s (descending inverse radius), (R, n_coarse+1) each."""
+    far = f32(far, "far").reshape(-1)
+    ctx = _ctx(far, ctx)
+    R = far.shape[0]
+    fg = torch.empty(R, n_coarse + 1, device=far.device)
+    bg = torch.empty(R, n_coarse + 1, device=far.device)
+    u_fg = f32(u_fg, "u_fg") if u_fg is not None else None
+    u_bg = f32(u_bg, "u_bg") if u_bg is not None else None
+    _lib.check(ctx.lib.neo_tp_sample_level0(ctx.handle, ptr(far), R, n_coarse, ptr(u_fg), ptr(u_bg), ptr(fg), ptr(bg),
+                                            ctx.stream()))
+    return fg, bg
+
+
+def resample_u(t_prev, weights, u, descending=False, ctx=None):
+    """sorted_piecewise_constant_pdf(randomized=True) + the sort of sample_pdf with the caller's uniforms u (R, n_new)."""
+    t_prev, weights, u = f32(t_prev, "t_prev"), f32(weights, "weights").detach(), f32(u, "u")
+    ctx = _ctx(t_prev, ctx)
+    R, n_prev = t_prev.shape
+    n_new = u.shape[1]
+    out = torch.empty(R, n_prev + n_new, device=t_prev.device)
+    _lib.check(ctx.lib.neo_resample_u(ctx.handle, ptr(t_prev), ptr(weights), ptr(u), R, n_prev, n_new, int(descending),
+                                      ptr(out), ctx.stream()))
+    return out
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx_, mode, rgb, sigma, t, rays_d, t_far, white_bkgd, lib_ctx):
+        rgbsigma = torch.cat([f32(rgb, "rgb"), f32(sigma, "sigma").reshape(*rgb.shape[:-1], 1)], dim=-1).contiguous()
+        t = f32(t, "t")
+        c = _ctx(t, lib_ctx)
+        R, N = t.shape
+        dev = t.device
+        rays_d = f32(rays_d, "rays_d") if rays_d is not None else None
+        t_far = f32(t_far, "t_far").reshape(-1) if t_far is not None else None
+        out_rgb, acc, depth = torch.empty(R, 3, device=dev), torch.empty(R, device=dev), torch.empty(R, device=dev)
+        w = torch.empty(R, N, device=dev)
+        lam = torch.empty(R, 1, device=dev) if mode == 1 else torch.zeros(R, 1, device=dev)
+        _lib.check(c.lib.neo_composite(c.handle, mode, ptr(rgbsigma), ptr(t), ptr(rays_d), ptr(t_far), R, N,
+                                       int(bool(white_bkgd)), ptr(out_rgb), ptr(acc), ptr(depth), ptr(w),
+                                       ptr(lam) if mode == 1 else None, c.stream()))
+        ctx_.save_for_backward(rgbsigma, t, rays_d if rays_d is not None else torch.empty(0, device=dev),
+                               t_far if t_far is not None else torch.empty(0, device=dev))
+        ctx_.meta = (mode, bool(white_bkgd), c, rays_d is not None, t_far is not None)
+        return out_rgb, acc, w, lam, depth
+
+    @staticmethod
+    def backward(ctx_, g_rgb, g_acc, g_w, g_lam, g_depth):
+        rgbsigma, t, rays_d, t_far = ctx_.saved_tensors
+        mode, white, c, has_d, has_far = ctx_.meta
+        R, N = t.shape
+        g = torch.empty(R, N, 4, device=t.device)
+        cont = lambda x: f32(x.contiguous(), "grad") if x is not None else None
+        g_rgb, g_acc, g_w, g_lam, g_depth = cont(g_rgb), cont(g_acc), cont(g_w), cont(g_lam), cont(g_depth)
+        _lib.check(c.lib.neo_composite_backward(c.handle, mode, ptr(rgbsigma), ptr(t), ptr(rays_d) if has_d else None,
+                                                ptr(t_far) if has_far else None, R, N, int(white), ptr(g_rgb), ptr(g_acc),
+                                                ptr(g_depth), ptr(g_w), ptr(g_lam), ptr(g), c.stream()))
+        return None, g[..., :3], g[..., 3:], None, None, None, None, None
+
+
+def composite(mode, rgb, sigma, t, rays_d=None, t_far=None, white_bkgd=False, ctx=None):
+    """Differentiable volumetric_rendering.  mode 0 vanilla, 1 NeO-360 inside the sphere, 2 outside.
+    rgb (R,N,3), sigma (R,N,1) -> (comp_rgb (R,3), acc (R,), weights (R,N), bg_lambda (R,1), depth (R,));
+    gradients flow to rgb and sigma (sample positions are detached in the reference, helper.py:224)."""
+    return _Composite.apply(mode, rgb, sigma, t, rays_d, t_far, white_bkgd, ctx)
+
+
+class _DistLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx_, w, m, interval, lib_ctx):
+        w2, m2 = f32(w, "w").reshape(-1, w.shape[-1]), f32(m, "m").reshape(-1, w.shape[-1])
+        c = _ctx(w2, lib_ctx)
+        R, N = w2.shape
+        loss = torch.empty(R, device=w2.device)
+        grad = torch.empty(R, N, device=w2.device)
+        _lib.check(c.lib.neo_distloss(c.handle, ptr(w2), ptr(m2), R, N, float(interval), ptr(loss), ptr(grad), c.stream()))
+        ctx_.save_for_backward(grad)
+        ctx_.shape = (w.shape, R)
+        return loss.sum() / R
+
+    @staticmethod
+    def backward(ctx_, g):
+        (grad,) = ctx_.saved_tensors
+        shape, R = ctx_.shape
+        return (grad * (g / R)).reshape(shape), None, None, None
+
+
+def eff_distloss(w, m, interval, ctx=None):
+    """torch_efficient_distloss.eff_distloss: w (..., N) weights, m (..., N) interval midpoints, scalar interval."""
+    return _DistLoss.apply(w, m, interval, ctx)
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx_, module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
+        # the module's context holds the channels-last copies (module.set_scene was called with these tensors)
+        pts = f32(pts, "pts").reshape(-1, 3)
+        c = module._context(pts.device)
+        host_poses, NV, focal, cx, cy = module._camera_args(rays)
+        P = pts.shape[0]
+        world = torch.empty(NV * P, 128, device=pts.device)
+        local = torch.empty(NV * P, 512, device=pts.device)
+        _lib.check(c.lib.neo_tp_gather(c.handle, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(world), ptr(local), c.stream()))
+        ctx_.save_for_backward(pts)
+        ctx_.meta = (c, host_poses, NV, focal, cx, cy, plane_xz.shape, latent.shape)
+        return world, local
+
+    @staticmethod
+    def backward(ctx_, g_world, g_local):
+        (pts,) = ctx_.saved_tensors
+        c, host_poses, NV, focal, cx, cy, pshape, lshape = ctx_.meta
+        dev = pts.device
+        _, Cw, Hp, Wp = pshape
+        _, Cl, Hf, Wf = lshape
+        gp = [torch.zeros(NV, Hp, Wp, Cw, device=dev) for _ in range(3)]
+        gl = torch.zeros(NV, Hf, Wf, Cl, device=dev)
+        gw, gloc = f32(g_world.contiguous(), "g_world"), f32(g_local.contiguous(), "g_local")
+        _lib.check(c.lib.neo_tp_gather_backward(c.handle, ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy, ptr(gw),
+                                                ptr(gloc), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(gl), c.stream()))
+        nchw = lambda x: x.permute(0, 3, 1, 2)
+        return None, None, nchw(gp[0]), nchw(gp[1]), nchw(gp[2]), nchw(gl), None
+
+
+def gather_features(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
+    """index_grid (three tri-planes summed) + get_local_feats at world points pts (P,3) for every source view of `rays`
+    (src_poses / src_focal / src_c): world (NV*P,128), local (NV*P,512), view-major rows.  `module` is the NeRF_TP whose
+    scene was set from these very tensors (`module.set_scene(plane_xz, plane_xy, plane_yz, latent, image_wh)`); gradients
+    flow to the four feature maps (NCHW, like the inputs)."""
+    return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays)

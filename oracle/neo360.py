@@ -49,7 +49,7 @@ def region_eval(params, prefix, rays, scene, tvals, inside, far=None):
     return _predict(params, prefix, cam, dir_cam, world, local, B, N, nv)
 
 
-def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_depth=True, keep=False):
+def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_depth=True, keep=False, uniforms=None):
     """Return value of NeRF_TP.forward for randomized=False
     (neo360/model.py:266-581, decoder half from :276).
 
@@ -57,7 +57,10 @@ def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_
     src_c (NV,2).  scene: plane_xz/xy/yz (NV,C,Hp,Wp), latent (NV,512,Hf,Wf),
     image_wh (W,H).  Per level: out_depth -> (rgb, fg_rgb, bg_rgb, fg_acc,
     bg_lambda, depth); else (rgb, fg_w, bg_w, fg_sdist, bg_sdist, bg_acc).
+    uniforms: None = randomized=False; else dict(fg0, bg0 (B,n_coarse+1), fg1, bg1 (B,n_fine)) = the draws the
+    reference's randomized=True path takes from torch.rand, in call order (helper.py:49 twice, :196 twice).
     """
+    from . import training
     o, d, vd = rays["rays_o"], rays["rays_d"], rays["viewdirs"]
     poses, focal, centre = rays["src_poses"], rays["src_focal"], rays["src_c"]
     nv = poses.shape[0]
@@ -73,16 +76,28 @@ def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_
     out, extra = [], []
     fg_t = bg_s = fg_w = bg_w = None
     for level in range(2):
-        if level == 0:
+        if level == 0 and uniforms is None:
             fg_t, fg_p = sampling.neo_fg_level0(o, d, n_coarse, near, far)
             bg_s, bg_p4, bg_lin = sampling.neo_bg_level0(o, d, n_coarse, far, 3.0)
             fg_name, bg_name = "fg_coarse_mlp.", "bg_coarse_mlp."
-        else:
+        elif level == 1 and uniforms is None:
             fg_mid = 0.5 * (fg_t[..., 1:] + fg_t[..., :-1])
             bg_mid = 0.5 * (bg_s[..., 1:] + bg_s[..., :-1])
             fg_t, fg_p = sampling.neo_fg_level1(fg_mid, fg_w[..., 1:-1], o, d, fg_t, n_fine)
             bg_s, bg_p4, bg_lin = sampling.neo_bg_level1(bg_mid, bg_w[..., 1:-1], o, d, bg_s, n_fine, far, 3.0)
             fg_name, bg_name = "fg_fine_mlp.", "bg_fine_mlp."
+        else:
+            # randomized=True: sample rows from the given draws, points exactly as the deterministic branches build them
+            if level == 0:
+                fg_t, bg_s = training.neo_level0_randomized(far, n_coarse, uniforms["fg0"], uniforms["bg0"])
+                fg_name, bg_name = "fg_coarse_mlp.", "bg_coarse_mlp."
+            else:
+                fg_t = training.resample_randomized(fg_t, fg_w, uniforms["fg1"], descending=False)
+                bg_s = training.resample_randomized(bg_s, bg_w, uniforms["bg1"], descending=True)
+                fg_name, bg_name = "fg_fine_mlp.", "bg_fine_mlp."
+            fg_p = sampling.points_on_rays(fg_t, o, d)
+            bg_p4 = sampling.inverted_sphere_points(o, d, bg_s)
+            bg_lin = sampling.points_on_rays(far * (1.0 - bg_s) + 3.0 * bg_s, o, d)
         B, N, _ = fg_p.shape
         fg_world, fg_local = feats(fg_p)
         bg_world, bg_local = feats(bg_lin[:, :, :3])

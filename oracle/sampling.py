@@ -87,7 +87,7 @@ def inverted_sphere_points(rays_o, rays_d, inv_r):
 # hierarchical (inverse-CDF) resampling — shared by vanilla and NeO-360
 # ----------------------------------------------------------------------------
 
-def piecewise_constant_samples(bins, weights, n_new, float_min_eps=2 ** -32):
+def piecewise_constant_samples(bins, weights, n_new, float_min_eps=2 ** -32, u=None):
     """n_new deterministic inverse-CDF samples per ray.
 
     Follows neo360/helper.py:174-215 == vanilla_nerf/helper.py:567-607
@@ -105,8 +105,9 @@ def piecewise_constant_samples(bins, weights, n_new, float_min_eps=2 ** -32):
     inner = torch.fmin(torch.ones_like(pdf[..., :-1]), torch.cumsum(pdf[..., :-1], dim=-1))
     lead = list(inner.shape[:-1]) + [1]
     cdf = torch.cat([torch.zeros(lead), inner, torch.ones(lead)], dim=-1)
-    u = torch.linspace(0.0, 1.0 - float_min_eps, n_new)
-    u = torch.broadcast_to(u, list(cdf.shape[:-1]) + [n_new])
+    if u is None:       # randomized=False; randomized=True passes its uniform draws (helper.py:195-196)
+        u = torch.linspace(0.0, 1.0 - float_min_eps, n_new)
+        u = torch.broadcast_to(u, list(cdf.shape[:-1]) + [n_new])
     ge = u[..., None, :] >= cdf[..., :, None]
 
     def below(x):  # largest x_j among those with u >= cdf_j (others read x_0)

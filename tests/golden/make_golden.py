@@ -305,6 +305,70 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0):
 
 
 # ---------------------------------------------------------------------------------
+# G8 training-side call: NeRF_TP.forward(out_depth=False) deterministic / white background / randomized
+# ---------------------------------------------------------------------------------
+
+class _QueuedRand:
+    """Stands in for torch.rand while the reference runs randomized=True: hands out prepared uniform tensors in call
+    order (helper.py:49 fg, :49 bg, :196 fg, :196 bg), so that the same draws can be given to the oracle and the GPU."""
+
+    def __init__(self, tensors):
+        self.queue = list(tensors)
+
+    def __call__(self, *shape, **kw):
+        t = self.queue.pop(0)
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        assert tuple(t.shape) == shape, (t.shape, shape)
+        return t
+
+
+def g8_training(n_rays=64, n_coarse=16, n_fine=24, seed=1234):
+    from oracle import training as otrain
+    scene = cases.small_scene()
+    net = ref_nerf_tp(synth.nerf_tp_state(0), scene)
+    net.num_coarse_samples, net.num_fine_samples = n_coarse, n_fine
+    batch = cases.neo_batch(cases.strided_rays(n_rays))
+    names = ("rgb", "fg_w", "bg_w", "fg_sd", "bg_sd", "bg_acc")
+    out = {}
+    for tag, randomized, white in (("det", False, False), ("white", False, True), ("rand", True, False)):
+        real_rand = torch.rand
+        if randomized:
+            u = [otrain.philox_uniform(seed, 0, n_rays, n_coarse + 1), otrain.philox_uniform(seed, 1, n_rays, n_coarse + 1),
+                 otrain.philox_uniform(seed, 2, n_rays, n_fine), otrain.philox_uniform(seed, 3, n_rays, n_fine)]
+            torch.rand = _QueuedRand(u)
+        try:
+            res = net(batch, randomized, white, 0.0, 0.0, out_depth=False)
+        finally:
+            torch.rand = real_rand
+        for lv in (0, 1):
+            for nm, v in zip(names, res[lv]):
+                out["%s_%s%d" % (tag, nm, lv)] = v
+    # stand-alone stratified sampler and randomized pdf sampler of the reference on the same draws
+    HN = ref.load("models.neo360.helper")
+    rays = cases.strided_rays(n_rays)
+    far = HN.intersect_sphere(rays["rays_o"], rays["rays_d"])
+    near = torch.full((n_rays, 1), 1e-4)
+    u0, u1 = otrain.philox_uniform(seed, 0, n_rays, n_coarse + 1), otrain.philox_uniform(seed, 1, n_rays, n_coarse + 1)
+    real_rand = torch.rand
+    torch.rand = _QueuedRand([u0, u1])
+    try:
+        t_fg, _ = HN.sample_along_rays(rays["rays_o"], rays["rays_d"], n_coarse, near, far, True, False, True)
+        s_bg, _, _ = HN.sample_along_rays(rays["rays_o"], rays["rays_d"], n_coarse, near, far, True, False, False, far_uncontracted=3)
+    finally:
+        torch.rand = real_rand
+    out.update(strat_fg=t_fg, strat_bg=s_bg)
+    pc = cases.pdf_cases()
+    up = otrain.philox_uniform(seed, 7, pc["asc"][0].shape[0], 48)
+    for tag in ("asc", "desc"):
+        torch.rand = _QueuedRand([up])
+        try:
+            out["pdf_rand_" + tag] = HN.sorted_piecewise_constant_pdf(pc[tag][0], pc[tag][1], 48, True)
+        finally:
+            torch.rand = real_rand
+    save("g8_training", **out)
+
+
+# ---------------------------------------------------------------------------------
 # G6 Mip-NeRF 360 (models/mipnerf360)
 # ---------------------------------------------------------------------------------
 
@@ -408,6 +472,7 @@ def main(which):
         "g4n_sharp_noise": lambda: g4_neo_noise("sharp", 256, 256, 32, 64, gain=8.0),
         "g6": g6_mip360,
         "g7": g7_pixelnerf,
+        "g8": g8_training,
     }
     for name, fn in jobs.items():
         if not which or name in which:

@@ -103,6 +103,7 @@ def test_mip360_full_frame_and_strip():
     sub = {k: v[idx].contiguous() for k, v in batch.items()}
     got, _ = net(sub, 1.0, False, False, 0.2, 3.0)
     torch.set_num_threads(32)
-    want, _ = oracle.mip360.render(state, {k: v.cpu() for k, v in sub.items()}, 1.0, 0.2, 3.0, num_prop_samples=64, num_nerf_samples=32)
+    from oracle import mip360 as oracle_mip360
+    want, _ = oracle_mip360.render(state, {k: v.cpu() for k, v in sub.items()}, 1.0, 0.2, 3.0, num_prop_samples=64, num_nerf_samples=32)
     assert torch.equal(got[-1]["rgb"], rend[-1]["rgb"][idx])                            # rays are independent
     assert max_abs(got[-1]["rgb"], want[-1]["rgb"]) < 1e-4

@@ -1,0 +1,176 @@
+"""GPU: training-side operators through the C ABI against the oracle: counter-based uniforms
+(bit-exact), stratified / randomized samplers, compositing backward, lookups forward + backward, distortion loss,
+and NeRF_TP's training-mode forward (out_depth=False) against the reference-generated fixture g8_training."""
+import pytest
+import torch
+
+import cases
+import oracle
+from conftest import max_abs
+from neo360_amd import models, ops, synth, training
+from oracle import training as T
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SEED, NR, NC, NF = 1234, 64, 16, 24
+
+
+def test_uniforms_bit_exact():
+    for seed, stream, rows, cols in ((SEED, 0, 64, 17), (2 ** 40 + 12345, 3, 300, 129), (1, 9, 1, 1)):
+        got = training.rand_uniform(seed, stream, rows, cols).cpu()
+        assert torch.equal(got, T.philox_uniform(seed, stream, rows, cols))
+
+
+def test_samplers_vs_reference_fixture(golden):
+    g = golden("g8_training")
+    rays = {k: v.to(DEV) for k, v in cases.strided_rays(NR).items()}
+    far, _ = ops.intersect_sphere(rays["rays_o"], rays["rays_d"])
+    u0, u1 = training.rand_uniform(SEED, 0, NR, NC + 1), training.rand_uniform(SEED, 1, NR, NC + 1)
+    fg, bg = training.sample_level0(far, NC, u0, u1)
+    assert max_abs(fg, g["strat_fg"]) < 5e-7 and max_abs(bg, g["strat_bg"]) < 2e-7     # fg carries the fp32 far of each ray
+    fg_d, bg_d = training.sample_level0(far, NC)                      # randomized=False
+    far_c, _ = oracle.rays.sphere_exit_depth(rays["rays_o"].cpu(), rays["rays_d"].cpu())
+    want, _ = oracle.sampling.neo_fg_level0(rays["rays_o"].cpu(), rays["rays_d"].cpu(), NC, torch.full_like(far_c, 1e-4), far_c)
+    assert max_abs(fg_d, want) < 2e-7
+    # randomized pdf sampling: the new samples are a permutation-free comparison after sorting (the op returns the merged set)
+    pc = cases.pdf_cases()
+    mids, w = pc["asc"]
+    up = training.rand_uniform(SEED, 7, mids.shape[0], 48)
+    # reconstruct a t_prev whose midpoints are `mids`: use the oracle path on the op's own convention instead
+    t_prev = torch.sort(torch.rand(mids.shape[0], 33, generator=torch.Generator().manual_seed(1)), dim=-1).values
+    wts = torch.rand(mids.shape[0], 33, generator=torch.Generator().manual_seed(2))
+    for desc in (False, True):
+        tp = torch.flip(t_prev, dims=[-1]) if desc else t_prev
+        got = training.resample_u(tp.to(DEV), wts.to(DEV), up, descending=desc).cpu()
+        want = T.resample_randomized(tp, wts, up.cpu(), descending=desc)
+        assert got.shape == want.shape
+        assert float((got - want).abs().median()) < 1e-6 and float((got - want).abs().quantile(0.99)) < 1e-4
+
+
+@pytest.mark.parametrize("mode,white", [(0, False), (0, True), (1, False), (1, True), (2, False), (2, True)])
+def test_composite_backward_matches_autograd(mode, white):
+    rgb, sigma, t, dirs, far = cases.composite_case()
+    if mode == 2:
+        t = torch.flip(t / t.max(), dims=[-1]).contiguous()
+    gen = torch.Generator().manual_seed(11)
+    up = [torch.randn(64, 3, generator=gen), torch.randn(64, generator=gen), torch.randn(64, 129, generator=gen) * 0.1,
+          torch.randn(64, 1, generator=gen), torch.randn(64, generator=gen)]
+    with torch.enable_grad():
+        rc, sc = rgb.clone().double().requires_grad_(True), sigma.clone().double().requires_grad_(True)
+        if mode == 0:
+            c_rgb, c_acc, c_w, c_depth = oracle.compositing.vanilla_composite(rc, sc, t.double(), dirs.double() * 1.3, white)
+            outs, ups = [c_rgb, c_acc, c_w, c_depth], [up[0], up[1], up[2], up[4]]
+        else:
+            c_rgb, c_acc, c_w, c_lam, c_depth = oracle.compositing.neo_composite(rc, sc, t.double(), dirs.double(), mode == 1,
+                                                                               far.double() if mode == 1 else None, white)
+            outs, ups = [c_rgb, c_acc, c_w, c_depth], [up[0], up[1], up[2], up[4]]
+            if mode == 1:
+                outs.append(c_lam); ups.append(up[3])
+        loss = sum((o * u.double()).sum() for o, u in zip(outs, ups))
+        g_rgb_c, g_sig_c = torch.autograd.grad(loss, [rc, sc])
+        rg, sg = rgb.clone().to(DEV).requires_grad_(True), sigma.clone().to(DEV).requires_grad_(True)
+        d_g = (dirs * (1.3 if mode == 0 else 1.0)).to(DEV) if mode != 2 else None
+        o_rgb, o_acc, o_w, o_lam, o_depth = training.composite(mode, rg, sg, t.to(DEV), d_g, far.to(DEV) if mode == 1 else None, white)
+        loss_g = ((o_rgb * up[0].to(DEV)).sum() + (o_acc * up[1].to(DEV)).sum() + (o_w * up[2].to(DEV)).sum() +
+                  (o_depth * up[4].to(DEV)).sum() + ((o_lam * up[3].to(DEV)).sum() if mode == 1 else 0.0))
+        g_rgb_g, g_sig_g = torch.autograd.grad(loss_g, [rg, sg])
+    assert max_abs(o_rgb, outs[0]) < 2e-6 and max_abs(o_w, outs[2]) < 2e-6
+    scale = float(g_sig_c.abs().max())
+    assert max_abs(g_rgb_g, g_rgb_c) < 2e-6 * max(1.0, float(g_rgb_c.abs().max()))
+    assert max_abs(g_sig_g, g_sig_c) < 2e-5 * max(1.0, scale), (mode, white, max_abs(g_sig_g, g_sig_c), scale)
+
+
+def test_distloss_forward_backward():
+    gen = torch.Generator().manual_seed(5)
+    w = torch.rand(200, 385, generator=gen)
+    w = w / w.sum(-1, keepdim=True) * torch.rand(200, 1, generator=gen)
+    m = torch.sort(torch.rand(200, 385, generator=gen), dim=-1).values
+    with torch.enable_grad():
+        wc = w.double().requires_grad_(True)
+        lc = T.eff_distloss(wc, m.double(), 1.0 / 385)
+        (gc,) = torch.autograd.grad(lc * 3.0, wc)
+        wg = w.to(DEV).requires_grad_(True)
+        lg = training.eff_distloss(wg, m.to(DEV), 1.0 / 385)
+        (gg,) = torch.autograd.grad(lg * 3.0, wg)
+    assert abs(float(lg) - float(lc)) < 1e-6 * max(1.0, abs(float(lc)))
+    assert max_abs(gg, gc) < 1e-6 * max(1.0, float(gc.abs().max()))
+
+
+def test_gather_forward_and_backward():
+    sc = cases.small_scene()
+    net = models.NeRF_TP(num_coarse_samples=32, num_fine_samples=64, num_src_views=cases.NV).to(DEV)
+    net.load_state_dict(synth.nerf_tp_state(0))
+    maps = {k: sc[k].to(DEV) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")}
+    net.set_scene(maps["plane_xz"], maps["plane_xy"], maps["plane_yz"], maps["latent"], sc["image_wh"])
+    batch = cases.neo_batch(cases.strided_rays(8))
+    gbatch = {k: v.to(DEV) for k, v in batch.items()}
+    pts = synth.uniform(13, "gpts", (16, 4, 3), -1.6, 1.6)           # includes points off every map (zero padding)
+    gen = torch.Generator().manual_seed(4)
+    uw, ul = torch.randn(cases.NV * 64, 128, generator=gen), torch.randn(cases.NV * 64, 512, generator=gen)
+    with torch.enable_grad():
+        cm = {k: v.clone().double().requires_grad_(True) for k, v in sc.items() if isinstance(v, torch.Tensor)}
+        world_c = oracle.gather.triplane_features(pts.double(), cm["plane_xz"], cm["plane_xy"], cm["plane_yz"], batch["src_poses"].double())
+        local_c = oracle.gather.pixel_aligned_features(pts.double(), cm["latent"], batch["src_poses"].double(), batch["src_focal"].double(),
+                                                       batch["src_c"].double(), sc["image_wh"])
+        loss = (world_c.reshape(-1, 128) * uw.double()).sum() + (local_c.reshape(-1, 512) * ul.double()).sum()
+        gc = torch.autograd.grad(loss, [cm["plane_xz"], cm["plane_xy"], cm["plane_yz"], cm["latent"]])
+        gm = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+        world_g, local_g = training.gather_features(net, pts.to(DEV), gm["plane_xz"], gm["plane_xy"], gm["plane_yz"], gm["latent"], gbatch)
+        loss_g = (world_g * uw.to(DEV)).sum() + (local_g * ul.to(DEV)).sum()
+        gg = torch.autograd.grad(loss_g, [gm["plane_xz"], gm["plane_xy"], gm["plane_yz"], gm["latent"]])
+    # forward: fp32 tap weights vs the float64 oracle on features of magnitude ~2 (three planes summed)
+    assert max_abs(world_g, world_c.reshape(-1, 128)) < 1e-5 and max_abs(local_g, local_c.reshape(-1, 512)) < 1e-5
+    w32 = oracle.gather.triplane_features(pts, sc["plane_xz"], sc["plane_xy"], sc["plane_yz"], batch["src_poses"])
+    assert max_abs(world_g, w32.reshape(-1, 128)) < 2e-6
+    for a, b in zip(gg, gc):
+        assert a.shape == b.shape and max_abs(a, b) < 1e-5 * max(1.0, float(b.abs().max()))
+
+
+def _train_net():
+    net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
+    net.load_state_dict(synth.nerf_tp_state(0))
+    sc = cases.small_scene()
+    net.set_scene(sc["plane_xz"].to(DEV), sc["plane_xy"].to(DEV), sc["plane_yz"].to(DEV), sc["latent"].to(DEV), sc["image_wh"])
+    return net
+
+
+def test_training_forward_vs_reference_fixture(golden):
+    g = golden("g8_training")
+    net = _train_net()
+    batch = {k: v.to(DEV) for k, v in cases.neo_batch(cases.strided_rays(NR)).items()}
+    names = ("rgb", "fg_w", "bg_w", "fg_sd", "bg_sd", "bg_acc")
+    for tag, randomized, white in (("det", False, False), ("white", False, True), ("rand", True, False)):
+        res = net(batch, randomized, white, 0.0, 0.0, out_depth=False, seed=SEED)
+        for lv in (0, 1):
+            for nm, v in zip(names, res[lv]):
+                ref = g["%s_%s%d" % (tag, nm, lv)]
+                err = (v.cpu() - ref).abs()
+                if lv == 1 and nm in ("fg_w", "bg_w", "fg_sd", "bg_sd"):
+                    # per-sample rows at the fine level: a resampled position that moves by an ulp re-orders nothing but
+                    # shifts a weight between neighbours; compare robustly per row
+                    assert float(err.median()) < 1e-6 and float(err.quantile(0.999)) < 1e-3, (tag, nm, lv)
+                else:
+                    assert float(err.max()) < 1e-4, (tag, nm, lv, float(err.max()))
+
+
+def test_training_forward_randomized_properties():
+    net = _train_net()
+    batch = {k: v.to(DEV) for k, v in cases.neo_batch(cases.strided_rays(NR)).items()}
+    a = net(batch, True, False, 0.0, 0.0, out_depth=False, seed=7)
+    b = net(batch, True, False, 0.0, 0.0, out_depth=False, seed=7)
+    c = net(batch, True, False, 0.0, 0.0, out_depth=False, seed=8)
+    d = net(batch, False, False, 0.0, 0.0, out_depth=False)
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)                                        # counter-based: same seed, same frame
+    assert max_abs(a[1][3], c[1][3]) > 1e-4 and max_abs(a[1][3], d[1][3]) > 1e-4
+    for res in (a, c, d):
+        for lv in (0, 1):
+            rgb, fg_w, bg_w, fg_sd, bg_sd, bg_acc = res[lv]
+            assert bool(torch.isfinite(rgb).all()) and float(rgb.min()) > -0.01 and float(rgb.max()) < 1.01
+            assert bool((fg_sd[:, 1:] >= fg_sd[:, :-1]).all()) and bool((bg_sd[:, 1:-1] <= bg_sd[:, :-2]).all())
+            assert float(fg_w.min()) >= 0.0 and float(bg_w.min()) >= 0.0 and float(bg_acc.max()) <= 1.0 + 1e-5
+    torch.manual_seed(0)
+    e = net(batch, True, False, 0.0, 0.0, out_depth=False)              # default seed: drawn from torch's generator
+    torch.manual_seed(0)
+    f = net(batch, True, False, 0.0, 0.0, out_depth=False)
+    assert torch.equal(e[1][0], f[1][0])
