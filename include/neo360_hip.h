@@ -205,6 +205,23 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d,
                   float focal, float cx, float cy, int n_coarse, int n_fine, int white_bkgd,
                   const neo_tp_level_out* level0, const neo_tp_level_out* level1, void* stream);
 
+/* ---- scene encoder: pillar stage -------------------------------------------------------- */
+/* Weights of the pillar stage of GridEncoder (models/neo360/encoder_tp_fusion_conv.py:263-279, :364-373).
+ * weights/biases [host arrays of 9 device pointers], order: depth_fc.common_branch.0 (512x518), depth_fc.common_branch.2,
+ * depth_fc.depth_encoder, pillar_aggregator_xz.0 (512x513), pillar_aggregator_xz.2 (1x512), pillar_aggregator_yz.0, .2,
+ * pillar_aggregator_xy.0, .2. */
+int neo_enc_upload(neo_ctx* ctx, const float* const* weights, const float* const* biases, void* stream);
+
+/* GridEncoder.forward from the world grid to the inputs of its floor-plan conv nets (:472-578): for every cell of the
+ * G0 x G1 x G2 world grid (x, y in [-1,1], z in [0,1]) and source view, [pixel-aligned latent | camera xyz | masked
+ * direction] -> depth_fc -> three axis scorers -> softmax along x / y / z -> weighted sums.  latent (NV,512,Hf,Wf) NCHW =
+ * SpatialEncoder's output; src_poses [host] NV*16; focal / cx / cy = view 0's intrinsics (:491-493).  Outputs
+ * channels-last: fp_yz (NV,G1,G2,512), fp_xz (NV,G0,G2,512), fp_xy (NV,G0,G1,512) (the reference permutes them to NCHW
+ * for its conv nets, :580-592).  Split-fp16 arithmetic (neo_ctx_set_precision mode 1). */
+int neo_enc_floorplans(neo_ctx* ctx, const float* latent, int NV, int Hf, int Wf, float image_w, float image_h,
+                       const float* src_poses, float focal, float cx, float cy, int G0, int G1, int G2,
+                       float* fp_yz, float* fp_xz, float* fp_xy, void* stream);
+
 /* ---- training-side operators ----------------------------------------------------------- */
 /* Counter-based uniforms in [0,1): out[r][c] = (Philox4x32-10(key = seed, counter = (r, c, stream_id, 0))[0] >> 8) 2^-24
  * - the generator behind every randomized=True sampler here (the reference draws torch.rand: helper.py:49, :196). */

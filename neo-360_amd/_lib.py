@@ -57,6 +57,8 @@ SIGNATURES = {
     "neo_tp_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i,
                            ctypes.POINTER(TpLevelOut), ctypes.POINTER(TpLevelOut), _vp]),
+    "neo_enc_upload": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
+    "neo_enc_floorplans": (_i, [_vp, _vp, _i, _i, _i, _f, _f, c_float_p, _f, _f, _f, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "neo_rand_uniform": (_i, [_vp, ctypes.c_uint64, ctypes.c_uint32, _i, _i, _vp, _vp]),
     "neo_tp_sample_level0": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "neo_resample_u": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -140,6 +140,10 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     for (auto& sl : ctx->pix) sl.release();
     ctx->pix_latent.release();
     ctx->boxes.release();
+    ctx->enc.release();
+    ctx->enc_latent.release();
+    ctx->enc_axes.release();
+    for (auto& b : ctx->enc_ws) b.release();
     ctx->latent.release();
     for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }

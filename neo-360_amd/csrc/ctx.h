@@ -132,6 +132,10 @@ struct neo_ctx {
     std::map<std::pair<int, uint64_t>, neo_host::DevBuf> edges;   // (n, near/far bits) -> level-0 t row
     neo_host::DevBuf ws[12];                                      // render workspaces (grow-only)
     neo_host::DevBuf boxes;                                       // neo_aabb_multi: box frames + bounds
+    // pillar stage of the scene encoder (neo_enc_*): packed weights, biases (6x512), scorer heads (3x512), workspaces
+    neo_host::MlpSlot enc;
+    float enc_head_b[3] = {0.f, 0.f, 0.f};
+    neo_host::DevBuf enc_latent, enc_axes, enc_ws[4];
     int precision = 1;   // 1 (default): fp16 MFMA with hi/lo-split operands (fp32-equivalent); 0: exact fp32 MFMA
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;

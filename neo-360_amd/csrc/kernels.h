@@ -184,6 +184,23 @@ void launch_pix_mlp_h(const TpMlpHDev& m, const TpScene& sc, const TpViews& view
                       const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N,
                       int chunk, float* out, hipStream_t s);
 
+// pillar.hip — pillar stage of the scene encoder
+struct PillarGeom {
+    int nv, G0, G1, G2;                // rows = nv * G0 * G1 * G2, x slowest (neo360/util.py:12-26)
+    int Hf, Wf;
+    float focal, cx, cy, sx, sy;       // view 0's intrinsics; latent_scaling / image size
+    const float* axes;                 // device: torch.linspace values of the three axes, [3][256]
+    float rot[TP_MAX_VIEWS][9], trans[TP_MAX_VIEWS][3], cpos[TP_MAX_VIEWS][3];
+};
+size_t pillar_wpack_bytes();
+// w: depth_fc.common_branch.0 (512x518), .2, depth_fc.depth_encoder, pillar_aggregator_{xz,yz,xy}.0 (512x513)
+void launch_pillar_pack(const float* const* w, void* wpack, hipStream_t s);
+// bias: 6 x 512 in that order; head_w: pillar_aggregator_{xz,yz,xy}.2 weights (3 x 512); head_b_host: their biases;
+// h1, h2, Lf: (M,512) workspaces, score (3,M); outputs channels-last floor-plans.  Returns -1 for unsupported grids.
+int launch_pillar(const PillarGeom& gm, const float* latent_cl, const void* wpack, const float* bias, const float* head_w,
+                  const float* head_b_host, float* h1, float* h2, float* Lf, float* score, uint32_t* flags, float* fp_yz,
+                  float* fp_xz, float* fp_xy, hipStream_t s);
+
 // sampling.hip — NeO-360 level-0 sample rows and fg/bg merge
 void launch_tp_level0(const float* far, const float* edges, int R, int N, float near, float* fg_t, float* bg_s,
                       hipStream_t s);

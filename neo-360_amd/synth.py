@@ -197,3 +197,22 @@ def scene_features(seed=0, nv=3, world_ch=128, plane_hw=(120, 160), local_ch=512
     planes = {k: normal(seed, "plane_" + k, (nv, world_ch) + tuple(plane_hw), std) for k in ("xz", "xy", "yz")}
     latent = normal(seed, "latent", (nv, local_ch) + tuple(latent_hw), std)
     return dict(plane_xz=planes["xz"], plane_xy=planes["xy"], plane_yz=planes["yz"], latent=latent)
+
+
+def pillar_state(seed=0, latent=512):
+    """Parameters of the pillar stage of GridEncoder (neo360/encoder_tp_fusion_conv.py:263-279, :364-373) under the
+    reference's key names: depth_fc (518 -> 512 -> 512 -> 512) and the three axis scorers (513 -> 512 -> 1).
+    kaiming_normal_ weights (std sqrt(2/fan_in)), biases U(-1e-3, 1e-3) (init_weights_kaiming, :255-260)."""
+    sd = {}
+
+    def lin(name, fan_out, fan_in):
+        sd[name + ".weight"] = normal(seed, name + ".weight", (fan_out, fan_in), math.sqrt(2.0 / fan_in))
+        sd[name + ".bias"] = uniform(seed, name + ".bias", (fan_out,), -1e-3, 1e-3)
+
+    lin("depth_fc.common_branch.0", latent, latent + 6)
+    lin("depth_fc.common_branch.2", latent, latent)
+    lin("depth_fc.depth_encoder", latent, latent)
+    for ax in ("xz", "yz", "xy"):
+        lin("pillar_aggregator_%s.0" % ax, latent, latent + 1)
+        lin("pillar_aggregator_%s.2" % ax, 1, latent)
+    return sd

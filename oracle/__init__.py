@@ -23,4 +23,4 @@ integer-hash generator `neo360_amd.synth`, fixtures hold expected outputs).
 renders against those fixtures on every CPU run; `tests/test_oracle_vs_reference.py`
 re-derives them live when /root/reference is present.
 """
-from . import rays, sampling, encoding, compositing, gather, mlp, vanilla, neo360, pixelnerf  # noqa: F401
+from . import rays, sampling, encoding, compositing, gather, mlp, vanilla, neo360, pixelnerf, pillar, training  # noqa: F401

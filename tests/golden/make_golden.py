@@ -450,6 +450,53 @@ def g7_pixelnerf():
     save("g7_pixelnerf", **out)
 
 
+# ---------------------------------------------------------------------------------
+# G9 pillar stage of the scene encoder: GridEncoder.forward from the world grid to the three floor-plans
+# ---------------------------------------------------------------------------------
+
+PILLAR_GRID = (12, 10, 8)
+
+
+def g9_pillar():
+    ENC = ref.load("models.neo360.encoder_tp_fusion_conv")
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc = ENC.GridEncoder(grid_size=list(PILLAR_GRID))
+    missing = enc.load_state_dict(synth.pillar_state(0), strict=False)
+    assert not missing.unexpected_keys, missing
+    enc.eval()
+    scene = cases.small_scene()
+    latent = scene["latent"]
+    Hf, Wf = latent.shape[-2:]
+    ls = torch.tensor([float(Wf), float(Hf)])
+    sp = enc.spatial_encoder
+    sp.forward = lambda images: None                     # the ResNet is outside the hot path: latent preset
+    sp.latent = latent
+    sp.latent_scaling = ls / (ls - 1) * 2.0
+    captured = {}
+    for ax in ("yz", "xz", "xy"):
+        getattr(enc, "floorplan_convnet_" + ax).register_forward_pre_hook(
+            lambda mod, inp, ax=ax: captured.__setitem__(ax, inp[0].detach().clone()))
+    poses, focal, centre = synth.source_views(cases.NV, *cases.IMG_WH)
+    images = torch.zeros(cases.NV, 3, cases.IMG_WH[1], cases.IMG_WH[0])
+    real_tensor = torch.tensor
+    torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})   # :465 hard-codes "cuda"
+    try:
+        enc(images, poses, focal, centre)
+    finally:
+        torch.tensor = real_tensor
+    # the conv nets receive NCHW permutes of the floor-plans (:580-592).  Stored channels-last, every 4th channel plus
+    # the per-cell sum and sum of squares over all 512 channels (keeps the fixture small, still touches every channel)
+    out = {}
+    for ax in captured:
+        fp = captured[ax].permute(0, 2, 3, 1).contiguous()
+        out["fp_" + ax] = fp[..., ::4].contiguous()
+        out["sum_" + ax] = fp.double().sum(-1)
+        out["sq_" + ax] = (fp.double() ** 2).sum(-1)
+    save("g9_pillar", **out)
+
+
 def main(which):
     jobs = {
         "g1": g1_raygen, "g2": g2_aabb, "g3": g3_stages, "g4v": g4_vanilla,
@@ -473,6 +520,7 @@ def main(which):
         "g6": g6_mip360,
         "g7": g7_pixelnerf,
         "g8": g8_training,
+        "g9": g9_pillar,
     }
     for name, fn in jobs.items():
         if not which or name in which:

@@ -250,3 +250,16 @@ def test_g7_pixelnerf_end_to_end(golden, tag, n_rays, chunk, gain, white):
     for k, v in lv.items():
         tol = 1e-6 if k.endswith("0") else (5e-5 if "depth" in k else 1e-5)   # level 1 passes through the resampler
         assert max_abs(torch.cat(v), g["%s_%s" % (k, tag)]) < tol, (k, tag)
+
+
+def test_g9_pillar_stage(golden):
+    """oracle.pillar.floorplans == the reference's GridEncoder.forward up to the inputs of its floor-plan conv nets
+    (world grid, masked directions, pixel-aligned lookup, depth_fc, the three axis scorers and softmaxes)."""
+    g = golden("g9_pillar")
+    sc = cases.small_scene()
+    poses, focal, centre = synth.source_views(cases.NV, *cases.IMG_WH)
+    got = oracle.pillar.floorplans(synth.pillar_state(0), sc["latent"], sc["image_wh"], poses, focal, centre, (12, 10, 8))
+    for name, fp in zip(("yz", "xz", "xy"), got):
+        assert max_abs(fp[..., ::4], g["fp_" + name]) < 1e-6, name
+        assert max_abs(fp.double().sum(-1), g["sum_" + name]) < 1e-4
+        assert max_abs((fp.double() ** 2).sum(-1), g["sq_" + name]) < 1e-4

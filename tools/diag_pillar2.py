@@ -1,0 +1,26 @@
+"""Pillar-stage repeatability under different host-side pacing.  usage: diag_pillar2.py <mode> [grid]
+modes: plain (calls back to back), sync (torch.cuda.synchronize between calls), sleep (host sleep 0.5 s between calls),
+dirty (a 2 GB device memset between calls: cold caches)"""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from neo360_amd import encoder, synth
+torch.set_grad_enabled(False)
+dev = "cuda"
+mode = sys.argv[1]
+grid = tuple(int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "64x64x64").split("x"))
+g = torch.Generator(device=dev); g.manual_seed(0)
+latent = torch.randn(3, 512, 60, 80, device=dev, generator=g) * 0.3
+poses, focal, centre = synth.source_views(3, 640, 480)
+enc = encoder.GridEncoder(grid_size=grid).to(dev)
+enc.load_state_dict(synth.pillar_state(0), strict=False)
+big = torch.empty(512 * 1024 * 1024, device=dev) if mode == "dirty" else None
+outs = []
+for r in range(5):
+    outs.append(enc.floorplans(latent, poses.to(dev), focal.to(dev), centre.to(dev), (640.0, 480.0)))
+    if mode == "sync": torch.cuda.synchronize()
+    if mode == "sleep": time.sleep(0.5)
+    if mode == "dirty": big.fill_(float(r)); torch.cuda.synchronize()
+bad = [int(sum(int((outs[0][i] != outs[r][i]).any(-1).sum()) for i in range(3))) for r in range(1, 5)]
+print(mode, grid, "plan cells differing from run 0 (runs 1..4):", bad)

@@ -1,7 +1,6 @@
-// Stand-alone reproducer attempt for the packed-fp32 glitch of round 1 (profiles/r01_tp_h_race_bisect.log):
-// in the split NeO-360 / PixelNeRF evaluators, bilinear blends compiled to v_pk_fma_f32 with op_sel broadcasts
-// returned run-to-run different values in lanes 48-63 when TWO workgroups shared a CU next to a
-// v_mfma_f32_32x32x16_f16 stream; scalar v_fma_f32 blends, or one workgroup per CU, were bitwise repeatable.
+// Stand-alone reproducer for the packed-fp32 glitch of round 1 (profiles/r01_tp_h_race_bisect.log), found in round 2
+// (profiles/r02_pk_f32_repro.log): v_pk_fma_f32 / v_pk_mul_f32 with an op_sel half-broadcast, executed while another
+// wave of the same SIMD runs v_mfma_f32_32x32x16_f16, occasionally returns wrong values in lanes 48-63.
 //
 // This program has no dependency on the library.  One kernel template reproduces the instruction mix of the blend
 // phase: per iteration 4 x global_load_dwordx4 taps (pseudo-random 16-B pieces of an L2-resident table), one
@@ -9,9 +8,12 @@
 //   BLEND 0: scalar v_fma_f32                       (what build.py's -packed-fp32-ops forces)
 //   BLEND 1: v_pk_fma_f32, weights splatted into register pairs (no op_sel)
 //   BLEND 2: v_pk_fma_f32 with op_sel / op_sel_hi broadcasting one half of the weight pair (the compiler's form)
-// All three are the same IEEE fma chain, so every output must be bitwise identical across BLEND, across launches,
-// and across occupancy (1 or 2 workgroups per CU, selected by the dynamic LDS size).  The host prints, per
-// configuration, the number of differing outputs vs the scalar single-workgroup run and a per-16-lane histogram.
+//   BLEND 3..10: BLEND 2 plus an unrelated second instruction in the same asm statement; they only differ in the
+//            schedule the compiler produces.  BLEND 4's schedule FAILS with 2 workgroups per CU; the others pass.
+// All are the same IEEE fma chain, so every output must be bitwise identical across BLEND, across launches and
+// across occupancy (1 or 2 workgroups per CU, selected by the dynamic LDS size).  The host prints, per configuration,
+// the number of differing outputs vs the scalar single-workgroup run and a per-16-lane histogram.
+// tools/pk_f32_variants.py perturbs the failing kernel's ISA one ingredient at a time (tools/pk_f32_co_run.cpp runs them).
 //   hipcc --offload-arch=gfx950 -O3 -o pk_f32_repro tools/pk_f32_repro.hip && ./pk_f32_repro
 #include <hip/hip_runtime.h>
 
@@ -55,6 +57,56 @@ __device__ __forceinline__ f32x2 pk_mul_lo(f32x2 a, f32x2 w) {
     return d;
 }
 
+// BLEND >= 3: a packed fma followed IMMEDIATELY by an instruction that overwrites one of its source pairs
+// (write-after-read), as the compiler schedules them in the real kernels (pillar.hip's packed build has
+// v_pk_fma_f32 v[46:47], v[86:87], v[42:43], v[46:47] op_sel_hi:[1,0,1] followed by v_cvt_pk_f16_f32 v42, ...).
+// The overwritten copy is private to the statement and dead afterwards, so the result must not change.
+//   3: op_sel forms, next instruction overwrites the WEIGHT pair (src1)      4: ... overwrites the TAP pair (src0)
+//   5: plain v_pk_fma_f32 (splatted weights, no op_sel), overwrites the tap pair
+//   6: as 4 with s_nop 0 between the two          7: as 4 with s_nop 1
+//   8: as 4, overwriting with v_lshlrev_b64 (a non-packed 64-bit VALU write)  9: as 4, overwriting with v_pk_mul_f32
+#define PK_LO "v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]"
+#define PK_HI "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+#define PK_PLAIN "v_pk_fma_f32 %0, %1, %2, %3"
+#define WAR_FN(name, head, tail, WHICH)                                                                   \
+    __device__ __forceinline__ f32x2 name(f32x2 a, f32x2 w, f32x2 c, f32x2 junk) {                         \
+        f32x2 d, ac = a, wc = w;                                                                           \
+        if (WHICH == 0) {                                                                                  \
+            asm volatile(head "\n\t" tail : "=&v"(d), "+v"(ac), "+v"(wc) : "v"(c), "v"(junk));             \
+        } else {                                                                                           \
+            asm volatile(head "\n\t" tail : "=&v"(d), "+v"(ac), "+v"(wc) : "v"(c), "v"(junk));             \
+        }                                                                                                  \
+        asm volatile("" ::"v"(ac), "v"(wc));                                                               \
+        return d;                                                                                          \
+    }
+WAR_FN(war3_lo, PK_LO, "v_pk_mov_b32 %2, %4, %4", 1)
+WAR_FN(war3_hi, PK_HI, "v_pk_mov_b32 %2, %4, %4", 1)
+WAR_FN(war10_lo, PK_LO, "v_pk_mov_b32 %1, %4, %4", 0)
+WAR_FN(war10_hi, PK_HI, "v_pk_mov_b32 %1, %4, %4", 0)
+// 4 is the form that FAILS (r02 log): the weight pair is a plain input, so the packed fma reads the ds_read_b128
+// destination directly; in the WAR_FN family the compiler first copies the weights with v_mov_b64 and all variants pass.
+__device__ __forceinline__ f32x2 war4_lo(f32x2 a, f32x2 w, f32x2 c, f32x2 junk) {
+    f32x2 d, ac = a;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]\n\tv_pk_mov_b32 %1, %4, %4" : "=&v"(d), "+v"(ac) : "v"(w), "v"(c), "v"(junk));
+    asm volatile("" :: "v"(ac));
+    return d;
+}
+__device__ __forceinline__ f32x2 war4_hi(f32x2 a, f32x2 w, f32x2 c, f32x2 junk) {
+    f32x2 d, ac = a;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\tv_pk_mov_b32 %1, %4, %4" : "=&v"(d), "+v"(ac) : "v"(w), "v"(c), "v"(junk));
+    asm volatile("" :: "v"(ac));
+    return d;
+}
+WAR_FN(war5, PK_PLAIN, "v_pk_mov_b32 %1, %4, %4", 0)
+WAR_FN(war6_lo, PK_LO, "s_nop 0\n\tv_pk_mov_b32 %1, %4, %4", 0)
+WAR_FN(war6_hi, PK_HI, "s_nop 0\n\tv_pk_mov_b32 %1, %4, %4", 0)
+WAR_FN(war7_lo, PK_LO, "s_nop 1\n\tv_pk_mov_b32 %1, %4, %4", 0)
+WAR_FN(war7_hi, PK_HI, "s_nop 1\n\tv_pk_mov_b32 %1, %4, %4", 0)
+WAR_FN(war8_lo, PK_LO, "v_lshlrev_b64 %1, 0, %4", 0)
+WAR_FN(war8_hi, PK_HI, "v_lshlrev_b64 %1, 0, %4", 0)
+WAR_FN(war9_lo, PK_LO, "v_pk_mul_f32 %1, %4, %4", 0)
+WAR_FN(war9_hi, PK_HI, "v_pk_mul_f32 %1, %4, %4", 0)
+
 template <int BLEND>
 __device__ __forceinline__ f32x4 blend(const f32x4 (&tap)[4], const f32x4 w) {
     f32x4 v;
@@ -74,6 +126,25 @@ __device__ __forceinline__ f32x4 blend(const f32x4 (&tap)[4], const f32x4 w) {
             a = pk_fma(f32x2{tap[1][2 * p], tap[1][2 * p + 1]}, f32x2{w[1], w[1]}, a);
             a = pk_fma(f32x2{tap[2][2 * p], tap[2][2 * p + 1]}, f32x2{w[2], w[2]}, a);
             a = pk_fma(f32x2{tap[3][2 * p], tap[3][2 * p + 1]}, f32x2{w[3], w[3]}, a);
+            v[2 * p] = a[0];
+            v[2 * p + 1] = a[1];
+        }
+    } else if (BLEND >= 3) {
+        const f32x2 w01{w[0], w[1]}, w23{w[2], w[3]};
+        const f32x2 junk{tap[0][3] * 7.0f, tap[1][2] - 3.0f};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x2 t1{tap[1][2 * p], tap[1][2 * p + 1]}, t2{tap[2][2 * p], tap[2][2 * p + 1]}, t3{tap[3][2 * p], tap[3][2 * p + 1]};
+            f32x2 a = BLEND == 5 ? pk_mul(f32x2{tap[0][2 * p], tap[0][2 * p + 1]}, f32x2{w[0], w[0]})
+                                 : pk_mul_lo(f32x2{tap[0][2 * p], tap[0][2 * p + 1]}, w01);
+            if (BLEND == 3) { a = war3_hi(t1, w01, a, junk); a = war3_lo(t2, w23, a, junk); a = war3_hi(t3, w23, a, junk); }
+            if (BLEND == 4) { a = war4_hi(t1, w01, a, junk); a = war4_lo(t2, w23, a, junk); a = war4_hi(t3, w23, a, junk); }
+            if (BLEND == 5) { a = war5(t1, f32x2{w[1], w[1]}, a, junk); a = war5(t2, f32x2{w[2], w[2]}, a, junk); a = war5(t3, f32x2{w[3], w[3]}, a, junk); }
+            if (BLEND == 6) { a = war6_hi(t1, w01, a, junk); a = war6_lo(t2, w23, a, junk); a = war6_hi(t3, w23, a, junk); }
+            if (BLEND == 7) { a = war7_hi(t1, w01, a, junk); a = war7_lo(t2, w23, a, junk); a = war7_hi(t3, w23, a, junk); }
+            if (BLEND == 8) { a = war8_hi(t1, w01, a, junk); a = war8_lo(t2, w23, a, junk); a = war8_hi(t3, w23, a, junk); }
+            if (BLEND == 10) { a = war10_hi(t1, w01, a, junk); a = war10_lo(t2, w23, a, junk); a = war10_hi(t3, w23, a, junk); }
+            if (BLEND == 9) { a = war9_hi(t1, w01, a, junk); a = war9_lo(t2, w23, a, junk); a = war9_hi(t3, w23, a, junk); }
             v[2 * p] = a[0];
             v[2 * p + 1] = a[1];
         }
@@ -188,6 +259,16 @@ int main(int argc, char** argv) {
         run<2, false>(table, n16, iters, blocks, lds2, out, sink); total += compare("pk op_sel, no MFMA, 2 WG/CU");
         run<2, true>(table, n16, iters, blocks, lds1, out, sink);  total += compare("pk op_sel    + MFMA, 1 WG/CU");
         run<2, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("pk op_sel    + MFMA, 2 WG/CU");
+        run<3, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("op_sel, WAR weights  + MFMA, 2 WG/CU");
+        run<4, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("op_sel, WAR taps     + MFMA, 2 WG/CU");
+        run<4, true>(table, n16, iters, blocks, lds1, out, sink);  total += compare("op_sel, WAR taps     + MFMA, 1 WG/CU");
+        run<4, false>(table, n16, iters, blocks, lds2, out, sink); total += compare("op_sel, WAR taps, no MFMA, 2 WG/CU");
+        run<10, true>(table, n16, iters, blocks, lds2, out, sink); total += compare("op_sel, WAR taps, weights copied + MFMA, 2 WG/CU");
+        run<5, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("plain pk, WAR taps   + MFMA, 2 WG/CU");
+        run<6, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("op_sel, s_nop 0, WAR taps + MFMA, 2 WG/CU");
+        run<7, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("op_sel, s_nop 1, WAR taps + MFMA, 2 WG/CU");
+        run<8, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("op_sel, WAR taps by lshlrev_b64 + MFMA, 2 WG/CU");
+        run<9, true>(table, n16, iters, blocks, lds2, out, sink);  total += compare("op_sel, WAR taps by pk_mul + MFMA, 2 WG/CU");
     }
     printf("total differing outputs: %zu (0 = this instruction mix is bitwise stable on this GPU)\n", total);
     return 0;
