@@ -1,4 +1,4 @@
-"""Pillar-stage repeatability under different host-side pacing.  usage: diag_pillar2.py <mode> [grid]
+"""Pillar-stage repeatability under different host-side pacing.  usage: diag_pillar.py <mode> [grid]
 modes: plain (calls back to back), sync (torch.cuda.synchronize between calls), sleep (host sleep 0.5 s between calls),
 dirty (a 2 GB device memset between calls: cold caches)"""
 import os, sys, time
