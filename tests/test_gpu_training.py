@@ -31,7 +31,7 @@ def test_samplers_vs_reference_fixture(golden):
     fg_d, bg_d = training.sample_level0(far, NC)                      # randomized=False
     far_c, _ = oracle.rays.sphere_exit_depth(rays["rays_o"].cpu(), rays["rays_d"].cpu())
     want, _ = oracle.sampling.neo_fg_level0(rays["rays_o"].cpu(), rays["rays_d"].cpu(), NC, torch.full_like(far_c, 1e-4), far_c)
-    assert max_abs(fg_d, want) < 2e-7
+    assert max_abs(fg_d, want) < 5e-7                                  # one ulp of t near far (far itself is 1 ulp apart on the two sides)
     # randomized pdf sampling: the new samples are a permutation-free comparison after sorting (the op returns the merged set)
     pc = cases.pdf_cases()
     mids, w = pc["asc"]
