@@ -17,14 +17,16 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-Wno-unused-result"]
 
-# Per-file additions.  mlp_tp_h.hip: no packed-fp32 VALU ops (v_pk_mul/add/fma_f32).  Measured on MI355X
-# (tools/diag_det_all.py, profiles/r01_tp_h_race_bisect.log): with two workgroups of that kernel sharing a CU,
-# the packed-fp32 bilinear blends that run next to the other workgroup's v_mfma_f32_32x32x16_f16 stream
-# returned wrong values in lanes 48-63 for ~0.3 % of the points, differently on every launch; one workgroup
-# per CU, or the same code with scalar fp32 VALU ops, is bitwise repeatable.  The fp32-MFMA kernels and the
-# vanilla split kernel are repeatable as built (tests/test_gpu_repeatable.py keeps checking all of them).
+# Per-file additions: no packed-fp32 VALU ops (v_pk_mul/add/fma_f32) in any file that runs fp32 VALU work next to a
+# v_mfma_f32_32x32x16_f16 stream.  Measured on MI355X (profiles/r01_tp_h_race_bisect.log, stand-alone reproducer
+# tools/pk_f32_repro.hip + profiles/r02_pk_f32_repro.log): a packed fp32 op that uses op_sel to broadcast one half of
+# a source pair, executed while another wave of the same SIMD runs that MFMA, occasionally returns wrong values in
+# lanes 48-63; no wait state fixes it.  The compiler picks those forms on its own (21 of them in mlp_vanilla_h.hip),
+# so the feature is switched off per file; the cost is nil (profiles/r02_power_envelope.log, "nopk").
+# tests/test_gpu_repeatable.py checks bitwise repeatability of every evaluator.
 _NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA_FLAGS = {
+    "mlp_vanilla_h.hip": _NO_PK_F32,
     "mlp_tp_h.hip": _NO_PK_F32,
     "mlp_mip_h.hip": _NO_PK_F32,
     "mlp_pix_h.hip": _NO_PK_F32,

@@ -32,7 +32,6 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 64;
 constexpr int ACT_LDH = 256;     // halves per activation row
 constexpr int SIDE_LDH = 64;     // halves per side-buffer row (x0, later the view-direction encoding)
 constexpr int NUM_STAGES = 10;   // L0..L7, bottleneck, view layer
@@ -86,6 +85,9 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 #define VH_SYNC() do { if (!(NEO_VH_ABLATE & 8)) __syncthreads(); } while (0)
 #ifndef NEO_VH_SETPRIO
 #define NEO_VH_SETPRIO 3      // s_setprio during the matrix phase: +0.5-0.7 % (tools/bench_kernel.py)
+#endif
+#ifndef NEO_VH_TILE_DEFAULT
+#define NEO_VH_TILE_DEFAULT 64   // points per workgroup: 64 (two workgroups per CU) or 128 (one; $NEO_VANILLA_H_TILE)
 #endif
 #ifndef NEO_VH_PREFETCH
 #define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
@@ -157,48 +159,89 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][MTW], const float* 
     }
 }
 
-// epilogue: (ReLU) -> split -> two fp16 planes.  D holds outputs 8g+4*half+e (e<4) of point l31 in
-// 4 consecutive registers: one 8-byte store per plane; lanes l and l+32 fill the two halves of a chunk.
+// epilogue: (ReLU) -> split -> two fp16 planes.  D holds outputs 8g+4*half+e (e<4) of point l31 in 4 consecutive
+// registers, i.e. lanes l and l+32 hold the two 8-byte halves of one 16-byte chunk.  v_permlane32_swap exchanges them
+// for a PAIR of chunks (g, g+1) so that lanes 0-31 own chunk g and lanes 32-63 chunk g+1 of their point: one
+// ds_write_b128 per plane and chunk pair, conflict-free under the XOR swizzle (the 8-byte form was 2-way conflicted:
+// rows r and r+16 of a 32-lane pass share banks).
+#ifndef NEO_VH_STORE128
+#define NEO_VH_STORE128 1
+#endif
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void swap_halves(u32x2& x, u32x2& y) {      // x[lanes 32-63] <-> y[lanes 0-31]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(x[i], y[i], false, false);   // builtin: the compiler inserts the wait states
+        x[i] = r[0];
+        y[i] = r[1];
+    }
+}
+template <bool RELU>
+__device__ __forceinline__ void split_quad(const f32x16& acc, int g, h4& vh, h4& vl, const LaneCtx& L) {
+    float xprev = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = acc[4 * g + e];
+        if (RELU) x = fmaxf(x, 0.0f);
+        if (e & 1) L.amax = fmaxf(fmaxf(L.amax, fabsf(x)), fabsf(xprev)); else xprev = x;   // range guard (split_tile.h)
+        _Float16 h, l;
+        split(x, h, l);
+        vh[e] = h;
+        vl[e] = l;
+    }
+}
 template <int NTW, int MTW, bool RELU>
 __device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][MTW], const HTile& act, int nt0, int mt0,
                                           const LaneCtx& L) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
+        for (int mt = 0; mt < MTW; ++mt) {
+#if NEO_VH_STORE128
+#pragma unroll
+            for (int gp = 0; gp < ((NEO_VH_ABLATE & 4) ? 1 : 2); ++gp) {
+                h4 h0, l0, h1, l1;
+                split_quad<RELU>(acc[nt][mt], 2 * gp, h0, l0, L);
+                split_quad<RELU>(acc[nt][mt], 2 * gp + 1, h1, l1, L);
+                u32x2 xh = __builtin_bit_cast(u32x2, h0), yh = __builtin_bit_cast(u32x2, h1);
+                u32x2 xl = __builtin_bit_cast(u32x2, l0), yl = __builtin_bit_cast(u32x2, l1);
+                swap_halves(xh, yh);      // lanes < 32: (xh | yh) = chunk 2gp; lanes >= 32: chunk 2gp+1
+                swap_halves(xl, yl);
+                const int o = chunk_off<ACT_LDH, 15>((mt0 + mt) * 32 + L.l31, (nt0 + nt) * 4 + 2 * gp + L.half);
+                *reinterpret_cast<u32x4*>(act.hi + o) = u32x4{xh[0], xh[1], yh[0], yh[1]};
+                *reinterpret_cast<u32x4*>(act.lo + o) = u32x4{xl[0], xl[1], yl[0], yl[1]};
+            }
+#else
 #pragma unroll
             for (int g = 0; g < ((NEO_VH_ABLATE & 4) ? 1 : 4); ++g) {
                 h4 vh, vl;
-                float xprev = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[nt][mt][4 * g + e];
-                    if (RELU) x = fmaxf(x, 0.0f);
-                    if (e & 1) L.amax = fmaxf(fmaxf(L.amax, fabsf(x)), fabsf(xprev)); else xprev = x;   // range guard (split_tile.h)
-                    _Float16 h, l;
-                    split(x, h, l);
-                    vh[e] = h;
-                    vl[e] = l;
-                }
+                split_quad<RELU>(acc[nt][mt], g, vh, vl, L);
                 const int o = chunk_off<ACT_LDH, 15>((mt0 + mt) * 32 + L.l31, (nt0 + nt) * 4 + g) + 4 * L.half;
                 *reinterpret_cast<h4*>(act.hi + o) = vh;
                 *reinterpret_cast<h4*>(act.lo + o) = vl;
             }
+#endif
+        }
 }
 
-// NW = 4 or 8 waves per 64-point tile.  With 8 waves each owns ONE 32-output N-tile of the 256-wide
-// layers (for both 32-point M-tiles): twice the resident waves per SIMD (4) to cover the VALU-heavy
-// epilogues, L2 round trips and barriers that the 5x shorter matrix phases no longer hide, at unchanged
-// weight traffic (every weight fragment is still fetched once per tile).
-template <int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(VanillaMlpHDev m,
-                                                                                const float* __restrict__ rays_o,
-                                                                                const float* __restrict__ dirs,
-                                                                                const float* __restrict__ t,
-                                                                                int t_row_stride, long P, int N,
-                                                                                float4* __restrict__ out) {
+// NW = 4 or 8 waves per tile of TM = 32 * MT points.
+//  * NW = 8 (MT = 2): each wave owns ONE 32-output N-tile of the 256-wide layers (for both M-tiles): twice the
+//    resident waves per SIMD (4), unchanged weight traffic, twice the LDS fragment reads.
+//  * MT = 4 (NW = 4): a 128-point tile, 2 N-tiles x 4 M-tiles per wave: every weight fragment feeds 24 instead of
+//    12 MFMAs (half the L2 -> L1 weight stream per point) at the price of the whole LDS (160 KB) and one wave per SIMD.
+template <int NW, int MT>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_vanilla_mlp_h(VanillaMlpHDev m,
+                                                                                             const float* __restrict__ rays_o,
+                                                                                             const float* __restrict__ dirs,
+                                                                                             const float* __restrict__ t,
+                                                                                             int t_row_stride, long P, int N,
+                                                                                             float4* __restrict__ out) {
+    constexpr int TM = 32 * MT;
     constexpr int NTW = 8 / NW;                 // N-tiles per wave in the 256-wide layers
-    constexpr int LP = NW;                      // lanes per point in the VALU heads
+    constexpr int LP = NW * 64 / TM;            // lanes per point in the VALU heads
+    constexpr int PW = TM / 64;                 // waves that together cover the points once
+    constexpr int NG = NW / PW;                 // such groups: they split the octaves of the encodings
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];
     HTile act{smem_h, smem_h + TM * ACT_LDH};
     HTile side{smem_h + 2 * TM * ACT_LDH, smem_h + 2 * TM * ACT_LDH + TM * SIDE_LDH};
@@ -207,11 +250,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
     const int tid = threadIdx.x;
     const long tile0 = (long)blockIdx.x * TM;
     const h8* wp = reinterpret_cast<const h8*>(m.wpack);
+    const int p_enc = (L.wv % PW) * 64 + L.lane, grp = L.wv / PW;      // this thread's point / octave group in the encodings
 
-    // ---- pos_enc of the 64 points into the side buffer (wave q: octaves q, q+NW, ...) ----
+    // ---- pos_enc of the TM points into the side buffer (group q: octaves q, q+NG, ...) ----
     int my_ray;
     {
-        const int p = L.lane;
+        const int p = p_enc;
         long g = tile0 + p;
         if (g >= P) g = P - 1;
         const int ray = (int)(g / N);
@@ -225,7 +269,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
             L.amax = fmaxf(L.amax, fabsf(x[a]));
         }
 #pragma unroll 1
-        for (int k = L.wv; k < 10; k += NW) {
+        for (int k = grp; k < 10; k += NG) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 float sn, cs;
@@ -234,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
                 put_feat<SIDE_LDH, 7>(side, p, 33 + k * 3 + a, cs);
             }
         }
-        if (L.wv == NW - 1) {
+        if (grp == NG - 1) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) put_feat<SIDE_LDH, 7>(side, p, a, x[a]);
             put_feat<SIDE_LDH, 7>(side, p, 63, 0.0f);
@@ -242,43 +286,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
     }
     VH_SYNC();
 
-    f32x16 acc[NTW][2];
+    f32x16 acc[NTW][MT];
     const int nt0 = L.wv * NTW;
     // ---- L0: 63 -> 256 ----
-    init_bias<NTW, 2>(acc, m.bias + stage_b_off(0), nt0, L);
-    gemm_h<NTW, 2, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 0, 4, side, L);
-    store_act<NTW, 2, true>(acc, act, nt0, 0, L);      // the activation planes are idle here
+    init_bias<NTW, MT>(acc, m.bias + stage_b_off(0), nt0, L);
+    gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 0, 4, side, L);
+    store_act<NTW, MT, true>(acc, act, nt0, 0, L);      // the activation planes are idle here
     VH_SYNC();
     // ---- L1..L7 (skip concat feeds L5) ----
 #pragma unroll 1
     for (int s = 1; s <= 7; ++s) {
         const int woff = stage_w_off(1) + (s - 1) * (8 * 16 * 128) + (s > 5 ? 8 * 4 * 128 : 0);
         const int KS = s == 5 ? 20 : 16;
-        init_bias<NTW, 2>(acc, m.bias + s * 256, nt0, L);
-        gemm_h<NTW, 2, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 0, 16, act, L);
-        if (s == 5) gemm_h<NTW, 2, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L);
+        init_bias<NTW, MT>(acc, m.bias + s * 256, nt0, L);
+        gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 0, 16, act, L);
+        if (s == 5) gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L);
         VH_SYNC();
-        store_act<NTW, 2, true>(acc, act, nt0, 0, L);
+        store_act<NTW, MT, true>(acc, act, nt0, 0, L);
         if (s == 5) {
-            // x0 is dead: the side buffer takes the view-direction encoding (wave q < 4: octave q)
-            const int p = L.lane;
+            // x0 is dead: the side buffer takes the view-direction encoding (group q: octaves q, q+NG, ... < 4)
+            const int p = p_enc;
             float d[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) d[a] = dirs[my_ray * 3 + a];
-            if (L.wv < 4) {
+#pragma unroll 1
+            for (int k = grp; k < 4; k += NG) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     float sn, cs;
-                    enc_pair(d[a], L.wv, sn, cs);
-                    put_feat<SIDE_LDH, 7>(side, p, 3 + L.wv * 3 + a, sn);
-                    put_feat<SIDE_LDH, 7>(side, p, 15 + L.wv * 3 + a, cs);
+                    enc_pair(d[a], k, sn, cs);
+                    put_feat<SIDE_LDH, 7>(side, p, 3 + k * 3 + a, sn);
+                    put_feat<SIDE_LDH, 7>(side, p, 15 + k * 3 + a, cs);
                 }
             }
-            if (L.wv == NW - 1) {
+            if (grp == NG - 1) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) put_feat<SIDE_LDH, 7>(side, p, a, d[a]);
             }
-            if (L.wv == NW - 2) {
+            if (grp == NG - 2) {
 #pragma unroll
                 for (int f = 27; f < 32; ++f) put_feat<SIDE_LDH, 7>(side, p, f, 0.0f);
             }
@@ -306,14 +351,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void k_vanilla_mlp_h(Va
         raw_sigma = s + m.heads[HD_DB];
     }
     // ---- bottleneck: 256 -> 256, no activation ----
-    init_bias<NTW, 2>(acc, m.bias + stage_b_off(8), nt0, L);
-    gemm_h<NTW, 2, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L);
+    init_bias<NTW, MT>(acc, m.bias + stage_b_off(8), nt0, L);
+    gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L);
     VH_SYNC();
-    store_act<NTW, 2, false>(acc, act, nt0, 0, L);
+    store_act<NTW, MT, false>(acc, act, nt0, 0, L);
     VH_SYNC();
     // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU (4 N-tiles: split over M as well when NW = 8) ----
     {
-        constexpr int MTV = NW == 8 ? 1 : 2;
+        constexpr int MTV = NW == 8 ? 1 : MT;
         const int ntv = L.wv & 3, mtv = NW == 8 ? (L.wv >> 2) : 0;
         f32x16 accv[1][MTV];
         init_bias<1, MTV>(accv, m.bias + stage_b_off(9), ntv, L);
@@ -393,22 +438,25 @@ void launch_vanilla_mlp_h(const VanillaMlpHDev& m, const float* rays_o, const fl
                           int t_row_stride, int R, int N, float* out, hipStream_t s) {
     const long P = (long)R * N;
     if (P <= 0) return;
-    const size_t lds = (size_t)(2 * TM * ACT_LDH + 2 * TM * SIDE_LDH) * sizeof(_Float16);   // 80 KiB
-    static int nw = 0;
+    static int nw = 0, tm = 0;
     if (nw == 0) {
         nw = 4;   // measured: 4 waves 396 TFLOP/s, 8 waves 381 (profiles/r01_vanilla_h_variants.log)
+        tm = NEO_VH_TILE_DEFAULT;
         if (const char* e = getenv("NEO_VANILLA_H_WAVES")) nw = atoi(e) == 8 ? 8 : 4;
+        if (const char* e = getenv("NEO_VANILLA_H_TILE")) tm = atoi(e) == 128 ? 128 : 64;
+        if (nw == 8) tm = 64;
     }
+    const size_t lds = (size_t)(2 * tm * ACT_LDH + 2 * tm * SIDE_LDH) * sizeof(_Float16);   // 80 KiB per 64 points
+    const long tiles = (P + tm - 1) / tm;
     // per-device attribute: set on every launch (a host-side table write), not once per process
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vanilla_mlp_h<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const long tiles = (P + TM - 1) / TM;
-    if (nw == 8)
-        hipLaunchKernelGGL(k_vanilla_mlp_h<8>, dim3((unsigned)tiles), dim3(512), lds, s, m, rays_o, dirs, t, t_row_stride,
-                           P, N, reinterpret_cast<float4*>(out));
-    else
-        hipLaunchKernelGGL(k_vanilla_mlp_h<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, rays_o, dirs, t, t_row_stride,
-                           P, N, reinterpret_cast<float4*>(out));
+    auto go = [&](auto kernel, int threads) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)tiles), dim3(threads), lds, s, m, rays_o, dirs, t, t_row_stride, P, N,
+                           reinterpret_cast<float4*>(out));
+    };
+    if (nw == 8) go(k_vanilla_mlp_h<8, 2>, 512);
+    else if (tm == 128) go(k_vanilla_mlp_h<4, 4>, 256);
+    else go(k_vanilla_mlp_h<4, 2>, 256);
 }
 
 }  // namespace neo
