@@ -61,3 +61,27 @@ def test_vanilla_largest_sample_counts():
     with pytest.raises(Exception):
         models.NeRF(num_coarse_samples=256, num_fine_samples=768).to(DEV)({k: v.to(DEV) for k, v in rays.items()},
                                                                          False, False, 0.2, 3.0)
+
+
+def test_pos_enc_large_and_non_finite_arguments():
+    """The encodings use a Cody-Waite sine for |x| <= 65536 and an fp64 range reduction beyond (csrc/common.h:sin_cw);
+    the reference calls torch.sin on the fp32 argument (helper.py:121-125).  Large scene coordinates, inf and NaN."""
+    from neo360_amd import ops
+    g = torch.Generator().manual_seed(5)
+    mags = torch.tensor([1e-3, 1.0, 100.0, 6.5e4, 7e4, 1e6, 3e7, 1e10, 1e30, 1e37])
+    x = (torch.rand(64, 10, 3, generator=g) * 2 - 1) * mags[None, :, None]
+    x = x.reshape(-1, 3)
+    got = ops.pos_enc(x.to(DEV), 0, 10).cpu()
+    # reference arithmetic: fp32 scaled argument (exact: power-of-two scales), correctly rounded sine of THAT argument
+    scaled = torch.cat([x] + [x * 2.0 ** k for k in range(10)] + [x * 2.0 ** k + 0.5 * torch.pi for k in range(10)], dim=-1)
+    exact = torch.cat([x.double()] + [torch.sin((x * 2.0 ** k).double()) for k in range(10)]
+                      + [torch.sin((x * 2.0 ** k + 0.5 * torch.pi).double()) for k in range(10)], dim=-1)
+    assert got.shape == exact.shape == scaled.shape
+    finite = torch.isfinite(scaled)
+    assert max_abs(got[:, 3:][finite[:, 3:]], exact[:, 3:][finite[:, 3:]].float()) < 2e-7
+    assert torch.equal(got[:, :3], x)
+    # an overflowed argument (2^k x = inf) gives NaN, as torch.sin(inf) does
+    assert torch.isnan(got[~finite]).all()
+    bad = torch.tensor([[float("inf"), float("nan"), -float("inf")]])
+    out = ops.pos_enc(bad.to(DEV), 0, 4).cpu()
+    assert torch.isnan(out[:, 3:]).all()
