@@ -174,3 +174,27 @@ def test_training_forward_randomized_properties():
     torch.manual_seed(0)
     f = net(batch, True, False, 0.0, 0.0, out_depth=False)
     assert torch.equal(e[1][0], f[1][0])
+
+
+def test_training_ops_empty_inputs():
+    """Zero rays through every training-side entry point: shapes kept, nothing launched, no error."""
+    assert training.rand_uniform(SEED, 0, 0, 5).shape == (0, 5)
+    far = torch.empty(0, 1, device=DEV)
+    fg, bg = training.sample_level0(far, NC)
+    assert fg.shape == bg.shape == (0, NC + 1)
+    out = training.resample_u(torch.empty(0, NC + 1, device=DEV), torch.empty(0, NC + 1, device=DEV), torch.empty(0, NF, device=DEV))
+    assert out.shape == (0, NC + 1 + NF)
+    with torch.enable_grad():
+        rgb = torch.empty(0, 8, 3, device=DEV, requires_grad=True)
+        sigma = torch.empty(0, 8, 1, device=DEV, requires_grad=True)
+        res = training.composite(0, rgb, sigma, torch.empty(0, 8, device=DEV), torch.empty(0, 3, device=DEV))
+        assert res[0].shape == (0, 3) and res[2].shape == (0, 8)
+        (res[0].sum() + res[2].sum()).backward()
+        assert rgb.grad.shape == rgb.shape and sigma.grad.shape == sigma.shape
+    net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
+    net.load_state_dict(synth.nerf_tp_state(0))
+    sc = cases.small_scene()
+    net.set_scene(*(sc[k].to(DEV) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")), sc["image_wh"])
+    batch = {k: (v.to(DEV) if k.startswith("src_") else v[:0].to(DEV)) for k, v in cases.neo_batch(cases.strided_rays(4)).items()}
+    lv = net(batch, True, False, 0.0, 0.0, out_depth=False, seed=3)
+    assert lv[1][0].shape == (0, 3) and lv[1][1].shape == (0, NC + 1 + NF)
