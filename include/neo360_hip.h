@@ -176,7 +176,9 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
  * (scene, MLP slot) through the local columns of pts_linears.0 and of pts_linears.3's skip half
  * (W . bilerp(F) = bilerp(W . F): neo360/model.py:110-158 is linear in the latent up to the first ReLU), and
  * the evaluator gathers the 256-channel result; costs 1 KB per latent texel and slot of context memory.
- * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order). */
+ * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order).
+ * enable == 2: as 1, evaluated by the producer / consumer kernel k_tp_mlp_pc (persistent 8-wave workgroups: four waves
+ * gather and encode, four run the matrix work; same results up to fp32 summation order, same speed: DESIGN.md 4.3). */
 int neo_tp_set_preproject(neo_ctx* ctx, int enable);
 
 /* `predict` + the feature lookups for one region at given sample positions

@@ -172,7 +172,7 @@ void launch_tp_preproject(const float* latent_cl, long texels, const float* wpac
                           hipStream_t s);
 void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
                       const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
-                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s);
+                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s, int variant = 0);
 
 // mlp_pix_h.hip — PixelNeRF baseline decoder evaluator (split-fp16 arithmetic only)
 size_t pix_wpack_h_bytes();

@@ -119,16 +119,17 @@ __device__ __forceinline__ float pe_feature(const float* x, int f) {
 
 
 // ---- per-point world-space quantities (once per tile; threads 0..63) ---------------------------
+// row `tid` of the tile (any thread may compute any row)
 template <int PE_C>
-__device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile0, long P, int N, int R, int chunk,
-                                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                            const float* __restrict__ viewdirs, const float* __restrict__ tvals,
-                                            const float* __restrict__ far_arr, uint32_t* __restrict__ flags,
-                                            bool t_shared = false) {
+__device__ __forceinline__ void point_setup_row(const Scratch& S, int tid, long tile0, long P, int N, int R, int chunk,
+                                                const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                const float* __restrict__ viewdirs, const float* __restrict__ tvals,
+                                                const float* __restrict__ far_arr, uint32_t* __restrict__ flags,
+                                                bool t_shared = false) {
     float* pe_world = S.pe_world;
     float* feat_world = S.feat_world;
     float* vdir_world = S.vdir_world;
-    if (tid < TM) {
+    {
         long g = tile0 + tid;
         if (g >= P) g = P - 1;
         const int ray = (int)(g / N);
@@ -189,6 +190,15 @@ __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile
 #pragma unroll
         for (int a = 0; a < 3; ++a) vdir_world[tid * 4 + a] = viewdirs[dray * 3 + a];
     }
+}
+
+template <int PE_C>
+__device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile0, long P, int N, int R, int chunk,
+                                            const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                            const float* __restrict__ viewdirs, const float* __restrict__ tvals,
+                                            const float* __restrict__ far_arr, uint32_t* __restrict__ flags,
+                                            bool t_shared = false) {
+    if (tid < TM) point_setup_row<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, t_shared);
 }
 
 // ---- per-view descriptors (all 4 waves; lane = row) ---------------------------------------------------

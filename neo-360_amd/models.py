@@ -281,13 +281,16 @@ class NeRF_TP(_HipModule):
         self._scene_ctx = None
         # split path: gather the latent pre-projected through each MLP's first-layer weights (256 instead of 512
         # channels per tap, 51 % fewer MACs per point-view; see csrc/mlp_tp_hp.hip).  False: the reference's order.
-        self.preproject = os.environ.get("NEO360_TP_PREPROJECT", "1") != "0"
+        # "pc": pre-projected, evaluated by the producer / consumer kernel (k_tp_mlp_pc; an equally fast alternative schedule)
+        env = os.environ.get("NEO360_TP_PREPROJECT", "1")
+        self.preproject = "pc" if env == "pc" else env != "0"
 
     def _context(self, device):
         ctx = super()._context(device)
-        if getattr(ctx, "_preproject", None) != bool(self.preproject):
-            _lib.check(ctx.lib.neo_tp_set_preproject(ctx.handle, int(bool(self.preproject))))
-            ctx._preproject = bool(self.preproject)
+        mode = 2 if self.preproject == "pc" else int(bool(self.preproject))
+        if getattr(ctx, "_preproject", None) != mode:
+            _lib.check(ctx.lib.neo_tp_set_preproject(ctx.handle, mode))
+            ctx._preproject = mode
         return ctx
 
     def _mlps(self):
@@ -312,7 +315,7 @@ class NeRF_TP(_HipModule):
         (neo360/model.py:267-269).  Re-laid out channels-last on the device, once.
         preproject (None = keep `self.preproject`): see that attribute."""
         if preproject is not None:
-            self.preproject = bool(preproject)
+            self.preproject = "pc" if preproject == "pc" else bool(preproject)
         planes = [f32(p, "plane") for p in (plane_xz, plane_xy, plane_yz)]
         latent = f32(latent, "latent")
         ctx = self._context(latent.device)

@@ -104,7 +104,7 @@ def test_sharp_density(golden):
                               golden("g4_neo_sharp_noise"), "sharp")
 
 
-@pytest.mark.parametrize("preproject", [True, False])
+@pytest.mark.parametrize("preproject", [True, False, "pc"])
 def test_reference_sample_counts_1024(golden, preproject):
     """One reference-sized chunk: 1024 rays, 128 coarse + 256 fine, fg + bg, 3 views; both split evaluators
     (latent pre-projected through the first-layer weights = default, and the reference's operation order)."""

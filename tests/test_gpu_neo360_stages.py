@@ -18,17 +18,19 @@ TOL = 1e-4
 R, NC, NF = 192, 128, 256
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f16x3-pc", "f32"])
 def setup(request):
-    """All three point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent
-    (default), split-fp16 in the reference's operation order, exact fp32 MFMA."""
+    """All four point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent
+    (default), split-fp16 in the reference's operation order, the producer / consumer schedule of the default, exact
+    fp32 MFMA."""
     params = synth.nerf_tp_state(0)
     scene = cases.small_scene()
     net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
     net.precision = request.param.split("-")[0]
     net.load_state_dict(params)
     net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
-                  scene["latent"].to(DEV), scene["image_wh"], preproject=not request.param.endswith("noproj"))
+                  scene["latent"].to(DEV), scene["image_wh"],
+                  preproject="pc" if request.param.endswith("pc") else not request.param.endswith("noproj"))
     batch = cases.neo_batch(cases.strided_rays(R))
     return params, scene, net, batch, {k: v.to(DEV) for k, v in batch.items()}
 
