@@ -15,7 +15,8 @@ from neo360_amd import models, ops, synth
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TOL = 1e-4
-R, NC, NF = 192, 128, 256
+R, NC, NF = 96, 128, 256
+_ORACLE_L0 = {}          # level-0 oracle outputs are the same for every kernel variant: evaluated once per session
 
 
 @pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f16x3-pc", "f32"])
@@ -48,7 +49,9 @@ def test_pipeline_stage_by_stage(setup):
     stages = {}
     for name, slot, prefix, tv, inside in (("fg0", 0, "fg_coarse_mlp.", fg_t, True), ("bg0", 2, "bg_coarse_mlp.", bg_s, False)):
         got = net.eval_mlp(slot, gbatch, tv.to(DEV), far=far_g).cpu()
-        rgb, sigma = oracle.neo360.region_eval(params, prefix, batch, scene, tv, inside, far_c)
+        if name not in _ORACLE_L0:
+            _ORACLE_L0[name] = oracle.neo360.region_eval(params, prefix, batch, scene, tv, inside, far_c)
+        rgb, sigma = _ORACLE_L0[name]
         assert max_abs(got[..., :3], rgb) < 2e-5, name
         assert max_abs(got[..., 3:], sigma) < 2e-5, name
         stages[name] = got
