@@ -292,6 +292,12 @@ int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights,
 int neo_pix_set_scene(neo_ctx* ctx, const float* latent, int NV, int Cl, int Hf, int Wf,
                       float image_w, float image_h, void* stream);
 
+/* enable != 0 (default): the 512-channel latent is pre-projected once per (scene, MLP slot) through the latent columns
+ * of pts_linears.0 (model_pixel.py:96-131 is linear in the latent up to the first ReLU) and the evaluator gathers the
+ * 128-channel result (512 B per latent texel and slot of context memory); 0: the latent itself is gathered and
+ * multiplied per point, the reference's operation order. */
+int neo_pix_set_preproject(neo_ctx* ctx, int enable);
+
 /* Per-point outputs at given sample positions (model_pixel.py:198-237): tvals (R,N) along rays_d;
  * out (R,N,4) = (sigmoid rgb, relu sigma).  chunk / src_poses / focal / cx / cy as for neo_pix_render. */
 int neo_pix_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,

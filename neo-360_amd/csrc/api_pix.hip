@@ -36,9 +36,22 @@ int pix_launch(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo::TpView
         neo::launch_f32_range_check(sc.latent, static_cast<size_t>(sc.nv) * sc.Hf * sc.Wf * 512, 65504.0f, ctx->flags, s);
         ctx->pix_latent_checked = true;
     }
+    const float* proj = nullptr;
+    if (ctx->pix_preproject) {
+        // latent pre-projected through this slot's pts_linears.0 latent columns (exact fp32 MFMA): rebuilt only when the
+        // scene or the slot's weights changed since the last launch
+        if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->pix_scene_epoch) {
+            const long texels = static_cast<long>(sc.nv) * sc.Hf * sc.Wf;
+            if (sl.proj.reserve(static_cast<size_t>(texels) * 512)) return NEO_ERR_NOMEM;
+            neo::launch_tp_preproject(sc.latent, texels, sl.wpack.as<float>(), 64, sl.proj.as<float>(), s, 128);
+            sl.proj_weights = sl.weights_epoch;
+            sl.proj_scene = ctx->pix_scene_epoch;
+        }
+        proj = sl.proj.as<float>();
+    }
     neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
     ctx->span_begin(s);
-    neo::launch_pix_mlp_h(mh, sc, views, rays_o, rays_d, viewdirs, tvals, t_shared, R, N, chunk, out, s);
+    neo::launch_pix_mlp_h(mh, proj, sc, views, rays_o, rays_d, viewdirs, tvals, t_shared, R, N, chunk, out, s);
     ctx->span_end(s, static_cast<double>(R) * N, pix_flop_per_point(sc.nv));
     return NEO_OK;
 }
@@ -57,8 +70,10 @@ int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, cons
     if (sl.wpack_h.reserve(neo::pix_wpack_h_bytes())) return NEO_ERR_NOMEM;
     if (sl.bias.reserve(neo::pix_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.heads.reserve(neo::pix_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.wpack.reserve(neo::pix_wproj_bytes())) return NEO_ERR_NOMEM;
     neo::launch_pix_pack_h(weights, biases, sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(),
                            static_cast<hipStream_t>(stream));
+    neo::launch_pix_pack_proj(weights[0], sl.wpack.as<float>(), static_cast<hipStream_t>(stream));
     sl.input_ch = 3;
     sl.weights_epoch += 1;
     sl.ready = true;
@@ -87,7 +102,16 @@ int neo_pix_set_scene(neo_ctx* ctx, const float* latent, int NV, int Cl, int Hf,
     ctx->pix_scene.fy_sign = 1.0f;                                     // model_pixel.py:203 passes (f, f)
     ctx->pix_scene_ready = true;
     ctx->pix_latent_checked = false;
+    ctx->pix_scene_epoch += 1;
     return check_launch();
+}
+
+int neo_pix_set_preproject(neo_ctx* ctx, int enable) {
+    ENTER(ctx);
+    ctx->pix_preproject = enable != 0;
+    if (!ctx->pix_preproject)
+        for (auto& sl : ctx->pix) { sl.proj.release(); sl.proj_weights = sl.proj_scene = 0; }
+    return NEO_OK;
 }
 
 int neo_pix_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d, const float* viewdirs,

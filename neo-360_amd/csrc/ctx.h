@@ -128,6 +128,8 @@ struct neo_ctx {
     neo::TpScene pix_scene{};
     bool pix_scene_ready = false;
     bool pix_latent_checked = false;
+    uint64_t pix_scene_epoch = 0;
+    int pix_preproject = 1;            // PixelNeRF: gather the latent pre-projected through pts_linears.0 (mlp_pix_h.hip)
     std::map<int, neo_host::DevBuf> quantiles;                    // n_new -> linspace(0, fl32(1-2^-32), n_new)
     std::map<std::pair<int, uint64_t>, neo_host::DevBuf> edges;   // (n, near/far bits) -> level-0 t row
     neo_host::DevBuf ws[12];                                      // render workspaces (grow-only)

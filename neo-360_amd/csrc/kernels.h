@@ -169,7 +169,7 @@ size_t tp_proj_bytes(long texels);    // pre-projected map: 256 fp32 channels pe
 void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipStream_t s);
 // G (texels, 256) = latent_cl (texels, 512) . [W0_loc | W3_loc]^T from the fp32 fragment pack's stage X
 void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
-                          hipStream_t s);
+                          hipStream_t s, int channels = 256);
 void launch_tp_mlp_pc(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
                       const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
                       const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s);
@@ -183,7 +183,9 @@ size_t pix_bias_floats();
 size_t pix_heads_floats();
 void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack_h, float* bias, float* heads,
                        hipStream_t s);
-void launch_pix_mlp_h(const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+size_t pix_wproj_bytes();        // fp32 MFMA fragments of pts_linears.0's latent columns (pre-projection, mlp_pix_h.hip)
+void launch_pix_pack_proj(const float* w0, float* wproj, hipStream_t s);
+void launch_pix_mlp_h(const TpMlpHDev& m, const float* proj /* null: gather the latent itself */, const TpScene& sc, const TpViews& views, const float* rays_o,
                       const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N,
                       int chunk, float* out, hipStream_t s);
 

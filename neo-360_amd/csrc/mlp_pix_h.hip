@@ -43,7 +43,13 @@ constexpr int B_0 = 0, B_1 = 128, B_2 = 256, B_3 = 384, B_B = 512, B_V0 = 640, B
 constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 516, HEADS_FLOATS = 520;
 constexpr int NST = 9;                                    // streamed stages: 8 latent, 1 pos_enc
 
-__global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(TpMlpHDev m, TpScene sc, TpViews views,
+// PROJ: the latent is gathered PRE-PROJECTED through pts_linears.0's latent columns (W . bilerp(F) = bilerp(W . F), as
+// in mlp_tp_hp.hip): G = F . W0_loc^T, 128 channels = 512 B per texel instead of 2 KB; its two 64-channel chunks are
+// blended into an fp32 LDS tile and ADDED to the L0 accumulators, and only the pos_enc stage (4 of the 36 k-steps of
+// the first layer) is still multiplied per point.
+template <bool PROJ>
+__global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(TpMlpHDev m, const float* __restrict__ proj,
+                                                      TpScene sc, TpViews views,
                                                       const float* __restrict__ rays_o,
                                                       const float* __restrict__ rays_d,
                                                       const float* __restrict__ viewdirs,
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
-        tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
+        tp::view_descriptors<PROJ ? 512 : 2048>(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
             const int di = p * 32 + (f ^ (p & 31));     // lane = p: XOR keeps the 64 lanes on distinct banks
             dsum[di] = v == 0 ? val : dsum[di] + val;   // (p, f) is owned by one thread in every view
         });
@@ -101,7 +107,109 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         f32x16 accx[1][2];
         bias_tile(accx[0][0], m.bias + B_0, L.wv, L);
         accx[0][1] = accx[0][0];
-        {
+        if constexpr (PROJ) {
+            const int col4 = tid & 15, rg = tid >> 4;
+            const uint32_t lane_b = 16u * col4;
+            float* fb = smem + tp::OFF_ACT;                       // two fp32 [64][64] chunk tiles = the 32 KB of `act`
+            f32x4 tap[2][2][4];                                   // two tap sets in flight (half a chunk each)
+            auto issue = [&](int set, int c, int hf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+                    const int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
+                    tap[set][i][0] = tp::load_tap(proj, (uint32_t)off.x + lane_b + 256u * c);
+                    tap[set][i][1] = tp::load_tap(proj, (uint32_t)off.y + lane_b + 256u * c);
+                    tap[set][i][2] = tp::load_tap(proj, (uint32_t)off.z + lane_b + 256u * c);
+                    tap[set][i][3] = tp::load_tap(proj, (uint32_t)off.w + lane_b + 256u * c);
+                }
+            };
+            auto finish = [&](int set, int c, int hf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = rg + 16 * (2 * hf + i);
+                    const f32x4 val = blend4(tap[set][i], *reinterpret_cast<const f32x4*>(loc_w + row * 4));
+                    *reinterpret_cast<f32x4*>(fb + c * (TM * 64) + row * 64 + ((col4 ^ (row & 15)) << 2)) = val;
+                }
+            };
+            // weights of the pos_enc stage: k-steps 32..35 of the packed first layer, both halves resident
+            h8 wh[4], wl[4];
+            {
+                const char* wxb = reinterpret_cast<const char*>(wp + PX_X);
+                const uint32_t wx_off = (uint32_t)(L.wv * KSX * 2 * 64 + L.lane) * 16u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wh[u] = *reinterpret_cast<const h8*>(wxb + (wx_off + 2048u * (32 + u)));
+                    wl[u] = *reinterpret_cast<const h8*>(wxb + (wx_off + 2048u * (32 + u) + 1024u));
+                }
+            }
+            issue(0, 0, 0);
+            issue(1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(0, 0, 0);
+            issue(0, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(1, 0, 1);
+            issue(1, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(0, 1, 0);
+            finish(1, 1, 1);
+            __syncthreads();
+            // this wave's pieces of both chunks (channel order: tp_hp_layout.h:proj_index) -> accumulators
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int row = mt * 32 + L.l31;
+                        const int piece = L.wv * 4 + gg * 2 + L.half;
+                        const f32x4 val = *reinterpret_cast<const f32x4*>(fb + c * (TM * 64) + row * 64 + ((piece ^ (row & 15)) << 2));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accx[0][mt][4 * (2 * c + gg) + e] += val[e];
+                    }
+            __syncthreads();
+            // pos_enc of the camera-frame point into the first stage tile, then its 4 k-steps
+            {
+                const HT buf = xbuf(0);
+                const int row = tid & 63, q = tid >> 6;
+                const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], 0.0f};
+                range_see(L, xc[0]); range_see(L, xc[1]); range_see(L, xc[2]);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int ch = hf * 4 + q;
+                    h8 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        _Float16 h, l;
+                        split(pe_feature<3>(xc, ch * 8 + e), h, l);
+                        vh[e] = h;
+                        vl[e] = l;
+                    }
+                    const int o = chunk_off<64>(row, ch);
+                    *reinterpret_cast<h8*>(buf.hi + o) = vh;
+                    *reinterpret_cast<h8*>(buf.lo + o) = vl;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const HT tile = xbuf(0);
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<64>(mt * 32 + L.l31, (u << 1) + L.half);
+                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    accx[0][mt] = NEO_MFMA_H(wl[u], bh[mt], accx[0][mt]);
+                    accx[0][mt] = NEO_MFMA_H(wh[u], bl[mt], accx[0][mt]);
+                    accx[0][mt] = NEO_MFMA_H(wh[u], bh[mt], accx[0][mt]);
+                }
+            }
+            __syncthreads();
+        } else {
             const int col4 = tid & 15, rg = tid >> 4;
             const uint32_t lane_b = 16u * col4;
             f32x4 tap[2][4];
@@ -358,15 +466,27 @@ void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack
     cp(w[7], 128, heads + HD_DW); cp(b[7], 1, heads + HD_DB); cp(w[8], 384, heads + HD_RW); cp(b[8], 3, heads + HD_RB);
 }
 
-void launch_pix_mlp_h(const TpMlpHDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
+size_t pix_wproj_bytes() { return (size_t)4 * 64 * 64 * 16; }        // 4 N-tiles x 64 k-chunks of 8 x 64 lanes x 4 floats
+
+void launch_pix_pack_proj(const float* w0, float* wproj, hipStream_t s) {
+    // fp32 MFMA fragments (mlp_tp.hip:pack_block order) of pts_linears.0[:, 63:575]: the latent columns of the 575-wide input
+    const PackSegs latent = {{0, 0, 0}, {512, 0, 0}, {63, 0, 0}};
+    pack_block(w0, 575, 128, 64, 0, latent, wproj, s);
+}
+
+void launch_pix_mlp_h(const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views, const float* rays_o,
                       const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N,
                       int chunk, float* out, hipStream_t s) {
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = tp::LDS_WORDS * sizeof(float);
     const long tiles = tp::xcd_grid((P + TM - 1) / TM);
-    hipLaunchKernelGGL(k_pix_mlp_h, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d, viewdirs,
-                       tvals, t_shared, R, N, chunk, reinterpret_cast<float4*>(out));
+    if (proj)
+        hipLaunchKernelGGL(k_pix_mlp_h<true>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, t_shared, R, N, chunk, reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL(k_pix_mlp_h<false>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, t_shared, R, N, chunk, reinterpret_cast<float4*>(out));
 }
 
 }  // namespace neo

@@ -418,14 +418,15 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 // One workgroup = 64 texels (2 M-tiles), wave w = N-tiles 2w, 2w+1.  B fragments come straight from global memory
 // (16 B per lane at a 2 KB row pitch: every line is consumed over four consecutive chunks); the kernel is bound by
 // the 64-cycle fp32 MFMA (60 GFLOP per MLP at 640x480 sources: ~1 ms).
+template <int NTW>      // N-tiles per wave: 2 -> 256 outputs per texel (NeRF_TP: [W0_loc | W3_loc]), 1 -> 128 (PixelNeRF: W0_loc)
 __global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restrict__ F, const f32x4* __restrict__ wx, int KC,
                                                            long T, float* __restrict__ G) {
     LaneCtx L;
     L.init();
     const long t0 = (long)blockIdx.x * 64;
-    f32x16 acc[2][2];
+    f32x16 acc[NTW][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NTW; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -439,31 +440,31 @@ __global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restric
     }
 #pragma unroll 2
     for (int c = 0; c < 64; ++c) {
-        f32x4 a[2], b[2];
+        f32x4 a[NTW], b[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) a[nt] = wx[((2 * L.wv + nt) * KC + c) * 64 + L.lane];
+        for (int nt = 0; nt < NTW; ++nt) a[nt] = wx[((NTW * L.wv + nt) * KC + c) * 64 + L.lane];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) b[mt] = *reinterpret_cast<const f32x4*>(frow[mt] + 8 * c);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = NEO_MFMA(a[nt][e], b[mt][e], acc[nt][mt]);
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const long t = t0 + mt * 32 + L.l31;
             if (t >= T) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int o = (2 * L.wv + nt) * 32 + 8 * g + 4 * L.half;
+                const int o = (NTW * L.wv + nt) * 32 + 8 * g + 4 * L.half;
                 f32x4 val;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) val[e] = acc[nt][mt][4 * g + e];
-                *reinterpret_cast<f32x4*>(G + t * 256 + proj_index(o)) = val;
+                *reinterpret_cast<f32x4*>(G + t * (NTW * 128) + proj_index(o)) = val;
             }
         }
 }
@@ -500,10 +501,14 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipS
 }
 
 void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
-                          hipStream_t s) {
+                          hipStream_t s, int channels) {
     if (texels <= 0) return;
-    hipLaunchKernelGGL(k_tp_preproject, dim3((unsigned)((texels + 63) / 64)), dim3(256), 0, s, latent_cl,
-                       reinterpret_cast<const f32x4*>(wpack_f32_stage_x), kc_x, texels, proj);
+    if (channels == 128)
+        hipLaunchKernelGGL(k_tp_preproject<1>, dim3((unsigned)((texels + 63) / 64)), dim3(256), 0, s, latent_cl,
+                           reinterpret_cast<const f32x4*>(wpack_f32_stage_x), kc_x, texels, proj);
+    else
+        hipLaunchKernelGGL(k_tp_preproject<2>, dim3((unsigned)((texels + 63) / 64)), dim3(256), 0, s, latent_cl,
+                           reinterpret_cast<const f32x4*>(wpack_f32_stage_x), kc_x, texels, proj);
 }
 
 void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,

@@ -514,11 +514,17 @@ class PixelNeRF(_HipModule):
         self.fine_mlp = PixelNeRFMLP(min_deg_point, max_deg_point, deg_view)
         self._scene_key = None
         self._scene_ctx = None
+        # gather the latent pre-projected through each MLP's first layer (128 instead of 512 channels per tap, 41 % fewer
+        # MACs per point-view; csrc/mlp_pix_h.hip).  False: the reference's operation order.
+        self.preproject = os.environ.get("NEO360_PIX_PREPROJECT", "1") != "0"
 
     def _context(self, device):
         ctx = super()._context(device)
         if getattr(ctx, "_precision", None) != "f16x3":
             raise _lib.NeoError("the PixelNeRF evaluator exists in the split-fp16 arithmetic only (precision 'f16x3')")
+        if getattr(ctx, "_pix_preproject", None) != bool(self.preproject):
+            _lib.check(ctx.lib.neo_pix_set_preproject(ctx.handle, int(bool(self.preproject))))
+            ctx._pix_preproject = bool(self.preproject)
         return ctx
 
     def _sync_weights(self, ctx):

@@ -14,16 +14,18 @@ TOL = 1e-4
 PER_RAY = ("rays_o", "rays_d", "viewdirs")
 
 
-def _net(gain=1.0):
+def _net(gain=1.0, preproject=True):
     scene = cases.small_scene()
     net = models.PixelNeRF(num_src_views=cases.NV).to(DEV)
+    net.preproject = preproject                 # True: latent pre-projected through the first layer (default); False: the reference's order
     net.load_state_dict(synth.pixelnerf_state(0, density_gain=gain))
     net.set_scene(scene["latent"].to(DEV), scene["image_wh"])
     return net, scene
 
 
-def test_mlp_stage_matches_oracle_and_reproduces_direction_tiling():
-    net, scene = _net()
+@pytest.mark.parametrize("preproject", [True, False])
+def test_mlp_stage_matches_oracle_and_reproduces_direction_tiling(preproject):
+    net, scene = _net(preproject=preproject)
     params = synth.pixelnerf_state(0)
     batch = cases.neo_batch(cases.strided_rays(128))
     gb = {k: v.to(DEV) for k, v in batch.items()}
@@ -45,9 +47,10 @@ def test_mlp_stage_matches_oracle_and_reproduces_direction_tiling():
 
 @pytest.mark.parametrize("tag,n_rays,chunk,gain,white", [("a", 300, 256, 1.0, False), ("sharp", 128, 128, 8.0, False),
                                                          ("white", 96, 96, 1.0, True)])
-def test_end_to_end_vs_reference_fixture(golden, tag, n_rays, chunk, gain, white):
+@pytest.mark.parametrize("preproject", [True, False])
+def test_end_to_end_vs_reference_fixture(golden, tag, n_rays, chunk, gain, white, preproject):
     g = golden("g7_pixelnerf")
-    net, _ = _net(gain)
+    net, _ = _net(gain, preproject)
     batch = {k: v.to(DEV) for k, v in cases.neo_batch(cases.strided_rays(n_rays)).items()}
     got = {k: [] for k in ("rgb0", "acc0", "depth0", "rgb1", "acc1", "depth1")}
     for i in range(0, n_rays, chunk):
@@ -60,3 +63,23 @@ def test_end_to_end_vs_reference_fixture(golden, tag, n_rays, chunk, gain, white
     # the whole-frame call with the chunk passed down reproduces the chunk loop bit for bit
     whole = render.render_rays_test(net, batch, chunk=chunk, white_bkgd=white, near=0.2, far=2.5)
     assert max_abs(whole["rgb"], torch.cat(got["rgb1"])) == 0.0 and max_abs(whole["depth"], torch.cat(got["depth1"])) == 0.0
+
+
+def test_preprojection_is_a_reassociation():
+    """Both operation orders agree to fp32 rounding on the per-point outputs, and new weights / a new latent rebuild the
+    projected map (the module re-uploads on parameter changes; the library tracks scene and weight epochs)."""
+    a, scene = _net(preproject=True)
+    b, _ = _net(preproject=False)
+    gb = {k: v.to(DEV) for k, v in cases.neo_batch(cases.strided_rays(64)).items()}
+    t = torch.sort(torch.rand(64, 65, generator=torch.Generator().manual_seed(4)) * 2.3 + 0.2, dim=-1).values.to(DEV)
+    ya, yb = a.eval_mlp(1, gb, t), b.eval_mlp(1, gb, t)
+    assert 0.0 < max_abs(ya, yb) < 5e-6
+    with torch.no_grad():
+        for net in (a, b):
+            net.fine_mlp.pts_linears[0].weight.mul_(1.25)
+    ya2, yb2 = a.eval_mlp(1, gb, t), b.eval_mlp(1, gb, t)
+    assert max_abs(ya2, ya) > 1e-4 and max_abs(ya2, yb2) < 5e-6
+    for net in (a, b):
+        net.set_scene(scene["latent"].to(DEV) * 0.5, scene["image_wh"])
+    ya3, yb3 = a.eval_mlp(1, gb, t), b.eval_mlp(1, gb, t)
+    assert max_abs(ya3, ya2) > 1e-4 and max_abs(ya3, yb3) < 5e-6
