@@ -38,6 +38,15 @@
 #ifndef NEO_TP_PC_DEFAULT
 #define NEO_TP_PC_DEFAULT 0   // 1: k_tp_mlp_pc (producer / consumer wave groups); $NEO_TP_PC overrides
 #endif
+#ifndef NEO_TP_XSTREAM
+#define NEO_TP_XSTREAM 2      // streamed-stage weight fragments in a ring this many k-steps ahead (0: the one-k-step scheme)
+#endif
+#ifndef NEO_TP_TSTREAM
+#define NEO_TP_TSTREAM 6      // the tail GEMMs (bottleneck, view layers) as one weight stream this many k-steps ahead (0: per-stage loops)
+#endif
+#ifndef NEO_TP_LSTREAM
+#define NEO_TP_LSTREAM 4      // L1..L3 as one weight stream requested this many k-steps ahead across the layer barriers (0: per-layer loops)
+#endif
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
 // tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
@@ -219,6 +228,44 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 *reinterpret_cast<h8*>(buf.hi + o) = vh;
                 *reinterpret_cast<h8*>(buf.lo + o) = vl;
             };
+#if NEO_TP_XSTREAM
+            // streamed-stage weights: k-steps 0..KSX-1 of N-tiles wv (L0) and 4 + wv (L3 skip) in a ring, XD k-steps ahead
+            constexpr int XD = NEO_TP_XSTREAM, XS = XD + 1;
+            h8 wh[XS][2], wl[XS][2];
+            const char* wxb = reinterpret_cast<const char*>(wp + hoff_x());
+            uint32_t wx_off[2];
+            wx_off[0] = (uint32_t)(L.wv * KSX * 2 * 64 + L.lane) * 16u;
+            wx_off[1] = (uint32_t)((4 + L.wv) * KSX * 2 * 64 + L.lane) * 16u;
+            auto load_wk = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks < KSX) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        wh[ks % XS][nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks));
+                        wl[ks % XS][nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks + 1024u));
+                    }
+                }
+            };
+            auto mma_k = [&](const HT& tile, auto kc) __attribute__((always_inline)) {      // k-step ks: tile k-step ks % 4
+                constexpr int ks = decltype(kc)::value;
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<64>(mt * 32 + L.l31, ((ks % 4) << 1) + L.half);
+                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
+                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        accx[nt][mt] = NEO_MFMA_H(wl[ks % XS][nt], bh[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[ks % XS][nt], bl[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[ks % XS][nt], bh[mt], accx[nt][mt]);
+                    }
+                load_wk(std::integral_constant<int, ks + XD>());
+            };
+#else
             h8 wh[2], wl[2];                                   // one k-step x 2 N-tiles, hi + lo
             const char* wxb = reinterpret_cast<const char*>(wp + hoff_x());
             uint32_t wx_off[2];
@@ -251,22 +298,47 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     }
             };
 
+#endif
             // ---- the flat gather pipeline ----
             static_for<0, RING - 1>([&](auto ic) { issue(ic); });
             static_for<0, NI>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 issue(std::integral_constant<int, i + RING - 1>());
                 if constexpr (i == 4 || i == 8 || i == 12 || i == 16) consume_chunk(std::integral_constant<int, i / 4 - 1>());
+#if NEO_TP_XSTREAM
+                if constexpr (i == 16) static_for<0, XD>([&](auto kc) { load_wk(kc); });
+                if constexpr (i >= 28 && (i - 28) % 3 == 0) mma_k(xbuf(0), std::integral_constant<int, (i - 28) / 3>());
+#else
                 if constexpr (i == 16) load_wq(0);
                 if constexpr (i >= 28 && (i - 28) % 3 == 0) {          // world stage 1 is gathered: multiply stage 0
                     constexpr int q = (i - 28) / 3;
                     mma_q(xbuf(0), q);
                     load_wq(q + 1);
                 }
+#endif
                 finish(ic);
                 __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
                 if constexpr (i == 3 || i == 7 || i == 11 || i == 15 || i == 27 || i == 39) TP_SYNC();
             });
+#if NEO_TP_XSTREAM
+            // ---- world stage 1 is multiplied while the first pos_enc stage is computed; then the pos_enc stage(s) ----
+            static_for<4, 8>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                mma_k(xbuf(1), kc);
+                if constexpr (ks & 1) finish_pe(xbuf(0), 0, (ks - 4) >> 1);
+            });
+            TP_SYNC();
+            static_for<8, 12>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                mma_k(xbuf(0), kc);
+                if constexpr (NPE == 2 && ks == 9) finish_pe(xbuf(1), 1, 0);      // features 64..95 (84..95 are padding)
+            });
+            TP_SYNC();
+            if constexpr (NPE == 2) {
+                static_for<12, 14>([&](auto kc) { mma_k(xbuf(1), kc); });
+                TP_SYNC();
+            }
+#else
             // ---- world stage 1 is multiplied while the first pos_enc stage is computed ----
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
@@ -291,7 +363,72 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 }
                 TP_SYNC();
             }
+#endif
         }
+#if NEO_TP_LSTREAM
+        // ---- L0 epilogue; L1, L2, L3 as ONE weight stream of 24 k-steps (N-tile = wave) requested LD k-steps ahead
+        //      across the layer boundaries: the weights of the next layer do not wait for the barriers ----
+        constexpr int LD = NEO_TP_LSTREAM, LS = LD + 1;
+        h8 lwh[LS], lwl[LS];
+        const char* lwb = reinterpret_cast<const char*>(wp);
+        const uint32_t lw_off = (uint32_t)(L.wv * 8 * 128 + L.lane) * 16u;
+        auto load_l = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 24) {
+                constexpr int layer = g / 8, ks = g % 8;
+                constexpr uint32_t base = (uint32_t)(layer == 0 ? hoff_1(PE_C) : layer == 1 ? hoff_2(PE_C) : hoff_3a(PE_C)) * 16u;
+                lwh[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks));
+                lwl[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks + 1024u));
+            }
+        };
+        static_for<0, LD>([&](auto gc) { load_l(gc); });
+        f32x16 acc[1][2];
+        store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
+        store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
+        TP_SYNC();
+        static_for<0, 24>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int layer = g / 8, ks = g % 8;
+            if constexpr (ks == 0) {
+                if constexpr (layer < 2) {
+                    bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : B_2), L.wv, L);
+                    acc[0][1] = acc[0][0];
+                } else {
+                    acc[0][0] = accx[1][0];
+                    acc[0][1] = accx[1][1];
+                }
+            }
+            load_l(std::integral_constant<int, g + LD>());
+            h8 bh[2], bl[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int o = chunk_off<128>(mt * 32 + L.l31, (ks << 1) + L.half);
+                bh[mt] = *reinterpret_cast<const h8*>(act.hi + o);
+                bl[mt] = *reinterpret_cast<const h8*>(act.lo + o);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[0][mt] = NEO_MFMA_H(lwl[g % LS], bh[mt], acc[0][mt]);
+                acc[0][mt] = NEO_MFMA_H(lwh[g % LS], bl[mt], acc[0][mt]);
+                acc[0][mt] = NEO_MFMA_H(lwh[g % LS], bh[mt], acc[0][mt]);
+            }
+            if constexpr (ks == 7) {
+                if constexpr (layer < 2) {
+                    TP_SYNC();
+                    store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
+                    store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
+                    TP_SYNC();
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
+                        hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#else
         // ---- L0 epilogue, L1, L2 ----
         f32x16 acc[1][2];
         if (!(NEO_TP_ABLATE & 128)) {
@@ -320,6 +457,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
             hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
         }
+#endif
         TP_SYNC();           // every wave is done reading this view's tiles
     }
 
@@ -354,6 +492,83 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         sg += __shfl_xor(sg, 2, 64);
         raw_sigma = sg + m.heads[HD_DB];
     }
+#if NEO_TP_TSTREAM
+    // ---- tail GEMMs as one weight stream of 22 k-steps, TD ahead across the stage boundaries:
+    //      bottleneck of the view mean (N-tile cw, 8 k-steps, both M-tiles), view layer 0 on [mean bottleneck | mean dir enc]
+    //      (N-tile vnt, M-tile vmt, 8 + 2 k-steps), 64 x 64 (4 k-steps) ----
+    {
+        const char* twb = reinterpret_cast<const char*>(wp);
+        constexpr int TD = NEO_TP_TSTREAM, TS = TD + 1;
+        h8 twh[TS], twl[TS];
+        auto load_t = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 22) {
+                constexpr int stage = g < 8 ? 0 : g < 18 ? 1 : 2;
+                constexpr int ks = stage == 0 ? g : stage == 1 ? g - 8 : g - 18;
+                constexpr int KS = stage == 0 ? 8 : stage == 1 ? 10 : 4;
+                constexpr uint32_t base = (uint32_t)(stage == 0 ? hoff_b(PE_C) : stage == 1 ? hoff_v0(PE_C) : hoff_v1(PE_C)) * 16u;
+                const int nt = stage == 0 ? L.wv : vnt;
+                const uint32_t off = base + (uint32_t)((nt * KS + ks) * 128 + L.lane) * 16u;
+                twh[g % TS] = *reinterpret_cast<const h8*>(twb + off);
+                twl[g % TS] = *reinterpret_cast<const h8*>(twb + off + 1024u);
+            }
+        };
+        static_for<0, TD>([&](auto gc) { load_t(gc); });
+        f32x16 acc2[2], y;
+        static_for<0, 22>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            load_t(std::integral_constant<int, g + TD>());
+            if constexpr (g < 8) {
+                if constexpr (g == 0) {
+                    bias_tile(acc2[0], m.bias + B_B, L.wv, L);
+                    acc2[1] = acc2[0];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<128>(mt * 32 + L.l31, (g << 1) + L.half);
+                    const h8 bh = *reinterpret_cast<const h8*>(act.hi + o);
+                    const h8 bl = *reinterpret_cast<const h8*>(act.lo + o);
+                    acc2[mt] = NEO_MFMA_H(twl[g % TS], bh, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bl, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bh, acc2[mt]);
+                }
+                if constexpr (g == 7) {
+                    __syncthreads();
+                    store_tile_h<false>(acc2[0], act, L.wv, 0, L);
+                    store_tile_h<false>(acc2[1], act, L.wv, 1, L);
+                    __syncthreads();
+                }
+            } else {
+                constexpr bool v0 = g < 18;
+                constexpr int ks = v0 ? g - 8 : g - 18;
+                if constexpr (ks == 0) bias_tile(y, m.bias + (v0 ? B_V0 : B_V1), vnt, L);
+                h8 bh, bl;
+                if constexpr (v0 && ks >= 8) {
+                    const int o = chunk_off<32>(vmt * 32 + L.l31, ((ks - 8) << 1) + L.half);
+                    bh = *reinterpret_cast<const h8*>(dsm.hi + o);
+                    bl = *reinterpret_cast<const h8*>(dsm.lo + o);
+                } else {
+                    const int o = chunk_off<128>(vmt * 32 + L.l31, (ks << 1) + L.half);
+                    bh = *reinterpret_cast<const h8*>(act.hi + o);
+                    bl = *reinterpret_cast<const h8*>(act.lo + o);
+                }
+                y = NEO_MFMA_H(twl[g % TS], bh, y);
+                y = NEO_MFMA_H(twh[g % TS], bl, y);
+                y = NEO_MFMA_H(twh[g % TS], bh, y);
+                if constexpr (g == 17) {
+                    __syncthreads();
+                    store_tile_h<true>(y, act, vnt, vmt, L);
+                    __syncthreads();
+                }
+                if constexpr (g == 21) {
+                    __syncthreads();
+                    store_tile_h<true>(y, act, vnt, vmt, L);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+#else
     // ---- bottleneck of the view mean (no activation) ----
     {
         f32x16 acc[1][2];
@@ -381,6 +596,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         __syncthreads();
         store_tile_h<true>(y, act, vnt, vmt, L);
     }
+#endif
     __syncthreads();
     {
         const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
