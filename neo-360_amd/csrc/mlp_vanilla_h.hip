@@ -89,14 +89,44 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 #ifndef NEO_VH_TILE_DEFAULT
 #define NEO_VH_TILE_DEFAULT 64   // points per workgroup: 64 (two workgroups per CU) or 128 (one; $NEO_VANILLA_H_TILE)
 #endif
+#ifndef NEO_VH_XLAYER
+#define NEO_VH_XLAYER 1        // the next stage's first weight fragments are requested before this stage's barrier
+#endif
 #ifndef NEO_VH_PREFETCH
 #define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
 #endif
+// Weight-fragment ring of a wave (NB slots x NTW N-tiles, hi + lo).  It lives in the kernel's scope so that the first
+// D k-steps of the NEXT stage can be requested before this stage's barrier (NEO_VH_XLAYER): weights do not depend on the
+// activations, and at a layer boundary nothing else is in flight.
+template <int NTW>
+struct WRing {
+    static constexpr int D = NEO_VH_PREFETCH, NB = D + 1;
+    h8 ah[NB][NTW], al[NB][NTW];
+};
+
+template <int NTW>
+__device__ __forceinline__ void ring_load(WRing<NTW>& r, int slot, const char* wb, int KS, int nt0, int ks, const LaneCtx& L) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const uint32_t off = (uint32_t)(((nt0 + nt) * KS + ks) * 128 + L.lane) * 16u;
+        r.ah[slot][nt] = *reinterpret_cast<const h8*>(wb + off);
+        r.al[slot][nt] = *reinterpret_cast<const h8*>(wb + off + 1024u);
+    }
+}
+// first D k-steps of a stage into slots 0..D-1 (what gemm_h expects when told `preloaded`)
+template <int NTW>
+__device__ __forceinline__ void ring_prime(WRing<NTW>& r, const h8* wp, int KS, int nt0, int ks0, const LaneCtx& L) {
+#pragma unroll
+    for (int d = 0; d < WRing<NTW>::D; ++d) ring_load(r, d, reinterpret_cast<const char*>(wp), KS, nt0, ks0 + d, L);
+}
+
 template <int NTW, int MTW, int LDH, int KM>
 __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __restrict__ wp, int KS, int nt0, int mt0,
-                                       int ks0, int n, const HTile& tile, const LaneCtx& L) {
-    constexpr int D = NEO_VH_PREFETCH, NB = D + 1;
-    h8 ah[NB][NTW], al[NB][NTW];
+                                       int ks0, int n, const HTile& tile, const LaneCtx& L, WRing<NTW>& ring,
+                                       bool preloaded = false) {
+    constexpr int D = WRing<NTW>::D, NB = WRing<NTW>::NB;
+    auto& ah = ring.ah;
+    auto& al = ring.al;
     // SGPR base + 32-bit VGPR byte offset; one k-step = 2 KB (hi 1 KB | lo 1 KB) further along an N-tile's stream
     const char* wb = reinterpret_cast<const char*>(wp);
     uint32_t off[NTW];
@@ -109,9 +139,11 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW][MTW], const h8* __rest
             al[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s + 1024u));
         }
     };
+    if (!preloaded) {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < n) load_w(d, d);
+        for (int d = 0; d < D; ++d)
+            if (d < n) load_w(d, d);
+    }
 #if NEO_VH_SETPRIO
     __builtin_amdgcn_s_setprio(NEO_VH_SETPRIO);      // matrix phase: issue ahead of the co-resident wave's epilogue VALU work
 #endif
@@ -288,9 +320,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
 
     f32x16 acc[NTW][MT];
     const int nt0 = L.wv * NTW;
+    WRing<NTW> ring;
+    constexpr bool XL = NEO_VH_XLAYER != 0 && (16 % WRing<NTW>::NB) == 0 && (4 % WRing<NTW>::NB) == 0;   // stages end on slot 0
     // ---- L0: 63 -> 256 ----
     init_bias<NTW, MT>(acc, m.bias + stage_b_off(0), nt0, L);
-    gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 0, 4, side, L);
+    gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 0, 4, side, L, ring);
+    if (XL) ring_prime(ring, wp + stage_w_off(1), 16, nt0, 0, L);
     store_act<NTW, MT, true>(acc, act, nt0, 0, L);      // the activation planes are idle here
     VH_SYNC();
     // ---- L1..L7 (skip concat feeds L5) ----
@@ -299,8 +334,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
         const int woff = stage_w_off(1) + (s - 1) * (8 * 16 * 128) + (s > 5 ? 8 * 4 * 128 : 0);
         const int KS = s == 5 ? 20 : 16;
         init_bias<NTW, MT>(acc, m.bias + s * 256, nt0, L);
-        gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 0, 16, act, L);
-        if (s == 5) gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L);
+        gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + woff, KS, nt0, 0, 0, 16, act, L, ring, XL);
+        if (s == 5) {
+            if (XL) ring_prime(ring, wp + woff, KS, nt0, 16, L);
+            gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L, ring, XL);
+        }
+        if (XL) {          // next stage: L(s+1) (its stream is 20 k-steps long for s + 1 == 5), or the bottleneck after L7
+            const int nwoff = s < 7 ? stage_w_off(1) + s * (8 * 16 * 128) + (s + 1 > 5 ? 8 * 4 * 128 : 0) : stage_w_off(8);
+            ring_prime(ring, wp + nwoff, s + 1 == 5 ? 20 : 16, nt0, 0, L);
+        }
         VH_SYNC();
         store_act<NTW, MT, true>(acc, act, nt0, 0, L);
         if (s == 5) {
@@ -352,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
     }
     // ---- bottleneck: 256 -> 256, no activation ----
     init_bias<NTW, MT>(acc, m.bias + stage_b_off(8), nt0, L);
-    gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L);
+    gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L, ring, XL);
     VH_SYNC();
     store_act<NTW, MT, false>(acc, act, nt0, 0, L);
     VH_SYNC();
@@ -361,9 +403,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
         constexpr int MTV = NW == 8 ? 1 : MT;
         const int ntv = L.wv & 3, mtv = NW == 8 ? (L.wv >> 2) : 0;
         f32x16 accv[1][MTV];
+        WRing<1> vring;
         init_bias<1, MTV>(accv, m.bias + stage_b_off(9), ntv, L);
-        gemm_h<1, MTV, ACT_LDH, 15>(accv, wp + stage_w_off(9), 18, ntv, mtv, 0, 16, act, L);
-        gemm_h<1, MTV, SIDE_LDH, 7>(accv, wp + stage_w_off(9), 18, ntv, mtv, 16, 2, side, L);
+        gemm_h<1, MTV, ACT_LDH, 15>(accv, wp + stage_w_off(9), 18, ntv, mtv, 0, 16, act, L, vring);
+        gemm_h<1, MTV, SIDE_LDH, 7>(accv, wp + stage_w_off(9), 18, ntv, mtv, 16, 2, side, L, vring);
         VH_SYNC();
         store_act<1, MTV, true>(accv, act, ntv, mtv, L);
         VH_SYNC();
