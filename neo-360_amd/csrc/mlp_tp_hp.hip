@@ -38,6 +38,9 @@
 #ifndef NEO_TP_PC_DEFAULT
 #define NEO_TP_PC_DEFAULT 0   // 1: k_tp_mlp_pc (producer / consumer wave groups); $NEO_TP_PC overrides
 #endif
+#ifndef NEO_TP_LDS_BIAS
+#define NEO_TP_LDS_BIAS 1     // biases / head weights staged in LDS once per workgroup
+#endif
 #ifndef NEO_TP_XSTREAM
 #define NEO_TP_XSTREAM 2      // streamed-stage weight fragments in a ring this many k-steps ahead (0: the one-k-step scheme)
 #endif
@@ -103,6 +106,17 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     float* dens_w = smem + tp::OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
+#if NEO_TP_LDS_BIAS
+    // biases and head weights are read from LDS: an accumulator initialisation is on the critical path of every layer
+    float* lbias_w = smem + tp::LDS_WORDS;
+    for (int i = tid; i < 768; i += 256) lbias_w[i] = m.bias[i];
+    for (int i = tid; i < HD_RB + 3; i += 256) lbias_w[768 + i] = m.heads[i];
+    const float* lbias = lbias_w;
+    const float* lheads = lbias_w + 768;
+#else
+    const float* lbias = m.bias;
+    const float* lheads = m.heads;
+#endif
     float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum[tid + 256 * j] = 0.0f;    // (p, f) is accumulated by another thread: zero BEFORE the barrier
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     f32x16 hsum[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; }
-    const int nts_1[1] = {L.wv};
+    [[maybe_unused]] const int nts_1[1] = {L.wv};
     const int vnt = L.wv & 1, vmt = L.wv >> 1;
 
 #pragma unroll 1
@@ -135,9 +149,9 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 
         // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
         f32x16 accx[2][2];
-        bias_tile(accx[0][0], m.bias + B_0, L.wv, L);
+        bias_tile(accx[0][0], lbias + B_0, L.wv, L);
         accx[0][1] = accx[0][0];
-        bias_tile(accx[1][0], m.bias + B_3, L.wv, L);
+        bias_tile(accx[1][0], lbias + B_3, L.wv, L);
         accx[1][1] = accx[1][0];
         {
             const int col4 = tid & 15, rg = tid >> 4;
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             constexpr int layer = g / 8, ks = g % 8;
             if constexpr (ks == 0) {
                 if constexpr (layer < 2) {
-                    bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : B_2), L.wv, L);
+                    bias_tile(acc[0][0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
                     acc[0][1] = acc[0][0];
                 } else {
                     acc[0][0] = accx[1][0];
@@ -438,7 +452,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         TP_SYNC();
 #pragma unroll 1
         for (int layer = 0; layer < 2; ++layer) {
-            bias_tile(acc[0][0], m.bias + (layer == 0 ? B_1 : B_2), L.wv, L);
+            bias_tile(acc[0][0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
             acc[0][1] = acc[0][0];
             if (!(NEO_TP_ABLATE & 16)) gemm2h<1, 128>(acc, wp + (layer == 0 ? hoff_1(PE_C) : hoff_2(PE_C)), 8, nts_1, 0, 0, 8, act, L);
             TP_SYNC();
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         float sg = density_partial(act, dens_w, L);
         sg += __shfl_xor(sg, 1, 64);
         sg += __shfl_xor(sg, 2, 64);
-        raw_sigma = sg + m.heads[HD_DB];
+        raw_sigma = sg + lheads[HD_DB];
     }
 #if NEO_TP_TSTREAM
     // ---- tail GEMMs as one weight stream of 22 k-steps, TD ahead across the stage boundaries:
@@ -520,7 +534,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             load_t(std::integral_constant<int, g + TD>());
             if constexpr (g < 8) {
                 if constexpr (g == 0) {
-                    bias_tile(acc2[0], m.bias + B_B, L.wv, L);
+                    bias_tile(acc2[0], lbias + B_B, L.wv, L);
                     acc2[1] = acc2[0];
                 }
 #pragma unroll
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             } else {
                 constexpr bool v0 = g < 18;
                 constexpr int ks = v0 ? g - 8 : g - 18;
-                if constexpr (ks == 0) bias_tile(y, m.bias + (v0 ? B_V0 : B_V1), vnt, L);
+                if constexpr (ks == 0) bias_tile(y, lbias + (v0 ? B_V0 : B_V1), vnt, L);
                 h8 bh, bl;
                 if constexpr (v0 && ks >= 8) {
                     const int o = chunk_off<32>(vmt * 32 + L.l31, ((ks - 8) << 1) + L.half);
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     // ---- bottleneck of the view mean (no activation) ----
     {
         f32x16 acc[1][2];
-        bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
+        bias_tile(acc[0][0], lbias + B_B, L.wv, L);
         acc[0][1] = acc[0][0];
         gemm2h<1, 128>(acc, wp + hoff_b(PE_C), 8, nts_1, 0, 0, 8, act, L);
         __syncthreads();
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     }
     // ---- view layer 0 on [mean bottleneck | mean dir enc] -> 64 ----
     f32x16 ysum;
-    bias_tile(ysum, m.bias + B_V0, vnt, L);
+    bias_tile(ysum, lbias + B_V0, vnt, L);
     gemm1h<128>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 0, 8, act, L);
     gemm1h<32>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 8, 2, dsm, L);
     __syncthreads();
@@ -591,7 +605,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     __syncthreads();
     {
         f32x16 y;
-        bias_tile(y, m.bias + B_V1, vnt, L);
+        bias_tile(y, lbias + B_V1, vnt, L);
         gemm1h<128>(y, wp + hoff_v1(PE_C), 4, vnt, vmt, 0, 4, act, L);
         __syncthreads();
         store_tile_h<true>(y, act, vnt, vmt, L);
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     __syncthreads();
     {
         const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
-        const float* wr = m.heads + HD_RW;
+        const float* wr = lheads + HD_RW;
         float r = 0.f, g = 0.f, b = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -622,8 +636,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         range_commit(L, m.flags);
         const long gi = tile0 + pt;
         if (part == 0 && gi < P) {
-            out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
-                                  colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));
+            out[gi] = make_float4(colour_act(r + lheads[HD_RB]), colour_act(g + lheads[HD_RB + 1]),
+                                  colour_act(b + lheads[HD_RB + 2]), density_act(raw_sigma));
         }
     }
 }
@@ -742,7 +756,7 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
         const char* e = getenv("NEO_TP_LDS_PAD");
         lds_pad = e ? (size_t)atol(e) : 0;
     }
-    const size_t lds = tp::LDS_WORDS * sizeof(float) + lds_pad;
+    const size_t lds = (tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0)) * sizeof(float) + lds_pad;
     if (lds > 65536) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
