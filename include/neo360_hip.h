@@ -50,6 +50,16 @@ int neo_ctx_destroy(neo_ctx* ctx);
  * sphere — the reference's AssertionError at models/neo360/helper.py:271,:426).
  * Synchronises `stream`.  [flags: host out] */
 int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream);
+/* The same read WITHOUT a synchronisation (what a caller's chunk loop wants: the reference's own loop makes 300
+ * forward calls per frame, neo360/model.py:861-907).  post: enqueue on `stream` a copy of the word into a pinned host
+ * slot + its clear + an event; returns at once.  take: OR of the posted reads that have completed (wait == 0), or of
+ * all posted reads after waiting for their events (wait != 0); a read is reported once.  pending [host out, may be
+ * NULL]: posted reads still in flight after the call.  Up to 64 reads may be outstanding; beyond that the oldest is
+ * retired into the next take.  sync_count: how many blocking waits (stream / event synchronisations) the flag calls
+ * of this context have issued so far - 0 for a loop of post + take(wait = 0). */
+int neo_ctx_post_flags(neo_ctx* ctx, void* stream);
+int neo_ctx_take_flags(neo_ctx* ctx, int wait, uint32_t* flags, int* pending);
+int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits);
 
 /* Arithmetic of the per-point MLP GEMMs of every renderer (vanilla, NeRF_TP, Mip-NeRF 360, PixelNeRF).
  * 1 (the context default, and the default of the Python modules, "f16x3"): fp16 MFMA with every fp32
@@ -176,9 +186,7 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
  * (scene, MLP slot) through the local columns of pts_linears.0 and of pts_linears.3's skip half
  * (W . bilerp(F) = bilerp(W . F): neo360/model.py:110-158 is linear in the latent up to the first ReLU), and
  * the evaluator gathers the 256-channel result; costs 1 KB per latent texel and slot of context memory.
- * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order).
- * enable == 2: as 1, evaluated by the producer / consumer kernel k_tp_mlp_pc (persistent 8-wave workgroups: four waves
- * gather and encode, four run the matrix work; same results up to fp32 summation order, same speed: DESIGN.md 4.3). */
+ * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order). */
 int neo_tp_set_preproject(neo_ctx* ctx, int enable);
 
 /* `predict` + the feature lookups for one region at given sample positions

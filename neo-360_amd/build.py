@@ -31,7 +31,6 @@ EXTRA_FLAGS = {
     "mlp_mip_h.hip": _NO_PK_F32,
     "mlp_pix_h.hip": _NO_PK_F32,
     "mlp_tp_hp.hip": _NO_PK_F32,
-    "mlp_tp_pc.hip": _NO_PK_F32,     # same instruction mix (fp16 MFMA stream next to fp32 VALU producers)
     "pillar.hip": _NO_PK_F32,        # built with packed ops it returned ~20 wrong rows of 786,432, differently on every run (r02)
 }
 
@@ -65,18 +64,29 @@ def build(force=False, verbose=False):
         stamp = op + ".cmd"
         same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
         if force or not same_cmd or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), newest_header):
-            with open(stamp, "w") as f:
-                f.write(" ".join(cmd))
+            # the stale object and its stamp go first; the stamp is written only after a successful compile, so an
+            # interrupted or failed build can never leave an old object next to a new command line
+            for stale in (op, stamp):
+                if os.path.exists(stale):
+                    os.remove(stale)
             if verbose:
                 print(" ".join(cmd))
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            procs.append((src, stamp, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
             rebuilt = True
-    for src, p in procs:
+    failed = []
+    for src, stamp, cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
+            failed.append("hipcc failed on %s:\n%s" % (src, out))
+            continue
+        with open(stamp, "w") as f:
+            f.write(" ".join(cmd))
         if verbose and out.strip():
             print(out)
+    if failed:
+        raise RuntimeError("\n".join(failed))
+    if not rebuilt and os.path.exists(LIB):
+        rebuilt = any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)     # an object newer than the library
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -72,6 +72,22 @@ class Context:
         _lib.check(self.lib.neo_ctx_poll_flags(self.handle, ctypes.byref(flags), self.stream()))
         return flags.value
 
+    def post_flags(self):
+        """Enqueue a read-and-clear of the assertion word on the current stream; no synchronisation."""
+        _lib.check(self.lib.neo_ctx_post_flags(self.handle, self.stream()))
+
+    def take_flags(self, wait=False):
+        """OR of the posted reads that have completed (wait=False) / of all posted reads (wait=True: blocks)."""
+        flags, pending = ctypes.c_uint32(0), ctypes.c_int(0)
+        _lib.check(self.lib.neo_ctx_take_flags(self.handle, 1 if wait else 0, ctypes.byref(flags), ctypes.byref(pending)))
+        return flags.value
+
+    def sync_count(self):
+        """Blocking waits (stream / event synchronisations) the flag calls of this context have issued."""
+        n = ctypes.c_uint64(0)
+        _lib.check(self.lib.neo_ctx_sync_count(self.handle, ctypes.byref(n)))
+        return n.value
+
     def set_precision(self, mode):
         """'f32' (exact fp32 MFMA) or 'f16x3' (fp16 MFMA, hi/lo-split operands, fp32-equivalent)."""
         code = {"f32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]

@@ -117,7 +117,12 @@ int neo_ctx_create(int device, neo_ctx** out) {
     c->device = device;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->flags), sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->flags, 0, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->flag_host), neo_ctx::FLAG_RING * sizeof(uint32_t), hipHostMallocDefault);
+    for (int i = 0; e == hipSuccess && i < neo_ctx::FLAG_RING; ++i) e = hipEventCreateWithFlags(&c->flag_ev[i], hipEventDisableTiming);
     if (e != hipSuccess) {
+        for (auto& ev : c->flag_ev) if (ev) (void)hipEventDestroy(ev);
+        if (c->flag_host) (void)hipHostFree(c->flag_host);
+        if (c->flags) (void)hipFree(c->flags);
         delete c;
         return fail(NEO_ERR_HIP, "context allocation: %s", hipGetErrorString(e));
     }
@@ -147,6 +152,8 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     ctx->latent.release();
     for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
+    for (auto& ev : ctx->flag_ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->flag_host) (void)hipHostFree(ctx->flag_host);
     if (ctx->flags) (void)hipFree(ctx->flags);
     delete ctx;
     return NEO_OK;
@@ -159,6 +166,59 @@ int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream) {
     HIP_TRY(hipMemcpyAsync(flags, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), s));
     HIP_TRY(hipStreamSynchronize(s));
+    ctx->blocking_waits += 1;
+    return NEO_OK;
+}
+
+// Deferred form of the same read: nothing here waits for the device.
+int neo_ctx_post_flags(neo_ctx* ctx, void* stream) {
+    ENTER(ctx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ctx->flag_posted - ctx->flag_taken == neo_ctx::FLAG_RING) {
+        // 64 reads in flight and nobody looked: retire the oldest (it has long completed unless the queue is that deep)
+        const int old = static_cast<int>(ctx->flag_taken % neo_ctx::FLAG_RING);
+        if (hipEventQuery(ctx->flag_ev[old]) != hipSuccess) {
+            HIP_TRY(hipEventSynchronize(ctx->flag_ev[old]));
+            ctx->blocking_waits += 1;
+        }
+        ctx->flag_carry |= ctx->flag_host[old];
+        ctx->flag_taken += 1;
+    }
+    const int slot = static_cast<int>(ctx->flag_posted % neo_ctx::FLAG_RING);
+    HIP_TRY(hipMemcpyAsync(ctx->flag_host + slot, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipEventRecord(ctx->flag_ev[slot], s));
+    ctx->flag_posted += 1;
+    return NEO_OK;
+}
+
+int neo_ctx_take_flags(neo_ctx* ctx, int wait, uint32_t* flags, int* pending) {
+    ENTER(ctx);
+    REQUIRE(flags != nullptr, "null flags");
+    uint32_t acc = ctx->flag_carry;
+    ctx->flag_carry = 0;
+    while (ctx->flag_taken < ctx->flag_posted) {          // posted in stream order: retire oldest first
+        const int slot = static_cast<int>(ctx->flag_taken % neo_ctx::FLAG_RING);
+        hipError_t q = hipEventQuery(ctx->flag_ev[slot]);
+        if (q == hipErrorNotReady) {
+            if (!wait) break;
+            HIP_TRY(hipEventSynchronize(ctx->flag_ev[slot]));
+            ctx->blocking_waits += 1;
+        } else if (q != hipSuccess) {
+            return fail(NEO_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+        }
+        acc |= ctx->flag_host[slot];
+        ctx->flag_taken += 1;
+    }
+    *flags = acc;
+    if (pending) *pending = static_cast<int>(ctx->flag_posted - ctx->flag_taken);
+    return NEO_OK;
+}
+
+int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits) {
+    ENTER(ctx);
+    REQUIRE(blocking_waits != nullptr, "null out pointer");
+    *blocking_waits = ctx->blocking_waits;
     return NEO_OK;
 }
 

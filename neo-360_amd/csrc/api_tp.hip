@@ -54,7 +54,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
             ctx->span_begin(s);
             neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
-                                  chunk, ctx->flags, out, s, ctx->preproject == 2 ? 1 : 0);
+                                  chunk, ctx->flags, out, s);
         } else {
             guard_split_weights(sl, sl.wpack_h.p, neo::tp_wpack_h_bytes(sl.input_ch), ctx->flags, s);
             if (ctx->latent_checked != ctx->scene_epoch) {
@@ -145,7 +145,7 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
 
 int neo_tp_set_preproject(neo_ctx* ctx, int enable) {
     ENTER(ctx);
-    ctx->preproject = enable == 2 ? 2 : (enable != 0);
+    ctx->preproject = enable != 0;
     for (auto& sl : ctx->tp) sl.range_checked = 0;       // the other fragment set is checked at its first launch
     if (!ctx->preproject)
         for (auto& sl : ctx->tp) { sl.proj.release(); sl.proj_weights = sl.proj_scene = 0; }

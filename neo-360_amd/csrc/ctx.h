@@ -139,6 +139,13 @@ struct neo_ctx {
     float enc_head_b[3] = {0.f, 0.f, 0.f};
     neo_host::DevBuf enc_latent, enc_axes, enc_ws[4];
     int precision = 1;   // 1 (default): fp16 MFMA with hi/lo-split operands (fp32-equivalent); 0: exact fp32 MFMA
+    // deferred reads of the flag word (neo_ctx_post_flags / neo_ctx_take_flags): pinned host words + one event each
+    static constexpr int FLAG_RING = 64;
+    uint32_t* flag_host = nullptr;
+    hipEvent_t flag_ev[FLAG_RING] = {};
+    uint64_t flag_posted = 0, flag_taken = 0;    // monotone; slot = index % FLAG_RING
+    uint32_t flag_carry = 0;                     // reads retired early because the ring was full
+    uint64_t blocking_waits = 0;                 // stream / event synchronisations issued by the flag calls
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
     double timed_points = 0.0, timed_flops = 0.0;

@@ -170,12 +170,9 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipS
 // G (texels, 256) = latent_cl (texels, 512) . [W0_loc | W3_loc]^T from the fp32 fragment pack's stage X
 void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
                           hipStream_t s, int channels = 256);
-void launch_tp_mlp_pc(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
-                      const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
-                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s);
 void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
                       const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
-                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s, int variant = 0);
+                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s);
 
 // mlp_pix_h.hip — PixelNeRF baseline decoder evaluator (split-fp16 arithmetic only)
 size_t pix_wpack_h_bytes();

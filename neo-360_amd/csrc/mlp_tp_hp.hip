@@ -35,9 +35,6 @@
 #ifndef NEO_TP_STAGGER_DEFAULT
 #define NEO_TP_STAGGER_DEFAULT 0      // x 64 cycles; $NEO_TP_STAGGER overrides (see k_tp_mlp_hp)
 #endif
-#ifndef NEO_TP_PC_DEFAULT
-#define NEO_TP_PC_DEFAULT 0   // 1: k_tp_mlp_pc (producer / consumer wave groups); $NEO_TP_PC overrides
-#endif
 #ifndef NEO_TP_LDS_BIAS
 #define NEO_TP_LDS_BIAS 1     // biases / head weights staged in LDS once per workgroup
 #endif
@@ -57,6 +54,15 @@
 #define NEO_TP_ABLATE 0
 #endif
 #define TP_SYNC() do { if (!(NEO_TP_ABLATE & 64)) __syncthreads(); } while (0)
+#ifndef NEO_TP_TRACE
+#define NEO_TP_TRACE 0        // 1: per-phase s_memtime sums of wave 0 of every workgroup -> g_tp_trace (tools/tp_phase_trace.py)
+#endif
+#if NEO_TP_TRACE
+__device__ unsigned long long g_tp_trace[16];
+#define TP_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tr_[k] += now_ - tlast_; tlast_ = now_; } while (0)
+#else
+#define TP_MARK(k) do { } while (0)
+#endif
 
 namespace neo {
 
@@ -103,6 +109,9 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     constexpr int KSX = ks_x(PE_C);
     constexpr int NPE = PE_C == 3 ? 1 : 2;     // pos_enc stages of 64 features
 
+#if NEO_TP_TRACE
+    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#endif
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     float* dens_w = smem + tp::OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
@@ -121,6 +130,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum[tid + 256 * j] = 0.0f;    // (p, f) is accumulated by another thread: zero BEFORE the barrier
     __syncthreads();
+    TP_MARK(0);
 
     // view means by linearity (see mlp_tp_h.hip): only sum_v relu(L3_v) and sum_v dir_enc_v are accumulated per view
     f32x16 hsum[2];
@@ -146,6 +156,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             dsum[di] += val;                            // (p, f) is owned by one thread in every view; zeroed before the loop
         });
         TP_SYNC();
+        TP_MARK(1);
 
         // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
         f32x16 accx[2][2];
@@ -319,6 +330,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 constexpr int i = decltype(ic)::value;
                 issue(std::integral_constant<int, i + RING - 1>());
                 if constexpr (i == 4 || i == 8 || i == 12 || i == 16) consume_chunk(std::integral_constant<int, i / 4 - 1>());
+                if constexpr (i == 16) TP_MARK(2);
 #if NEO_TP_XSTREAM
                 if constexpr (i == 16) static_for<0, XD>([&](auto kc) { load_wk(kc); });
                 if constexpr (i >= 28 && (i - 28) % 3 == 0) mma_k(xbuf(0), std::integral_constant<int, (i - 28) / 3>());
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
                 if constexpr (i == 3 || i == 7 || i == 11 || i == 15 || i == 27 || i == 39) TP_SYNC();
             });
+            TP_MARK(3);
 #if NEO_TP_XSTREAM
             // ---- world stage 1 is multiplied while the first pos_enc stage is computed; then the pos_enc stage(s) ----
             static_for<4, 8>([&](auto kc) {
@@ -379,6 +392,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             }
 #endif
         }
+        TP_MARK(4);
 #if NEO_TP_LSTREAM
         // ---- L0 epilogue; L1, L2, L3 as ONE weight stream of 24 k-steps (N-tile = wave) requested LD k-steps ahead
         //      across the layer boundaries: the weights of the next layer do not wait for the barriers ----
@@ -473,6 +487,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         }
 #endif
         TP_SYNC();           // every wave is done reading this view's tiles
+        TP_MARK(5);
     }
 
     // ---- view mean of the trunk -> density head ----
@@ -640,6 +655,14 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                                   colour_act(b + lheads[HD_RB + 2]), density_act(raw_sigma));
         }
     }
+#if NEO_TP_TRACE
+    TP_MARK(6);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_tp_trace[k], tr_[k]);
+        atomicAdd(&g_tp_trace[7], 1ull);
+    }
+#endif
 }
 
 // ---- G = F . [W0_loc | W3_loc]^T: exact fp32 MFMA, once per (scene, MLP) ----------------------------------
@@ -701,6 +724,17 @@ __global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restric
 
 }  // namespace
 
+#if NEO_TP_TRACE
+extern "C" void neo_debug_tp_trace(unsigned long long* host16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_tp_trace), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tp_trace), z, sizeof(z));
+    }
+}
+#endif
+
 size_t tp_wpack_hp_bytes(int input_ch) { return (size_t)hpack_h8(input_ch) * 16; }
 size_t tp_proj_bytes(long texels) { return (size_t)texels * PROJ_TEXEL_BYTES; }
 
@@ -743,7 +777,7 @@ void launch_tp_preproject(const float* latent_cl, long texels, const float* wpac
 
 void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
                       const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
-                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s, int variant) {
+                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s) {
     const long P = (long)R * N;
     if (P <= 0) return;
     static int stagger = -1;
@@ -762,15 +796,6 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const long tiles = tp::xcd_grid((P + TM - 1) / TM);
-    static int env_pc = -1;
-    if (env_pc < 0) {
-        const char* e = getenv("NEO_TP_PC");
-        env_pc = e ? atoi(e) : NEO_TP_PC_DEFAULT;
-    }
-    if (variant == 1 || (variant == 0 && env_pc)) {                 // producer / consumer wave groups (mlp_tp_pc.hip)
-        launch_tp_mlp_pc(input_ch, m, proj, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, flags, out, s);
-        return;
-    }
     if (input_ch == 3)
         hipLaunchKernelGGL(k_tp_mlp_hp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
                            viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), stagger);

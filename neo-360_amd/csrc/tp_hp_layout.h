@@ -1,5 +1,5 @@
-// Layout shared by the NeO-360 evaluators that gather the PRE-PROJECTED latent (mlp_tp_hp.hip: k_tp_mlp_hp, k_tp_preproject;
-// mlp_tp_pc.hip: k_tp_mlp_pc): packed split-fp16 weight stream, bias / head offsets, channel order of the projected map.
+// Layout of the NeO-360 evaluator that gathers the PRE-PROJECTED latent (mlp_tp_hp.hip: k_tp_mlp_hp, k_tp_preproject):
+// packed split-fp16 weight stream, bias / head offsets, channel order of the projected map.
 #pragma once
 #include <type_traits>
 

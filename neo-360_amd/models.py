@@ -105,14 +105,46 @@ class _HipModule(nn.Module):
     # ~3x faster), "f32" = exact fp32 MFMA.  None -> $NEO360_PRECISION or the class default.
     precision = None
     default_precision = "f16x3"
-    # Read the device assertion word after every call (one stream sync): the unit-sphere assertion of NeRF_TP and the
-    # range guard of the split-fp16 arithmetic.  False skips the sync on NeRF / MipNeRF360 / PixelNeRF calls (no
-    # assertion in the reference there); `check_flags()` then reads it on demand.
-    poll_flags = True
+    # The device assertion word (bit 0: the unit-sphere assertion of NeRF_TP, bit 1: the range guard of the split-fp16
+    # arithmetic) is read WITHOUT synchronising by default (no sync inside the call):
+    #   "deferred"  (default) every call enqueues a read-and-clear of the word behind its kernels; reads that have
+    #               completed are looked at when the NEXT call on this module starts, and all of them in
+    #               `check_flags()` (which waits) - render.render_rays_test calls it before returning a frame, and a
+    #               caller running its own chunk loop calls `model.check_flags()` once before it consumes the results;
+    #   "immediate" / True   one stream synchronisation + read after every call: the exception is raised by the very
+    #               call that tripped it, exactly like the reference's assert (300 syncs per frame under a chunk loop);
+    #   "never" / False   no reads at all; `check_flags()` reads the word on demand.
+    poll_flags = "deferred"
+
+    def _flag_mode(self):
+        m = self.poll_flags
+        if m is True or m == "immediate":
+            return "immediate"
+        if m is False or m is None or m == "never":
+            return "never"
+        if m == "deferred":
+            return "deferred"
+        raise ValueError("poll_flags must be 'deferred', 'immediate' (True) or 'never' (False), got %r" % (m,))
 
     def check_flags(self):
+        """Wait for every outstanding read of the assertion word and raise what it reports (AssertionError for a ray
+        that missed the unit sphere, NeoError for the split-fp16 range guard)."""
         for ctx in self._ctx_cache.values():
+            flags = ctx.take_flags(wait=True)
+            if self._flag_mode() == "never":
+                flags |= ctx.poll_flags()
+            self._raise_flags(flags)
+
+    def _before_call(self, ctx):
+        if self._flag_mode() == "deferred":
+            self._raise_flags(ctx.take_flags(wait=False), late=True)      # completed reads of earlier calls; never blocks
+
+    def _after_call(self, ctx):
+        mode = self._flag_mode()
+        if mode == "immediate":
             self._raise_flags(ctx.poll_flags())
+        elif mode == "deferred":
+            ctx.post_flags()
 
     def _context(self, device):
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
@@ -132,14 +164,16 @@ class _HipModule(nn.Module):
         self._ctx_cache.clear()
 
     @staticmethod
-    def _raise_flags(flags):
-        """Device assertion word -> the reference's AssertionError / a NeoError for the split-fp16 range guard."""
+    def _raise_flags(flags, late=False):
+        """Device assertion word -> the reference's AssertionError / a NeoError for the split-fp16 range guard.
+        late: the word was posted by an EARLIER call on this module (deferred mode)."""
+        where = " (raised by an earlier call on this module: poll_flags='deferred')" if late else ""
         if flags & 1:
-            raise AssertionError("1.0 - p_norm_sq should be greater than 0")
+            raise AssertionError("1.0 - p_norm_sq should be greater than 0" + where)
         if flags & 2:
             raise _lib.NeoError(
                 "split-fp16 arithmetic (precision 'f16x3') met an operand outside the fp16 range (|x| >= 65504 or "
-                "non-finite weights / features / activations): results of this call are invalid; use precision 'f32'")
+                "non-finite weights / features / activations): results of that call are invalid; use precision 'f32'" + where)
 
     @staticmethod
     def _check_mode(randomized):
@@ -184,6 +218,7 @@ class NeRF(_HipModule):
         dev = rays_o.device
         ctx = self._context(dev)
         self._sync_weights(ctx)
+        self._before_call(ctx)
         B = rays_o.shape[0]
         outs = [(torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
                 for _ in range(2)]
@@ -192,8 +227,7 @@ class NeRF(_HipModule):
             self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
             ptr(outs[0][0]), ptr(outs[0][1]), ptr(outs[0][2]), ptr(outs[1][0]), ptr(outs[1][1]), ptr(outs[1][2]),
             ctx.stream()))
-        if self.poll_flags:
-            self._raise_flags(ctx.poll_flags())
+        self._after_call(ctx)
         return outs
 
     @torch.no_grad()
@@ -207,8 +241,7 @@ class NeRF(_HipModule):
         out = torch.empty(B, N, 4, device=rays_o.device)
         _lib.check(ctx.lib.neo_vanilla_mlp(ctx.handle, level, ptr(rays_o), ptr(dirs), ptr(t), N, B, N, ptr(out),
                                            ctx.stream()))
-        if self.poll_flags:
-            self._raise_flags(ctx.poll_flags())
+        self._raise_flags(ctx.poll_flags())     # stage-level access: always immediate
         return out
 
 
@@ -281,13 +314,11 @@ class NeRF_TP(_HipModule):
         self._scene_ctx = None
         # split path: gather the latent pre-projected through each MLP's first-layer weights (256 instead of 512
         # channels per tap, 51 % fewer MACs per point-view; see csrc/mlp_tp_hp.hip).  False: the reference's order.
-        # "pc": pre-projected, evaluated by the producer / consumer kernel (k_tp_mlp_pc; an equally fast alternative schedule)
-        env = os.environ.get("NEO360_TP_PREPROJECT", "1")
-        self.preproject = "pc" if env == "pc" else env != "0"
+        self.preproject = os.environ.get("NEO360_TP_PREPROJECT", "1") != "0"
 
     def _context(self, device):
         ctx = super()._context(device)
-        mode = 2 if self.preproject == "pc" else int(bool(self.preproject))
+        mode = int(bool(self.preproject))
         if getattr(ctx, "_preproject", None) != mode:
             _lib.check(ctx.lib.neo_tp_set_preproject(ctx.handle, mode))
             ctx._preproject = mode
@@ -309,13 +340,16 @@ class NeRF_TP(_HipModule):
             ctx.uploaded[("tp", slot)] = fp
 
     @torch.no_grad()
-    def set_scene(self, plane_xz, plane_xy, plane_yz, latent, image_wh, preproject=None):
+    def set_scene(self, plane_xz, plane_xy, plane_yz, latent, image_wh, preproject=None, _source=None):
         """Scene features in the reference's layout: planes (NV,128,Hp,Wp), latent
         (NV,512,Hf,Wf), image_wh = (W,H) of the source images the latent was encoded from
         (neo360/model.py:267-269).  Re-laid out channels-last on the device, once.
         preproject (None = keep `self.preproject`): see that attribute."""
+        src = _source if _source is not None else (plane_xz, plane_xy, plane_yz, latent)
+        self._scene_fp = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in src)
+        self._scene_wh = (float(image_wh[0]), float(image_wh[1]))
         if preproject is not None:
-            self.preproject = "pc" if preproject == "pc" else bool(preproject)
+            self.preproject = bool(preproject)
         planes = [f32(p, "plane") for p in (plane_xz, plane_xy, plane_yz)]
         latent = f32(latent, "latent")
         ctx = self._context(latent.device)
@@ -326,6 +360,21 @@ class NeRF_TP(_HipModule):
                                             ctx.stream()))
         torch.cuda.current_stream(latent.device).synchronize()   # inputs may be freed by the caller
         self._scene_ctx = ctx
+
+    def scene_matches(self, maps):
+        """True when the device-side scene is a copy of exactly these four tensors at their current version."""
+        fp = getattr(self, "_scene_fp", None)
+        return (self._scene_ctx is not None and fp is not None
+                and fp == tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in maps))
+
+    def scene_image_wh(self, rays=None):
+        """(W,H) of the source images: from the last set_scene, else from rays["src_imgs"]."""
+        wh = getattr(self, "_scene_wh", None)
+        if wh is None:
+            if rays is None or "src_imgs" not in rays:
+                raise _lib.NeoError("image size unknown: call set_scene(...) first or pass rays['src_imgs']")
+            wh = (float(rays["src_imgs"].shape[-1]), float(rays["src_imgs"].shape[-2]))
+        return wh
 
     def _ensure_scene(self, rays, dev):
         enc = getattr(self, "encoder", None)
@@ -396,6 +445,7 @@ class NeRF_TP(_HipModule):
         if self._scene_ctx is not ctx:
             raise _lib.NeoError("scene features were uploaded on a different device")
         self._sync_weights(ctx)
+        self._before_call(ctx)
         B = rays_o.shape[0]
         host_poses, NV, focal, cx, cy = self._camera_args(rays)
         if randomized:
@@ -415,7 +465,7 @@ class NeRF_TP(_HipModule):
             ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
             self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)), seed,
             ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
-        self._raise_flags(ctx.poll_flags())
+        self._after_call(ctx)
         out = []
         for t in levels:
             fg_t, bg_t = t["fg_t"], t["bg_t"]
@@ -444,6 +494,7 @@ class NeRF_TP(_HipModule):
         if self._scene_ctx is not ctx:
             raise _lib.NeoError("scene features were uploaded on a different device")
         self._sync_weights(ctx)
+        self._before_call(ctx)
         B = rays_o.shape[0]
         host_poses, NV, focal, cx, cy = self._camera_args(rays)
         levels, structs = [], []
@@ -457,7 +508,7 @@ class NeRF_TP(_HipModule):
             ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
             self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
             ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
-        self._raise_flags(ctx.poll_flags())
+        self._after_call(ctx)
         return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]
 
 
@@ -580,8 +631,7 @@ class PixelNeRF(_HipModule):
         out = torch.empty(B, N, 4, device=rays_o.device)
         _lib.check(ctx.lib.neo_pix_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(tvals), B, N,
                                        int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy, ptr(out), ctx.stream()))
-        if self.poll_flags:
-            self._raise_flags(ctx.poll_flags())
+        self._raise_flags(ctx.poll_flags())     # stage-level access: always immediate
         return out
 
     @torch.no_grad()
@@ -596,6 +646,7 @@ class PixelNeRF(_HipModule):
         if self._scene_ctx is not ctx:
             raise _lib.NeoError("the scene latent was uploaded on a different device")
         self._sync_weights(ctx)
+        self._before_call(ctx)
         B = rays_o.shape[0]
         host_poses, NV, focal, cx, cy = self._camera_args(rays)
         lv = [(torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)) for _ in range(2)]
@@ -603,8 +654,7 @@ class PixelNeRF(_HipModule):
             ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
             float(near), float(far), self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
             ptr(lv[0][0]), ptr(lv[0][1]), ptr(lv[0][2]), ptr(lv[1][0]), ptr(lv[1][1]), ptr(lv[1][2]), ctx.stream()))
-        if self.poll_flags:
-            self._raise_flags(ctx.poll_flags())
+        self._after_call(ctx)
         return lv
 
 
@@ -687,6 +737,7 @@ class MipNeRF360(_HipModule):
         dev = rays_o.device
         ctx = self._context(dev)
         self._sync_weights(ctx)
+        self._before_call(ctx)
         B = rays_o.shape[0]
         counts = (self.num_prop_samples, self.num_prop_samples, self.num_nerf_samples)
         bufs = [dict(rgb=torch.empty(B, 3, device=dev), sdist=torch.empty(B, n + 1, device=dev),
@@ -696,8 +747,7 @@ class MipNeRF360(_HipModule):
         _lib.check(ctx.lib.neo_mip_render(ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), B,
                                           float(train_frac), float(near), float(far), self.num_prop_samples,
                                           self.num_nerf_samples, arr, ctx.stream()))
-        if self.poll_flags:
-            self._raise_flags(ctx.poll_flags())
+        self._after_call(ctx)
         renderings = [{"rgb": b["rgb"]} for b in bufs]
         history = [dict(density=b["rgbdens"][..., 3], rgb=b["rgbdens"][..., :3], sdist=b["sdist"], weights=b["weights"])
                    for b in bufs]
@@ -714,6 +764,5 @@ class MipNeRF360(_HipModule):
         out = torch.empty(B, n1 - 1, 4, device=rays_o.device)
         _lib.check(ctx.lib.neo_mip_mlp(ctx.handle, slot, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), ptr(tdist),
                                        B, n1 - 1, ptr(out), ctx.stream()))
-        if self.poll_flags:
-            self._raise_flags(ctx.poll_flags())
+        self._raise_flags(ctx.poll_flags())     # stage-level access: always immediate
         return out

@@ -70,9 +70,17 @@ def sample_rays_in_bbox(RTs, rays_o, view_dirs, ctx=None, return_per_box=False):
         mats.append(np.linalg.inv(box))
         bounds.append(np.asarray(sca, dtype=np.float64).reshape(6))
     n = len(mats)
+    dev = rays_o.device
+    if n == 0:
+        # a scene without objects: the reference's loops never run and its zero-initialised outputs come back
+        # (helper.py:359-373): near = far = 0, mask all False
+        zero = torch.zeros(R, 1, device=dev)
+        mask = torch.zeros(R, 1, dtype=torch.bool, device=dev)
+        if return_per_box:
+            return zero, zero.clone(), mask, torch.empty(0, R, dtype=torch.uint8, device=dev)
+        return zero, zero.clone(), mask
     hm = (ctypes.c_double * (16 * n))(*np.stack(mats).astype(np.float64).reshape(-1).tolist())
     hb = (ctypes.c_double * (6 * n))(*np.stack(bounds).reshape(-1).tolist())
-    dev = rays_o.device
     near = torch.empty(R, 1, device=dev)
     far = torch.empty(R, 1, device=dev)
     mask = torch.empty(R, 1, dtype=torch.uint8, device=dev)

@@ -40,26 +40,42 @@ def _buffer(tag, shape, like):
     return buf
 
 
-def gather_tiles(tile, n_rays, world, unit=1024, group=None):
+def clear_buffers():
+    """Drop the cached exchange buffers (they are otherwise kept for the life of the process)."""
+    _buffers.clear()
+
+
+def gather_tiles(tile, n_rays, world, unit=1024, group=None, out=None, reuse=False):
     """All ranks' (r_i, C) tiles -> the full (n_rays, C) frame on every rank.
-    Unequal shards are padded to the largest so one all_gather_into_tensor suffices.  The padded send tile, the
-    receive buffer and (for unequal shards) the compacted frame are cached per shape: the returned tensor is
-    overwritten by the next call with the same shapes."""
+    Unequal shards are padded to the largest so one all_gather_into_tensor suffices.  The padded send tile and the
+    receive buffer are scratch, cached per (shape, device, dtype, group).  The RETURNED frame is a fresh tensor by
+    default (callers may keep frame k while frame k+1 is rendered); pass `out=` (an (n_rays, C) tensor to fill) or
+    `reuse=True` (a cached frame buffer, overwritten by the next call of the same shape: a steady-state loop that
+    consumes each frame before rendering the next allocates nothing)."""
     import torch.distributed as dist
     counts = shard_counts(n_rays, world, unit)
     biggest = max(counts)
     C = tile.shape[1]
+    gid = id(group) if group is not None else 0
     if tile.shape[0] != biggest or not tile.is_contiguous():
-        pad = _buffer("send", (biggest, C), tile)
+        pad = _buffer(("send", gid), (biggest, C), tile)
         pad[: tile.shape[0]].copy_(tile)
         tile = pad
-    out = _buffer("recv", (world * biggest, C), tile)
-    dist.all_gather_into_tensor(out, tile, group=group)
-    if all(c == biggest for c in counts):
-        return out
-    frame = _buffer("frame", (n_rays, C), tile)
+    equal = all(c == biggest for c in counts)
+    if out is not None:
+        assert tuple(out.shape) == (n_rays, C) and out.is_contiguous(), "out must be a contiguous (n_rays, C) tensor"
+        frame = out
+    elif reuse:
+        frame = _buffer(("frame", gid), (n_rays, C), tile)
+    else:
+        frame = torch.empty(n_rays, C, device=tile.device, dtype=tile.dtype)
+    if equal:                                  # gather straight into the frame: no compaction pass
+        dist.all_gather_into_tensor(frame, tile, group=group)
+        return frame
+    recv = _buffer(("recv", gid), (world * biggest, C), tile)
+    dist.all_gather_into_tensor(recv, tile, group=group)
     lo = 0
     for r in range(world):
-        frame[lo: lo + counts[r]].copy_(out[r * biggest: r * biggest + counts[r]])
+        frame[lo: lo + counts[r]].copy_(recv[r * biggest: r * biggest + counts[r]])
         lo += counts[r]
     return frame

@@ -28,10 +28,12 @@ def _slice(batch, lo, hi):
 
 
 @torch.no_grad()
-def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0, train_frac=1.0):
+def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0, train_frac=1.0, check=True):
     """Fine-level rgb / depth of every ray in `batch` (one image), as the reference's
     render_rays_test returns them: dict(rgb (R,3), depth (R,)) plus `target` /
-    `instance_mask` passed through when present."""
+    `instance_mask` passed through when present.  check=True waits for the frame and raises what the device-side
+    assertions reported (a ray that missed the unit sphere, the split-fp16 range guard); check=False leaves that to
+    a later `model.check_flags()` (a loop over frames that never wants to block)."""
     if isinstance(model, models.NeRF_TP):
         res = model(batch, False, white_bkgd, near, far, out_depth=True, chunk=chunk)
         out = dict(rgb=res[1][0], depth=res[1][5], fg_rgb=res[1][1], bg_rgb=res[1][2], acc=res[1][3])
@@ -48,6 +50,8 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
         out = dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
     else:
         raise TypeError("unsupported renderer %r" % type(model))
+    if check:
+        model.check_flags()      # the deferred reads of the assertion word: raise before the frame is handed out
     for k in ("target", "instance_mask"):
         if k in batch:
             out[k] = batch[k]
@@ -56,11 +60,12 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
 
 @torch.no_grad()
 def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False, near=0.2, far=3.0, group=None,
-                         gather=True, train_frac=1.0, n_rays=None):
+                         gather=True, train_frac=1.0, n_rays=None, out=None, reuse=False, check=True):
     """This rank renders its contiguous range of whole chunks; `gather=True` reassembles
     the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather.
     `batch` holds the whole frame's rays, or - with n_rays = R given - only this rank's shard
-    (rays [shard_bounds(R, world, rank)), e.g. from ops.get_ray_directions_and_rays(ray_range=...))."""
+    (rays [shard_bounds(R, world, rank)), e.g. from ops.get_ray_directions_and_rays(ray_range=...)).
+    The gathered frame is a fresh tensor unless `out=` / `reuse=True` are given (parallel.gather_tiles)."""
     if n_rays is None:
         R = batch["rays_o"].shape[0]
         lo, hi = shard_bounds(R, world, rank, unit=chunk)
@@ -70,11 +75,11 @@ def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False
         lo, hi = shard_bounds(R, world, rank, unit=chunk)
         assert batch["rays_o"].shape[0] == hi - lo, "batch must hold exactly this rank's shard"
         mine = batch
-    part = render_rays_test(model, mine, chunk, white_bkgd, near, far, train_frac)
+    part = render_rays_test(model, mine, chunk, white_bkgd, near, far, train_frac, check=check)
     tile = torch.cat([part["rgb"], part["depth"][:, None], part["acc"][:, None]], dim=1)
     if world == 1 or not gather:
         return tile
-    return gather_tiles(tile, R, world, unit=chunk, group=group)
+    return gather_tiles(tile, R, world, unit=chunk, group=group, out=out, reuse=reuse)
 
 
 def psnr(pred, gt):

@@ -74,13 +74,16 @@ class _Composite(torch.autograd.Function):
                                        ptr(lam) if mode == 1 else None, c.stream()))
         ctx_.save_for_backward(rgbsigma, t, rays_d if rays_d is not None else torch.empty(0, device=dev),
                                t_far if t_far is not None else torch.empty(0, device=dev))
-        ctx_.meta = (mode, bool(white_bkgd), c, rays_d is not None, t_far is not None)
+        ctx_.meta = (mode, bool(white_bkgd), c, rays_d is not None, t_far is not None, tuple(sigma.shape))
         return out_rgb, acc, w, lam, depth
 
     @staticmethod
     def backward(ctx_, g_rgb, g_acc, g_w, g_lam, g_depth):
         rgbsigma, t, rays_d, t_far = ctx_.saved_tensors
-        mode, white, c, has_d, has_far = ctx_.meta
+        mode, white, c, has_d, has_far, sigma_shape = ctx_.meta
+        need_rgb, need_sigma = ctx_.needs_input_grad[1], ctx_.needs_input_grad[2]
+        if not (need_rgb or need_sigma):
+            return (None,) * 8
         R, N = t.shape
         g = torch.empty(R, N, 4, device=t.device)
         cont = lambda x: f32(x.contiguous(), "grad") if x is not None else None
@@ -88,7 +91,9 @@ class _Composite(torch.autograd.Function):
         _lib.check(c.lib.neo_composite_backward(c.handle, mode, ptr(rgbsigma), ptr(t), ptr(rays_d) if has_d else None,
                                                 ptr(t_far) if has_far else None, R, N, int(white), ptr(g_rgb), ptr(g_acc),
                                                 ptr(g_depth), ptr(g_w), ptr(g_lam), ptr(g), c.stream()))
-        return None, g[..., :3], g[..., 3:], None, None, None, None, None
+        # sigma may have been (R,N) or (R,N,1) in the forward: its gradient takes that shape
+        return (None, g[..., :3] if need_rgb else None, g[..., 3].reshape(sigma_shape) if need_sigma else None,
+                None, None, None, None, None)
 
 
 def composite(mode, rgb, sigma, t, rays_d=None, t_far=None, white_bkgd=False, ctx=None):
@@ -126,8 +131,14 @@ def eff_distloss(w, m, interval, ctx=None):
 class _Gather(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
-        # the module's context holds the channels-last copies (module.set_scene was called with these tensors)
+        # the module's context holds channels-last copies of the scene: they must be copies of THESE tensors at THIS
+        # version (an optimizer step or a fresh encoder output would otherwise leave the forward values stale while
+        # gradients still flow to the arguments) - re-upload when the fingerprint differs
         pts = f32(pts, "pts").reshape(-1, 3)
+        maps = (plane_xz, plane_xy, plane_yz, latent)
+        if not module.scene_matches(maps):
+            module.set_scene(plane_xz.detach(), plane_xy.detach(), plane_yz.detach(), latent.detach(),
+                             module.scene_image_wh(rays), _source=maps)
         c = module._context(pts.device)
         host_poses, NV, focal, cx, cy = module._camera_args(rays)
         P = pts.shape[0]
@@ -156,7 +167,9 @@ class _Gather(torch.autograd.Function):
 
 def gather_features(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
     """index_grid (three tri-planes summed) + get_local_feats at world points pts (P,3) for every source view of `rays`
-    (src_poses / src_focal / src_c): world (NV*P,128), local (NV*P,512), view-major rows.  `module` is the NeRF_TP whose
-    scene was set from these very tensors (`module.set_scene(plane_xz, plane_xy, plane_yz, latent, image_wh)`); gradients
-    flow to the four feature maps (NCHW, like the inputs)."""
+    (src_poses / src_focal / src_c): world (NV*P,128), local (NV*P,512), view-major rows.  `module` is the NeRF_TP that
+    holds the device-side copies: when they are not copies of these very tensors at their current version (fingerprint
+    recorded by `module.set_scene`), the four maps are uploaded again first (image size from the previous `set_scene` or
+    `rays["src_imgs"]`), so forward values and gradients always refer to the same data.  Gradients flow to the four
+    feature maps (NCHW, like the inputs)."""
     return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays)

@@ -104,7 +104,7 @@ def test_sharp_density(golden):
                               golden("g4_neo_sharp_noise"), "sharp")
 
 
-@pytest.mark.parametrize("preproject", [True, False, "pc"])
+@pytest.mark.parametrize("preproject", [True, False])
 def test_reference_sample_counts_1024(golden, preproject):
     """One reference-sized chunk: 1024 rays, 128 coarse + 256 fine, fg + bg, 3 views; both split evaluators
     (latent pre-projected through the first-layer weights = default, and the reference's operation order)."""
@@ -245,6 +245,10 @@ def test_sphere_miss_raises():
     batch["rays_o"][3] = torch.tensor([0.0, 0.0, 5.0], device=DEV)
     batch["rays_d"] = batch["rays_d"].clone()
     batch["rays_d"][3] = torch.tensor([1.0, 0.0, 0.0], device=DEV)
+    with pytest.raises(AssertionError):              # default: deferred read, raised by check_flags()
+        net(batch, False, False, 0.0, 0.0, out_depth=True)
+        net.check_flags()
+    net.poll_flags = "immediate"                     # the reference's behaviour: the call itself raises
     with pytest.raises(AssertionError):
         net(batch, False, False, 0.0, 0.0, out_depth=True)
 

@@ -19,7 +19,7 @@ R, NC, NF = 96, 128, 256
 _ORACLE_L0 = {}          # level-0 oracle outputs are the same for every kernel variant: evaluated once per session
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f16x3-pc", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f32"])
 def setup(request):
     """All four point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent
     (default), split-fp16 in the reference's operation order, the producer / consumer schedule of the default, exact
@@ -31,7 +31,7 @@ def setup(request):
     net.load_state_dict(params)
     net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
                   scene["latent"].to(DEV), scene["image_wh"],
-                  preproject="pc" if request.param.endswith("pc") else not request.param.endswith("noproj"))
+                  preproject=not request.param.endswith("noproj"))
     batch = cases.neo_batch(cases.strided_rays(R))
     return params, scene, net, batch, {k: v.to(DEV) for k, v in batch.items()}
 

@@ -30,21 +30,29 @@ def test_vanilla_weight_out_of_range_raises():
     state["fine_mlp.pts_linears.3.weight"] = state["fine_mlp.pts_linears.3.weight"].clone()
     state["fine_mlp.pts_linears.3.weight"][5, 7] = 7.0e4
     with pytest.raises(_lib.NeoError, match="fp16 range"):
-        _vanilla(state)(_rays(64), False, False, 0.2, 3.0)
+        net = _vanilla(state)
+        net(_rays(64), False, False, 0.2, 3.0)
+        net.check_flags()
     # the exact fp32 path has no such limit and the flag does not leak into it
-    out = _vanilla(state, "f32")(_rays(64), False, False, 0.2, 3.0)
+    net = _vanilla(state, "f32")
+    out = net(_rays(64), False, False, 0.2, 3.0)
+    net.check_flags()
     assert bool(torch.isfinite(out[1][0]).all())
     # non-finite weights
     state["fine_mlp.pts_linears.3.weight"][5, 7] = float("nan")
     with pytest.raises(_lib.NeoError):
-        _vanilla(state)(_rays(64), False, False, 0.2, 3.0)
+        net = _vanilla(state)
+        net.poll_flags = "immediate"
+        net(_rays(64), False, False, 0.2, 3.0)
 
 
 def test_vanilla_activation_overflow_raises():
     """Weights in range, activations not: every trunk weight x40 grows the activations ~40x per layer."""
     state = {k: (v * 40.0 if "pts_linears" in k and k.endswith("weight") else v) for k, v in synth.vanilla_state(0).items()}
     with pytest.raises(_lib.NeoError, match="fp16 range"):
-        _vanilla(state)(_rays(64), False, False, 0.2, 3.0)
+        net = _vanilla(state)
+        net(_rays(64), False, False, 0.2, 3.0)
+        net.check_flags()
 
 
 @pytest.mark.parametrize("scale", [1e3, 1e-4])

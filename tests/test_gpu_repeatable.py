@@ -56,13 +56,12 @@ def test_neo360_evaluators_repeatable(built_lib):
         far, _ = ops.intersect_sphere(gb["rays_o"], gb["rays_d"])
         t_fg = torch.linspace(0.05, 0.95, NC, device=dev)[None, :] * far.reshape(-1, 1)
         t_bg = torch.linspace(0.98, 0.02, NC, device=dev)[None, :].expand(R, NC).contiguous()
-        ref_net, h_net, n_net, p_net = mk("f32"), mk("f16x3"), mk("f16x3"), mk("f16x3")
+        ref_net, h_net, n_net = mk("f32"), mk("f16x3"), mk("f16x3")
         n_net.preproject = False                        # the split evaluator that gathers the 512-channel latent
-        p_net.preproject = "pc"                         # producer / consumer wave groups (LDS progress counters)
         for slot, tt in ((0, t_fg), (1, t_fg), (2, t_bg), (3, t_bg)):
             ref = ref_net.eval_mlp(slot, gb, tt, far=far)
             assert torch.equal(ref, ref_net.eval_mlp(slot, gb, tt, far=far))
-            for net in (h_net, n_net, p_net):
+            for net in (h_net, n_net):
                 runs = [net.eval_mlp(slot, gb, tt, far=far) for _ in range(3)]
                 assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
                 assert (runs[0] - ref).abs().max().item() < 5e-6

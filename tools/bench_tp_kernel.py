@@ -53,3 +53,19 @@ pe = 63 if SLOT < 2 else 84
 macs = NV * ((pe + 640) * 128 + 2 * 128 * 128 + (pe + 640 + 128) * 128 + 128 * 128 + 155 * 64) + 128 + 64 * 64 + 64 * 3
 print("%s %s slot %d R=%d N=%d  %.2f ms  %.1f algorithmic TFLOP/s  checksum %.6f" % (
     os.environ.get("TAG", ""), PREC, SLOT, R, N, dt * 1e3, R * N * macs * 2 / dt / 1e12, float(out.double().sum())))
+if os.environ.get("TRACE"):
+    # variant built with -DNEO_TP_TRACE=1: per-phase s_memtime sums of wave 0 of every workgroup
+    import ctypes
+    from neo360_amd import _lib
+    lib = _lib.load()
+    buf = (ctypes.c_ulonglong * 16)()
+    lib.neo_debug_tp_trace(buf, 1)                 # reset (drops warm-up + timed launches above)
+    net.eval_mlp(SLOT, rays, t, far=far)
+    lib.neo_debug_tp_trace(buf, 0)
+    names = ["setup", "descriptors", "G gather+consume", "planes (+X ks0-3)", "X ks4.. + pos_enc", "L0 epi + L1..L3", "tail"]
+    n = max(int(buf[7]), 1)
+    tot = sum(int(buf[k]) for k in range(7))
+    print("%s phase trace slot %d: %d workgroups, %.0f cycles (s_memtime ticks, 100 MHz?) per tile" % (os.environ.get("TAG", ""), SLOT, n, tot / n))
+    for k, nm in enumerate(names):
+        print("   %-22s %10.1f per tile  (%5.1f %%)%s" % (nm, int(buf[k]) / n, 100.0 * int(buf[k]) / max(tot, 1),
+                                                       "   [per view: %.1f]" % (int(buf[k]) / n / NV) if 1 <= k <= 5 else ""))
