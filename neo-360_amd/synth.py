@@ -30,13 +30,30 @@ def _stream_id(tag):
     return h
 
 
-def uniform01(seed, tag, n):
-    """n float64 values in [0,1), a pure function of (seed, tag, index)."""
+def _uniform01_range(seed, tag, lo, hi):
     with np.errstate(over="ignore"):
         base = _splitmix64(np.uint64(seed) ^ np.uint64(_stream_id(tag)))
-        idx = np.arange(n, dtype=np.uint64)
+        idx = np.arange(lo, hi, dtype=np.uint64)
         bits = _splitmix64(base + idx * np.uint64(0xD1342543DE82EF95))
     return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _in_pieces(fn, n, piece=1 << 22):
+    """fn(lo, hi) over [0, n) in pieces on a few threads (numpy releases the GIL): values depend on the index only,
+    so the result is identical to one call - full-size feature maps (118 M values) take seconds instead of half a minute."""
+    if n <= piece:
+        return fn(0, n)
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    bounds = [(lo, min(lo + piece, n)) for lo in range(0, n, piece)]
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        parts = list(ex.map(lambda b: fn(*b), bounds))
+    return np.concatenate(parts)
+
+
+def uniform01(seed, tag, n):
+    """n float64 values in [0,1), a pure function of (seed, tag, index)."""
+    return _in_pieces(lambda lo, hi: _uniform01_range(seed, tag, lo, hi), n)
 
 
 def uniform(seed, tag, shape, lo, hi):
@@ -48,11 +65,25 @@ def uniform(seed, tag, shape, lo, hi):
 def normal(seed, tag, shape, std=1.0):
     n = int(np.prod(shape))
     m = (n + 1) // 2
-    u1 = uniform01(seed, tag + "/a", m)
-    u2 = uniform01(seed, tag + "/b", m)
-    r = np.sqrt(-2.0 * np.log(1.0 - u1))
-    v = np.concatenate([r * np.cos(2 * math.pi * u2), r * np.sin(2 * math.pi * u2)])[:n]
-    return torch.from_numpy((std * v).astype(np.float32).reshape(shape))
+
+    def pairs(lo, hi):                                   # Box-Muller on index pairs: (cos half, sin half)
+        u1 = _uniform01_range(seed, tag + "/a", lo, hi)
+        u2 = _uniform01_range(seed, tag + "/b", lo, hi)
+        r = np.sqrt(-2.0 * np.log(1.0 - u1))
+        return np.stack([(std * (r * np.cos(2 * math.pi * u2))).astype(np.float32),
+                         (std * (r * np.sin(2 * math.pi * u2))).astype(np.float32)])
+
+    if m <= (1 << 22):
+        both = pairs(0, m)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        piece = 1 << 22
+        bounds = [(lo, min(lo + piece, m)) for lo in range(0, m, piece)]
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            both = np.concatenate(list(ex.map(lambda b: pairs(*b), bounds)), axis=1)
+    v = np.concatenate([both[0], both[1]])[:n]
+    return torch.from_numpy(v.reshape(shape))
 
 
 # ----------------------------------------------------------------------------

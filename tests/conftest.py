@@ -54,3 +54,69 @@ def max_abs(a, b):
     a = torch.as_tensor(a).detach().cpu() if not isinstance(a, torch.Tensor) else a.detach().cpu()
     b = torch.as_tensor(b).detach().cpu() if not isinstance(b, torch.Tensor) else b.detach().cpu()
     return float((a.double() - b.double()).abs().max())
+
+
+# ---- parity report: every GPU parity test records its worst-case numbers here; written as JSON at session end ------
+_PARITY = {}
+
+
+def record_parity(test, **numbers):
+    """Worst-case error numbers of one parity check (max / p99 per output, counts of ill-conditioned rays ...)."""
+    _PARITY.setdefault(test, {}).update({k: (float(v) if isinstance(v, (int, float)) or hasattr(v, "__float__") else v)
+                                         for k, v in numbers.items()})
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+    path = os.environ.get("NEO360_PARITY_REPORT") or os.path.join(ROOT, "gpurun_out", "parity_report.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    merged = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                merged = json.load(f)
+        except Exception:
+            merged = {}
+    merged.update(_PARITY)
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
+
+
+# ---- the end-to-end NeO-360 contract, separated by how well the REFERENCE determines each ray ---------------------
+NEO_KEYS = ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")
+
+
+def per_ray_abs(x):
+    return x.abs().amax(dim=-1) if x.dim() == 2 and x.shape[-1] == 3 else x.abs().reshape(x.shape[0])
+
+
+def check_vs_reference_noise(got, g, noise, label, tol=1e-4):
+    """The fixture g4_neo_<tag>_noise holds, per ray and output, |ref32 - ref64|: the reference's decoder run in fp32
+    (= the fixture g) and by its own fp64 twin (tests/golden/make_golden.py:g4_neo_noise).  At 128 + 256 samples that
+    self-disagreement is < 1e-5 on > 99 % of the rays and reaches a few 1e-4 on the rest: the background fine level
+    inverts a cdf over DEscending bins (neo360/model.py:319-331), where one ulp of the fp32 cdf moves a sample along
+    the whole ray.
+      * every ray the reference determines to better than 1e-5 must meet the 1e-4 contract - no exceptions;
+      * a ray where the reference disagrees with itself by n >= 1e-5 must land within 1e-4 + 3 n of the fp32
+        reference (GPU outliers are the reference's own outliers, with comparable magnitude).
+    Records max / p99 / ill-conditioned counts per output in the parity report."""
+    rec = {}
+    for k in NEO_KEYS:
+        err = per_ray_abs(got[k] - g[k])
+        n = noise["noise_" + k]
+        well = n < 1e-5
+        ill = ~well
+        rec[k] = dict(max=float(err.max()), p99=float(err.quantile(0.99)), max_well_conditioned=float(err[well].max()),
+                      ill_conditioned_rays=int(ill.sum()), reference_self_noise_max=float(n.max()), rays=int(err.numel()))
+        assert float(err[well].max()) < tol, (label, k, "well-conditioned ray above 1e-4", float(err[well].max()))
+        if bool(ill.any()):
+            excess = err[ill] - (tol + 3.0 * n[ill])
+            assert float(excess.max()) <= 0.0, (label, k, "ill-conditioned ray beyond the reference's own noise",
+                                                float(err[ill].max()), float(n[ill].max()))
+    mse = float(((got["rgb1"].clamp(0, 1) - g["rgb1"].clamp(0, 1)) ** 2).mean())
+    rec["psnr_db_vs_reference"] = float("inf") if mse == 0 else -10.0 * __import__("math").log10(mse)
+    record_parity(label, **rec)
+    print(label, {k: "%.2e (%d ill)" % (v["max"], v["ill_conditioned_rays"]) for k, v in rec.items() if isinstance(v, dict)})
+    assert mse < 1e-10       # PSNR vs the reference frame > 100 dB

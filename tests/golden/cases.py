@@ -61,6 +61,38 @@ def strided_rays(n, H=48, W=64, **kw):
     return take(rays, idx)
 
 
+# ---- the BASELINE C3 configuration at full size (640x480, 3 views, 128 + 256 samples) -----------------------
+FULL_WH = (640, 480)
+FULL_PLANE_HW = (120, 160)
+FULL_LATENT_HW = (240, 320)
+
+
+def full_scene(seed=0, nv=NV):
+    """Stand-ins for the scene encoder's outputs at the reference's shapes for 640x480 sources (tri-planes
+    3 x 128 x 120 x 160, latent 3 x 512 x 240 x 320, N(0, 0.1^2)), from the hash generator: the build container
+    (reference run -> fixture g4_neo_full), the GPU tests and bench.py regenerate them bit for bit."""
+    sc = synth.scene_features(seed, nv, 128, FULL_PLANE_HW, 512, FULL_LATENT_HW, std=0.1)
+    sc["image_wh"] = (float(FULL_WH[0]), float(FULL_WH[1]))
+    return sc
+
+
+def full_strip_index(n):
+    """n rays of the 640x480 frame: a stride-601 walk starting at the image centre row (hits every region of the
+    frame; as ONE reference chunk when n = 1024)."""
+    W, H = FULL_WH
+    return (torch.arange(n, dtype=torch.int64) * 601 + 230 * W) % (H * W)
+
+
+def full_batch(n, nv=NV):
+    """Rays of the bench camera (look_at_origin(40 deg), focal 0.8 W; fp64 NumPy ray generation so the fixture does
+    not depend on either ray generator) + the bench's source cameras."""
+    W, H = FULL_WH
+    rays = take(crop_rays(H, W), full_strip_index(n))
+    poses, focal, centre = synth.source_views(nv, W, H)
+    rays.update(src_poses=poses, src_focal=focal, src_c=centre, src_imgs=torch.zeros(nv, 3, H, W))
+    return rays
+
+
 def aabb_cases(seed=3, n=4096):
     """Rays in box frame (float64) vs three boxes; includes exact-zero direction
     components, origins inside the box, and rays parallel to faces."""

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import cases
-from conftest import max_abs
+from conftest import check_vs_reference_noise, max_abs, record_parity
 from neo360_amd import models, synth
 
 pytestmark = pytest.mark.gpu
@@ -37,20 +37,23 @@ def _render(net, n, chunk, nv=cases.NV, white=False):
                 lam1=cat(1, 4), depth1=cat(1, 5))
 
 
-def _check(got, g, depth_tol=TOL):
-    for k in ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1"):
-        assert max_abs(got[k], g[k]) < (depth_tol if k.startswith("depth") else TOL), k
+def _check(got, g, depth_tol=TOL, label=None):
+    errs = {k: max_abs(got[k], g[k]) for k in ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")}
+    if label:
+        record_parity("neo360_e2e/" + label, **{"max_" + k: v for k, v in errs.items()})
+    for k, e in errs.items():
+        assert e < (depth_tol if k.startswith("depth") else TOL), (k, e)
 
 
 def test_small_two_chunks(golden):
     """300 rays, caller chunk 256: exercises the view-direction tiling quirk and the short last chunk."""
-    _check(_render(_net(32, 64), 300, 256), golden("g4_neo_small"))
+    _check(_render(_net(32, 64), 300, 256), golden("g4_neo_small"), label="small_two_chunks")
 
 
 def test_chunk_dependence_reproduced(golden):
     net = _net(32, 64)
-    _check(_render(net, 128, 128), golden("g4_neo_c128"))
-    _check(_render(net, 128, 64), golden("g4_neo_c64"))
+    _check(_render(net, 128, 128), golden("g4_neo_c128"), label="chunk128")
+    _check(_render(net, 128, 64), golden("g4_neo_c64"), label="chunk64")
 
 
 def test_internal_chunking_equals_callers(golden):
@@ -62,39 +65,8 @@ def test_internal_chunking_equals_callers(golden):
     assert max_abs(res[1][0].cpu(), g["rgb1"]) < TOL and max_abs(res[1][5].cpu(), g["depth1"]) < TOL
 
 
-KEYS = ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")
-
-
-def _per_ray(x):
-    return x.abs().amax(dim=-1) if x.dim() == 2 and x.shape[-1] == 3 else x.abs().reshape(x.shape[0])
-
-
 def _check_vs_reference_noise(got, g, noise, label):
-    """End-to-end contract, separated by how well the REFERENCE determines each ray.
-
-    The fixture g4_neo_<tag>_noise holds, per ray and output, |ref32 - ref64|: the reference's decoder run in fp32
-    (= the fixture) and by its own fp64 twin (tests/golden/make_golden.py:g4_neo_noise).  At the default 128+256
-    samples that self-disagreement is < 1e-5 on 99.4-99.6 % of the rays and reaches 2.2e-4 (rgb1) / 3.4e-4 (bg1) on
-    the rest: the background fine level inverts a cdf over DEscending bins (neo360/model.py:319-331), where one ulp
-    of the fp32 cdf moves a sample along the whole ray.
-      * every ray the reference determines to better than 1e-5 must meet the 1e-4 contract - no exceptions;
-      * a ray where the reference disagrees with itself by n >= 1e-5 must land within 1e-4 + 3 n of the fp32
-        reference (i.e. GPU outliers are the reference's own outliers, with comparable magnitude)."""
-    worst = {}
-    for k in KEYS:
-        err = _per_ray(got[k] - g[k])
-        n = noise["noise_" + k]
-        well = n < 1e-5
-        assert float(err[well].max()) < TOL, (label, k, "well-conditioned ray above 1e-4", float(err[well].max()))
-        ill = ~well
-        if bool(ill.any()):
-            excess = err[ill] - (TOL + 3.0 * n[ill])
-            assert float(excess.max()) <= 0.0, (label, k, "ill-conditioned ray beyond the reference's own noise",
-                                                float(err[ill].max()), float(n[ill].max()))
-        worst[k] = (float(err.max()), int(ill.sum()))
-    print(label, {k: "%.2e (%d ill)" % v for k, v in worst.items()})
-    mse = float(((got["rgb1"].clamp(0, 1) - g["rgb1"].clamp(0, 1)) ** 2).mean())
-    assert mse < 1e-10       # PSNR vs the reference frame > 100 dB
+    check_vs_reference_noise(got, g, noise, "neo360_e2e/" + label)
 
 
 def test_sharp_density(golden):

@@ -9,7 +9,7 @@ import torch
 
 import cases
 import oracle
-from conftest import max_abs
+from conftest import max_abs, record_parity
 from neo360_amd import models, ops, synth
 
 pytestmark = pytest.mark.gpu
@@ -22,12 +22,12 @@ _ORACLE_L0 = {}          # level-0 oracle outputs are the same for every kernel 
 @pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f32"])
 def setup(request):
     """All four point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent
-    (default), split-fp16 in the reference's operation order, the producer / consumer schedule of the default, exact
-    fp32 MFMA."""
+    (default), split-fp16 in the reference's operation order, exact fp32 MFMA."""
     params = synth.nerf_tp_state(0)
     scene = cases.small_scene()
     net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
     net.precision = request.param.split("-")[0]
+    net._variant = request.param
     net.load_state_dict(params)
     net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
                   scene["latent"].to(DEV), scene["image_wh"],
@@ -52,6 +52,8 @@ def test_pipeline_stage_by_stage(setup):
         if name not in _ORACLE_L0:
             _ORACLE_L0[name] = oracle.neo360.region_eval(params, prefix, batch, scene, tv, inside, far_c)
         rgb, sigma = _ORACLE_L0[name]
+        record_parity("neo360_stages/%s/%s_mlp" % (net._variant, name), max_rgb=max_abs(got[..., :3], rgb),
+                      max_sigma=max_abs(got[..., 3:], sigma), points=int(got.shape[0] * got.shape[1]))
         assert max_abs(got[..., :3], rgb) < 2e-5, name
         assert max_abs(got[..., 3:], sigma) < 2e-5, name
         stages[name] = got
@@ -73,11 +75,30 @@ def test_pipeline_stage_by_stage(setup):
     assert float(bg_s1.min()) >= 0.0 and float(bg_s1.max()) <= 1.0
     mids = 0.5 * (fg_t[:, 1:] + fg_t[:, :-1])
     fg_want = oracle.sampling.merge_sorted(fg_t, oracle.sampling.piecewise_constant_samples(mids, cf["weights"].cpu()[:, 1:-1], NF))
-    assert float((fg_t1 - fg_want).abs().median()) < 1e-6
+    # sample POSITIONS are ill-conditioned where the density is ~0 (an ulp of the cdf moves them by ulp / density); their
+    # CDF values are not: every sample of every ray must agree in cdf space (the bound of test_gpu_stages.py)
+    from test_gpu_stages import _cdf_space
+    w_in = cf["weights"].cpu()[:, 1:-1]
+    assert max_abs(_cdf_space(fg_t1, mids, w_in), _cdf_space(fg_want, mids, w_in)) < 2e-6
+    # outside the sphere the bins DEscend: what the reference computes there is not an inverse cdf (mask / max / min
+    # over descending bins, neo360/model.py:319-331) and an ulp of the fp32 cdf moves a sample across the whole ray, so
+    # the bound is the reference arithmetic's own fp32-vs-fp64 disagreement on these very inputs (pinned oracle)
+    bg_mids = 0.5 * (bg_s[:, 1:] + bg_s[:, :-1])
+    wb_in = cb["weights"].cpu()[:, 1:-1]
+    bg_want = torch.flip(oracle.sampling.merge_sorted(bg_s, oracle.sampling.piecewise_constant_samples(bg_mids, wb_in, NF)), dims=[-1])
+    bg_w64 = torch.flip(oracle.sampling.merge_sorted(bg_s.double(), oracle.sampling.piecewise_constant_samples(
+        bg_mids.double(), wb_in.double(), NF)), dims=[-1])
+    noise = (bg_want.double() - bg_w64).abs()
+    excess = (bg_s1.double() - bg_want.double()).abs() - (5e-6 + 3.0 * noise.amax(dim=-1, keepdim=True))
+    record_parity("neo360_stages/%s/bg_resample" % net._variant, max_pos_err=float((bg_s1 - bg_want).abs().max()),
+                  reference_self_noise_max=float(noise.max()), rows=int(bg_s1.shape[0]))
+    assert float(excess.max()) <= 0.0, (float((bg_s1 - bg_want).abs().max()), float(noise.max()))
     # ---- level 1: both sides evaluate the MLP at the GPU's sample positions ----------------
     for name, slot, prefix, tv, inside in (("fg1", 1, "fg_fine_mlp.", fg_t1, True), ("bg1", 3, "bg_fine_mlp.", bg_s1, False)):
         got = net.eval_mlp(slot, gbatch, tv.to(DEV), far=far_g).cpu()
         rgb, sigma = oracle.neo360.region_eval(params, prefix, batch, scene, tv, inside, far_c)
+        record_parity("neo360_stages/%s/%s_mlp" % (net._variant, name), max_rgb=max_abs(got[..., :3], rgb),
+                      max_sigma=max_abs(got[..., 3:], sigma), points=int(got.shape[0] * got.shape[1]))
         assert max_abs(got[..., :3], rgb) < 2e-5, name
         assert max_abs(got[..., 3:], sigma) < 2e-5, name
         stages[name] = got
@@ -90,6 +111,8 @@ def test_pipeline_stage_by_stage(setup):
     depth_g = cf1["depth"] + cf1["bg_lambda"].squeeze(-1) * cb1["depth"]
     rgb_c = wf[0] + wf[3] * wb[0]
     depth_c = wf[4] + wf[3].squeeze(-1) * wb[4]
+    record_parity("neo360_stages/%s/final_same_positions" % net._variant, max_rgb=max_abs(rgb_g.cpu(), rgb_c),
+                  max_depth=max_abs(depth_g.cpu(), depth_c), rays=R)
     assert max_abs(rgb_g.cpu(), rgb_c) < TOL and max_abs(depth_g.cpu(), depth_c) < TOL
     # ---- and the fused render call reproduces this chain bit for bit ----
     res = net(gbatch, False, False, 0.0, 0.0, out_depth=True)

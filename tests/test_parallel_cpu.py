@@ -43,7 +43,19 @@ def _worker(rank, world, port, n, unit, ret):
         frame = torch.arange(n * 5, dtype=torch.float32).reshape(n, 5)     # stand-in for (rgb, depth, acc)
         lo, hi = parallel.shard_bounds(n, world, rank, unit)
         got = parallel.gather_tiles(frame[lo:hi].clone(), n, world, unit)
-        ret[rank] = bool(torch.equal(got, frame))
+        ok = bool(torch.equal(got, frame))
+        # a second frame must not overwrite the first: fresh tensor by default ...
+        got2 = parallel.gather_tiles((frame[lo:hi] + 1.0).clone(), n, world, unit)
+        ok = ok and bool(torch.equal(got, frame)) and bool(torch.equal(got2, frame + 1.0)) and got2.data_ptr() != got.data_ptr()
+        # ... `out=` fills the caller's tensor, `reuse=True` hands out the cached one
+        mine = torch.empty(n, 5)
+        got3 = parallel.gather_tiles(frame[lo:hi].clone(), n, world, unit, out=mine)
+        ok = ok and got3 is mine and bool(torch.equal(mine, frame))
+        a = parallel.gather_tiles(frame[lo:hi].clone(), n, world, unit, reuse=True)
+        b = parallel.gather_tiles((frame[lo:hi] + 2.0).clone(), n, world, unit, reuse=True)
+        ok = ok and a.data_ptr() == b.data_ptr() and bool(torch.equal(b, frame + 2.0))
+        parallel.clear_buffers()
+        ret[rank] = ok
     finally:
         dist.destroy_process_group()
 
