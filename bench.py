@@ -33,8 +33,56 @@ CHUNK = 1024
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector peak)
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_HBM_BYTES = 8.0e12               # MI355X_MICROARCH.md: HBM3E spec peak
-CPU_THREADS = 32                      # fastest of an 8..256 sweep on the GPU box (profiles/cpu_threads_r01.log)
+CPU_THREADS = 32                      # fastest of the NeO-360 sweep on the GPU box's host (profiles/r03_cpu_threads_neo360.log)
 CPU_REPS = 3                          # >= 3 repetitions of the CPU sample
+CPU_REP_BUDGET_S = 75.0               # a repetition slower than this ends the CPU leg early (the default run must finish in minutes)
+
+
+def physical_cores():
+    """Physical cores of the host (unique (package, core) pairs of /proc/cpuinfo); os.cpu_count() counts SMT threads."""
+    try:
+        seen, pkg, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    pkg = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if pkg is not None and core is not None:
+                        seen.add((pkg, core))
+                    pkg = core = None
+        if pkg is not None and core is not None:
+            seen.add((pkg, core))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the HIP sources + headers the library is built from: stamps PMC summaries
+    (tools/pmc_summarize.py) so a profile of an OLDER kernel is never attached to this build's numbers."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "neo-360_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+# MFMA products k_tp_mlp_hp really issues per point (NV source views; each algorithmic multiply = 3 fp16 products
+# a_hi b_hi + a_hi b_lo + a_lo b_hi; padded k-steps counted): per view the streamed [world | pos_enc] stage
+# (12 k-steps of 16 inside the sphere, 14 outside, x 256 outputs) + L1, L2, L3 (3 x 128 x 128); once per point the
+# view-mean tail (bottleneck 128 x 128, view layers 160 x 64 and 64 x 64).  The 512-channel latent does not appear:
+# it is pre-projected once per scene (scene_setup_ms).
+def executed_flop_per_point_tp_hp(nv, outside):
+    per_view = (14 if outside else 12) * 16 * 256 + 3 * 128 * 128
+    macs = nv * per_view + 128 * 128 + 160 * 64 + 64 * 64
+    return macs * 3 * 2.0
 
 
 def build_vanilla(dev):
@@ -47,17 +95,20 @@ def build_vanilla(dev):
     return net, state, {}, None, desc, dict(near=0.2, far=3.0), "k_vanilla_mlp", 4096
 
 
+_SCENE_CACHE = {}
+
+
 def build_neo360(dev):
     from neo360_amd import models, synth
     nv = 3
     state = synth.nerf_tp_state(0)
     net = models.NeRF_TP(num_coarse_samples=128, num_fine_samples=256, num_src_views=nv).to(dev)
     net.load_state_dict(state)
-    g = torch.Generator(device=dev)
-    g.manual_seed(0)
-    # stand-ins for the scene encoder's outputs, reference shapes: N(0, 0.1^2)
-    scene = {k: torch.randn(nv, 128, 120, 160, device=dev, generator=g) * 0.1 for k in ("plane_xz", "plane_xy", "plane_yz")}
-    scene["latent"] = torch.randn(nv, 512, 240, 320, device=dev, generator=g) * 0.1
+    # stand-ins for the scene encoder's outputs, reference shapes: N(0, 0.1^2) from the hash generator -
+    # the very scene the reference was run on for the fixture tests/golden/g4_neo_full.npz (tests/golden/cases.py:full_scene)
+    if "neo360" not in _SCENE_CACHE:
+        _SCENE_CACHE["neo360"] = synth.scene_features(0, nv, 128, (120, 160), 512, (240, 320), std=0.1)
+    scene = {k: v.to(dev) for k, v in _SCENE_CACHE["neo360"].items()}
     scene["image_wh"] = (float(W), float(H))
     net.set_scene(scene["plane_xz"], scene["plane_xy"], scene["plane_yz"], scene["latent"], scene["image_wh"])
     poses, focal, centre = synth.source_views(nv, W, H)
@@ -65,8 +116,9 @@ def build_neo360(dev):
                  src_imgs=torch.zeros(nv, 3, H, W, device=dev))
     desc = ("neo360 tri-planar decoder 640x480 full frame, 3 source views, 128 coarse + 256 fine samples/ray, "
             "inside + outside sphere ((129+385)x2 = 1028 MLP points/ray x 3 views), reference chunk 1024, "
-            "random-init MLPs, synthetic N(0,0.1) tri-planes (3x128x120x160) + latents (3x512x240x320)")
-    return net, state, extra, scene, desc, dict(near=0.0, far=0.0), "k_tp_mlp", 128
+            "random-init MLPs, synthetic N(0,0.1) tri-planes (3x128x120x160) + latents (3x512x240x320) from the hash generator "
+            "(= the scene of the reference-generated fixture g4_neo_full)")
+    return net, state, extra, scene, desc, dict(near=0.0, far=0.0), "k_tp_mlp", CHUNK
 
 
 def build_pixelnerf(dev):
@@ -103,8 +155,11 @@ BUILDERS = {"vanilla": build_vanilla, "neo360": build_neo360, "pixelnerf": build
 
 
 def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
-    """The oracle (CPU restatement of the reference: kind 'port'; oracle == reference is pinned by tests/golden and
-    tests/test_oracle_vs_reference.py) timed CPU_REPS times on a bounded sample of the same frame on the host cores."""
+    """The oracle (CPU restatement of the reference: kind 'port'; oracle == reference is pinned by tests/golden,
+    tests/test_oracle_fullsize.py and tests/test_oracle_vs_reference.py) timed up to CPU_REPS times on a bounded sample
+    of the same frame on the host cores: for NeO-360 ONE WHOLE reference chunk (1024 rays: BASELINE.md 3),
+    thread count from a NeO-360 sweep on the GPU box's host.  A repetition slower than CPU_REP_BUDGET_S ends the leg
+    early so the default run still finishes in minutes."""
     import oracle
     torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
     sample = {k: v[:n] for k, v in rays_cpu.items()}
@@ -127,14 +182,18 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
             batch = dict(sample)
             batch.update({k: v.cpu() for k, v in extra.items()})
             sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
-            rgb, depth = oracle.neo360.render_chunked(state, batch, sc, chunk=n)
+            rgb, depth = oracle.neo360.render_chunked(state, batch, sc, chunk=min(n, CHUNK))
         times.append(time.perf_counter() - t0)
+        if times[-1] > CPU_REP_BUDGET_S:
+            break
     dt = statistics.median(times)
-    base = dict(value=n / dt, unit="rays/s", cores=torch.get_num_threads(), kind="port",
-                sample="first %d rays of the same 640x480 frame as one%s reference chunk%s, same weights / features, "
-                       "torch fp32 CPU oracle (validated equal to the reference: tests/golden, "
-                       "tests/test_oracle_vs_reference.py); median of %d repetitions, %s s"
-                       % (n, "" if n <= CHUNK else " run of", "" if n <= CHUNK else "s", CPU_REPS,
+    base = dict(value=n / dt, unit="rays/s", cores=physical_cores(), threads=torch.get_num_threads(), kind="port",
+                sample="first %d rays of the same 640x480 frame as %s, same weights / features, "
+                       "torch fp32 CPU oracle (validated equal to the reference: tests/golden, tests/test_oracle_fullsize.py, "
+                       "tests/test_oracle_vs_reference.py) on %d of the host's %d physical cores (%d logical); median of %d "
+                       "repetition%s, %s s"
+                       % (n, "ONE whole reference chunk" if n == CHUNK else ("%d reference chunks" % (n // CHUNK) if n > CHUNK else "one (short) reference chunk"),
+                          torch.get_num_threads(), physical_cores(), os.cpu_count() or 1, len(times), "" if len(times) == 1 else "s",
                           "/".join("%.1f" % t for t in times)))
     return base, rgb, depth
 
@@ -143,13 +202,22 @@ def pmc_profile(workload, precision):
     """Summary of the committed rocprofv3 PMC passes of this same command (tools/pmc_bench.sh ->
     profiles/rNN_pmc_<workload>_<precision>.json; newest round wins): HBM bytes per dominant-kernel launch =
     (2 x FETCH_SIZE + WRITE_SIZE) KiB, mean over the launches of a frame (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950), MFMA-busy fraction, effective clock.  {} when none is committed."""
+    MI355X_MICROARCH.md prescribes for gfx950), MFMA-busy fraction, effective clock.  The summary carries the hash of
+    the kernel sources it was taken on (`kernel_source_sha16`, written by tools/pmc_summarize.py); when that is not the
+    hash of THIS tree the counter fields are dropped (-> null in the bench line) instead of describing another kernel.
+    {} when none is committed."""
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s_%s.json" % (workload, precision))))
     if not paths:
         return {}
     with open(paths[-1]) as f:
-        d = json.load(f).get("derived", {})
-    d["source"] = os.path.relpath(paths[-1], ROOT)
+        full = json.load(f)
+    src = os.path.relpath(paths[-1], ROOT)
+    have, want = full.get("kernel_source_sha16"), kernel_source_hash()
+    if have != want:
+        return {"source": src, "stale": "PMC summary %s was taken on kernel sources %s, this tree is %s: counter fields dropped"
+                                        % (src, have or "(unstamped)", want)}
+    d = full.get("derived", {})
+    d["source"] = src
     return d
 
 
@@ -175,6 +243,33 @@ class Runner:
         self.lo, self.hi = shard_bounds(self.R, world, rank, unit=CHUNK)
         self.ctx = self.net._context(dev)
         self._rays = None
+        self.scene_setup = None
+        if workload == "neo360":
+            self.scene_setup = self._time_scene_setup()
+
+    def _time_scene_setup(self):
+        """Once-per-scene work that the per-frame numbers do not contain: channels-last re-layout of the feature maps
+        (set_scene), weight upload + fragment packing, and the pre-projection of the latent through each of the four
+        MLPs' first-layer weights (k_tp_preproject; the 131,072 MACs per point-view the evaluator no longer executes)."""
+        sc, net = self.scene, self.net
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        net.set_scene(sc["plane_xz"], sc["plane_xy"], sc["plane_yz"], sc["latent"], sc["image_wh"])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tiny = self.shard_rays()
+        tiny = {k: (v if k.startswith("src_") else v[:CHUNK]) for k, v in tiny.items()}
+        net(tiny, False, False, 0.0, 0.0, out_depth=True)        # uploads + packs the weights, pre-projects 4 slots, renders 1 chunk
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        net(tiny, False, False, 0.0, 0.0, out_depth=True)        # the same chunk in the steady state
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        net.check_flags()
+        return {"set_scene_ms": (t1 - t0) * 1e3, "pack_and_preproject_ms": max(0.0, (t2 - t1) - (t3 - t2)) * 1e3,
+                "total_ms": ((t1 - t0) + max(0.0, (t2 - t1) - (t3 - t2))) * 1e3,
+                "note": "once per scene / per weight update, not part of ms_per_step: channels-last re-layout of 3 tri-planes + latent, "
+                        "weight upload + fragment packing, 4 x k_tp_preproject (exact fp32 MFMA)"}
 
     def shard_rays(self):
         # only this rank's rays are generated, into the previous frame's tensors
@@ -218,9 +313,9 @@ class Runner:
         kern_ms, launches, points, flops = kern
         achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
         alg_bytes_per_point = 20.0 + {"neo360": 3 * 14336.0, "pixelnerf": 3 * 8192.0}.get(self.workload, 0.0)
-        # split path: every algorithmic product costs three fp16 MFMA products, so the ceiling for
-        # ALGORITHMIC flops on the fp16 pipe is peak/3
-        peak = PEAK_F16_MFMA_TFLOPS / 3.0 if self.split else PEAK_F32_MFMA_TFLOPS
+        # the path computes on the matrix pipe of its dtype: fp16 MFMA (dense peak 2500) for the split arithmetic,
+        # fp32 MFMA (157.3) for the exact kernels.  `frac` = ALGORITHMIC flops (reference formulation) / that peak.
+        peak = PEAK_F16_MFMA_TFLOPS if self.split else PEAK_F32_MFMA_TFLOPS
         pmc = pmc_profile(self.workload, self.precision)
         avg_ms = kern_ms / max(launches, 1)
         traffic = pmc.get("hbm_bytes_per_launch")
@@ -230,18 +325,32 @@ class Runner:
                 "algorithmic_bytes_per_launch": points / max(launches, 1) * alg_bytes_per_point,
                 # HBM side of the roofline (north_star): PMC bytes of the profiled run / this run's launch time
                 "hbm_frac": (traffic / (avg_ms * 1e-3) / PEAK_HBM_BYTES) if traffic and avg_ms > 0 else None,
-                "mfma_busy": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"),
-                "peak_definition": ("dense fp16 MFMA peak 2500 TFLOP/s / 3 products per algorithmic multiply "
-                                    "(a_hi*b_hi + a_hi*b_lo + a_lo*b_hi); executed matrix rate = 3 x achieved x (executed / "
-                                    "algorithmic MACs); the exact-fp32-MFMA kernel (--precision f32) peaks at 157.3")
-                if self.split else "dense fp32 MFMA peak",
-                "note": "rank 0's launches, HIP events on the kernel's stream; algorithmic flops = reference formulation "
-                        "MACs x 2 (SURVEY.md 8d) whatever the kernel executes; traffic / hbm_frac / mfma_busy from the "
-                        "committed PMC passes (profiles/); algorithmic bytes = 4 B t in + 16 B (rgb,sigma) out per point" +
-                        (" + 3 views x 14,336 B of feature taps per point as the reference gathers them (no reuse; "
-                         "SURVEY.md 8d upper bound; every texel once would be 560 MB per frame); k_tp_mlp_hp gathers "
-                         "the latent pre-projected through the first-layer weights (8,192 -> 4,096 B per point-view, "
-                         "131,072 of 255,424 MACs per point-view not executed)" if self.workload == "neo360" else "")}
+                "mfma_busy": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"), "pmc_stale": pmc.get("stale"),
+                "kernel_source_sha16": kernel_source_hash()}
+        if self.split:
+            # every algorithmic multiply costs three fp16 products: the ceiling for ALGORITHMIC flops on this arithmetic
+            roof["frac_of_split_ceiling"] = achieved / (PEAK_F16_MFMA_TFLOPS / 3.0)
+            roof["split_ceiling"] = PEAK_F16_MFMA_TFLOPS / 3.0
+        if self.workload == "neo360" and self.split and self.kernel_name == "k_tp_mlp_hp":
+            # what the matrix pipe really executed (a frame's launches hold inside- and outside-sphere points 1:1)
+            ex = 0.5 * (executed_flop_per_point_tp_hp(3, False) + executed_flop_per_point_tp_hp(3, True))
+            roof["executed_tflops"] = points * ex / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+            roof["frac_executed"] = roof["executed_tflops"] / PEAK_F16_MFMA_TFLOPS
+            roof["executed_flop_per_point"] = ex
+        roof["peak_definition"] = (
+            "dense fp16 MFMA peak (MI355X_MICROARCH.md); frac = algorithmic (reference-formulation) flops / time / peak; "
+            "frac_executed = fp16 MFMA flops the kernel really issues (3 products per multiply, padded k-steps, WITHOUT the "
+            "latent GEMM that is pre-projected once per scene) / time / peak - the occupancy of the matrix pipe, comparable "
+            "with mfma_busy; frac_of_split_ceiling = algorithmic flops / (peak / 3), the ceiling of this arithmetic; the "
+            "exact-fp32-MFMA kernel is priced against 157.3 in the exact_f32 record" if self.split else "dense fp32 MFMA peak")
+        roof["note"] = ("rank 0's launches, HIP events on the kernel's stream; algorithmic flops = reference formulation MACs x 2 "
+                        "(SURVEY.md 8d) whatever the kernel executes; traffic / hbm_frac / mfma_busy from the committed PMC passes "
+                        "(profiles/) when their kernel_source_sha16 matches this tree, else null; algorithmic bytes = 4 B t in + "
+                        "16 B (rgb,sigma) out per point" +
+                        (" + 3 views x 14,336 B of feature taps per point as the reference gathers them (no reuse; SURVEY.md 8d "
+                         "upper bound; every texel once would be 560 MB per frame); k_tp_mlp_hp gathers the latent pre-projected "
+                         "through the first-layer weights (8,192 -> 4,096 B per point-view, 131,072 of 255,424 MACs per "
+                         "point-view not executed per point: they are in scene_setup_ms)" if self.workload == "neo360" else ""))
         return roof
 
 
@@ -256,6 +365,8 @@ def main():
                          "the default of every renderer)")
     ap.add_argument("--cpu-rays", type=int, default=-1, help="rays in the CPU-baseline sample (0 = skip, -1 = default)")
     ap.add_argument("--others", type=int, default=-1, help="1/0: also time one step of the other BASELINE configs (default: N == 1)")
+    ap.add_argument("--exact-f32", type=int, default=-1, dest="exact_f32",
+                    help="1/0: also time 2 frames of the same workload on the exact fp32-MFMA kernels (default: as --others)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -289,6 +400,9 @@ def main():
                        "rays_per_frame": R, "parallelism": "ray-shard x%d" % world},
             "roofline": run.roofline(kern),
         }
+        if run.scene_setup:
+            out["scene_setup_ms"] = run.scene_setup["total_ms"]
+            out["scene_setup"] = run.scene_setup
         n_cpu = run.cpu_default if args.cpu_rays < 0 else args.cpu_rays
         if world == 1 and n_cpu > 0:
             batch = run.shard_rays()
@@ -309,8 +423,29 @@ def main():
                                     "psnr_db": render.psnr(rgb_g, rgb_c), "rays": n}
             out["speedup_vs_cpu"] = out["value"] / base["value"]
         others = (world == 1) if args.others < 0 else bool(args.others)
+        exact = others if args.exact_f32 < 0 else bool(args.exact_f32)
+        if exact and world == 1 and run.split:
+            # the same workload on the EXACT fp32-MFMA kernels (module.precision = "f32"), 1 warm-up + 2 timed frames:
+            # the number priced against the contract's own ceiling (fp32 matrix peak 157.3)
+            wl, kw_run = args.workload, run
+            run.net.close()
+            del run, frame
+            torch.cuda.empty_cache()
+            r32 = Runner(wl, "f32", dev, 1, 0, None)
+            dt32, kern32, f32_ = r32.timed(2, 1)
+            roof32 = r32.roofline(kern32)
+            out["exact_f32"] = {"value": R * 2 / dt32, "unit": "rays/s", "ms_per_step": dt32 / 2 * 1e3, "steps": 2, "warmup": 1,
+                                "dtype": "f32 (v_mfma_f32_32x32x2_f32)", "kernel": roof32["kernel"],
+                                "achieved": roof32["achieved"], "peak": roof32["peak"], "unit_roofline": "TFLOP/s",
+                                "frac": roof32["frac"], "avg_launch_ms": roof32["avg_launch_ms"], "launches": roof32["launches"]}
+            r32.net.close()
+            del r32, f32_
+            torch.cuda.empty_cache()
+            run = frame = None
         if others and world == 1:
             # the other BASELINE.json single-GPU configurations, 1 warm-up + 2 timed frames each, same code path
+            if run is not None:
+                run.net.close()
             del run, frame
             torch.cuda.empty_cache()
             out["other_workloads"] = {}

@@ -54,11 +54,13 @@ int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream);
  * forward calls per frame, neo360/model.py:861-907).  post: enqueue on `stream` a copy of the word into a pinned host
  * slot + its clear + an event; returns at once.  take: OR of the posted reads that have completed (wait == 0), or of
  * all posted reads after waiting for their events (wait != 0); a read is reported once.  pending [host out, may be
- * NULL]: posted reads still in flight after the call.  Up to 64 reads may be outstanding; beyond that the oldest is
- * retired into the next take.  sync_count: how many blocking waits (stream / event synchronisations) the flag calls
- * of this context have issued so far - 0 for a loop of post + take(wait = 0). */
+ * NULL]: posted reads still in flight after the call.  Up to 64 reads may be outstanding; a post that finds all 64
+ * still in flight posts nothing (the device word is sticky until a read clears it: a later read reports it, and
+ * take(wait != 0) finishes with one synchronous read on `stream` in that case).  Neither post nor take(wait = 0)
+ * ever blocks.  sync_count: how many blocking waits (stream / event synchronisations) the flag calls of this context
+ * have issued so far - 0 for a loop of post + take(wait = 0). */
 int neo_ctx_post_flags(neo_ctx* ctx, void* stream);
-int neo_ctx_take_flags(neo_ctx* ctx, int wait, uint32_t* flags, int* pending);
+int neo_ctx_take_flags(neo_ctx* ctx, int wait, void* stream, uint32_t* flags, int* pending);
 int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits);
 
 /* Arithmetic of the per-point MLP GEMMs of every renderer (vanilla, NeRF_TP, Mip-NeRF 360, PixelNeRF).

@@ -38,7 +38,7 @@ SIGNATURES = {
     "neo_ctx_destroy": (_i, [_vp]),
     "neo_ctx_poll_flags": (_i, [_vp, ctypes.POINTER(ctypes.c_uint32), _vp]),
     "neo_ctx_post_flags": (_i, [_vp, _vp]),
-    "neo_ctx_take_flags": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_i)]),
+    "neo_ctx_take_flags": (_i, [_vp, _i, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_i)]),
     "neo_ctx_sync_count": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "neo_ctx_set_precision": (_i, [_vp, _i]),
     "neo_linspace_host": (None, [_f, _f, _i, c_float_p]),

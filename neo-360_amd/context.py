@@ -79,7 +79,8 @@ class Context:
     def take_flags(self, wait=False):
         """OR of the posted reads that have completed (wait=False) / of all posted reads (wait=True: blocks)."""
         flags, pending = ctypes.c_uint32(0), ctypes.c_int(0)
-        _lib.check(self.lib.neo_ctx_take_flags(self.handle, 1 if wait else 0, ctypes.byref(flags), ctypes.byref(pending)))
+        _lib.check(self.lib.neo_ctx_take_flags(self.handle, 1 if wait else 0, self.stream(), ctypes.byref(flags),
+                                               ctypes.byref(pending)))
         return flags.value
 
     def sync_count(self):

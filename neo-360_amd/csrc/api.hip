@@ -174,16 +174,19 @@ int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream) {
 int neo_ctx_post_flags(neo_ctx* ctx, void* stream) {
     ENTER(ctx);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ctx->flag_posted - ctx->flag_taken == neo_ctx::FLAG_RING) {
-        // 64 reads in flight and nobody looked: retire the oldest (it has long completed unless the queue is that deep)
+    // ring full (the host runs far ahead of the device and nobody looked): retire what has completed; if every slot
+    // is still in flight, post nothing - the device word is sticky until a read clears it, so the next posted read
+    // (or the synchronous read of take(wait)) reports whatever this call raised
+    while (ctx->flag_posted - ctx->flag_taken == neo_ctx::FLAG_RING) {
         const int old = static_cast<int>(ctx->flag_taken % neo_ctx::FLAG_RING);
         if (hipEventQuery(ctx->flag_ev[old]) != hipSuccess) {
-            HIP_TRY(hipEventSynchronize(ctx->flag_ev[old]));
-            ctx->blocking_waits += 1;
+            ctx->flag_unposted = true;
+            return NEO_OK;
         }
         ctx->flag_carry |= ctx->flag_host[old];
         ctx->flag_taken += 1;
     }
+    ctx->flag_unposted = false;
     const int slot = static_cast<int>(ctx->flag_posted % neo_ctx::FLAG_RING);
     HIP_TRY(hipMemcpyAsync(ctx->flag_host + slot, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), s));
@@ -192,7 +195,7 @@ int neo_ctx_post_flags(neo_ctx* ctx, void* stream) {
     return NEO_OK;
 }
 
-int neo_ctx_take_flags(neo_ctx* ctx, int wait, uint32_t* flags, int* pending) {
+int neo_ctx_take_flags(neo_ctx* ctx, int wait, void* stream, uint32_t* flags, int* pending) {
     ENTER(ctx);
     REQUIRE(flags != nullptr, "null flags");
     uint32_t acc = ctx->flag_carry;
@@ -209,6 +212,17 @@ int neo_ctx_take_flags(neo_ctx* ctx, int wait, uint32_t* flags, int* pending) {
         }
         acc |= ctx->flag_host[slot];
         ctx->flag_taken += 1;
+    }
+    if (wait && ctx->flag_unposted) {
+        // calls after the last posted read (their post found the ring full): one synchronous read covers them
+        uint32_t now = 0;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        HIP_TRY(hipMemcpyAsync(&now, ctx->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemsetAsync(ctx->flags, 0, sizeof(uint32_t), s));
+        HIP_TRY(hipStreamSynchronize(s));
+        ctx->blocking_waits += 1;
+        ctx->flag_unposted = false;
+        acc |= now;
     }
     *flags = acc;
     if (pending) *pending = static_cast<int>(ctx->flag_posted - ctx->flag_taken);

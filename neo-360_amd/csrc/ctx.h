@@ -144,7 +144,8 @@ struct neo_ctx {
     uint32_t* flag_host = nullptr;
     hipEvent_t flag_ev[FLAG_RING] = {};
     uint64_t flag_posted = 0, flag_taken = 0;    // monotone; slot = index % FLAG_RING
-    uint32_t flag_carry = 0;                     // reads retired early because the ring was full
+    uint32_t flag_carry = 0;                     // reads retired by post() while making room
+    bool flag_unposted = false;                  // the last post() found the ring full and posted nothing
     uint64_t blocking_waits = 0;                 // stream / event synchronisations issued by the flag calls
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;

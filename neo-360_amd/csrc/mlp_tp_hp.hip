@@ -47,6 +47,9 @@
 #ifndef NEO_TP_LSTREAM
 #define NEO_TP_LSTREAM 4      // L1..L3 as one weight stream requested this many k-steps ahead across the layer barriers (0: per-layer loops)
 #endif
+#ifndef NEO_TP_HALFPIPE
+#define NEO_TP_HALFPIPE 0     // 1: L0 epilogue .. L3 pipelined by half tiles (measured SLOWER: profiles/r03_tp_hp_experiments.log); kept as an experiment branch
+#endif
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
 // tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
@@ -393,7 +396,119 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 #endif
         }
         TP_MARK(4);
-#if NEO_TP_LSTREAM
+#if NEO_TP_HALFPIPE
+        // ---- L0 epilogue, L1, L2, L3 pipelined by HALF TILES (the two M-tiles of 32 points) ----------------------------
+        // Seven segments separated by one barrier each; in segment s one M-tile runs the 8 k-steps of a layer on the
+        // matrix pipe while the OTHER M-tile's previous-layer epilogue (ReLU, hi/lo split, 8-byte plane stores) issues in
+        // the shadow of those MFMAs, two values per k-step:
+        //     S0            epi L0(m0)        S1  L1(m0) | epi L0(m1)      S2  L1(m1) | epi L1(m0)
+        //     S3  L2(m0) | epi L1(m1)         S4  L2(m1) | epi L2(m0)      S5  L3(m0) | epi L2(m1)
+        //     S6  L3(m1) | sum_v relu(L3)(m0)                         then      sum_v relu(L3)(m1)
+        // A segment reads activation rows of one M-tile and writes rows of the other, so ONE barrier per segment orders
+        // the in-place tile.  Each k-step accumulates hi*hi into A and the two cross terms into B (summed at the
+        // end): consecutive MFMAs on one accumulator are back to back (forwarded), and VALU work placed between A and
+        // B never sits inside a dependent pair.
+#ifndef NEO_TP_HP_LD
+#define NEO_TP_HP_LD 4            // weight prefetch distance in k-steps (ring of LD + 1 fragment pairs, 8 VGPRs each)
+#endif
+#ifndef NEO_TP_HP_BPF
+#define NEO_TP_HP_BPF 1           // 1: the activation fragments of k-step ks + 1 are read before the MFMAs of k-step ks
+#endif
+        // weight fragments: ONE stream of 48 k-steps (every layer twice: once per M-tile), LD k-steps ahead across the
+        // segment barriers, in a ring of LD + 1 slots
+        constexpr int LD = NEO_TP_HP_LD, LS = LD + 1;
+        h8 lwh[LS], lwl[LS];
+        const char* lwb = reinterpret_cast<const char*>(wp);
+        const uint32_t lw_off = (uint32_t)(L.wv * 8 * 128 + L.lane) * 16u;
+        auto load_lw = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;          // 0..47: segment g / 8 (layer = segment / 2), k-step g % 8
+            if constexpr (g < 48) {
+                constexpr int layer = g / 16, ks = g % 8;
+                constexpr uint32_t base = (uint32_t)(layer == 0 ? hoff_1(PE_C) : layer == 1 ? hoff_2(PE_C) : hoff_3a(PE_C)) * 16u;
+                lwh[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks));
+                lwl[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks + 1024u));
+            }
+        };
+        static_for<0, LD>([&](auto gc) { load_lw(gc); });
+        // EPI: 0 none, 1 ReLU + split + store rows `emt` of act (columns of N-tile wv), 2 hsum[emt] += relu
+        auto segment = [&](auto sc_, auto ec, f32x16& A, f32x16& Bc, const f32x16& src) __attribute__((always_inline)) {
+            constexpr int seg = decltype(sc_)::value, mt = seg & 1, EPI = decltype(ec)::value, emt = mt ^ 1;
+            h8 bh[2], bl[2];
+            if constexpr (NEO_TP_HP_BPF) {
+                const int o = chunk_off<128>(mt * 32 + L.l31, L.half);
+                bh[0] = *reinterpret_cast<const h8*>(act.hi + o);
+                bl[0] = *reinterpret_cast<const h8*>(act.lo + o);
+            }
+            h4 th, tl;
+            static_for<0, 8>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value, g = seg * 8 + ks;
+                if constexpr (NEO_TP_HP_BPF ? ks < 7 : true) {
+                    constexpr int kr = NEO_TP_HP_BPF ? ks + 1 : ks;
+                    const int o = chunk_off<128>(mt * 32 + L.l31, (kr << 1) + L.half);
+                    bh[kr & 1] = *reinterpret_cast<const h8*>(act.hi + o);
+                    bl[kr & 1] = *reinterpret_cast<const h8*>(act.lo + o);
+                }
+                A = NEO_MFMA_H(lwh[g % LS], bh[ks & 1], A);
+                if constexpr (EPI == 1) {
+                    constexpr int gq = ks >> 1, e0 = 2 * (ks & 1);
+#pragma unroll
+                    for (int e = e0; e < e0 + 2; ++e) {
+                        const float x = fmaxf(src[4 * gq + e], 0.0f);
+                        range_see(L, x);
+                        _Float16 h, l;
+                        split(x, h, l);
+                        th[e] = h;
+                        tl[e] = l;
+                    }
+                } else if constexpr (EPI == 2) {
+                    hsum[emt][2 * ks] += fmaxf(src[2 * ks], 0.0f);
+                    hsum[emt][2 * ks + 1] += fmaxf(src[2 * ks + 1], 0.0f);
+                }
+                Bc = NEO_MFMA_H(lwl[g % LS], bh[ks & 1], Bc);
+                Bc = NEO_MFMA_H(lwh[g % LS], bl[ks & 1], Bc);
+                load_lw(std::integral_constant<int, g + LD>());
+                if constexpr (EPI == 1 && (ks & 1)) {
+                    constexpr int gq = ks >> 1;
+                    const int o = chunk_off<128>(emt * 32 + L.l31, L.wv * 4 + gq) + 4 * L.half;
+                    *reinterpret_cast<h4*>(act.hi + o) = th;
+                    *reinterpret_cast<h4*>(act.lo + o) = tl;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int r = 0; r < 16; ++r) A[r] += Bc[r];
+        };
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        auto SG = [](auto c) { return c; };
+        f32x16 a0, a1, bq;
+        auto zero16 = [&](f32x16& z) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+        };
+        store_tile_h<true>(accx[0][0], act, L.wv, 0, L);                                        // S0
+        TP_SYNC();
+        bias_tile(a0, lbias + B_1, L.wv, L); zero16(bq);
+        segment(std::integral_constant<int, 0>(), I1(), a0, bq, accx[0][1]);                     // S1: L1(m0) | epi L0(m1)
+        TP_SYNC();
+        bias_tile(a1, lbias + B_1, L.wv, L); zero16(bq);
+        segment(std::integral_constant<int, 1>(), I1(), a1, bq, a0);                             // S2: L1(m1) | epi L1(m0)
+        TP_SYNC();
+        bias_tile(a0, lbias + B_2, L.wv, L); zero16(bq);
+        segment(std::integral_constant<int, 2>(), I1(), a0, bq, a1);                             // S3: L2(m0) | epi L1(m1)
+        TP_SYNC();
+        bias_tile(a1, lbias + B_2, L.wv, L); zero16(bq);
+        segment(std::integral_constant<int, 3>(), I1(), a1, bq, a0);                             // S4: L2(m1) | epi L2(m0)
+        TP_SYNC();
+        zero16(bq);
+        segment(std::integral_constant<int, 4>(), I1(), accx[1][0], bq, a1);                     // S5: L3(m0) = skip half + W3a h2 | epi L2(m1)
+        TP_SYNC();
+        zero16(bq);
+        segment(std::integral_constant<int, 5>(), I2(), accx[1][1], bq, accx[1][0]);             // S6: L3(m1) | sum_v relu(L3)(m0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hsum[1][r] += fmaxf(accx[1][1][r], 0.0f);
+        (void)SG;
+#elif NEO_TP_LSTREAM
         // ---- L0 epilogue; L1, L2, L3 as ONE weight stream of 24 k-steps (N-tile = wave) requested LD k-steps ahead
         //      across the layer boundaries: the weights of the next layer do not wait for the barriers ----
         constexpr int LD = NEO_TP_LSTREAM, LS = LD + 1;

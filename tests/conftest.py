@@ -92,31 +92,50 @@ def per_ray_abs(x):
     return x.abs().amax(dim=-1) if x.dim() == 2 and x.shape[-1] == 3 else x.abs().reshape(x.shape[0])
 
 
+FLIP_MARGIN = 1e-6      # ~16 ulps of a cdf in [0,1]: what faithful fp32 evaluations of the coarse level differ by (measured:
+                        # GPU-vs-reference coarse weights 5e-7, profiles/r03_full_chunk_anatomy.log)
+
+
 def check_vs_reference_noise(got, g, noise, label, tol=1e-4):
-    """The fixture g4_neo_<tag>_noise holds, per ray and output, |ref32 - ref64|: the reference's decoder run in fp32
-    (= the fixture g) and by its own fp64 twin (tests/golden/make_golden.py:g4_neo_noise).  At 128 + 256 samples that
-    self-disagreement is < 1e-5 on > 99 % of the rays and reaches a few 1e-4 on the rest: the background fine level
-    inverts a cdf over DEscending bins (neo360/model.py:319-331), where one ulp of the fp32 cdf moves a sample along
-    the whole ray.
-      * every ray the reference determines to better than 1e-5 must meet the 1e-4 contract - no exceptions;
-      * a ray where the reference disagrees with itself by n >= 1e-5 must land within 1e-4 + 3 n of the fp32
-        reference (GPU outliers are the reference's own outliers, with comparable magnitude).
-    Records max / p99 / ill-conditioned counts per output in the parity report."""
+    """End-to-end NeO-360 contract, separated by how well the REFERENCE determines each ray.  Evidence, all produced by
+    the reference itself in the build container (tests/golden/make_golden.py:g4_neo_noise):
+      noise_<k>   per ray and output |ref32 - ref64| (its decoder run in fp32 = the fixture g, and by its own fp64 twin;
+                  for the full-size fixture also the maximum over fp32 runs with every weight moved within +-1 ulp);
+      margin_bg1  per ray min_ij |u_j - cdf_i| inside its inverse-CDF sampler for the background fine level.  There the
+                  bins DEscend (neo360/model.py:319-331), bin0 / bin1 are always the first / last bin, and the sampler
+                  is DISCONTINUOUS at every u_j = cdf_i: one of the 256 new samples crosses the whole range.  A ray with
+                  margin < 1e-6 flips under any re-evaluation of the coarse level that is not bit-identical - which rays
+                  do flip differs from one realisation to the next (fp64 twin, ulp trials and the GPU each flip a
+                  different handful of the ~6 % flip-prone rays), so no finite set of twins can list them, the margin does.
+    Rule:
+      * a ray with noise < 1e-5 and margin >= 1e-6 must meet 1e-4 on every output - no exceptions;
+      * a ray the reference disagrees with itself on (n >= 1e-5) must land within 1e-4 + 3 n;
+      * a flip-prone ray (margin < 1e-6) must land within 1e-4 + 3 max(n, F), F = the largest self-disagreement the
+        reference shows on ANY ray of the fixture for that output (the size of a flip, ~1e-4), and at most 2 % of the
+        rays may exceed 1e-4 at all.
+    Records max / p99 / counts per output in the parity report."""
     rec = {}
+    nrays = int(noise["noise_rgb1"].numel())
+    flip = (noise["margin_bg1"] < FLIP_MARGIN) if "margin_bg1" in noise else torch.zeros(nrays, dtype=torch.bool)
     for k in NEO_KEYS:
         err = per_ray_abs(got[k] - g[k])
         n = noise["noise_" + k]
-        well = n < 1e-5
-        ill = ~well
+        well = (n < 1e-5) & ~flip
+        F = float(n.max())
+        bound = tol + 3.0 * torch.where(flip, torch.clamp(n, min=F), n)
         rec[k] = dict(max=float(err.max()), p99=float(err.quantile(0.99)), max_well_conditioned=float(err[well].max()),
-                      ill_conditioned_rays=int(ill.sum()), reference_self_noise_max=float(n.max()), rays=int(err.numel()))
+                      self_noise_rays=int((n >= 1e-5).sum()), flip_prone_rays=int(flip.sum()),
+                      rays_above_1e_4=int((err >= tol).sum()), reference_self_noise_max=F, rays=int(err.numel()))
         assert float(err[well].max()) < tol, (label, k, "well-conditioned ray above 1e-4", float(err[well].max()))
-        if bool(ill.any()):
-            excess = err[ill] - (tol + 3.0 * n[ill])
+        bad = ~well
+        if bool(bad.any()):
+            excess = err[bad] - bound[bad]
             assert float(excess.max()) <= 0.0, (label, k, "ill-conditioned ray beyond the reference's own noise",
-                                                float(err[ill].max()), float(n[ill].max()))
+                                                float(err[bad].max()), F)
+        assert int((err >= tol).sum()) <= max(1, int(0.02 * err.numel())), (label, k, "too many rays above 1e-4")
     mse = float(((got["rgb1"].clamp(0, 1) - g["rgb1"].clamp(0, 1)) ** 2).mean())
     rec["psnr_db_vs_reference"] = float("inf") if mse == 0 else -10.0 * __import__("math").log10(mse)
     record_parity(label, **rec)
-    print(label, {k: "%.2e (%d ill)" % (v["max"], v["ill_conditioned_rays"]) for k, v in rec.items() if isinstance(v, dict)})
+    print(label, {k: "%.2e (%d noisy, %d flip-prone)" % (v["max"], v["self_noise_rays"], v["flip_prone_rays"])
+                  for k, v in rec.items() if isinstance(v, dict)})
     assert mse < 1e-10       # PSNR vs the reference frame > 100 dB

@@ -281,13 +281,60 @@ def g4_neo(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, nv=cases.NV, 
     save("g4_neo_" + tag, **{k: torch.cat(v, 0) for k, v in acc.items()})
 
 
-def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=False):
+class _MarginProbe:
+    """Records, for every call of the reference's inverse-CDF sampler (neo360/helper.py:174-215) while active, the
+    per-ray distance between its quantiles u and the interior values of ITS OWN cdf (captured from its torch.cumsum):
+    margin = min_ij |u_j - cdf_i|.  With DEscending bins (the background branch) the sampler is discontinuous at
+    every u_j = cdf_i: bin0 / bin1 are always the first / last bin, so the interpolation weight jumps from 1 to 0 and
+    one sample crosses the whole range.  A ray whose margin is a few ulps of the cdf changes under ANY faithful
+    re-evaluation of the coarse level; the tests use the margin to recognise such rays (flip-prone rays)."""
+
+    def __init__(self, helper_module):
+        self.h = helper_module
+        self.orig = helper_module.sorted_piecewise_constant_pdf
+        self.margins = []
+
+    def __enter__(self):
+        probe = self
+
+        def wrapped(bins, weights, num_samples, randomized, float_min_eps=2 ** -32):
+            real_cumsum, seen = torch.cumsum, []
+
+            def spy(*a, **k):
+                out = real_cumsum(*a, **k)
+                seen.append(out)
+                return out
+
+            torch.cumsum = spy
+            try:
+                res = probe.orig(bins, weights, num_samples, randomized, float_min_eps)
+            finally:
+                torch.cumsum = real_cumsum
+            inner = torch.fmin(torch.ones_like(seen[0]), seen[0]).double()
+            u = torch.linspace(0.0, 1.0 - float_min_eps, num_samples).double()
+            probe.margins.append((u[None, None, :] - inner[:, :, None]).abs().reshape(inner.shape[0], -1).min(dim=-1).values.float())
+            return res
+
+        self.h.sorted_piecewise_constant_pdf = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.h.sorted_piecewise_constant_pdf = self.orig
+
+
+def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=False, ulp_trials=0):
     """The reference's OWN rounding noise on the rays of fixture g4_neo_<tag>: the same call evaluated by the
     reference in fp32 and by its fp64 twin (module.double(), fp64 rays / latent; the tri-planes stay fp32 because
     index_grid casts its coordinates with .float(), encoder_tp_fusion_conv.py:128-130).  Stored per ray:
     |ref32 - ref64| (max over channels) for every output of the fixture, plus the fp64 values themselves.
     tests/test_gpu_neo360.py uses it to separate well-conditioned rays (contract: 1e-4 on every one) from rays on
-    which the reference disagrees with itself."""
+    which the reference disagrees with itself.
+    ulp_trials > 0 adds that many fp32 runs of the reference with every MLP weight moved by a random amount within
+    +-1 ulp (w (1 + eta), eta ~ U(-2^-24, 2^-24), hash-seeded): what ANY faithful fp32 evaluation of the same network
+    (another summation order, fused multiply-adds, a split-fp16 matrix pipe) does to the coarse densities, ~1e-6.
+    The fp64 twin samples that sensitivity once per ray; on a chaotic ray (descending-bin inversion,
+    neo360/model.py:319-331) one sample can land near zero by luck, so the stored noise is the MAXIMUM over the twin
+    and the trials."""
     scene, batch = _neo_inputs(n_rays, cases.NV, full)
     state = synth.nerf_tp_state(0, density_gain=gain)
     per_ray = ("rays_o", "rays_d", "viewdirs")
@@ -305,7 +352,12 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=Fa
 
     net32 = ref_nerf_tp(state, scene)
     net32.num_coarse_samples, net32.num_fine_samples = n_coarse, n_fine
-    r32 = run(net32, batch)
+    with _MarginProbe(ref.load("models.neo360.helper")) as probe:
+        r32 = run(net32, batch)
+    # per forward call the reference resamples inside the sphere first, then outside (neo360/model.py:309-331)
+    margin_fg = torch.cat(probe.margins[0::2])
+    margin_bg = torch.cat(probe.margins[1::2])
+    assert margin_fg.shape == (n_rays,) and margin_bg.shape == (n_rays,)
     del net32
     scene64 = dict(scene)
     scene64["latent"] = scene["latent"].double()
@@ -313,13 +365,37 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=Fa
     net64.num_coarse_samples, net64.num_fine_samples = n_coarse, n_fine
     b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
     r64 = run(net64, b64)
+    del net64
+    per_ray_max = lambda d: (d.amax(dim=-1) if d.dim() == 2 and d.shape[-1] == 3 else d.reshape(n_rays))
+    trial_noise = {k: torch.zeros(n_rays, dtype=torch.float64) for k in keys}
+    for t in range(ulp_trials):
+        st = {}
+        for name, w in state.items():
+            if name.endswith(".weight"):
+                eta = synth.uniform(1000 + t, "ulp/" + name, tuple(w.shape), -2.0 ** -24, 2.0 ** -24)
+                st[name] = (w.double() * (1.0 + eta.double())).float()
+            else:
+                st[name] = w
+        net_t = ref_nerf_tp(st, scene)
+        net_t.num_coarse_samples, net_t.num_fine_samples = n_coarse, n_fine
+        rt = run(net_t, batch)
+        del net_t
+        for k in keys:
+            trial_noise[k] = torch.maximum(trial_noise[k], per_ray_max((r32[k].double() - rt[k].double()).abs()))
+        print("ulp trial %d: rgb1 max %.2e, bg1 max %.2e, rays >= 1e-5 on bg1: %d" % (
+            t, float(trial_noise["rgb1"].max()), float(trial_noise["bg1"].max()), int((trial_noise["bg1"] >= 1e-5).sum())))
     out = {}
     for k in keys:
         assert r64[k].dtype == torch.float64, (k, r64[k].dtype)
         d = (r32[k].double() - r64[k]).abs()
-        out["noise_" + k] = (d.amax(dim=-1) if d.dim() == 2 and d.shape[-1] == 3 else d.reshape(n_rays)).float()
+        out["noise_" + k] = torch.maximum(per_ray_max(d), trial_noise[k]).float()
+        if ulp_trials:
+            out["noise64_" + k] = per_ray_max(d).float()          # the fp64 twin alone, for the record
         if not full:                      # the full-size fixture stays small: the tests only read the noise arrays
             out["ref64_" + k] = r64[k]
+    out["margin_fg1"], out["margin_bg1"] = margin_fg, margin_bg
+    print("margins: bg < 1e-6 on %d rays, < 1e-7 on %d; fg < 1e-6 on %d" % (
+        int((margin_bg < 1e-6).sum()), int((margin_bg < 1e-7).sum()), int((margin_fg < 1e-6).sum())))
     # the fp32 run here must be the committed fixture (same code, same inputs)
     fx = np.load(os.path.join(HERE, "g4_neo_%s.npz" % tag))
     for k in keys:
@@ -544,7 +620,7 @@ def main(which):
         # latents 3x512x240x320, 128 + 256 samples (neo360/model.py:266-581, :169-171; chunk 1024: opt.py:195-200),
         # and the reference's fp64 twin on the same rays.  ~10 GB of RAM, a few minutes.
         "g4n_full": lambda: g4_neo("full", 1024, 1024, full=True),
-        "g4n_full_noise": lambda: g4_neo_noise("full", 1024, 1024, full=True),
+        "g4n_full_noise": lambda: g4_neo_noise("full", 1024, 1024, full=True, ulp_trials=2),
         "g6": g6_mip360,
         "g7": g7_pixelnerf,
         "g8": g8_training,

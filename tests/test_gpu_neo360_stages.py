@@ -89,7 +89,11 @@ def test_pipeline_stage_by_stage(setup):
     bg_w64 = torch.flip(oracle.sampling.merge_sorted(bg_s.double(), oracle.sampling.piecewise_constant_samples(
         bg_mids.double(), wb_in.double(), NF)), dims=[-1])
     noise = (bg_want.double() - bg_w64).abs()
-    excess = (bg_s1.double() - bg_want.double()).abs() - (5e-6 + 3.0 * noise.amax(dim=-1, keepdim=True))
+    row_noise = noise.amax(dim=-1, keepdim=True)
+    excess = (bg_s1.double() - bg_want.double()).abs() - (1e-4 + 3.0 * row_noise)       # the end-to-end rule, per ray
+    well = row_noise.squeeze(-1) < 1e-5
+    if bool(well.any()):
+        assert float((bg_s1 - bg_want).abs()[well].max()) < 1e-4
     record_parity("neo360_stages/%s/bg_resample" % net._variant, max_pos_err=float((bg_s1 - bg_want).abs().max()),
                   reference_self_noise_max=float(noise.max()), rows=int(bg_s1.shape[0]))
     assert float(excess.max()) <= 0.0, (float((bg_s1 - bg_want).abs().max()), float(noise.max()))

@@ -172,7 +172,11 @@ def test_resample_matches_oracle(desc, n_prev, n_new):
         record_parity("resample_vs_oracle/desc_%d_%d" % (n_prev, n_new), max_pos_err=float(err[good].max()),
                       reference_self_noise_max=float(noise[good].max()))
         row_noise = noise.amax(dim=-1, keepdim=True)            # per row, as the end-to-end rule is per ray
-        assert float((err - (5e-6 + 3.0 * row_noise))[good].max()) <= 0.0, (float(err[good].max()), float(noise[good].max()))
+        # same rule as the end-to-end test: 1e-4 on every row the reference arithmetic determines to better than 1e-5,
+        # otherwise within 1e-4 + 3 x that row's fp32-vs-fp64 disagreement
+        assert float((err - (1e-4 + 3.0 * row_noise))[good].max()) <= 0.0, (float(err[good].max()), float(noise[good].max()))
+        well = good & (row_noise.squeeze(-1) < 1e-5)
+        assert float(err[well].max()) < 1e-4
 
 
 @pytest.mark.parametrize("tag", ["asc", "desc"])
@@ -204,10 +208,15 @@ def test_resample_golden_bins(golden, tag):
                   reference_self_noise_max=float(self_noise[keep].max()), rows=int(keep.sum()))
     if not desc:
         assert max_abs(_cdf_space(got[keep], bins[keep], w[keep]), _cdf_space(want[keep], bins[keep], w[keep])) < 2e-6
-    # positions: within 5e-6 + 3 x the reference's own fp32-vs-fp64 disagreement on that row, and never above 1e-4
+    # positions: 1e-4 on every row the reference determines to better than 1e-5 (all ascending rows are), the other rows
+    # within 1e-4 + 3 x the reference's own fp32-vs-fp64 disagreement on that row (fixture g3_pdf_noise)
     row_noise = self_noise.amax(dim=-1, keepdim=True)
-    assert float((err - (5e-6 + 3.0 * row_noise))[keep].max()) <= 0.0, (float(err[keep].max()), float(self_noise[keep].max()))
-    assert float(err[keep].max()) < 1e-4
+    assert float((err - (1e-4 + 3.0 * row_noise))[keep].max()) <= 0.0, (float(err[keep].max()), float(self_noise[keep].max()))
+    well = keep & (row_noise.squeeze(-1) < 1e-5)
+    if bool(well.any()):
+        assert float(err[well].max()) < 1e-4
+    if not desc:
+        assert bool(well[keep].all()) and float(err[keep].max()) < 1e-5
 
 
 def test_composite_modes(golden):
