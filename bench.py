@@ -33,9 +33,14 @@ CHUNK = 1024
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector peak)
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_HBM_BYTES = 8.0e12               # MI355X_MICROARCH.md: HBM3E spec peak
-CPU_THREADS = 32                      # fastest of the NeO-360 sweep on the GPU box's host (profiles/r03_cpu_threads_neo360.log)
+# torch threads of the CPU leg = the fastest setting of a sweep on the GPU box's host (2 x EPYC 9575F, 128 physical cores):
+# NeO-360 is fastest on 8 threads (26.5 rays/s; 16: 21.5, 32: 8.4, 64: 6.3, 128: 2.5 - profiles/r03_cpu_threads_neo360.log:
+# the gathers are memory-bound and the container's threads migrate), the dense vanilla / mip360 MLPs on 32
+# (profiles/cpu_threads_r01.log)
+CPU_THREADS = {"neo360": 8, "pixelnerf": 8}
+CPU_THREADS_DEFAULT = 32
 CPU_REPS = 3                          # >= 3 repetitions of the CPU sample
-CPU_REP_BUDGET_S = 75.0               # a repetition slower than this ends the CPU leg early (the default run must finish in minutes)
+CPU_BUDGET_S = 130.0                  # no further repetition once the CPU leg has used this much (the default run finishes in minutes)
 
 
 def physical_cores():
@@ -158,10 +163,10 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
     """The oracle (CPU restatement of the reference: kind 'port'; oracle == reference is pinned by tests/golden,
     tests/test_oracle_fullsize.py and tests/test_oracle_vs_reference.py) timed up to CPU_REPS times on a bounded sample
     of the same frame on the host cores: for NeO-360 ONE WHOLE reference chunk (1024 rays: BASELINE.md 3),
-    thread count from a NeO-360 sweep on the GPU box's host.  A repetition slower than CPU_REP_BUDGET_S ends the leg
-    early so the default run still finishes in minutes."""
+    thread count from a NeO-360 sweep on the GPU box's host.  No further repetition is started once CPU_BUDGET_S would
+    be exceeded, so the default run still finishes in minutes."""
     import oracle
-    torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
+    torch.set_num_threads(min(CPU_THREADS.get(workload, CPU_THREADS_DEFAULT), os.cpu_count() or 1))
     sample = {k: v[:n] for k, v in rays_cpu.items()}
     times = []
     for _ in range(CPU_REPS):
@@ -184,7 +189,7 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
             sc = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in scene.items()}
             rgb, depth = oracle.neo360.render_chunked(state, batch, sc, chunk=min(n, CHUNK))
         times.append(time.perf_counter() - t0)
-        if times[-1] > CPU_REP_BUDGET_S:
+        if sum(times) + times[-1] > CPU_BUDGET_S:
             break
     dt = statistics.median(times)
     base = dict(value=n / dt, unit="rays/s", cores=physical_cores(), threads=torch.get_num_threads(), kind="port",
@@ -457,7 +462,8 @@ def main():
                 roof = r2.roofline(kern2)
                 out["other_workloads"][wl] = {"value": R * 2 / dt2, "unit": "rays/s", "ms_per_step": dt2 / 2 * 1e3, "steps": 2,
                                               "kernel": roof["kernel"], "achieved_tflops": roof["achieved"],
-                                              "roofline_frac": roof["frac"], "workload": r2.desc}
+                                              "roofline_frac": roof["frac"], "peak": roof["peak"],
+                                              "frac_of_split_ceiling": roof.get("frac_of_split_ceiling"), "workload": r2.desc}
                 r2.net.close()
                 del r2, f2
                 torch.cuda.empty_cache()

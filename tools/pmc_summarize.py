@@ -25,7 +25,13 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
         else:
             mean[k] = sum(vals) / len(vals)
 c = mean
-out = {"kernel_match": pat, "launches_per_pass": nl, "note": note, "mean_per_launch": c, "derived": {}}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from bench import kernel_source_hash          # the tree the passes ran on: bench.py drops summaries of other trees
+    src_hash = kernel_source_hash()
+except Exception:
+    src_hash = None
+out = {"kernel_match": pat, "launches_per_pass": nl, "note": note, "kernel_source_sha16": src_hash, "mean_per_launch": c, "derived": {}}
 d = out["derived"]
 if dur:
     ms = d["avg_launch_ms_under_pmc"] = sum(dur) / len(dur)
