@@ -105,6 +105,7 @@ void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpV
 
 // weight re-packing into MFMA fragment order (defined in mlp_tp.hip)
 struct PackSegs { int k0[3], len[3], col[3]; };
+struct PackPerm { short col[256]; };      // packed k -> source column (-1: zero), passed by value (pack_h_perm)
 void pack_block(const float* src, int ld, int rows, int KC, int nt0, PackSegs sg, float* dst, hipStream_t s);
 void copy_floats(const float* src, int n, float* dst, hipStream_t s);
 

@@ -50,6 +50,9 @@
 #ifndef NEO_TP_HALFPIPE
 #define NEO_TP_HALFPIPE 0     // 1: L0 epilogue .. L3 pipelined by half tiles (measured SLOWER: profiles/r03_tp_hp_experiments.log); kept as an experiment branch
 #endif
+#ifndef NEO_TP_ZSKIP
+#define NEO_TP_ZSKIP 1        // skip a view's latent / tri-plane gather pipeline when no row of the tile has a non-zero tap weight in it
+#endif
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
 // tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
@@ -160,6 +163,24 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         });
         TP_SYNC();
         TP_MARK(1);
+#if NEO_TP_ZSKIP
+        // Which rows have any non-zero tap weight, per map (0 = latent, 1..3 = planes): samples outside a feature map
+        // blend to exactly zero (grid_sample's zero padding).  (Skipping single gather items was measured first: loads
+        // under a branch cost the software pipeline its exact vmcnt bookkeeping, and zero-weight taps are cheap on the
+        // memory path anyway - all lanes read texel 0, one cache line, ~3 cycles instead of 16-23: tools/ta_cost.hip.)
+        unsigned long long zm[4];       // bit p: row p of the tile has a non-zero weight in map m (wave-uniform, SGPRs)
+        {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(loc_w + L.lane * 4);
+            zm[0] = __ballot(w0[0] != 0.0f || w0[1] != 0.0f || w0[2] != 0.0f || w0[3] != 0.0f);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 wj = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + L.lane) * 4);
+                zm[1 + j] = __ballot(wj[0] != 0.0f || wj[1] != 0.0f || wj[2] != 0.0f || wj[3] != 0.0f);
+            }
+        }
+#else
+        const unsigned long long zm[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+#endif
 
         // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
         f32x16 accx[2][2];
@@ -237,26 +258,58 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                         for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += val[e];
                     }
             };
-            // pos_enc: half hf of a stage = chunks 4hf..4hf+3, one per wave
+            // pos_enc: half hf of a stage = chunks 4hf..4hf+3, one per wave; a chunk = 8 features = 4 (sin, cos) PAIRS of the
+            // pair order (launch_tp_pack_hp): pair p = 4 chunk + jj = octave * C + coordinate.  Both features of a pair
+            // come out of one argument reduction (common.h:sincos_pair).  C = 4: a chunk is one octave, coordinate = jj.
             auto finish_pe = [&](const HT& buf, int pstage, int hf) __attribute__((always_inline)) {
                 if constexpr ((NEO_TP_ABLATE & 4) != 0) return;
                 const int row = tid & 63, q = tid >> 6;
-                const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
-                range_see(L, xc[0]); range_see(L, xc[1]); range_see(L, xc[2]);     // identity features (the rest are sines)
-                const int ch = hf * 4 + q;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(cam_enc + row * 4);
+                const int chs = hf * 4 + q;                    // chunk inside this 64-feature stage (wave-uniform)
+                const int ch = pstage * 8 + chs;               // chunk of the whole encoding
+                float f[8];
+                if (ch * 4 < 10 * PE_C) {                      // pairs (C = 3: chunk 7 holds pairs 28, 29 and the identity features)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (PE_C == 3 && jj >= 2 && ch == 7) {  // pairs 30, 31 do not exist: positions 60..63 = x, y, z, 0
+                            f[2 * jj] = jj == 2 ? xv[0] : xv[2];
+                            f[2 * jj + 1] = jj == 2 ? xv[1] : 0.0f;
+                            range_see(L, f[2 * jj]); range_see(L, f[2 * jj + 1]);
+                            continue;
+                        }
+                        float x;
+                        int oct;
+                        if constexpr (PE_C == 4) {
+                            x = xv[jj];
+                            oct = ch;
+                        } else {
+                            const int p = ch * 4 + jj;         // wave-uniform: scalar arithmetic
+                            oct = p / 3;
+                            const int a = p - 3 * oct;
+                            x = a == 0 ? xv[0] : a == 1 ? xv[1] : xv[2];
+                        }
+                        sincos_pair(ldexpf(x, oct), f[2 * jj], f[2 * jj + 1]);
+                    }
+                } else {                                        // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = 0.0f;
+                    if (ch * 4 == 10 * PE_C) {
+                        range_see(L, xv[0]); range_see(L, xv[1]); range_see(L, xv[2]); range_see(L, xv[3]);
+                        f[0] = xv[0]; f[1] = xv[1]; f[2] = xv[2]; f[3] = xv[3];
+                    }
+                }
                 h8 vh, vl;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    _Float16 h, l;
-                    split(pe_feature<PE_C>(xc, pstage * 64 + ch * 8 + e), h, l);
-                    vh[e] = h;
-                    vl[e] = l;
+                for (int e = 0; e < 8; e += 2) {
+                    h2 h, l;
+                    split2(f[e], f[e + 1], h, l);
+                    vh[e] = h[0]; vh[e + 1] = h[1];
+                    vl[e] = l[0]; vl[e + 1] = l[1];
                 }
-                const int o = chunk_off<64>(row, ch);
+                const int o = chunk_off<64>(row, chs);
                 *reinterpret_cast<h8*>(buf.hi + o) = vh;
                 *reinterpret_cast<h8*>(buf.lo + o) = vl;
             };
-#if NEO_TP_XSTREAM
             // streamed-stage weights: k-steps 0..KSX-1 of N-tiles wv (L0) and 4 + wv (L3 skip) in a ring, XD k-steps ahead
             constexpr int XD = NEO_TP_XSTREAM, XS = XD + 1;
             h8 wh[XS][2], wl[XS][2];
@@ -293,71 +346,64 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     }
                 load_wk(std::integral_constant<int, ks + XD>());
             };
-#else
-            h8 wh[2], wl[2];                                   // one k-step x 2 N-tiles, hi + lo
-            const char* wxb = reinterpret_cast<const char*>(wp + hoff_x());
-            uint32_t wx_off[2];
-            wx_off[0] = (uint32_t)(L.wv * KSX * 2 * 64 + L.lane) * 16u;
-            wx_off[1] = (uint32_t)((4 + L.wv) * KSX * 2 * 64 + L.lane) * 16u;
-            auto load_wq = [&](int ks) __attribute__((always_inline)) {
-                if constexpr ((NEO_TP_ABLATE & 8) != 0) return;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    wh[nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks));
-                    wl[nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * ks + 1024u));
-                }
-            };
-            auto mma_q = [&](const HT& tile, int tks) __attribute__((always_inline)) {
-                if constexpr ((NEO_TP_ABLATE & 8) != 0) return;
-                h8 bh[2], bl[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int o = chunk_off<64>(mt * 32 + L.l31, (tks << 1) + L.half);
-                    bh[mt] = *reinterpret_cast<const h8*>(tile.hi + o);
-                    bl[mt] = *reinterpret_cast<const h8*>(tile.lo + o);
-                }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        accx[nt][mt] = NEO_MFMA_H(wl[nt], bh[mt], accx[nt][mt]);
-                        accx[nt][mt] = NEO_MFMA_H(wh[nt], bl[mt], accx[nt][mt]);
-                        accx[nt][mt] = NEO_MFMA_H(wh[nt], bh[mt], accx[nt][mt]);
-                    }
-            };
-
+            // ---- gathers: two software pipelines (items 0..15 pre-projected latent, 16..39 tri-planes), each skipped as a
+            //      whole when NO row of the tile has a non-zero tap weight in its maps for this view.  That is the normal
+            //      case outside the unit sphere (half of all points): the far samples project outside every source image
+            //      and lie outside the [-1,1]^3 tri-plane volume of the view (profiles/r03_tile_footprint.json: the median
+            //      background tile-view touches ONE texel per map, i.e. only the zero-weight placeholder).  Their features are
+            //      exactly zero (grid_sample zero padding), so the latent adds, the 8 world k-steps of the streamed GEMM and
+            //      their weight fragments are skipped too.  zm[] is identical in all four waves: the barriers stay uniform.
+            const bool any_latent = !NEO_TP_ZSKIP || zm[0] != 0ull;
+            const bool any_plane = !NEO_TP_ZSKIP || (zm[1] | zm[2] | zm[3]) != 0ull;
+            if (any_latent) {
+                static_for<0, RING - 1>([&](auto ic) { issue(ic); });
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i + RING - 1 < 16) issue(std::integral_constant<int, i + RING - 1>());
+                    if constexpr (i == 4 || i == 8 || i == 12) consume_chunk(std::integral_constant<int, i / 4 - 1>());
+                    finish(ic);
+                    __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
+                    if constexpr (i == 3 || i == 7 || i == 11 || i == 15) TP_SYNC();
+                });
+                consume_chunk(std::integral_constant<int, 3>());
+            }
+            TP_MARK(2);
+            static_for<0, XD>([&](auto kc) { load_wk(kc); });
+#ifndef NEO_TP_PLANE_MMA_INSIDE
+#define NEO_TP_PLANE_MMA_INSIDE 1     // 1: world stage 0 is multiplied between the gather items of stage 1 and the tri-plane pipeline always runs (measured best); 0: tri-plane pipeline skipped when no tap carries weight, stage 0 multiplied afterwards
 #endif
-            // ---- the flat gather pipeline ----
-            static_for<0, RING - 1>([&](auto ic) { issue(ic); });
-            static_for<0, NI>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                issue(std::integral_constant<int, i + RING - 1>());
-                if constexpr (i == 4 || i == 8 || i == 12 || i == 16) consume_chunk(std::integral_constant<int, i / 4 - 1>());
-                if constexpr (i == 16) TP_MARK(2);
-#if NEO_TP_XSTREAM
-                if constexpr (i == 16) static_for<0, XD>([&](auto kc) { load_wk(kc); });
-                if constexpr (i >= 28 && (i - 28) % 3 == 0) mma_k(xbuf(0), std::integral_constant<int, (i - 28) / 3>());
-#else
-                if constexpr (i == 16) load_wq(0);
-                if constexpr (i >= 28 && (i - 28) % 3 == 0) {          // world stage 1 is gathered: multiply stage 0
-                    constexpr int q = (i - 28) / 3;
-                    mma_q(xbuf(0), q);
-                    load_wq(q + 1);
-                }
-#endif
-                finish(ic);
-                __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
-                if constexpr (i == 3 || i == 7 || i == 11 || i == 15 || i == 27 || i == 39) TP_SYNC();
-            });
+            if (any_plane || NEO_TP_PLANE_MMA_INSIDE) {
+                static_for<16, 16 + RING - 1>([&](auto ic) { issue(ic); });
+                static_for<16, NI>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (i + RING - 1 < NI) issue(std::integral_constant<int, i + RING - 1>());
+                    if constexpr (NEO_TP_PLANE_MMA_INSIDE && i >= 28 && (i - 28) % 3 == 0)
+                        mma_k(xbuf(0), std::integral_constant<int, (i - 28) / 3>());
+                    finish(ic);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (i == 27 || i == 39) TP_SYNC();
+                });
+            } else {
+                // no tap of any tri-plane carries weight: the world features of this view are exactly zero.  Both stage
+                // tiles are cleared and the same k-steps run on them (one instruction stream on both paths keeps the 64
+                // accumulator registers out of scratch); the 24 gather items, their blends and a barrier are saved.
+                if (any_latent) TP_SYNC();                             // chunk 3 of the latent is still being read
+                const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                _Float16* zb = hbase + tid * 8;                        // the act area (32 KB) as 2048 x 16 B: 8 chunks per thread
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<h8*>(zb + j * 2048) = z;
+                TP_SYNC();
+            }
+            if constexpr (!NEO_TP_PLANE_MMA_INSIDE) static_for<0, 4>([&](auto kc) { mma_k(xbuf(0), kc); });
             TP_MARK(3);
-#if NEO_TP_XSTREAM
-            // ---- world stage 1 is multiplied while the first pos_enc stage is computed; then the pos_enc stage(s) ----
+            // world stage 1 is multiplied while the first pos_enc stage is computed
             static_for<4, 8>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
                 mma_k(xbuf(1), kc);
                 if constexpr (ks & 1) finish_pe(xbuf(0), 0, (ks - 4) >> 1);
             });
             TP_SYNC();
+            // ---- the pos_enc stage(s) ----
             static_for<8, 12>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
                 mma_k(xbuf(0), kc);
@@ -368,32 +414,6 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 static_for<12, 14>([&](auto kc) { mma_k(xbuf(1), kc); });
                 TP_SYNC();
             }
-#else
-            // ---- world stage 1 is multiplied while the first pos_enc stage is computed ----
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                mma_q(xbuf(1), q);
-                load_wq(4 + q + 1);
-                if (q & 1) finish_pe(xbuf(0), 0, q >> 1);
-            }
-            TP_SYNC();
-            // ---- pos_enc stage(s) ----
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                mma_q(xbuf(0), q);
-                if (8 + q + 1 < KSX) load_wq(8 + q + 1);
-                if constexpr (NPE == 2) { if (q == 1) finish_pe(xbuf(1), 1, 0); }   // features 64..95 (84..95 are padding)
-            }
-            TP_SYNC();
-            if constexpr (NPE == 2) {
-#pragma unroll 1
-                for (int q = 0; q < 2; ++q) {
-                    mma_q(xbuf(1), q);
-                    if (12 + q + 1 < KSX) load_wq(12 + q + 1);
-                }
-                TP_SYNC();
-            }
-#endif
         }
         TP_MARK(4);
 #if NEO_TP_HALFPIPE
@@ -564,8 +584,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
-                        hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
+                        hsum[0][r] += relu1(acc[0][0][r]);
+                        hsum[1][r] += relu1(acc[0][1][r]);
                     }
                 }
             }
@@ -619,11 +639,11 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     {
         h8 vh, vl;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 h, l;
-            split(dmean[j], h, l);
-            vh[j] = h;
-            vl[j] = l;
+        for (int j = 0; j < 8; j += 2) {
+            h2 h, l;
+            split2(dmean[j], dmean[j + 1], h, l);
+            vh[j] = h[0]; vh[j + 1] = h[1];
+            vl[j] = l[0]; vl[j + 1] = l[1];
         }
         const int o = chunk_off<32>(tid >> 2, tid & 3);
         *reinterpret_cast<h8*>(dsm.hi + o) = vh;
@@ -860,11 +880,20 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipS
     const int x0w = pe + 512 + 128;
     const int ksx = ks_x(input_ch);
     const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    PackSegs sx = {{0, 128, 0}, {128, pe, 0}, {pe + 512, 0, 0}};   // packed [world | pe] <- x0 columns [pe | local | world]
-    pack_h(w[0], x0w, 128, ksx, 0, sx, base + (long)hoff_x() * 8, s);
-    PackSegs sx3 = sx;
-    for (int q = 0; q < 2; ++q) sx3.col[q] += 128;                 // L3 input = [h(128) | x0]
-    pack_h(w[3], 128 + x0w, 128, ksx, 4, sx3, base + (long)hoff_x() * 8, s);
+    // streamed stage: packed k = [world 128 | pos_enc in PAIR order | pad] <- x0 columns [pe | local 512 | world 128].
+    // Pair order (finish_pe): position 2 p / 2 p + 1 = sin / cos feature of pair p = octave * C + coordinate (reference
+    // columns C + p and C + 10 C + p), then the C identity features (columns 0..C-1), zero padding to the stage width.
+    const int C = input_ch;
+    PackPerm px;
+    for (int k = 0; k < 256; ++k) px.col[k] = -1;
+    for (int k = 0; k < 128; ++k) px.col[k] = (short)(pe + 512 + k);
+    for (int j = 0; j < 20 * C; ++j) px.col[128 + j] = (short)(C + ((j & 1) ? 10 * C : 0) + (j >> 1));
+    for (int a = 0; a < C; ++a) px.col[128 + 20 * C + a] = (short)a;
+    pack_h_perm(w[0], x0w, 128, ksx, 0, px, base + (long)hoff_x() * 8, s);
+    PackPerm px3 = px;
+    for (int k = 0; k < 256; ++k)
+        if (px3.col[k] >= 0) px3.col[k] = (short)(px3.col[k] + 128);               // L3 input = [h(128) | x0]
+    pack_h_perm(w[3], 128 + x0w, 128, ksx, 4, px3, base + (long)hoff_x() * 8, s);
     PackSegs p128 = none;
     p128.len[0] = 128;
     pack_h(w[1], 128, 128, 8, 0, p128, base + (long)hoff_1(input_ch) * 8, s);

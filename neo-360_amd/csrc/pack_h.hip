@@ -27,6 +27,24 @@ __global__ void k_pack_block_h(const float* __restrict__ src, int ld, int rows, 
     }
 }
 
+__global__ void k_pack_block_h_perm(const float* __restrict__ src, int ld, int rows, int KS, int nt0, PackPerm pm,
+                                    _Float16* __restrict__ dst) {
+    const int total = (rows / 32) * KS * 512;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9;
+        const int ks = blk % KS, ntl = blk / KS;
+        const int n = ntl * 32 + (lane & 31);
+        const int k = ks * 16 + 8 * (lane >> 5) + e;
+        const int col = pm.col[k];
+        const float w = col >= 0 ? src[(long)n * ld + col] : 0.0f;
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        const long base = ((long)((nt0 + ntl) * KS + ks) * 2) * 512 + lane * 8 + e;
+        dst[base] = hi;
+        dst[base + 512] = lo;
+    }
+}
+
 // any fp16 inf / NaN (exponent all ones) among n halves -> flags |= FLAG_SPLIT_RANGE
 __global__ void k_half_range_check(const uint16_t* __restrict__ h, size_t n, uint32_t* __restrict__ flags) {
     bool bad = false;
@@ -59,6 +77,11 @@ void launch_f32_range_check(const float* x, size_t n, float limit, uint32_t* fla
     if (n == 0) return;
     const size_t n4 = n / 4, blocks = (n4 + 255) / 256 + 1;
     hipLaunchKernelGGL(k_f32_range_check, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, x, n4, n, limit, flags);
+}
+
+void pack_h_perm(const float* src, int ld, int rows, int KS, int nt0, const PackPerm& perm, _Float16* dst, hipStream_t s) {
+    const int total = (rows / 32) * KS * 512;
+    hipLaunchKernelGGL(k_pack_block_h_perm, dim3((total + 255) / 256), dim3(256), 0, s, src, ld, rows, KS, nt0, perm, dst);
 }
 
 void pack_h(const float* src, int ld, int rows, int KS, int nt0, PackSegs sg, _Float16* dst, hipStream_t s) {

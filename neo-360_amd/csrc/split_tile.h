@@ -11,6 +11,8 @@ namespace neo {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define NEO_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
@@ -50,7 +52,23 @@ __device__ __forceinline__ void range_commit(const LaneCtx& L, uint32_t* __restr
     if (!(L.amax < SPLIT_LIMIT)) atomicOr(flags, FLAG_SPLIT_RANGE);
 }
 
+// Two values at once, 2 instructions per value: hi pair = v_cvt_pk_f16_f32 (round to nearest, both halves in one
+// instruction and already packed); lo = x - hi with the fp16 hi read straight out of the packed pair by v_fma_mix_f32
+// (one instruction instead of cvt_f32_f16 + sub); lo pair packed by a second v_cvt_pk_f16_f32.  Same values bit for
+// bit as split(): hi = fp16(x), lo = fp16(x - hi) (the subtraction is exact).  The compiler's own lowering of the
+// scalar form costs 5 instructions per value (separate conversions, a re-widening and a pack).
+__device__ __forceinline__ void split2(float x0, float x1, h2& hi, h2& lo) {
+    const f32x2 v = {x0, x1};
+    hi = __builtin_convertvector(v, h2);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+    const f32x2 r = {r0, r1};
+    lo = __builtin_convertvector(r, h2);
+}
+
 __device__ __forceinline__ void split4(const f32x4 v, h4& vh, h4& vl) {
+#ifdef NEO_DBG_NO_SPLIT2
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         _Float16 h, l;
@@ -58,6 +76,22 @@ __device__ __forceinline__ void split4(const f32x4 v, h4& vh, h4& vl) {
         vh[e] = h;
         vl[e] = l;
     }
+    return;
+#endif
+    h2 a, b, c, d;
+    split2(v[0], v[1], a, b);
+    split2(v[2], v[3], c, d);
+    vh = h4{a[0], a[1], c[0], c[1]};
+    vl = h4{b[0], b[1], d[0], d[1]};
+}
+
+// max(x, 0) in ONE instruction (v_max_i32 on the bit pattern: negative floats are negative integers, -0.0 -> +0.0,
+// NaN / inf pass through to the range guard).  fmaxf() costs two: the compiler canonicalises an operand that comes out
+// of the matrix pipe first (v_max x, x, x).  (Not inline asm: the hazard recogniser does not see an asm statement's read
+// of an in-flight MFMA result - measured: wrong values.)
+__device__ __forceinline__ float relu1(float x) {
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, xi > 0 ? xi : 0);
 }
 
 // D tile (N-tile nt, M-tile mt) -> (ReLU) -> split -> the two planes of an activation tile with LDH halves per row
@@ -69,7 +103,7 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = acc[4 * g + e];
-            v[e] = RELU ? fmaxf(x, 0.0f) : x;
+            v[e] = RELU ? relu1(x) : x;
         }
         range_see4(L, v);
         h4 vh, vl;
@@ -166,5 +200,7 @@ __device__ __forceinline__ float density_partial(const HT& act, const float* __r
 // with KS 16-deep k-steps; h8 index ((nt * KS + ks) * 2 + {hi 0, lo 1}) * 64 + lane; packed k -> source column
 // through up to three segments, zero elsewhere
 void pack_h(const float* src, int ld, int rows, int KS, int nt0, PackSegs sg, _Float16* dst, hipStream_t s);
+// the same with an arbitrary packed-k -> source-column table (KS * 16 <= 256 entries; -1 = zero)
+void pack_h_perm(const float* src, int ld, int rows, int KS, int nt0, const PackPerm& perm, _Float16* dst, hipStream_t s);
 
 }  // namespace neo
