@@ -74,6 +74,18 @@ def main():
                     "plane_yz": taps(camn[..., 1], camn[..., 2], 160, 120)}
             key = "%s_%s" % (region, "coarse" if level == 0 else "fine")
             res[key] = {}
+            # tile-views with NO weighted tap at all: latent / all three planes / everything (texel id 0 is the placeholder
+            # of invalid taps; a valid tap at texel 0 is possible but rare enough not to matter for this statistic)
+            none_lat, none_pl, none_all, nt = 0, 0, 0, 0
+            for gi in range(GROUPS):
+                lo, hi = gi * RAYS_PER_GROUP * N, (gi + 1) * RAYS_PER_GROUP * N
+                for t0 in range(lo, hi - 63, 64):
+                    for v in range(NV):
+                        a = not maps["latent"][v, t0:t0 + 64].any()
+                        b = not (maps["plane_xz"][v, t0:t0 + 64].any() or maps["plane_xy"][v, t0:t0 + 64].any() or maps["plane_yz"][v, t0:t0 + 64].any())
+                        none_lat += a; none_pl += b; none_all += (a and b); nt += 1
+            res[key]["tile_views_without_weighted_taps"] = dict(latent=none_lat / nt, all_planes=none_pl / nt, everything=none_all / nt)
+            print(key, "tile-views without any weighted tap: latent %.3f, all three planes %.3f, both %.3f" % (none_lat / nt, none_pl / nt, none_all / nt))
             for name, t in maps.items():
                 counts = []
                 for gi in range(GROUPS):                                   # tiles inside a group of consecutive rays
