@@ -264,6 +264,22 @@ int neo_composite_backward(neo_ctx* ctx, int mode, const float* rgbsigma, const 
 int neo_distloss(neo_ctx* ctx, const float* w, const float* m, int R, int N, float interval, float* loss_rays,
                  float* grad_w, void* stream);
 
+/* NeRFPPMLP for TRAINING (the module the reference's training step differentiates, neo360/model.py:110-158 under
+ * :697-820) on materialised rows, as the reference forms them: x0 (NV*P, 21 input_ch + 640) = [pos_enc | local 512 |
+ * world 128] and cond (NV*P, 27) = view-direction encodings, view-major rows (row = v P + p).  w / b [host]: nine DEVICE
+ * pointers each, order and nn.Linear (out, in) layout of neo_tp_upload_mlp (pts_linears.0..3, views_linear.0, .1,
+ * bottleneck, density, rgb).  forward: raw_rgb (P,3), raw_sigma (P,1) (pre-activation, as the module returns them); the
+ * activations stay in a context-owned tape.  backward (after the forward of the same shapes; g_* = upstream gradients):
+ * gw / gb [host]: nine device pointers each to gradient buffers of the weights' / biases' shapes, ZEROED by the caller
+ * (partial sums are accumulated atomically); g_x0 (NV*P, K0) = gradient of the input rows (overwritten; may be NULL) -
+ * its local / world columns feed neo_tp_gather_backward.  Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32).  At most
+ * 4.19 M rows per call. */
+int neo_tp_mlp_train_forward(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x0,
+                             const float* cond, int NV, long P, float* raw_rgb, float* raw_sigma, void* stream);
+int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w, const float* x0, const float* cond, int NV,
+                              long P, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
+                              float* g_x0, void* stream);
+
 /* Stand-alone feature lookups of the scene set with neo_tp_set_scene, view-major rows (row = v P + p):
  * world (NV*P,128) = index_grid (encoder_tp_fusion_conv.py:122-209: three planes summed), local (NV*P,512) =
  * get_local_feats / SpatialEncoder.index (neo360/model.py:239-264).  pts (P,3) world points. */

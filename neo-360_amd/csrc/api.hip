@@ -150,6 +150,8 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     ctx->enc_axes.release();
     for (auto& b : ctx->enc_ws) b.release();
     ctx->latent.release();
+    ctx->train_tape.release();
+    ctx->train_scratch.release();
     for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     for (auto& ev : ctx->flag_ev) if (ev) (void)hipEventDestroy(ev);

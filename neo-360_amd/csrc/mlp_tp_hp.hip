@@ -59,7 +59,18 @@
 // 64 no barriers inside the view loop, 128 no layer-epilogue stores
 #define NEO_TP_ABLATE 0
 #endif
+#ifndef NEO_TP_TIMELINE
+#define NEO_TP_TIMELINE 0     // 1: s_memtime before / after every barrier of every wave of one workgroup -> g_tp_stamps (tools/tp_timeline.py)
+#endif
+#if NEO_TP_TIMELINE
+__device__ unsigned long long g_tp_stamps[4 * 1024];
+__device__ int g_tp_stamp_block = 1000;
+#define TP_STAMP() do { if (stamp_on_) { if ((threadIdx.x & 63) == 0 && stamp_n_ < 1024) g_tp_stamps[(threadIdx.x >> 6) * 1024 + stamp_n_] = __builtin_amdgcn_s_memtime(); ++stamp_n_; } } while (0)
+#define TP_SYNC() do { TP_STAMP(); __syncthreads(); TP_STAMP(); } while (0)
+#else
+#define TP_STAMP() do { } while (0)
 #define TP_SYNC() do { if (!(NEO_TP_ABLATE & 64)) __syncthreads(); } while (0)
+#endif
 #ifndef NEO_TP_TRACE
 #define NEO_TP_TRACE 0        // 1: per-phase s_memtime sums of wave 0 of every workgroup -> g_tp_trace (tools/tp_phase_trace.py)
 #endif
@@ -118,6 +129,11 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 #if NEO_TP_TRACE
     unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
+#if NEO_TP_TIMELINE
+    const bool stamp_on_ = (int)blockIdx.x == g_tp_stamp_block;
+    int stamp_n_ = 0;
+    TP_STAMP();
+#endif
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     float* dens_w = smem + tp::OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
 #pragma unroll
     for (int j = 0; j < 8; ++j) dsum[tid + 256 * j] = 0.0f;    // (p, f) is accumulated by another thread: zero BEFORE the barrier
-    __syncthreads();
+    TP_SYNC();
     TP_MARK(0);
 
     // view means by linearity (see mlp_tp_h.hip): only sum_v relu(L3_v) and sum_v dir_enc_v are accumulated per view
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     float dmean[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) dmean[j] = dsum[(tid >> 2) * 32 + ((((tid & 3) << 3) + j) ^ ((tid >> 2) & 31))] / nvf;
-    __syncthreads();
+    TP_SYNC();
     {
         h8 vh, vl;
 #pragma unroll
@@ -697,10 +713,10 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     acc2[mt] = NEO_MFMA_H(twh[g % TS], bh, acc2[mt]);
                 }
                 if constexpr (g == 7) {
-                    __syncthreads();
+                    TP_SYNC();
                     store_tile_h<false>(acc2[0], act, L.wv, 0, L);
                     store_tile_h<false>(acc2[1], act, L.wv, 1, L);
-                    __syncthreads();
+                    TP_SYNC();
                 }
             } else {
                 constexpr bool v0 = g < 18;
@@ -720,12 +736,12 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 y = NEO_MFMA_H(twh[g % TS], bl, y);
                 y = NEO_MFMA_H(twh[g % TS], bh, y);
                 if constexpr (g == 17) {
-                    __syncthreads();
+                    TP_SYNC();
                     store_tile_h<true>(y, act, vnt, vmt, L);
-                    __syncthreads();
+                    TP_SYNC();
                 }
                 if constexpr (g == 21) {
-                    __syncthreads();
+                    TP_SYNC();
                     store_tile_h<true>(y, act, vnt, vmt, L);
                 }
             }
@@ -739,29 +755,29 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         bias_tile(acc[0][0], lbias + B_B, L.wv, L);
         acc[0][1] = acc[0][0];
         gemm2h<1, 128>(acc, wp + hoff_b(PE_C), 8, nts_1, 0, 0, 8, act, L);
-        __syncthreads();
+        TP_SYNC();
         store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
         store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
-        __syncthreads();
+        TP_SYNC();
     }
     // ---- view layer 0 on [mean bottleneck | mean dir enc] -> 64 ----
     f32x16 ysum;
     bias_tile(ysum, lbias + B_V0, vnt, L);
     gemm1h<128>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 0, 8, act, L);
     gemm1h<32>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 8, 2, dsm, L);
-    __syncthreads();
+    TP_SYNC();
     // ---- ReLU -> 64x64 -> ReLU -> rgb head ----
     store_tile_h<true>(ysum, act, vnt, vmt, L);
-    __syncthreads();
+    TP_SYNC();
     {
         f32x16 y;
         bias_tile(y, lbias + B_V1, vnt, L);
         gemm1h<128>(y, wp + hoff_v1(PE_C), 4, vnt, vmt, 0, 4, act, L);
-        __syncthreads();
+        TP_SYNC();
         store_tile_h<true>(y, act, vnt, vmt, L);
     }
 #endif
-    __syncthreads();
+    TP_SYNC();
     {
         const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
         const float* wr = lheads + HD_RW;
@@ -790,6 +806,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                                   colour_act(b + lheads[HD_RB + 2]), density_act(raw_sigma));
         }
     }
+    TP_STAMP();
 #if NEO_TP_TRACE
     TP_MARK(6);
     if (threadIdx.x == 0) {
@@ -859,6 +876,15 @@ __global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restric
 
 }  // namespace
 
+#if NEO_TP_TIMELINE
+extern "C" void neo_debug_tp_stamps(unsigned long long* host4096, int block) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(g_tp_stamps), sizeof(unsigned long long) * 4096);
+    unsigned long long z[4096] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tp_stamps), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tp_stamp_block), &block, sizeof(int));
+}
+#endif
 #if NEO_TP_TRACE
 extern "C" void neo_debug_tp_trace(unsigned long long* host16, int reset) {
     (void)hipDeviceSynchronize();

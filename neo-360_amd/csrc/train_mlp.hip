@@ -1,0 +1,259 @@
+// Training-side NeRFPPMLP (the reference's training step neo360/model.py:697-820 calls the MLP of
+// :110-158 under autograd): forward that keeps the activations, and the backward - gradients of all nine weight matrices
+// and biases and of the input rows - on MATERIALISED rows, the formulation the reference trains with
+// (x0 = [pos_enc | local 512 | world 128] per point-view, view-major rows).
+//
+// Everything is dense fp32 GEMM work on the matrix cores in EXACT fp32 (v_mfma_f32_32x32x2_f32): gradients span many
+// orders of magnitude, which the fp16 hi/lo split of the inference kernels would have to rescale tile by tile; the
+// training step is not the path the headline metric measures, so it takes the simple exact arithmetic.
+//
+//   k_sgemm<AT, BT>   C[M][N] (+)= op(A)[M][K] . op(B)[N][K]^T, 64 x 64 tiles, 4 waves of 32 x 32, K stepped by 32 through
+//                     two K-major LDS tiles; operands in any of the layouts the chain needs:
+//                       AT = false: A stored [M][K] (K fastest)      AT = true: A stored [K][M]   (reduction index slowest)
+//                       BT = false: B stored [N][K]                  BT = true: B stored [K][N]
+//                     forward  Z = X W^T   : (false, false)   B = W (out, in)
+//                     dX = dZ W            : (false, true)    B = W (out, in) read as [K = out][N = in]
+//                     dW = dZ^T X          : (true,  true)    A = dZ [K = rows][M = out], B = X [K = rows][N = in], split over K
+//                     fused epilogue: + bias[n], ReLU, x (mask[m][n] > 0), C += (beta = 1), atomic accumulation (split-K)
+//   k_view_mean / k_view_bcast / k_colsum / k_relu_mask: the few elementwise / reduction pieces in between.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "mfma_tile.h"
+
+namespace neo {
+
+namespace {
+
+constexpr int GT = 64;        // C tile (M and N)
+constexpr int GK = 32;        // K step
+constexpr int GP = GK + 4;    // LDS row pitch in floats: 16-B fragment reads of 16 consecutive rows hit 16 distinct bank groups
+
+struct GemmEpi {
+    const float* bias;        // [N] or null
+    const float* mask;        // [M][ldm]: output multiplied by (mask > 0) - ReLU backward - or null
+    int ldm;
+    int relu;                 // max(x, 0) after the bias
+    int accumulate;           // 0: C = result   1: C += result   2: atomicAdd (split-K partials; C zeroed by the caller)
+    float scale;              // result multiplied by this first (1 / NV of the view means)
+};
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float* __restrict__ A, long lda,
+                                               const float* __restrict__ B, long ldb, float* __restrict__ C, long ldc,
+                                               GemmEpi ep, int k_per_split) {
+    __shared__ __attribute__((aligned(16))) float As[GT * GP];
+    __shared__ __attribute__((aligned(16))) float Bs[GT * GP];
+    LaneCtx L;
+    L.init();
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    const int wm = L.wv & 1, wn = L.wv >> 1;            // this wave's 32 x 32 quadrant
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        // ---- global -> LDS, K-major tiles; 2048 elements per operand, 8 per thread, coalesced along the stored-fast index ----
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j;
+            int r, k;
+            if (AT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
+            const int gm = m0 + r, gk = k0 + k;
+            float v = 0.0f;
+            if (gm < M && gk < kend) v = AT ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk];
+            As[r * GP + k] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j;
+            int r, k;
+            if (BT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
+            const int gn = n0 + r, gk = k0 + k;
+            float v = 0.0f;
+            if (gn < N && gk < kend) v = BT ? B[(long)gk * ldb + gn] : B[(long)gn * ldb + gk];
+            Bs[r * GP + k] = v;
+        }
+        __syncthreads();
+        // ---- 4 chunks of 8 k: lane half h supplies k = 8 c + 4 h + e to MFMA e (both operands alike) ----
+#pragma unroll
+        for (int c = 0; c < GK / 8; ++c) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + L.l31) * GP + 8 * c + 4 * L.half);   // D rows = n
+            const f32x4 b = *reinterpret_cast<const f32x4*>(As + (wm * 32 + L.l31) * GP + 8 * c + 4 * L.half);   // D cols = m
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = NEO_MFMA(a[e], b[e], acc);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: lane = row m (l31), registers 4 g + e = columns n = 8 g + 4 half + e ----
+    const int gm = m0 + wm * 32 + L.l31;
+    if (gm >= M) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gn = n0 + wn * 32 + 8 * g + 4 * L.half + e;
+            if (gn >= N) continue;
+            float v = acc[4 * g + e] * ep.scale;
+            if (ep.bias && blockIdx.z == 0) v += ep.bias[gn];
+            if (ep.relu) v = fmaxf(v, 0.0f);
+            if (ep.mask && !(ep.mask[(long)gm * ep.ldm + gn] > 0.0f)) v = 0.0f;
+            float* dst = C + (long)gm * ldc + gn;
+            if (ep.accumulate == 2) atomicAdd(dst, v);
+            else if (ep.accumulate == 1) *dst += v;
+            else *dst = v;
+        }
+}
+
+// out[p][c] = (1 / NV) sum_v in[v P + p][c]   (neo360/util.py:599-610 combine_interleaved 'average'), optional ReLU
+__global__ void k_view_mean(const float* __restrict__ in, int NV, long P, int C, int relu, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * C) return;
+    float s = 0.0f;
+    for (int v = 0; v < NV; ++v) s += in[(long)v * P * C + i];
+    s = s / (float)NV;
+    out[i] = relu ? fmaxf(s, 0.0f) : s;
+}
+
+// its backward: out[v P + p][c] (+)= g[p][c] / NV
+__global__ void k_view_bcast(const float* __restrict__ g, int NV, long P, int C, int accumulate, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * C) return;
+    const float v = g[i] / (float)NV;
+    for (int w = 0; w < NV; ++w) {
+        float* d = out + (long)w * P * C + i;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+// g[i] = mask[i] > 0 ? g[i] : 0   (ReLU backward in place)
+__global__ void k_relu_mask(float* __restrict__ g, const float* __restrict__ mask, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(mask[i] > 0.0f)) g[i] = 0.0f;
+}
+
+// out[c] += sum_m g[m][c]: one column per thread, 256 rows per block, atomics across blocks (out zeroed by the caller)
+__global__ void k_colsum(const float* __restrict__ g, long M, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * 256, r1 = r0 + 256 < M ? r0 + 256 : M;
+    float s = 0.0f;
+    for (long r = r0; r < r1; ++r) s += g[r * C + c];
+    atomicAdd(out + c, s);
+}
+
+template <bool AT, bool BT>
+void gemm(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const GemmEpi& ep,
+          int splits, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    int kps = (K + splits - 1) / splits;
+    kps = ((kps + GK - 1) / GK) * GK;
+    const int nz = (K + kps - 1) / kps;
+    hipLaunchKernelGGL((k_sgemm<AT, BT>), dim3((N + GT - 1) / GT, (M + GT - 1) / GT, nz), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C,
+                       ldc, ep, kps);
+}
+
+inline GemmEpi epi(const float* bias = nullptr, int relu = 0, int accumulate = 0, const float* mask = nullptr, int ldm = 0,
+                   float scale = 1.0f) {
+    return GemmEpi{bias, mask, ldm, relu, accumulate, scale};
+}
+
+inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+// ---- tape layout (floats): h0, h1, h2, h3, bott (R x 128 each), y0 (R x 64), hm (P x 128), ym (P x 64), y1 (P x 64) ----
+size_t tp_train_tape_floats(int NV, long P) {
+    const long R = (long)NV * P;
+    return (size_t)(R * (5 * 128 + 64) + P * (128 + 64 + 64));
+}
+// scratch of the backward: two R x 128 gradient buffers, one R x 64, three P-sized
+size_t tp_train_scratch_floats(int NV, long P) {
+    const long R = (long)NV * P;
+    return (size_t)(R * (2 * 128 + 64) + P * (128 + 64 + 64));
+}
+
+// w / b order as neo_tp_upload_mlp: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
+void launch_tp_train_forward(int pe, const float* const* w, const float* const* b, const float* x0, const float* cond, int NV,
+                             long P, float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s) {
+    const long R = (long)NV * P;
+    const int K0 = pe + 640;
+    float* h0 = tape; float* h1 = h0 + R * 128; float* h2 = h1 + R * 128; float* h3 = h2 + R * 128;
+    float* bott = h3 + R * 128; float* y0 = bott + R * 128; float* hm = y0 + R * 64; float* ym = hm + P * 128; float* y1 = ym + P * 64;
+    gemm<false, false>((int)R, 128, K0, x0, K0, w[0], K0, h0, 128, epi(b[0], 1), 1, s);
+    gemm<false, false>((int)R, 128, 128, h0, 128, w[1], 128, h1, 128, epi(b[1], 1), 1, s);
+    gemm<false, false>((int)R, 128, 128, h1, 128, w[2], 128, h2, 128, epi(b[2], 1), 1, s);
+    // layer 3 on [h2 | x0] (the skip concat after layer index 2): two accumulating GEMMs, ReLU after the second
+    gemm<false, false>((int)R, 128, 128, h2, 128, w[3], 128 + K0, h3, 128, epi(b[3], 0), 1, s);
+    gemm<false, false>((int)R, 128, K0, x0, K0, w[3] + 128, 128 + K0, h3, 128, epi(nullptr, 0, 1), 1, s);
+    hipLaunchKernelGGL(k_view_mean, dim3(blocks(R * 128)), dim3(256), 0, s, h3, 1, R * 128, 1, 1, h3);          // ReLU in place
+    gemm<false, false>((int)R, 128, 128, h3, 128, w[6], 128, bott, 128, epi(b[6], 0), 1, s);                     // bottleneck, per view
+    hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
+    gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
+    // view layer 0 on [bott | cond]
+    gemm<false, false>((int)R, 64, 128, bott, 128, w[4], 155, y0, 64, epi(b[4], 0), 1, s);
+    gemm<false, false>((int)R, 64, 27, cond, 27, w[4] + 128, 155, y0, 64, epi(nullptr, 0, 1), 1, s);
+    hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 64)), dim3(256), 0, s, y0, NV, P, 64, 1, ym);               // mean over views, ReLU
+    gemm<false, false>((int)P, 64, 64, ym, 64, w[5], 64, y1, 64, epi(b[5], 1), 1, s);
+    gemm<false, false>((int)P, 3, 64, y1, 64, w[8], 64, raw_rgb, 3, epi(b[8], 0), 1, s);
+}
+
+// gw / gb: nine weight / bias gradients, ZEROED by the caller (split-K partials are accumulated atomically); g_x0 may be null
+void launch_tp_train_backward(int pe, const float* const* w, const float* x0, const float* cond, int NV, long P,
+                              const float* tape, float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw,
+                              float* const* gb, float* g_x0, hipStream_t s) {
+    const long R = (long)NV * P;
+    const int K0 = pe + 640;
+    const float* h0 = tape; const float* h1 = h0 + R * 128; const float* h2 = h1 + R * 128; const float* h3 = h2 + R * 128;
+    const float* bott = h3 + R * 128; const float* y0 = bott + R * 128; const float* hm = y0 + R * 64;
+    const float* ym = hm + P * 128; const float* y1 = ym + P * 64;
+    (void)y0;
+    float* ga = scratch; float* gb2 = ga + R * 128; float* gy0 = gb2 + R * 128;                 // R-sized
+    float* g_hm = gy0 + R * 64; float* g_y1 = g_hm + P * 128; float* g_ym = g_y1 + P * 64;       // P-sized
+    const int SP = (int)((P + 8191) / 8192), SR = (int)((R + 8191) / 8192);                     // split-K of the weight gradients
+    // rgb head
+    gemm<true, true>(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, epi(nullptr, 0, 2), SP, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_rgb, P, 3, gb[8]);
+    gemm<false, true>((int)P, 64, 3, g_rgb, 3, w[8], 64, g_y1, 64, epi(nullptr, 0, 0, y1, 64), 1, s);            // x relu'(y1)
+    // view layer 1
+    gemm<true, true>(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, epi(nullptr, 0, 2), SP, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_y1, P, 64, gb[5]);
+    gemm<false, true>((int)P, 64, 64, g_y1, 64, w[5], 64, g_ym, 64, epi(nullptr, 0, 0, ym, 64), 1, s);           // x relu'(mean)
+    // mean over views -> per-view rows; view layer 0 on [bott | cond]
+    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0);
+    gemm<true, true>(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, gy0, R, 64, gb[4]);
+    gemm<false, true>((int)R, 128, 64, gy0, 64, w[4], 155, ga, 128, epi(), 1, s);                                // g_bott (R x 128)
+    // bottleneck
+    gemm<true, true>(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[6]);
+    gemm<false, true>((int)R, 128, 128, ga, 128, w[6], 128, gb2, 128, epi(), 1, s);                              // g_h3 from the bottleneck
+    // density head on the view mean of h3
+    gemm<true, true>(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, epi(nullptr, 0, 2), SP, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_sigma, P, 1, gb[7]);
+    gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
+    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 1, gb2);          // g_h3 += g_hm / NV
+    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, h3, R * 128);                   // g_z3
+    // layer 3 on [h2 | x0]
+    gemm<true, true>(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(128, K0, (int)R, gb2, 128, x0, K0, gw[3] + 128, 128 + K0, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[3]);
+    if (g_x0) gemm<false, true>((int)R, K0, 128, gb2, 128, w[3] + 128, 128 + K0, g_x0, K0, epi(), 1, s);
+    gemm<false, true>((int)R, 128, 128, gb2, 128, w[3], 128 + K0, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);    // g_z2 = (g_z3 W3a) relu'(h2)
+    // layer 2
+    gemm<true, true>(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[2]);
+    gemm<false, true>((int)R, 128, 128, ga, 128, w[2], 128, gb2, 128, epi(nullptr, 0, 0, h1, 128), 1, s);         // g_z1
+    // layer 1
+    gemm<true, true>(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[1]);
+    gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, ga, 128, epi(nullptr, 0, 0, h0, 128), 1, s);         // g_z0
+    // layer 0
+    gemm<true, true>(128, K0, (int)R, ga, 128, x0, K0, gw[0], K0, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[0]);
+    if (g_x0) gemm<false, true>((int)R, K0, 128, ga, 128, w[0], K0, g_x0, K0, epi(nullptr, 0, 1), 1, s);
+}
+
+}  // namespace neo

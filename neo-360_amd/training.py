@@ -173,3 +173,58 @@ def gather_features(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
     `rays["src_imgs"]`), so forward values and gradients always refer to the same data.  Gradients flow to the four
     feature maps (NCHW, like the inputs)."""
     return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays)
+
+
+class _TrainMLP(torch.autograd.Function):
+    """NeRFPPMLP on materialised rows with a native backward (neo_tp_mlp_train_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx_, lib_ctx, input_ch, nv, x_enc, cond_rows, world_feat, local_feat, *params):
+        ws, bs = params[:9], params[9:]
+        npts = x_enc.shape[1]
+        x0 = torch.cat([f32(x_enc, "x_enc").reshape(-1, x_enc.shape[-1]), f32(local_feat, "local_feat"),
+                        f32(world_feat, "world_feat")], dim=-1).contiguous()
+        cond = f32(cond_rows, "cond_rows")
+        c = _ctx(x0, lib_ctx)
+        wd = [f32(w.detach(), "weight") for w in ws]
+        bd = [f32(b.detach(), "bias") for b in bs]
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        raw_rgb = torch.empty(npts, 3, device=x0.device)
+        raw_sigma = torch.empty(npts, 1, device=x0.device)
+        _lib.check(c.lib.neo_tp_mlp_train_forward(c.handle, input_ch, tab(wd), tab(bd), ptr(x0), ptr(cond), nv, npts,
+                                                  ptr(raw_rgb), ptr(raw_sigma), c.stream()))
+        ctx_.save_for_backward(x0, cond, *wd)
+        ctx_.meta = (c, input_ch, nv, npts, x_enc.shape, [tuple(w.shape) for w in ws], [tuple(b.shape) for b in bs])
+        return raw_rgb, raw_sigma
+
+    @staticmethod
+    def backward(ctx_, g_rgb, g_sigma):
+        x0, cond, *wd = ctx_.saved_tensors
+        c, input_ch, nv, npts, xshape, wshapes, bshapes = ctx_.meta
+        dev = x0.device
+        g_rgb = f32(g_rgb.contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(npts, 3, device=dev)
+        g_sigma = f32(g_sigma.contiguous(), "g_sigma") if g_sigma is not None else torch.zeros(npts, 1, device=dev)
+        gw = [torch.zeros(s, device=dev) for s in wshapes]
+        gb = [torch.zeros(s, device=dev) for s in bshapes]
+        need_x = any(ctx_.needs_input_grad[3:7])
+        g_x0 = torch.empty_like(x0) if need_x else None
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(c.lib.neo_tp_mlp_train_backward(c.handle, input_ch, tab(wd), ptr(x0), ptr(cond), nv, npts, ptr(g_rgb),
+                                                   ptr(g_sigma), tab(gw), tab(gb), ptr(g_x0), c.stream()))
+        pe = input_ch * 21
+        gx = g_x0[:, :pe].reshape(xshape) if need_x and ctx_.needs_input_grad[3] else None
+        gworld = g_x0[:, pe + 512:] if need_x and ctx_.needs_input_grad[5] else None
+        glocal = g_x0[:, pe:pe + 512] if need_x and ctx_.needs_input_grad[6] else None
+        return (None, None, None, gx, None, gworld, glocal, *gw, *gb)
+
+
+def nerfpp_mlp(mlp, x_enc, cond_rows, world_feat, local_feat, nv, ctx=None):
+    """The reference's NeRFPPMLP.forward (neo360/model.py:110-158) with autograd support, for training steps:
+    x_enc (NV,P,63|84) encoded camera-frame points, cond_rows (NV*P,27) view-direction encodings, world_feat (NV*P,128),
+    local_feat (NV*P,512), view-major rows -> raw_rgb (P,3), raw_sigma (P,1) (pre-activation).  `mlp` is a
+    models.NeRFPPMLP (parameter container, reference state_dict layout); gradients flow to all of its parameters and to
+    x_enc / world_feat / local_feat (the latter two continue into gather_features' backward).  Exact fp32 matrix
+    arithmetic; the fused inference evaluators are untouched."""
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    return _TrainMLP.apply(ctx, mlp.input_ch, nv, x_enc, cond_rows, world_feat, local_feat, *params)

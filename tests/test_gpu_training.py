@@ -198,3 +198,145 @@ def test_training_ops_empty_inputs():
     batch = {k: (v.to(DEV) if k.startswith("src_") else v[:0].to(DEV)) for k, v in cases.neo_batch(cases.strided_rays(4)).items()}
     lv = net(batch, True, False, 0.0, 0.0, out_depth=False, seed=3)
     assert lv[1][0].shape == (0, 3) and lv[1][1].shape == (0, NC + 1 + NF)
+
+
+@pytest.mark.parametrize("input_ch,nv", [(3, 3), (4, 3), (3, 1), (4, 2)])
+def test_nerfpp_mlp_backward_vs_autograd(input_ch, nv):
+    """neo_tp_mlp_train_forward / _backward against torch autograd through the oracle's NeRFPPMLP
+    (oracle.mlp.nerfpp_mlp == neo360/model.py:110-158): outputs, all 18 parameter gradients and the gradients of the
+    encoded points / world / local features."""
+    from neo360_amd import models
+    torch.manual_seed(5)
+    P = 64 * 41 + 7                                   # not a multiple of the 64-row GEMM tile
+    pe = 21 * input_ch
+    prefix = "fg_fine_mlp." if input_ch == 3 else "bg_fine_mlp."
+    sd = synth.nerf_tp_state(0)
+    mlp = models.NeRFPPMLP(0, 10, 4, input_ch=input_ch, num_src_views=nv).to(DEV)
+    mlp.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
+    x_enc = torch.randn(nv, P, pe)
+    cond = torch.randn(nv * P, 27)
+    world = torch.randn(nv * P, 128) * 0.3
+    local = torch.randn(nv * P, 512) * 0.3
+    # ReLU kinks: a unit whose pre-activation is ~0 has derivative 0 or 1 depending on the last bit, in ANY arithmetic;
+    # gradients can only be compared away from them.  Points with a pre-activation within 1e-5 of zero (fp64 forward of
+    # the same network, ~3 % of the points) are dropped from the test input.
+    W = {k[len(prefix):]: v.double() for k, v in sd.items() if k.startswith(prefix)}
+    lin = lambda n, x: torch.nn.functional.linear(x, W[n + ".weight"], W[n + ".bias"])
+    x0 = torch.cat([x_enc.reshape(-1, pe), local, world], -1).double()
+    z = [lin("pts_linears.0", x0)]
+    z.append(lin("pts_linears.1", z[-1].relu()))
+    z.append(lin("pts_linears.2", z[-1].relu()))
+    z.append(lin("pts_linears.3", torch.cat([z[-1].relu(), x0], -1)))
+    h3 = z[-1].relu()
+    y0 = lin("views_linear.0", torch.cat([lin("bottleneck_layer", h3), cond.double()], -1)).reshape(nv, P, -1).mean(0)
+    y1 = lin("views_linear.1", y0.relu())
+    near = torch.stack([zz.abs().amin(-1) for zz in z]).amin(0).reshape(nv, P).amin(0)
+    near = torch.minimum(near, torch.minimum(y0.abs().amin(-1), y1.abs().amin(-1)))
+    keep = near > 1e-5
+    assert int(keep.sum()) > 0.9 * P
+    x_enc = x_enc[:, keep].contiguous()
+    sel = keep.repeat(nv)
+    cond, world, local = cond[sel].contiguous(), world[sel].contiguous(), local[sel].contiguous()
+    P = int(keep.sum())
+    g_rgb, g_sig = torch.randn(P, 3) * 1e-3, torch.randn(P, 1) * 1e-3
+    with torch.enable_grad():
+        # oracle + autograd, CPU fp64 as the truth, fp32 for the scale of fp32 rounding
+        def cpu(dtype):
+            p = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in mlp.state_dict(prefix=prefix).items()}
+            ins = [t.detach().clone().to(dtype).requires_grad_(True) for t in (x_enc, world, local)]
+            rgb, sig = oracle.mlp.nerfpp_mlp(p, prefix, ins[0], cond.to(dtype), ins[1], ins[2], nv)
+            (rgb * g_rgb.to(dtype)).sum().add((sig * g_sig.to(dtype)).sum()).backward()
+            return rgb.detach(), sig.detach(), {k: v.grad for k, v in p.items()}, [t.grad for t in ins]
+        rgb64, sig64, gp64, gi64 = cpu(torch.float64)
+        gin = [t.detach().clone().to(DEV).requires_grad_(True) for t in (x_enc, world, local)]
+        for p in mlp.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        rgb, sig = training.nerfpp_mlp(mlp, gin[0], cond.to(DEV), gin[1], gin[2], nv)
+        ((rgb * g_rgb.to(DEV)).sum() + (sig * g_sig.to(DEV)).sum()).backward()
+    assert max_abs(rgb, rgb64) < 2e-5 and max_abs(sig, sig64) < 2e-5
+
+    def close(got, ref64, name):
+        """every entry within 2e-5 of the fp64 gradient, relative to the tensor's largest entry"""
+        scale = float(ref64.abs().max()) + 1e-12
+        err = float((got.detach().cpu().double() - ref64).abs().max()) / scale
+        assert err < 2e-5, (name, err)
+        return err
+
+    worst = 0.0
+    for name, p in mlp.named_parameters():
+        worst = max(worst, close(p.grad, gp64[prefix + name], name))
+    for t, r64, nm in zip(gin, gi64, ("x_enc", "world", "local")):
+        worst = max(worst, close(t.grad, r64, nm))
+    from conftest import record_parity
+    record_parity("train_nerfpp_mlp_backward/ch%d_nv%d" % (input_ch, nv), max_rel_grad_err_vs_fp64=worst, rows=nv * P)
+
+
+def test_training_step_end_to_end_gradients():
+    """One differentiable pass through the whole hot path with the library's training operators - feature lookups
+    (gather_features), encodings, NeRFPPMLP (nerfpp_mlp), the reference's activations, compositing (composite), an L2
+    photometric loss - and its backward, against the same chain of oracle functions under torch autograd in fp64
+    (the reference's training step, neo360/model.py:697-820, differentiates exactly this chain): gradients of the loss
+    with respect to every MLP parameter, the three tri-planes and the latent."""
+    from neo360_amd import models
+    sc = cases.small_scene()
+    nv, R, N = cases.NV, 24, 17
+    prefix = "fg_fine_mlp."
+    sd = synth.nerf_tp_state(0)
+    net = models.NeRF_TP(num_coarse_samples=32, num_fine_samples=64, num_src_views=nv).to(DEV)
+    net.load_state_dict(sd)
+    batch = cases.neo_batch(cases.strided_rays(R))
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    far, _ = oracle.rays.sphere_exit_depth(batch["rays_o"], batch["rays_d"])
+    t = (torch.linspace(0.05, 0.9, N)[None, :] * far).contiguous()
+    pts = oracle.sampling.points_on_rays(t, batch["rays_o"], batch["rays_d"])          # (R,N,3): sample positions carry no gradient
+    target = synth.uniform(31, "e2e_target", (R, 3), 0.0, 1.0)
+    cam = oracle.gather.world_to_camera(pts.reshape(-1, 3), batch["src_poses"])          # (NV,P,3)
+    dir_cam = oracle.gather.world_to_camera_dirs(batch["viewdirs"], batch["src_poses"])
+    d_enc = oracle.encoding.pos_enc(dir_cam, 0, 4)
+    cond = torch.tile(d_enc[:, None, :], (1, N, 1)).reshape(-1, d_enc.shape[-1])         # the reference's tiling (quirk Q1)
+    x_enc = oracle.encoding.pos_enc(cam, 0, 10)
+
+    def chain(world, local, mlp_fn, act_dtype):
+        rgb_raw, sig_raw = mlp_fn(world, local)
+        rgb = oracle.mlp.colour_activation(rgb_raw).reshape(R, N, 3)
+        sigma = oracle.mlp.density_activation(sig_raw).reshape(R, N, 1)
+        return rgb, sigma
+
+    with torch.enable_grad():
+        # ---- oracle, fp64 ----
+        cm = {k: v.clone().double().requires_grad_(True) for k, v in sc.items() if isinstance(v, torch.Tensor)}
+        pp = {k: v.double().requires_grad_(True) for k, v in sd.items() if k.startswith(prefix)}
+        world_c = oracle.gather.triplane_features(pts.double(), cm["plane_xz"], cm["plane_xy"], cm["plane_yz"], batch["src_poses"].double())
+        local_c = oracle.gather.pixel_aligned_features(pts.double(), cm["latent"], batch["src_poses"].double(), batch["src_focal"].double(),
+                                                       batch["src_c"].double(), sc["image_wh"])
+        rgb_c, sig_c = chain(world_c, local_c, lambda w, l: oracle.mlp.nerfpp_mlp(pp, prefix, x_enc.double(), cond.double(), w, l, nv), torch.float64)
+        comp_c = oracle.compositing.neo_composite(rgb_c, sig_c, t.double(), batch["rays_d"].double(), True, far.double())[0]
+        loss_c = ((comp_c - target.double()) ** 2).mean()
+        names = sorted(pp)
+        g_c = torch.autograd.grad(loss_c, [pp[k] for k in names] + [cm["plane_xz"], cm["plane_xy"], cm["plane_yz"], cm["latent"]])
+        # ---- library ----
+        gm = {k: sc[k].to(DEV).clone().requires_grad_(True) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")}
+        net.set_scene(gm["plane_xz"].detach(), gm["plane_xy"].detach(), gm["plane_yz"].detach(), gm["latent"].detach(), sc["image_wh"])
+        mlp = net.fg_fine_mlp
+        for p in mlp.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        world_g, local_g = training.gather_features(net, pts.reshape(-1, 3).to(DEV), gm["plane_xz"], gm["plane_xy"], gm["plane_yz"],
+                                                    gm["latent"], gb)
+        rgb_g, sig_g = chain(world_g, local_g, lambda w, l: training.nerfpp_mlp(mlp, x_enc.to(DEV), cond.to(DEV), w, l, nv), torch.float32)
+        comp_g = training.composite(1, rgb_g, sig_g, t.to(DEV), gb["rays_d"], far.to(DEV))[0]
+        loss_g = ((comp_g - target.to(DEV)) ** 2).mean()
+        params = dict(mlp.named_parameters())
+        g_g = torch.autograd.grad(loss_g, [params[k[len(prefix):]] for k in names] + [gm["plane_xz"], gm["plane_xy"], gm["plane_yz"], gm["latent"]])
+    assert abs(float(loss_g) - float(loss_c)) < 1e-6
+    worst = 0.0
+    for nm, a, b in zip(names + ["plane_xz", "plane_xy", "plane_yz", "latent"], g_g, g_c):
+        scale = float(b.abs().max()) + 1e-15
+        err = float((a.detach().cpu().double() - b).abs().max()) / scale
+        worst = max(worst, err)
+        # 5e-3 of the tensor's largest entry: a ReLU unit within an ulp of its kink contributes one row differently (see
+        # test_nerfpp_mlp_backward_vs_autograd, which excludes such points and holds 2e-5); here the inputs are what they are
+        assert a.shape == b.shape and err < 5e-3, (nm, err)
+    from conftest import record_parity
+    record_parity("train_step_end_to_end", max_rel_grad_err_vs_fp64=worst, loss_abs_err=abs(float(loss_g) - float(loss_c)))
