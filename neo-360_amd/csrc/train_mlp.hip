@@ -53,17 +53,17 @@ __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float*
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        // ---- global -> LDS, K-major tiles; 2048 elements per operand, 8 per thread, coalesced along the stored-fast index ----
+    // global -> registers -> LDS, K-major tiles; 2048 elements per operand, 8 per thread, coalesced along the stored-fast
+    // index.  The NEXT K-step's elements are requested before this step's MFMAs (one stage of software pipelining).
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = tid + 256 * j;
             int r, k;
             if (AT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
             const int gm = m0 + r, gk = k0 + k;
-            float v = 0.0f;
-            if (gm < M && gk < kend) v = AT ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk];
-            As[r * GP + k] = v;
+            ra[j] = (gm < M && gk < kend) ? (AT ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk]) : 0.0f;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -71,11 +71,30 @@ __global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float*
             int r, k;
             if (BT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
             const int gn = n0 + r, gk = k0 + k;
-            float v = 0.0f;
-            if (gn < N && gk < kend) v = BT ? B[(long)gk * ldb + gn] : B[(long)gn * ldb + gk];
-            Bs[r * GP + k] = v;
+            rb[j] = (gn < N && gk < kend) ? (BT ? B[(long)gk * ldb + gn] : B[(long)gn * ldb + gk]) : 0.0f;
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j;
+            int r, k;
+            if (AT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
+            As[r * GP + k] = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = tid + 256 * j;
+            int r, k;
+            if (BT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
+            Bs[r * GP + k] = rb[j];
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        stage();
         __syncthreads();
+        if (k0 + GK < kend) fetch(k0 + GK);
         // ---- 4 chunks of 8 k: lane half h supplies k = 8 c + 4 h + e to MFMA e (both operands alike) ----
 #pragma unroll
         for (int c = 0; c < GK / 8; ++c) {
