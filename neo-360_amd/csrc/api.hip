@@ -150,6 +150,7 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     ctx->enc_axes.release();
     for (auto& b : ctx->enc_ws) b.release();
     ctx->latent.release();
+    ctx->tp_dirsum.release();
     ctx->train_tape.release();
     ctx->train_scratch.release();
     for (auto& b : ctx->plane) b.release();

@@ -52,9 +52,13 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             }
             guard_split_weights(sl, sl.wpack_hp.p, neo::tp_wpack_hp_bytes(sl.input_ch), ctx->flags, s);
             neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
+            // the view-direction encodings enter the MLP only through their mean over the views, and they depend on the
+            // ray alone: summed once per ray here instead of once per sample and view inside the evaluator
+            if (ctx->tp_dirsum.reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
+            neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum.as<float>(), s);
             ctx->span_begin(s);
             neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
-                                  chunk, ctx->flags, out, s);
+                                  chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
         } else {
             guard_split_weights(sl, sl.wpack_h.p, neo::tp_wpack_h_bytes(sl.input_ch), ctx->flags, s);
             if (ctx->latent_checked != ctx->scene_epoch) {

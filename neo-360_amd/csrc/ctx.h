@@ -122,6 +122,7 @@ struct neo_ctx {
     bool scene_ready = false;
     uint64_t scene_epoch = 0;          // bumped by every neo_tp_set_scene
     uint64_t planes_checked = 0, latent_checked = 0;   // scene_epoch whose maps passed the split range check
+    neo_host::DevBuf tp_dirsum;        // (rays, 32): view-summed direction encodings of the current launch (k_tp_mlp_hp)
     int preproject = 1;                // split path: gather the latent pre-projected through the first-layer weights
     // PixelNeRF scene latent: its own buffer / descriptor / ready flag (a context may hold both decoders)
     neo_host::DevBuf pix_latent;

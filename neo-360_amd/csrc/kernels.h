@@ -171,9 +171,13 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipS
 // G (texels, 256) = latent_cl (texels, 512) . [W0_loc | W3_loc]^T from the fp32 fragment pack's stage X
 void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
                           hipStream_t s, int channels = 256);
+// dirsum (R, 32): per ray the SUM over the source views of its view-direction encoding in each view's camera frame
+// (27 features + 5 zeros), built by launch_tp_dirsum before every evaluator launch
+void launch_tp_dirsum(const float* viewdirs, int R, const TpViews& views, int nv, float* dirsum, hipStream_t s);
 void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
                       const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
-                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s);
+                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, const float* dirsum,
+                      hipStream_t s);
 
 // train_mlp.hip — NeRFPPMLP forward-with-tape + backward on materialised rows (exact fp32 MFMA GEMMs)
 size_t tp_train_tape_floats(int NV, long P);

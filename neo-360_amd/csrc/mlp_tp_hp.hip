@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                                                              const float* __restrict__ viewdirs,
                                                              const float* __restrict__ tvals,
                                                              const float* __restrict__ far_arr, int R, int N, int chunk,
-                                                             uint32_t* __restrict__ flags, float4* __restrict__ out, int stagger) {
+                                                             uint32_t* __restrict__ flags, float4* __restrict__ out, int stagger,
+                                                             const float* __restrict__ dirsum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // Two workgroups share a CU.  Launched together they run their phases (gather-bound, matrix-bound) in lockstep and
     // contend for the same pipe all the time; the second generation of resident workgroups (blocks 256..511 on this
@@ -148,9 +149,17 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
     const float* lbias = m.bias;
     const float* lheads = m.heads;
 #endif
-    float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32 running sum of the direction encodings (same 8 KB as dsm)
+    float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32: sum over the views of each point's direction encoding (same 8 KB as dsm)
+    TP_SYNC();                                 // point_setup has recorded which ray's direction every row carries
+    {
+        // the sums come ready-made from the per-ray table of this launch (k_tp_dirsum): 8 features per thread
+        const int p = tid >> 2, f0 = (tid & 3) << 3;
+        const int dray = __float_as_int(S.vdir_world[p * 4 + 3]);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(dirsum + (long)dray * 32 + f0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(dirsum + (long)dray * 32 + f0 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dsum[tid + 256 * j] = 0.0f;    // (p, f) is accumulated by another thread: zero BEFORE the barrier
+        for (int j = 0; j < 8; ++j) dsum[p * 32 + ((f0 + j) ^ (p & 31))] = j < 4 ? s0[j] : s1[j - 4];
+    }
     TP_SYNC();
     TP_MARK(0);
 
@@ -173,10 +182,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
         if (!(NEO_TP_ABLATE & 32) || v == 0)
-        tp::view_descriptors<PROJ_TEXEL_BYTES>(S, L, sc, rot, trn, v, [&](int p, int f, float val) {
-            const int di = p * 32 + (f ^ (p & 31));     // lane = p: XOR keeps the 64 lanes on distinct banks
-            dsum[di] += val;                            // (p, f) is owned by one thread in every view; zeroed before the loop
-        });
+        tp::view_descriptors<PROJ_TEXEL_BYTES, false>(S, L, sc, rot, trn, v, [](int, int, float) {});
         TP_SYNC();
         TP_MARK(1);
 #if NEO_TP_ZSKIP
@@ -817,6 +823,40 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 #endif
 }
 
+// ---- per-ray sum over the source views of the view-direction encoding (neo360/model.py:339-341, :357-360 feed
+// pos_enc(R_v d, 0, 4) of the chunk's rays to every sample; the MLP sees it only through the view mean) ----
+// one thread per ray; the arithmetic and the summation order (views 0, 1, .. onto 0.0f) are those the evaluator used
+// per sample and view before this table existed
+__global__ void k_tp_dirsum(const float* __restrict__ viewdirs, int R, TpViews views, int nv, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float dx = viewdirs[r * 3], dy = viewdirs[r * 3 + 1], dz = viewdirs[r * 3 + 2];
+    float acc[27];
+#pragma unroll
+    for (int f = 0; f < 27; ++f) acc[f] = 0.0f;
+    for (int v = 0; v < nv; ++v) {
+        const float* rot = views.rot[v];
+        const float dc[3] = {rot[0] * dx + rot[1] * dy + rot[2] * dz, rot[3] * dx + rot[4] * dy + rot[5] * dz,
+                             rot[6] * dx + rot[7] * dy + rot[8] * dz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc[a] += dc[a];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float sn, cs;
+                enc_pair(dc[a], k, sn, cs);
+                acc[3 + k * 3 + a] += sn;
+                acc[15 + k * 3 + a] += cs;
+            }
+    }
+    float* o = out + (long)r * 32;
+#pragma unroll
+    for (int f = 0; f < 27; ++f) o[f] = acc[f];
+#pragma unroll
+    for (int f = 27; f < 32; ++f) o[f] = 0.0f;
+}
+
 // ---- G = F . [W0_loc | W3_loc]^T: exact fp32 MFMA, once per (scene, MLP) ----------------------------------
 // F: channels-last latent (T texels, 512); wx: the fp32 fragment stream of stage X of mlp_tp.hip's pack
 // (8 N-tiles x KC chunks of 8, packed k = [local 512 | world | pe]): its chunks 0..63 are exactly [W0_loc; W3_loc].
@@ -945,9 +985,15 @@ void launch_tp_preproject(const float* latent_cl, long texels, const float* wpac
                            reinterpret_cast<const f32x4*>(wpack_f32_stage_x), kc_x, texels, proj);
 }
 
+void launch_tp_dirsum(const float* viewdirs, int R, const TpViews& views, int nv, float* dirsum, hipStream_t s) {
+    if (R <= 0) return;
+    hipLaunchKernelGGL(k_tp_dirsum, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, viewdirs, R, views, nv, dirsum);
+}
+
 void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views,
                       const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
-                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, hipStream_t s) {
+                      const float* far, int R, int N, int chunk, uint32_t* flags, float* out, const float* dirsum,
+                      hipStream_t s) {
     const long P = (long)R * N;
     if (P <= 0) return;
     static int stagger = -1;
@@ -968,10 +1014,10 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
     const long tiles = tp::xcd_grid((P + TM - 1) / TM);
     if (input_ch == 3)
         hipLaunchKernelGGL(k_tp_mlp_hp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
-                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), stagger);
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), stagger, dirsum);
     else
         hipLaunchKernelGGL(k_tp_mlp_hp<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, sc, views, rays_o, rays_d,
-                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), stagger);
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), stagger, dirsum);
 }
 
 }  // namespace neo

@@ -189,6 +189,7 @@ __device__ __forceinline__ void point_setup_row(const Scratch& S, int tid, long 
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) vdir_world[tid * 4 + a] = viewdirs[dray * 3 + a];
+        vdir_world[tid * 4 + 3] = __int_as_float(dray);          // the ray whose direction this point carries (quirk Q1)
     }
 }
 
@@ -205,7 +206,9 @@ __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile
 // put_dir(row, feature, value) stores one feature of the 27(+5 pad)-wide view-direction encoding.
 // LOC_TEXEL_BYTES: bytes per latent texel the local taps address (512 fp32 channels, or 256 for the
 // pre-projected map of mlp_tp_hp.hip).
-template <int LOC_TEXEL_BYTES = 2048, class PutDir>
+// DIRS = false: the view-direction encoding is not computed here (mlp_tp_hp.hip takes the per-ray sum over the views
+// from a table built once per launch, k_tp_dirsum).
+template <int LOC_TEXEL_BYTES = 2048, bool DIRS = true, class PutDir>
 __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx& L, const TpScene& sc,
                                                  const float* rot, const float* trn, int v, PutDir put_dir) {
     int* loc_off = S.loc_off; float* loc_w = S.loc_w; int* pl_off = S.pl_off; float* pl_w = S.pl_w;
@@ -252,6 +255,7 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 dst_off[p * 4 + k] = (int)((uint32_t)(base + t.off[k]) * (uint32_t)texel_bytes);   // byte offset mod 2^32
                 dst_w[p * 4 + k] = t.w[k];
             }
+            if constexpr (!DIRS) return;
             // view-direction encoding in this view's camera frame; wave q takes octave q
             const float dx = vdir_world[p * 4], dy = vdir_world[p * 4 + 1], dz = vdir_world[p * 4 + 2];
             const float dc[3] = {rot[0] * dx + rot[1] * dy + rot[2] * dz, rot[3] * dx + rot[4] * dy + rot[5] * dz,
