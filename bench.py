@@ -66,16 +66,25 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def kernel_source_hash():
-    """sha256 (first 16 hex digits) over the HIP sources + headers the library is built from: stamps PMC summaries
-    (tools/pmc_summarize.py) so a profile of an OLDER kernel is never attached to this build's numbers."""
+# the translation unit of each workload's dominant kernel (split arithmetic) + the headers it is built from
+KERNEL_SOURCES = {
+    "neo360": ("mlp_tp_hp.hip", "tp_hp_layout.h", "tp_common.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+    "vanilla": ("mlp_vanilla_h.hip", "mfma_tile.h", "common.h", "kernels.h"),
+    "mip360": ("mlp_mip_h.hip", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+    "mip360_128": ("mlp_mip_h.hip", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+    "pixelnerf": ("mlp_pix_h.hip", "tp_common.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+}
+
+
+def kernel_source_hash(workload="neo360"):
+    """sha256 (first 16 hex digits) over the HIP source of the workload's dominant kernel and the headers it includes:
+    stamps PMC summaries (tools/pmc_summarize.py) so a profile of an OLDER kernel is never attached to this build's numbers."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "neo-360_amd", "csrc")
-    for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(csrc, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+    for name in KERNEL_SOURCES[workload]:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
@@ -217,7 +226,7 @@ def pmc_profile(workload, precision):
     with open(paths[-1]) as f:
         full = json.load(f)
     src = os.path.relpath(paths[-1], ROOT)
-    have, want = full.get("kernel_source_sha16"), kernel_source_hash()
+    have, want = full.get("kernel_source_sha16"), kernel_source_hash(workload)
     if have != want:
         return {"source": src, "stale": "PMC summary %s was taken on kernel sources %s, this tree is %s: counter fields dropped"
                                         % (src, have or "(unstamped)", want)}
@@ -331,7 +340,7 @@ class Runner:
                 # HBM side of the roofline (north_star): PMC bytes of the profiled run / this run's launch time
                 "hbm_frac": (traffic / (avg_ms * 1e-3) / PEAK_HBM_BYTES) if traffic and avg_ms > 0 else None,
                 "mfma_busy": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"), "pmc_stale": pmc.get("stale"),
-                "kernel_source_sha16": kernel_source_hash()}
+                "kernel_source_sha16": kernel_source_hash(self.workload)}
         if self.split:
             # every algorithmic multiply costs three fp16 products: the ceiling for ALGORITHMIC flops on this arithmetic
             roof["frac_of_split_ceiling"] = achieved / (PEAK_F16_MFMA_TFLOPS / 3.0)

@@ -269,16 +269,19 @@ int neo_distloss(neo_ctx* ctx, const float* w, const float* m, int R, int N, flo
  * world 128] and cond (NV*P, 27) = view-direction encodings, view-major rows (row = v P + p).  w / b [host]: nine DEVICE
  * pointers each, order and nn.Linear (out, in) layout of neo_tp_upload_mlp (pts_linears.0..3, views_linear.0, .1,
  * bottleneck, density, rgb).  forward: raw_rgb (P,3), raw_sigma (P,1) (pre-activation, as the module returns them); the
- * activations stay in a context-owned tape.  backward (after the forward of the same shapes; g_* = upstream gradients):
+ * activations the backward needs are written to `tape`, a CALLER-owned device buffer of neo_tp_mlp_train_tape_floats(NV, P)
+ * floats (a training step runs the four MLPs of both levels forward before the first backward: one tape per call).
+ * backward (with the tape, x0, cond and weights of that forward; g_* = upstream gradients):
  * gw / gb [host]: nine device pointers each to gradient buffers of the weights' / biases' shapes, ZEROED by the caller
  * (partial sums are accumulated atomically); g_x0 (NV*P, K0) = gradient of the input rows (overwritten; may be NULL) -
  * its local / world columns feed neo_tp_gather_backward.  Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32).  At most
  * 4.19 M rows per call. */
+long neo_tp_mlp_train_tape_floats(int NV, long P);
 int neo_tp_mlp_train_forward(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x0,
-                             const float* cond, int NV, long P, float* raw_rgb, float* raw_sigma, void* stream);
+                             const float* cond, int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, void* stream);
 int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w, const float* x0, const float* cond, int NV,
-                              long P, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
-                              float* g_x0, void* stream);
+                              long P, const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
+                              float* const* gb, float* g_x0, void* stream);
 
 /* Stand-alone feature lookups of the scene set with neo_tp_set_scene, view-major rows (row = v P + p):
  * world (NV*P,128) = index_grid (encoder_tp_fusion_conv.py:122-209: three planes summed), local (NV*P,512) =

@@ -151,7 +151,6 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     for (auto& b : ctx->enc_ws) b.release();
     ctx->latent.release();
     ctx->tp_dirsum.release();
-    ctx->train_tape.release();
     ctx->train_scratch.release();
     for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }

@@ -215,34 +215,34 @@ int neo_tp_render_train(neo_ctx* ctx, const float* rays_o, const float* rays_d, 
 }
 
 
+long neo_tp_mlp_train_tape_floats(int NV, long P) { return NV >= 1 && P >= 0 ? (long)neo::tp_train_tape_floats(NV, P) : 0; }
+
 int neo_tp_mlp_train_forward(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x0,
-                             const float* cond, int NV, long P, float* raw_rgb, float* raw_sigma, void* stream) {
+                             const float* cond, int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, void* stream) {
     ENTER(ctx);
     REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (inside the sphere) or 4 (outside)");
     REQUIRE(NV >= 1 && P >= 0, "bad shape");
     if (P == 0) return NEO_OK;
     REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
-    REQUIRE(w && b && x0 && cond && raw_rgb && raw_sigma, "null pointer");
+    REQUIRE(w && b && x0 && cond && tape && raw_rgb && raw_sigma, "null pointer");
     for (int i = 0; i < 9; ++i) REQUIRE(w[i] && b[i], "null weight / bias pointer");
-    if (ctx->train_tape.reserve(neo::tp_train_tape_floats(NV, P) * sizeof(float))) return NEO_ERR_NOMEM;
-    neo::launch_tp_train_forward(input_ch * 21, w, b, x0, cond, NV, P, ctx->train_tape.as<float>(), raw_rgb, raw_sigma,
+    neo::launch_tp_train_forward(input_ch * 21, w, b, x0, cond, NV, P, tape, raw_rgb, raw_sigma,
                                  static_cast<hipStream_t>(stream));
-    ctx->train_nv = NV; ctx->train_p = P; ctx->train_ch = input_ch;
     return check_launch();
 }
 
 int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w, const float* x0, const float* cond, int NV,
-                              long P, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb, float* g_x0,
-                              void* stream) {
+                              long P, const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
+                              float* const* gb, float* g_x0, void* stream) {
     ENTER(ctx);
     REQUIRE(NV >= 1 && P >= 0, "bad shape");
     if (P == 0) return NEO_OK;
-    if (ctx->train_nv != NV || ctx->train_p != P || ctx->train_ch != input_ch)
-        return fail(NEO_ERR_STATE, "no matching neo_tp_mlp_train_forward before this backward (NV, P, input_ch differ)");
-    REQUIRE(w && x0 && cond && g_rgb && g_sigma && gw && gb, "null pointer");
+    REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (inside the sphere) or 4 (outside)");
+    REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
+    REQUIRE(w && x0 && cond && tape && g_rgb && g_sigma && gw && gb, "null pointer");
     for (int i = 0; i < 9; ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
     if (ctx->train_scratch.reserve(neo::tp_train_scratch_floats(NV, P) * sizeof(float))) return NEO_ERR_NOMEM;
-    neo::launch_tp_train_backward(input_ch * 21, w, x0, cond, NV, P, ctx->train_tape.as<float>(), ctx->train_scratch.as<float>(),
+    neo::launch_tp_train_backward(input_ch * 21, w, x0, cond, NV, P, tape, ctx->train_scratch.as<float>(),
                                   g_rgb, g_sigma, gw, gb, g_x0, static_cast<hipStream_t>(stream));
     return check_launch();
 }

@@ -139,10 +139,9 @@ struct neo_ctx {
     neo_host::MlpSlot enc;
     float enc_head_b[3] = {0.f, 0.f, 0.f};
     neo_host::DevBuf enc_latent, enc_axes, enc_ws[4];
-    // training-side NeRFPPMLP (neo_tp_mlp_train_*): activations kept by the last forward, and what they belong to
-    neo_host::DevBuf train_tape, train_scratch;
-    int train_nv = 0, train_ch = 0;
-    long train_p = 0;
+    // training-side NeRFPPMLP (neo_tp_mlp_train_backward): gradient scratch (the activation tape is the caller's: a
+    // training step runs several MLP forwards before the first backward)
+    neo_host::DevBuf train_scratch;
     int precision = 1;   // 1 (default): fp16 MFMA with hi/lo-split operands (fp32-equivalent); 0: exact fp32 MFMA
     // deferred reads of the flag word (neo_ctx_post_flags / neo_ctx_take_flags): pinned host words + one event each
     static constexpr int FLAG_RING = 64;

@@ -191,15 +191,18 @@ class _TrainMLP(torch.autograd.Function):
         tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         raw_rgb = torch.empty(npts, 3, device=x0.device)
         raw_sigma = torch.empty(npts, 1, device=x0.device)
+        # the activations live in a tensor owned by THIS autograd node: a training step runs several MLP forwards
+        # (inside / outside the sphere, coarse / fine) before the first backward
+        tape = torch.empty(c.lib.neo_tp_mlp_train_tape_floats(nv, npts), device=x0.device)
         _lib.check(c.lib.neo_tp_mlp_train_forward(c.handle, input_ch, tab(wd), tab(bd), ptr(x0), ptr(cond), nv, npts,
-                                                  ptr(raw_rgb), ptr(raw_sigma), c.stream()))
-        ctx_.save_for_backward(x0, cond, *wd)
+                                                  ptr(tape), ptr(raw_rgb), ptr(raw_sigma), c.stream()))
+        ctx_.save_for_backward(x0, cond, tape, *wd)
         ctx_.meta = (c, input_ch, nv, npts, x_enc.shape, [tuple(w.shape) for w in ws], [tuple(b.shape) for b in bs])
         return raw_rgb, raw_sigma
 
     @staticmethod
     def backward(ctx_, g_rgb, g_sigma):
-        x0, cond, *wd = ctx_.saved_tensors
+        x0, cond, tape, *wd = ctx_.saved_tensors
         c, input_ch, nv, npts, xshape, wshapes, bshapes = ctx_.meta
         dev = x0.device
         g_rgb = f32(g_rgb.contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(npts, 3, device=dev)
@@ -209,8 +212,8 @@ class _TrainMLP(torch.autograd.Function):
         need_x = any(ctx_.needs_input_grad[3:7])
         g_x0 = torch.empty_like(x0) if need_x else None
         tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        _lib.check(c.lib.neo_tp_mlp_train_backward(c.handle, input_ch, tab(wd), ptr(x0), ptr(cond), nv, npts, ptr(g_rgb),
-                                                   ptr(g_sigma), tab(gw), tab(gb), ptr(g_x0), c.stream()))
+        _lib.check(c.lib.neo_tp_mlp_train_backward(c.handle, input_ch, tab(wd), ptr(x0), ptr(cond), nv, npts, ptr(tape),
+                                                   ptr(g_rgb), ptr(g_sigma), tab(gw), tab(gb), ptr(g_x0), c.stream()))
         pe = input_ch * 21
         gx = g_x0[:, :pe].reshape(xshape) if need_x and ctx_.needs_input_grad[3] else None
         gworld = g_x0[:, pe + 512:] if need_x and ctx_.needs_input_grad[5] else None

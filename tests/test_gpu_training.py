@@ -340,3 +340,36 @@ def test_training_step_end_to_end_gradients():
         assert a.shape == b.shape and err < 5e-3, (nm, err)
     from conftest import record_parity
     record_parity("train_step_end_to_end", max_rel_grad_err_vs_fp64=worst, loss_abs_err=abs(float(loss_g) - float(loss_c)))
+
+
+def test_nerfpp_mlp_tapes_are_per_call():
+    """A training step runs several MLP forwards before the first backward (inside / outside the sphere, coarse / fine):
+    every call keeps its own activation tape.  Two calls of the same module on different inputs, one backward through
+    both: the gradients equal the sum of the gradients of the two calls taken alone."""
+    from neo360_amd import models
+    torch.manual_seed(9)
+    nv, P = 3, 700
+    prefix = "fg_coarse_mlp."
+    sd = synth.nerf_tp_state(0)
+    mlp = models.NeRFPPMLP(0, 10, 4, input_ch=3, num_src_views=nv).to(DEV)
+    mlp.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
+    ins = [[torch.randn(nv, P, 63, device=DEV), torch.randn(nv * P, 27, device=DEV), torch.randn(nv * P, 128, device=DEV) * 0.3,
+            torch.randn(nv * P, 512, device=DEV) * 0.3] for _ in range(2)]
+    ups = [(torch.randn(P, 3, device=DEV), torch.randn(P, 1, device=DEV)) for _ in range(2)]
+    params = list(mlp.parameters())
+
+    def grads(which):
+        for p in params:
+            p.grad = None
+        with torch.enable_grad():
+            outs = [training.nerfpp_mlp(mlp, *ins[i], nv) for i in which]           # all forwards first
+            loss = sum((o[0] * ups[i][0]).sum() + (o[1] * ups[i][1]).sum() for o, i in zip(outs, which))
+            loss.backward()
+        return [p.grad.clone() for p in params]
+
+    for p in params:
+        p.requires_grad_(True)
+    both, a, b = grads([0, 1]), grads([0]), grads([1])
+    for g2, ga, gb_ in zip(both, a, b):
+        scale = float((ga + gb_).abs().max()) + 1e-12
+        assert max_abs(g2, ga + gb_) / scale < 1e-5

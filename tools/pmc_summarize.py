@@ -27,8 +27,10 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
 c = mean
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 try:
-    from bench import kernel_source_hash          # the tree the passes ran on: bench.py drops summaries of other trees
-    src_hash = kernel_source_hash()
+    from bench import kernel_source_hash          # the kernel sources the passes ran on: bench.py drops summaries of other sources
+    wl = os.environ.get("PMC_WORKLOAD") or {"k_tp_mlp": "neo360", "k_vanilla": "vanilla", "k_mip": "mip360", "k_pix": "pixelnerf"}[
+        next(k for k in ("k_tp_mlp", "k_vanilla", "k_mip", "k_pix") if pat.startswith(k))]
+    src_hash = kernel_source_hash(wl)
 except Exception:
     src_hash = None
 out = {"kernel_match": pat, "launches_per_pass": nl, "note": note, "kernel_source_sha16": src_hash, "mean_per_launch": c, "derived": {}}
