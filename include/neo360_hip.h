@@ -283,6 +283,18 @@ int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w,
                               long P, const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
                               float* const* gb, float* g_x0, void* stream);
 
+/* The vanilla NeRFMLP for training (vanilla_nerf/model.py:100-125 under the training step :255-283), same contract:
+ * x0 (R, 63) encoded points, cond (R, 27) = each row's view-direction encoding (the ray's, tiled over its samples);
+ * w / b [host]: twelve device pointers each in the order of neo_vanilla_upload_mlp; tape: caller-owned,
+ * neo_vanilla_mlp_train_tape_floats(R) floats; backward: gw / gb zeroed by the caller, g_x0 (R, 63) / g_cond (R, 27) may
+ * be NULL.  Exact fp32 arithmetic. */
+long neo_vanilla_mlp_train_tape_floats(long R);
+int neo_vanilla_mlp_train_forward(neo_ctx* ctx, const float* const* w, const float* const* b, const float* x0, const float* cond,
+                                  long R, float* tape, float* raw_rgb, float* raw_sigma, void* stream);
+int neo_vanilla_mlp_train_backward(neo_ctx* ctx, const float* const* w, const float* x0, const float* cond, long R,
+                                   const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
+                                   float* const* gb, float* g_x0, float* g_cond, void* stream);
+
 /* Stand-alone feature lookups of the scene set with neo_tp_set_scene, view-major rows (row = v P + p):
  * world (NV*P,128) = index_grid (encoder_tp_fusion_conv.py:122-209: three planes summed), local (NV*P,512) =
  * get_local_feats / SpatialEncoder.index (neo360/model.py:239-264).  pts (P,3) world points. */

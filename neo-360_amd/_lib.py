@@ -73,6 +73,10 @@ SIGNATURES = {
     "neo_tp_mlp_train_forward": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp, _vp]),
     "neo_tp_mlp_train_backward": (_i, [_vp, _i, ctypes.POINTER(_vp), _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp, ctypes.POINTER(_vp),
                                        ctypes.POINTER(_vp), _vp, _vp]),
+    "neo_vanilla_mlp_train_tape_floats": (ctypes.c_long, [ctypes.c_long]),
+    "neo_vanilla_mlp_train_forward": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp]),
+    "neo_vanilla_mlp_train_backward": (_i, [_vp, ctypes.POINTER(_vp), _vp, _vp, ctypes.c_long, _vp, _vp, _vp, ctypes.POINTER(_vp),
+                                            ctypes.POINTER(_vp), _vp, _vp, _vp]),
     "neo_tp_render_train": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _i, _i, _i, ctypes.c_uint64,
                                  ctypes.POINTER(TpTrainOut), ctypes.POINTER(TpTrainOut), _vp]),
     "neo_pix_upload_mlp": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),

@@ -247,4 +247,32 @@ int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w,
     return check_launch();
 }
 
+
+long neo_vanilla_mlp_train_tape_floats(long R) { return R >= 0 ? (long)neo::vanilla_train_tape_floats(R) : 0; }
+
+int neo_vanilla_mlp_train_forward(neo_ctx* ctx, const float* const* w, const float* const* b, const float* x0, const float* cond,
+                                  long R, float* tape, float* raw_rgb, float* raw_sigma, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && R <= 4190000L, "0 <= rows <= 4.19 M per call");
+    if (R == 0) return NEO_OK;
+    REQUIRE(w && b && x0 && cond && tape && raw_rgb && raw_sigma, "null pointer");
+    for (int i = 0; i < 12; ++i) REQUIRE(w[i] && b[i], "null weight / bias pointer");
+    neo::launch_vanilla_train_forward(w, b, x0, cond, R, tape, raw_rgb, raw_sigma, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_vanilla_mlp_train_backward(neo_ctx* ctx, const float* const* w, const float* x0, const float* cond, long R,
+                                   const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
+                                   float* const* gb, float* g_x0, float* g_cond, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && R <= 4190000L, "0 <= rows <= 4.19 M per call");
+    if (R == 0) return NEO_OK;
+    REQUIRE(w && x0 && cond && tape && g_rgb && g_sigma && gw && gb, "null pointer");
+    for (int i = 0; i < 12; ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
+    if (ctx->train_scratch.reserve(neo::vanilla_train_scratch_floats(R) * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_vanilla_train_backward(w, x0, cond, R, tape, ctx->train_scratch.as<float>(), g_rgb, g_sigma, gw, gb, g_x0, g_cond,
+                                       static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
 }  // extern "C"

@@ -339,14 +339,14 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
     }
 
     // ---- view mean of the trunk -> density head (ReLU, model_pixel.py:232) ----
-    const float nvf = (float)sc.nv;
+    const float inv_nv = 1.0f / (float)sc.nv;     // x * (1 / nv): 1 instruction instead of the 11 of an fp32 division, <= 1 ulp (see mlp_tp_hp.hip)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] / nvf; hsum[1][r] = hsum[1][r] / nvf; }
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] * inv_nv; hsum[1][r] = hsum[1][r] * inv_nv; }
     store_tile_h<false>(hsum[0], act, L.wv, 0, L);
     store_tile_h<false>(hsum[1], act, L.wv, 1, L);
     float dmean[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dmean[j] = dsum[(tid >> 2) * 32 + ((((tid & 3) << 3) + j) ^ ((tid >> 2) & 31))] / nvf;
+    for (int j = 0; j < 8; ++j) dmean[j] = dsum[(tid >> 2) * 32 + ((((tid & 3) << 3) + j) ^ ((tid >> 2) & 31))] * inv_nv;
     __syncthreads();
     {
         h8 vh, vl;

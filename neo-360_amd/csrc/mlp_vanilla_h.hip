@@ -64,6 +64,7 @@ template <int LDH, int KM>
 __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * LDH + ((chunk ^ (row & KM)) << 3); }
 
 __device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
+    asm("" : "+v"(x));          // opaque: no folding of a producing multiply into the conversion (see split_tile.h:split)
     hi = (_Float16)x;
     lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);      // x - hi, exact; one mixed-precision fma
 }

@@ -31,6 +31,12 @@ __device__ __forceinline__ int chunk_off(int row, int chunk) {
 }
 
 __device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
+    // x is made opaque first.  When x is the direct result of a multiply the compiler folds (float)(_Float16)(a * b) into
+    // v_fma_mixlo_f16 - ONE rounding, from the exact product - for the subtraction below, but stores fp16(fl32(a * b)) as
+    // hi: two roundings of "the same" value that differ by an ulp of fp16 in rare cases, so hi + lo misses x by 2^-11
+    // instead of 2^-22 (measured: 1e-5 outliers in rgb when the view mean became sum * (1 / nv); tests/test_build_cpu.py
+    // keeps that instruction out of the library).
+    asm("" : "+v"(x));
     hi = (_Float16)x;
     lo = (_Float16)__builtin_fmaf((float)hi, -1.0f, x);      // x - hi, exact; one mixed-precision fma
 }

@@ -275,4 +275,86 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x0, co
     if (g_x0) gemm<false, true>((int)R, K0, 128, ga, 128, w[0], K0, g_x0, K0, epi(nullptr, 0, 1), 1, s);
 }
 
+// ---- vanilla NeRFMLP (vanilla_nerf/model.py:100-125) ---------------------------------------------------------------------
+// rows R = rays x samples; x0 (R, 63) encoded points, cond (R, 27) the ray's direction encoding tiled over its samples.
+// w / b order as neo_vanilla_upload_mlp: pts_linears.0..7 (256 wide, layer 5 on [h4 | x0]), views_linear.0 (283 -> 128),
+// bottleneck (256 -> 256), density (256 -> 1), rgb (128 -> 3).
+// tape (floats): h0..h7 (R x 256 each), bott (R x 256), v (R x 128)
+size_t vanilla_train_tape_floats(long R) { return (size_t)(R * (9 * 256 + 128)); }
+size_t vanilla_train_scratch_floats(long R) { return (size_t)(R * (2 * 256 + 128)); }
+
+void launch_vanilla_train_forward(const float* const* w, const float* const* b, const float* x0, const float* cond, long R,
+                                  float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s) {
+    float* h[8];
+    for (int i = 0; i < 8; ++i) h[i] = tape + (size_t)i * R * 256;
+    float* bott = tape + (size_t)8 * R * 256;
+    float* v = bott + (size_t)R * 256;
+    const int M = (int)R;
+    gemm<false, false>(M, 256, 63, x0, 63, w[0], 63, h[0], 256, epi(b[0], 1), 1, s);
+    for (int i = 1; i < 8; ++i) {
+        if (i == 5) {              // the skip concat after layer index 4: layer 5 reads [h4 | x0]
+            gemm<false, false>(M, 256, 256, h[4], 256, w[5], 319, h[5], 256, epi(b[5], 0), 1, s);
+            gemm<false, false>(M, 256, 63, x0, 63, w[5] + 256, 319, h[5], 256, epi(nullptr, 0, 1), 1, s);
+            hipLaunchKernelGGL(k_view_mean, dim3(blocks(R * 256)), dim3(256), 0, s, h[5], 1, R * 256, 1, 1, h[5]);   // ReLU in place
+        } else {
+            gemm<false, false>(M, 256, 256, h[i - 1], 256, w[i], 256, h[i], 256, epi(b[i], 1), 1, s);
+        }
+    }
+    gemm<false, false>(M, 1, 256, h[7], 256, w[10], 256, raw_sigma, 1, epi(b[10], 0), 1, s);
+    gemm<false, false>(M, 256, 256, h[7], 256, w[9], 256, bott, 256, epi(b[9], 0), 1, s);
+    gemm<false, false>(M, 128, 256, bott, 256, w[8], 283, v, 128, epi(b[8], 0), 1, s);
+    gemm<false, false>(M, 128, 27, cond, 27, w[8] + 256, 283, v, 128, epi(nullptr, 0, 1), 1, s);
+    hipLaunchKernelGGL(k_view_mean, dim3(blocks(R * 128)), dim3(256), 0, s, v, 1, R * 128, 1, 1, v);                   // ReLU in place
+    gemm<false, false>(M, 3, 128, v, 128, w[11], 128, raw_rgb, 3, epi(b[11], 0), 1, s);
+}
+
+// gw / gb: twelve gradients ZEROED by the caller; g_x0 (R, 63) / g_cond (R, 27) may be null
+void launch_vanilla_train_backward(const float* const* w, const float* x0, const float* cond, long R, const float* tape,
+                                   float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
+                                   float* g_x0, float* g_cond, hipStream_t s) {
+    const float* h[8];
+    for (int i = 0; i < 8; ++i) h[i] = tape + (size_t)i * R * 256;
+    const float* bott = tape + (size_t)8 * R * 256;
+    const float* v = bott + (size_t)R * 256;
+    float* ga = scratch; float* gb2 = ga + (size_t)R * 256; float* gv = gb2 + (size_t)R * 256;
+    const int M = (int)R, SR = (int)((R + 8191) / 8192);
+    // rgb head, view layer on [bott | cond]
+    gemm<true, true>(3, 128, M, g_rgb, 3, v, 128, gw[11], 128, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, g_rgb, R, 3, gb[11]);
+    gemm<false, true>(M, 128, 3, g_rgb, 3, w[11], 128, gv, 128, epi(nullptr, 0, 0, v, 128), 1, s);
+    gemm<true, true>(128, 256, M, gv, 128, bott, 256, gw[8], 283, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(128, 27, M, gv, 128, cond, 27, gw[8] + 256, 283, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gv, R, 128, gb[8]);
+    if (g_cond) gemm<false, true>(M, 27, 128, gv, 128, w[8] + 256, 283, g_cond, 27, epi(), 1, s);
+    gemm<false, true>(M, 256, 128, gv, 128, w[8], 283, ga, 256, epi(), 1, s);                                     // g_bott
+    // bottleneck + density head -> g_h7
+    gemm<true, true>(256, 256, M, ga, 256, h[7], 256, gw[9], 256, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, ga, R, 256, gb[9]);
+    gemm<false, true>(M, 256, 256, ga, 256, w[9], 256, gb2, 256, epi(), 1, s);
+    gemm<true, true>(1, 256, M, g_sigma, 1, h[7], 256, gw[10], 256, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, g_sigma, R, 1, gb[10]);
+    gemm<false, true>(M, 256, 1, g_sigma, 1, w[10], 256, gb2, 256, epi(nullptr, 0, 1), 1, s);
+    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 256)), dim3(256), 0, s, gb2, h[7], R * 256);                  // g_z7
+    float* cur = gb2;
+    float* nxt = ga;
+    for (int i = 7; i >= 1; --i) {
+        // cur = g_z_i (R x 256)
+        if (i == 5) {
+            gemm<true, true>(256, 256, M, cur, 256, h[4], 256, gw[5], 319, epi(nullptr, 0, 2), SR, s);
+            gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[5] + 256, 319, epi(nullptr, 0, 2), SR, s);
+            if (g_x0) gemm<false, true>(M, 63, 256, cur, 256, w[5] + 256, 319, g_x0, 63, epi(), 1, s);
+            hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[5]);
+            gemm<false, true>(M, 256, 256, cur, 256, w[5], 319, nxt, 256, epi(nullptr, 0, 0, h[4], 256), 1, s);
+        } else {
+            gemm<true, true>(256, 256, M, cur, 256, h[i - 1], 256, gw[i], 256, epi(nullptr, 0, 2), SR, s);
+            hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[i]);
+            gemm<false, true>(M, 256, 256, cur, 256, w[i], 256, nxt, 256, epi(nullptr, 0, 0, h[i - 1], 256), 1, s);
+        }
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[0], 63, epi(nullptr, 0, 2), SR, s);
+    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[0]);
+    if (g_x0) gemm<false, true>(M, 63, 256, cur, 256, w[0], 63, g_x0, 63, epi(nullptr, 0, 1), 1, s);
+}
+
 }  // namespace neo

@@ -231,3 +231,53 @@ def nerfpp_mlp(mlp, x_enc, cond_rows, world_feat, local_feat, nv, ctx=None):
     layers = mlp.ordered_layers()
     params = [l.weight for l in layers] + [l.bias for l in layers]
     return _TrainMLP.apply(ctx, mlp.input_ch, nv, x_enc, cond_rows, world_feat, local_feat, *params)
+
+
+class _TrainVanillaMLP(torch.autograd.Function):
+    """Vanilla NeRFMLP on materialised rows with a native backward (neo_vanilla_mlp_train_forward / _backward)."""
+
+    @staticmethod
+    def forward(ctx_, lib_ctx, x_enc, dir_enc, *params):
+        ws, bs = params[:12], params[12:]
+        B, N, F = x_enc.shape
+        x0 = f32(x_enc, "x_enc").reshape(-1, F).contiguous()
+        cond = torch.tile(f32(dir_enc, "dir_enc")[:, None, :], (1, N, 1)).reshape(-1, dir_enc.shape[-1]).contiguous()
+        c = _ctx(x0, lib_ctx)
+        wd = [f32(w.detach(), "weight") for w in ws]
+        bd = [f32(b.detach(), "bias") for b in bs]
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        R = B * N
+        raw_rgb, raw_sigma = torch.empty(R, 3, device=x0.device), torch.empty(R, 1, device=x0.device)
+        tape = torch.empty(c.lib.neo_vanilla_mlp_train_tape_floats(R), device=x0.device)
+        _lib.check(c.lib.neo_vanilla_mlp_train_forward(c.handle, tab(wd), tab(bd), ptr(x0), ptr(cond), R, ptr(tape), ptr(raw_rgb),
+                                                       ptr(raw_sigma), c.stream()))
+        ctx_.save_for_backward(x0, cond, tape, *wd)
+        ctx_.meta = (c, B, N, F, [tuple(w.shape) for w in ws], [tuple(b.shape) for b in bs])
+        return raw_rgb.reshape(B, N, 3), raw_sigma.reshape(B, N, 1)
+
+    @staticmethod
+    def backward(ctx_, g_rgb, g_sigma):
+        x0, cond, tape, *wd = ctx_.saved_tensors
+        c, B, N, F, wshapes, bshapes = ctx_.meta
+        dev, R = x0.device, B * N
+        g_rgb = f32(g_rgb.reshape(R, 3).contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(R, 3, device=dev)
+        g_sigma = f32(g_sigma.reshape(R, 1).contiguous(), "g_sigma") if g_sigma is not None else torch.zeros(R, 1, device=dev)
+        gw = [torch.zeros(s, device=dev) for s in wshapes]
+        gb = [torch.zeros(s, device=dev) for s in bshapes]
+        g_x0 = torch.empty_like(x0) if ctx_.needs_input_grad[1] else None
+        g_cond = torch.empty_like(cond) if ctx_.needs_input_grad[2] else None
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(c.lib.neo_vanilla_mlp_train_backward(c.handle, tab(wd), ptr(x0), ptr(cond), R, ptr(tape), ptr(g_rgb), ptr(g_sigma),
+                                                        tab(gw), tab(gb), ptr(g_x0), ptr(g_cond), c.stream()))
+        gx = g_x0.reshape(B, N, F) if g_x0 is not None else None
+        gd = g_cond.reshape(B, N, -1).sum(dim=1) if g_cond is not None else None      # the tiling's backward
+        return (None, gx, gd, *gw, *gb)
+
+
+def nerf_mlp(mlp, x_enc, dir_enc, ctx=None):
+    """The reference's vanilla NeRFMLP.forward (vanilla_nerf/model.py:100-125) with autograd support: x_enc (B,N,63) encoded
+    sample points, dir_enc (B,27) per-ray view-direction encodings -> raw_rgb (B,N,3), raw_sigma (B,N,1).  `mlp` is a
+    models.NeRFMLP; gradients flow to all 24 parameter tensors and to both inputs.  Exact fp32 matrix arithmetic."""
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    return _TrainVanillaMLP.apply(ctx, x_enc, dir_enc, *params)

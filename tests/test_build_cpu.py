@@ -37,3 +37,48 @@ def test_failed_compile_leaves_no_stamp_and_no_object(tmp_path, monkeypatch):
     os.utime(out / "libtest.so", (1, 1))
     build.build()
     assert os.path.getmtime(out / "libtest.so") > 1
+
+
+def _disassemble_library(tmp_path):
+    """ISA text of every gfx950 code object inside the built library (llvm-objdump --offloading writes the bundles next
+    to its input, so it works on a copy)."""
+    import shutil
+    import subprocess
+    lib = build.build()
+    llvm = os.path.join(os.path.dirname(os.path.realpath(build._hipcc())), "..", "lib", "llvm", "bin")
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        llvm = "/opt/rocm/lib/llvm/bin"
+    cp = tmp_path / "lib.so"
+    shutil.copyfile(lib, cp)
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(cp)], check=True, stdout=subprocess.DEVNULL,
+                   stderr=subprocess.DEVNULL)
+    cos = sorted(f for f in os.listdir(tmp_path) if f.endswith("amdgcn-amd-amdhsa--" + build.ARCH))
+    assert len(cos) >= 10                      # one per translation unit with device code
+    text = []
+    for co in cos:
+        text.append(subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", str(tmp_path / co)],
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout)
+    return "\n".join(text)
+
+
+def test_library_isa_has_no_inconsistent_split_conversions(tmp_path):
+    """hi/lo splits must round hi ONCE.  hipcc folds (float)(_Float16)(a * b) into v_fma_mixlo_f16 (a single rounding from
+    the exact product) in one use of the value and converts the rounded product in another: hi + lo then misses x by an ulp
+    of fp16 (measured 1e-5 outliers in rgb).  split_tile.h:split makes its argument opaque; this keeps the instruction
+    from coming back through some other route.  Also: the kernels that run fp16 MFMAs carry no packed fp32 op with an
+    op_sel modifier (the forms that glitch beside v_mfma_f32_32x32x16_f16: profiles/r02_pk_f32_repro.log)."""
+    isa = _disassemble_library(tmp_path)
+    assert "v_mfma_f32_32x32x16_f16" in isa                                     # the disassembly is the real thing
+    assert "v_fma_mixlo_f16" not in isa and "v_fma_mixhi_f16" not in isa
+    # walk kernel by kernel: a kernel with split-fp16 MFMAs must not contain op_sel'd packed fp32 arithmetic
+    kernel, has_mfma, bad = None, {}, {}
+    for line in isa.splitlines():
+        if line.endswith(">:") and "<" in line:
+            kernel = line.split("<", 1)[1][:-2]
+        elif kernel:
+            if "v_mfma_f32_32x32x16_f16" in line:
+                has_mfma[kernel] = True
+            elif "v_pk_" in line and "_f32" in line and "op_sel" in line:
+                bad.setdefault(kernel, line.strip())
+    offenders = {k: v for k, v in bad.items() if has_mfma.get(k)}
+    assert not offenders, offenders

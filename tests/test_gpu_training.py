@@ -373,3 +373,59 @@ def test_nerfpp_mlp_tapes_are_per_call():
     for g2, ga, gb_ in zip(both, a, b):
         scale = float((ga + gb_).abs().max()) + 1e-12
         assert max_abs(g2, ga + gb_) / scale < 1e-5
+
+
+def test_vanilla_mlp_backward_vs_autograd():
+    """neo_vanilla_mlp_train_forward / _backward against torch autograd through the oracle's NeRFMLP (fp64): outputs, all
+    24 parameter gradients, the gradients of the encoded points and of the per-ray direction encodings."""
+    from neo360_amd import models
+    torch.manual_seed(11)
+    B, N = 600, 4          # few samples per ray: the kink filter below drops whole rays
+    prefix = "fine_mlp."
+    sd = synth.vanilla_state(0)
+    mlp = models.NeRFMLP().to(DEV)
+    mlp.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
+    x_enc, d_enc = torch.randn(B, N, 63), torch.randn(B, 27)
+    # drop rays with a pre-activation within 1e-5 of a ReLU kink (fp64 forward), as in test_nerfpp_mlp_backward_vs_autograd
+    W = {k[len(prefix):]: v.double() for k, v in sd.items() if k.startswith(prefix)}
+    lin = lambda n, x: torch.nn.functional.linear(x, W[n + ".weight"], W[n + ".bias"])
+    x0 = x_enc.reshape(-1, 63).double()
+    h, near = x0, torch.full((B * N,), 1e9, dtype=torch.float64)
+    for i in range(8):
+        z = lin("pts_linears.%d" % i, h)
+        near = torch.minimum(near, z.abs().amin(-1))
+        h = z.relu()
+        if i == 4:
+            h = torch.cat([h, x0], -1)
+    cond = torch.tile(d_enc[:, None, :], (1, N, 1)).reshape(-1, 27).double()
+    zv = lin("views_linear.0", torch.cat([lin("bottleneck_layer", h), cond], -1))
+    near = torch.minimum(near, zv.abs().amin(-1)).reshape(B, N).amin(-1)
+    keep = near > 1e-5
+    assert int(keep.sum()) > 0.4 * B
+    x_enc, d_enc = x_enc[keep].contiguous(), d_enc[keep].contiguous()
+    B = int(keep.sum())
+    g_rgb, g_sig = torch.randn(B, N, 3) * 1e-3, torch.randn(B, N, 1) * 1e-3
+    with torch.enable_grad():
+        p = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mlp.state_dict(prefix=prefix).items()}
+        ins = [x_enc.double().requires_grad_(True), d_enc.double().requires_grad_(True)]
+        rgb, sig = oracle.mlp.vanilla_mlp(p, prefix, ins[0], ins[1])
+        ((rgb * g_rgb.double()).sum() + (sig * g_sig.double()).sum()).backward()
+        gin = [x_enc.to(DEV).requires_grad_(True), d_enc.to(DEV).requires_grad_(True)]
+        for q in mlp.parameters():
+            q.requires_grad_(True)
+            q.grad = None
+        rgb_g, sig_g = training.nerf_mlp(mlp, gin[0], gin[1])
+        ((rgb_g * g_rgb.to(DEV)).sum() + (sig_g * g_sig.to(DEV)).sum()).backward()
+    assert max_abs(rgb_g, rgb.detach()) < 2e-5 and max_abs(sig_g, sig.detach()) < 2e-5
+    worst = 0.0
+    for name, q in mlp.named_parameters():
+        ref = p[prefix + name].grad
+        err = max_abs(q.grad, ref) / (float(ref.abs().max()) + 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-5, (name, err)
+    for t, r, nm in zip(gin, ins, ("x_enc", "dir_enc")):
+        err = max_abs(t.grad, r.grad) / (float(r.grad.abs().max()) + 1e-12)
+        worst = max(worst, err)
+        assert err < 2e-5, (nm, err)
+    from conftest import record_parity
+    record_parity("train_vanilla_mlp_backward", max_rel_grad_err_vs_fp64=worst, rows=B * N)
