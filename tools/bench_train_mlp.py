@@ -33,3 +33,26 @@ with torch.enable_grad():
     torch.cuda.synchronize(); ts = (time.perf_counter() - t0) / 3
 print("NeRFPPMLP training op, %d rows (%d points x %d views): forward %.1f ms (%.1f TFLOP/s), forward + backward %.1f ms (%.1f TFLOP/s of 3 x forward flops; exact fp32 MFMA peak 157.3)"
       % (NV * P, P, NV, tf * 1e3, fwd_flop / tf / 1e12, ts * 1e3, 3 * fwd_flop / ts / 1e12))
+
+# ---- the vanilla NeRFMLP (neo_vanilla_mlp_train_forward / _backward): 1024 rays x 193 fine samples, 593,408 MAC per row ----
+B, N = int(os.environ.get("VB", 1024)), int(os.environ.get("VN", 193))
+vmlp = models.NeRFMLP().to(dev)
+vsd = synth.vanilla_state(0)
+vmlp.load_state_dict({k[len("fine_mlp."):]: v for k, v in vsd.items() if k.startswith("fine_mlp.")})
+vx = torch.randn(B, N, 63, device=dev, generator=g).requires_grad_(True)
+vd = torch.randn(B, 27, device=dev, generator=g)
+vflop = 2.0 * B * N * (63 * 256 + 6 * 256 * 256 + 319 * 256 + 256 + 256 * 256 + 283 * 128 + 128 * 3)
+def vstep():
+    rgb, sig = training.nerf_mlp(vmlp, vx, vd)
+    (rgb.sum() + sig.sum()).backward()
+with torch.enable_grad():
+    vstep(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for _ in range(3): training.nerf_mlp(vmlp, vx, vd)
+    torch.cuda.synchronize(); tf = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    for _ in range(3): vstep()
+    torch.cuda.synchronize(); ts = (time.perf_counter() - t0) / 3
+print("NeRFMLP (vanilla) training op, %d rows: forward %.1f ms (%.1f TFLOP/s), forward + backward %.1f ms (%.1f TFLOP/s of 3 x forward flops)"
+      % (B * N, tf * 1e3, vflop / tf / 1e12, ts * 1e3, 3 * vflop / ts / 1e12))
