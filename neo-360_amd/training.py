@@ -181,7 +181,18 @@ class _TrainMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, lib_ctx, input_ch, nv, x_enc, cond_rows, world_feat, local_feat, *params):
         ws, bs = params[:9], params[9:]
-        npts = x_enc.shape[1]
+        # the library reads rows of fixed widths: anything else is caught here, as the reference's matmuls would
+        pe, npts = input_ch * 21, x_enc.shape[1]
+        if x_enc.dim() != 3 or tuple(x_enc.shape) != (nv, npts, pe):
+            raise ValueError("x_enc must be (NV, P, %d), got %s" % (pe, tuple(x_enc.shape)))
+        for name, t, width in (("cond_rows", cond_rows, 27), ("world_feat", world_feat, 128), ("local_feat", local_feat, 512)):
+            if tuple(t.shape) != (nv * npts, width):
+                raise ValueError("%s must be (NV*P, %d) = (%d, %d), got %s" % (name, width, nv * npts, width, tuple(t.shape)))
+        want = [(128, pe + 640), (128, 128), (128, 128), (128, 128 + pe + 640), (64, 155), (64, 64), (128, 128), (1, 128), (3, 64)]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if tuple(w.shape) != want[i] or tuple(b.shape) != (want[i][0],):
+                raise ValueError("NeRFPPMLP layer %d: weight %s / bias %s, expected %s / (%d,)"
+                                 % (i, tuple(w.shape), tuple(b.shape), want[i], want[i][0]))
         x0 = torch.cat([f32(x_enc, "x_enc").reshape(-1, x_enc.shape[-1]), f32(local_feat, "local_feat"),
                         f32(world_feat, "world_feat")], dim=-1).contiguous()
         cond = f32(cond_rows, "cond_rows")
@@ -201,9 +212,12 @@ class _TrainMLP(torch.autograd.Function):
         return raw_rgb, raw_sigma
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx_, g_rgb, g_sigma):
         x0, cond, tape, *wd = ctx_.saved_tensors
         c, input_ch, nv, npts, xshape, wshapes, bshapes = ctx_.meta
+        if ctx_.needs_input_grad[4]:
+            raise NotImplementedError("nerfpp_mlp: no gradient for cond_rows (the reference's view directions are data)")
         dev = x0.device
         g_rgb = f32(g_rgb.contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(npts, 3, device=dev)
         g_sigma = f32(g_sigma.contiguous(), "g_sigma") if g_sigma is not None else torch.zeros(npts, 1, device=dev)
@@ -239,6 +253,13 @@ class _TrainVanillaMLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, lib_ctx, x_enc, dir_enc, *params):
         ws, bs = params[:12], params[12:]
+        if x_enc.dim() != 3 or x_enc.shape[-1] != 63 or tuple(dir_enc.shape) != (x_enc.shape[0], 27):
+            raise ValueError("x_enc must be (B, N, 63) and dir_enc (B, 27), got %s / %s" % (tuple(x_enc.shape), tuple(dir_enc.shape)))
+        want = [(256, 63)] + [(256, 256)] * 4 + [(256, 319)] + [(256, 256)] * 2 + [(128, 283), (256, 256), (1, 256), (3, 128)]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if tuple(w.shape) != want[i] or tuple(b.shape) != (want[i][0],):
+                raise ValueError("NeRFMLP layer %d: weight %s / bias %s, expected %s / (%d,)"
+                                 % (i, tuple(w.shape), tuple(b.shape), want[i], want[i][0]))
         B, N, F = x_enc.shape
         x0 = f32(x_enc, "x_enc").reshape(-1, F).contiguous()
         cond = torch.tile(f32(dir_enc, "dir_enc")[:, None, :], (1, N, 1)).reshape(-1, dir_enc.shape[-1]).contiguous()
@@ -256,6 +277,7 @@ class _TrainVanillaMLP(torch.autograd.Function):
         return raw_rgb.reshape(B, N, 3), raw_sigma.reshape(B, N, 1)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx_, g_rgb, g_sigma):
         x0, cond, tape, *wd = ctx_.saved_tensors
         c, B, N, F, wshapes, bshapes = ctx_.meta

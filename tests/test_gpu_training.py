@@ -429,3 +429,39 @@ def test_vanilla_mlp_backward_vs_autograd():
         assert err < 2e-5, (nm, err)
     from conftest import record_parity
     record_parity("train_vanilla_mlp_backward", max_rel_grad_err_vs_fp64=worst, rows=B * N)
+
+
+def test_training_mlps_reject_wrong_shapes():
+    """The training ops read rows of fixed widths through raw pointers: shape errors must surface as ValueError before the
+    launch (the reference's matmuls would raise), and an unsupported gradient as NotImplementedError."""
+    from neo360_amd import models
+    mlp = models.NeRFPPMLP(0, 10, 4, input_ch=3, num_src_views=2).to(DEV)
+    NVv, P = 2, 8
+    ok = dict(x_enc=torch.randn(NVv, P, 63, device=DEV), cond=torch.randn(NVv * P, 27, device=DEV),
+              world=torch.randn(NVv * P, 128, device=DEV), local=torch.randn(NVv * P, 512, device=DEV))
+    rgb, sig = training.nerfpp_mlp(mlp, ok["x_enc"], ok["cond"], ok["world"], ok["local"], NVv)
+    assert rgb.shape == (P, 3) and sig.shape == (P, 1)
+    for key, bad in (("x_enc", torch.randn(NVv, P, 84, device=DEV)), ("cond", torch.randn(NVv * P, 32, device=DEV)),
+                     ("world", torch.randn(P, 128, device=DEV)), ("local", torch.randn(NVv * P, 256, device=DEV))):
+        args = dict(ok)
+        args[key] = bad
+        with pytest.raises(ValueError):
+            training.nerfpp_mlp(mlp, args["x_enc"], args["cond"], args["world"], args["local"], NVv)
+    with pytest.raises(ValueError):
+        training.nerfpp_mlp(models.NeRFPPMLP(0, 10, 4, input_ch=4, num_src_views=2).to(DEV), ok["x_enc"], ok["cond"], ok["world"],
+                            ok["local"], NVv)                                      # a 4-channel MLP on 63-wide encodings
+    with torch.enable_grad():
+        cond = ok["cond"].clone().requires_grad_(True)
+        for q in mlp.parameters():
+            q.requires_grad_(True)
+        r, s = training.nerfpp_mlp(mlp, ok["x_enc"], cond, ok["world"], ok["local"], NVv)
+        with pytest.raises(NotImplementedError):
+            (r.sum() + s.sum()).backward()
+    vm = models.NeRFMLP().to(DEV)
+    with pytest.raises(ValueError):
+        training.nerf_mlp(vm, torch.randn(4, 5, 60, device=DEV), torch.randn(4, 27, device=DEV))
+    with pytest.raises(ValueError):
+        training.nerf_mlp(vm, torch.randn(4, 5, 63, device=DEV), torch.randn(5, 27, device=DEV))
+    # empty batches are no-ops, not errors
+    r, s = training.nerf_mlp(vm, torch.zeros(0, 5, 63, device=DEV), torch.zeros(0, 27, device=DEV))
+    assert r.shape == (0, 5, 3) and s.shape == (0, 5, 1)
