@@ -25,104 +25,152 @@ namespace neo {
 
 namespace {
 
-constexpr int GT = 64;        // C tile (M and N)
+constexpr int GTM = 128;      // C tile: rows of op(A)
+constexpr int GTN = 64;       //         rows of op(B)
 constexpr int GK = 32;        // K step
-constexpr int GP = GK + 4;    // LDS row pitch in floats: 16-B fragment reads of 16 consecutive rows hit 16 distinct bank groups
+constexpr int GP = GK + 4;    // pitch (floats) of a K-major LDS tile [rows][k]: 16-B fragment reads of 16 consecutive rows hit 16 distinct bank groups
+constexpr int PRA = GTM + 4;  // pitch of a row-major LDS tile [k][rows] (operands stored with the row index fastest): 4 * pitch = 16 mod 32,
+constexpr int PRB = GTN + 4;  //   so the two lane halves of a fragment read (k and k + 4) fall into different bank halves
+constexpr int AS_FLOATS = GTM * GP > GK * PRA ? GTM * GP : GK * PRA;
+constexpr int BS_FLOATS = GTN * GP > GK * PRB ? GTN * GP : GK * PRB;
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-B global access at 4-B alignment (rows of 703 floats)
 
 struct GemmEpi {
     const float* bias;        // [N] or null
     const float* mask;        // [M][ldm]: output multiplied by (mask > 0) - ReLU backward - or null
     int ldm;
-    int relu;                 // max(x, 0) after the bias
-    int accumulate;           // 0: C = result   1: C += result   2: atomicAdd (split-K partials; C zeroed by the caller)
+    int relu;                 // max(x, 0), applied AFTER the bias and after the accumulation into C
+    int accumulate;           // 0: C = result   1: C = C + result   2: atomicAdd (split-K partials; C zeroed by the caller)
     float scale;              // result multiplied by this first (1 / NV of the view means)
 };
 
+// C[M][N] (+)= op(A) . op(B)^T on 128 x 64 tiles: 4 waves of 64 (m) x 32 (n) = two accumulators sharing the n fragment.
+// Operands travel global -> registers (16-B loads along the stored-fast index, guarded element-wise at the edges) -> LDS
+// (double-buffered: the next K-step is staged into the other buffer while this one is multiplied, one barrier per step).
 template <bool AT, bool BT>
-__global__ __launch_bounds__(256) void k_sgemm(int M, int N, int K, const float* __restrict__ A, long lda,
-                                               const float* __restrict__ B, long ldb, float* __restrict__ C, long ldc,
-                                               GemmEpi ep, int k_per_split) {
-    __shared__ __attribute__((aligned(16))) float As[GT * GP];
-    __shared__ __attribute__((aligned(16))) float Bs[GT * GP];
+__global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const float* __restrict__ A, long lda,
+                                                  const float* __restrict__ B, long ldb, float* __restrict__ C, long ldc,
+                                                  GemmEpi ep, int k_per_split) {
+    __shared__ __attribute__((aligned(16))) float As[2][AS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BS_FLOATS];
     LaneCtx L;
     L.init();
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int m0 = blockIdx.y * GTM, n0 = blockIdx.x * GTN;
     const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
-    const int wm = L.wv & 1, wn = L.wv >> 1;            // this wave's 32 x 32 quadrant
-    f32x16 acc;
+    const int wm = L.wv & 1, wn = L.wv >> 1;            // this wave: rows m0 + 64 wm .. + 63, columns n0 + 32 wn .. + 31
+    f32x16 acc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    // global -> registers -> LDS, K-major tiles; 2048 elements per operand, 8 per thread, coalesced along the stored-fast
-    // index.  The NEXT K-step's elements are requested before this step's MFMAs (one stage of software pipelining).
-    float ra[8], rb[8];
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+    f32x4 ra[4], rb[2];
+    // one 16-B piece of an operand tile: T = stored with the row index fastest ([K][rows]), else K fastest ([rows][K])
+    auto piece = [&](const float* __restrict__ P, long ld, bool T, int rows0, int rows_end, int k0, int idx4, int rows_tile) -> f32x4 {
+        int r, k, dr, dk;
+        if (T) { const int q = rows_tile / 4; r = (idx4 % q) * 4; k = idx4 / q; dr = 1; dk = 0; }
+        else { r = idx4 >> 3; k = (idx4 & 7) * 4; dr = 0; dk = 1; }
+        const int gr = rows0 + r, gk = k0 + k;
+        const float* src = T ? P + (long)gk * ld + gr : P + (long)gr * ld + gk;
+        if (gr + 3 * dr < rows_end && gk + 3 * dk < kend) return *reinterpret_cast<const f4u*>(src);
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (gr + e * dr < rows_end && gk + e * dk < kend) v[e] = src[e];
+        return v;
+    };
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j;
-            int r, k;
-            if (AT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
-            const int gm = m0 + r, gk = k0 + k;
-            ra[j] = (gm < M && gk < kend) ? (AT ? A[(long)gk * lda + gm] : A[(long)gm * lda + gk]) : 0.0f;
-        }
+        for (int j = 0; j < 4; ++j) ra[j] = piece(A, lda, AT, m0, M, k0, tid + 256 * j, GTM);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j;
-            int r, k;
-            if (BT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
-            const int gn = n0 + r, gk = k0 + k;
-            rb[j] = (gn < N && gk < kend) ? (BT ? B[(long)gk * ldb + gn] : B[(long)gn * ldb + gk]) : 0.0f;
-        }
+        for (int j = 0; j < 2; ++j) rb[j] = piece(B, ldb, BT, n0, N, k0, tid + 256 * j, GTN);
     };
-    auto stage = [&]() {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j;
-            int r, k;
-            if (AT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
-            As[r * GP + k] = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int idx = tid + 256 * j;
-            int r, k;
-            if (BT) { r = idx & 63; k = idx >> 6; } else { k = idx & 31; r = idx >> 5; }
-            Bs[r * GP + k] = rb[j];
-        }
+    auto put = [&](float* tile, bool T, int idx4, int rows_tile, int pitch_t, const f32x4 v) {
+        if (T) { const int q = rows_tile / 4; *reinterpret_cast<f32x4*>(tile + (idx4 / q) * pitch_t + (idx4 % q) * 4) = v; }
+        else *reinterpret_cast<f32x4*>(tile + (idx4 >> 3) * GP + (idx4 & 7) * 4) = v;
     };
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        stage();
-        __syncthreads();
-        if (k0 + GK < kend) fetch(k0 + GK);
-        // ---- 4 chunks of 8 k: lane half h supplies k = 8 c + 4 h + e to MFMA e (both operands alike) ----
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(As[buf], AT, tid + 256 * j, GTM, PRA, ra[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) put(Bs[buf], BT, tid + 256 * j, GTN, PRB, rb[j]);
+    };
+    // fragment of 4 consecutive k (k = 8 c + 4 half + e) of one tile row
+    auto frag = [&](const float* tile, bool T, int pitch_t, int row, int c) -> f32x4 {
+        if (!T) return *reinterpret_cast<const f32x4*>(tile + row * GP + 8 * c + 4 * L.half);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[(8 * c + 4 * L.half + e) * pitch_t + row];
+        return v;
+    };
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
+        const bool more = k0 + GK < kend;
+        if (more) fetch(k0 + GK);
 #pragma unroll
         for (int c = 0; c < GK / 8; ++c) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(Bs + (wn * 32 + L.l31) * GP + 8 * c + 4 * L.half);   // D rows = n
-            const f32x4 b = *reinterpret_cast<const f32x4*>(As + (wm * 32 + L.l31) * GP + 8 * c + 4 * L.half);   // D cols = m
+            const f32x4 a = frag(Bs[buf], BT, PRB, wn * 32 + L.l31, c);                    // D rows = n
+            const f32x4 b0 = frag(As[buf], AT, PRA, wm * 64 + L.l31, c);                   // D cols = m
+            const f32x4 b1 = frag(As[buf], AT, PRA, wm * 64 + 32 + L.l31, c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = NEO_MFMA(a[e], b[e], acc);
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = NEO_MFMA(a[e], b0[e], acc[0]);
+                acc[1] = NEO_MFMA(a[e], b1[e], acc[1]);
+            }
         }
+        if (more) stage(buf ^ 1);
         __syncthreads();
     }
-    // ---- epilogue: lane = row m (l31), registers 4 g + e = columns n = 8 g + 4 half + e ----
-    const int gm = m0 + wm * 32 + L.l31;
-    if (gm >= M) return;
+    // ---- epilogue: lane = row m (l31), registers 4 g + e = columns n = 8 g + 4 half + e: 16 B per lane and g ----
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int t = 0; t < 2; ++t) {
+        const int gm = m0 + wm * 64 + 32 * t + L.l31;
+        if (gm >= M) continue;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int gn = n0 + wn * 32 + 8 * g + 4 * L.half + e;
+        for (int g = 0; g < 4; ++g) {
+            const int gn = n0 + wn * 32 + 8 * g + 4 * L.half;
             if (gn >= N) continue;
-            float v = acc[4 * g + e] * ep.scale;
-            if (ep.bias && blockIdx.z == 0) v += ep.bias[gn];
-            if (ep.relu) v = fmaxf(v, 0.0f);
-            if (ep.mask && !(ep.mask[(long)gm * ep.ldm + gn] > 0.0f)) v = 0.0f;
             float* dst = C + (long)gm * ldc + gn;
-            if (ep.accumulate == 2) atomicAdd(dst, v);
-            else if (ep.accumulate == 1) *dst += v;
-            else *dst = v;
+            const bool full = gn + 3 < N;
+            f32x4 v, old = {0.0f, 0.0f, 0.0f, 0.0f}, mk = {1.0f, 1.0f, 1.0f, 1.0f}, bs = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (full) {
+                if (ep.bias && blockIdx.z == 0) bs = *reinterpret_cast<const f4u*>(ep.bias + gn);
+                if (ep.accumulate == 1) old = *reinterpret_cast<const f4u*>(dst);
+                if (ep.mask) mk = *reinterpret_cast<const f4u*>(ep.mask + (long)gm * ep.ldm + gn);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gn + e < N) {
+                        if (ep.bias && blockIdx.z == 0) bs[e] = ep.bias[gn + e];
+                        if (ep.accumulate == 1) old[e] = dst[e];
+                        if (ep.mask) mk[e] = ep.mask[(long)gm * ep.ldm + gn + e];
+                    }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[t][4 * g + e] * ep.scale + bs[e];
+                if (ep.accumulate == 1) x = old[e] + x;
+                if (ep.relu) x = fmaxf(x, 0.0f);
+                if (!(mk[e] > 0.0f)) x = 0.0f;
+                v[e] = x;
+            }
+            if (ep.accumulate == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gn + e < N) atomicAdd(dst + e, v[e]);
+            } else if (full) {
+                *reinterpret_cast<f4u*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (gn + e < N) dst[e] = v[e];
+            }
         }
+    }
 }
 
 // out[p][c] = (1 / NV) sum_v in[v P + p][c]   (neo360/util.py:599-610 combine_interleaved 'average'), optional ReLU
@@ -169,8 +217,8 @@ void gemm(int M, int N, int K, const float* A, long lda, const float* B, long ld
     int kps = (K + splits - 1) / splits;
     kps = ((kps + GK - 1) / GK) * GK;
     const int nz = (K + kps - 1) / kps;
-    hipLaunchKernelGGL((k_sgemm<AT, BT>), dim3((N + GT - 1) / GT, (M + GT - 1) / GT, nz), dim3(256), 0, s, M, N, K, A, lda, B, ldb, C,
-                       ldc, ep, kps);
+    hipLaunchKernelGGL((k_sgemm<AT, BT>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
+                       ldb, C, ldc, ep, kps);
 }
 
 inline GemmEpi epi(const float* bias = nullptr, int relu = 0, int accumulate = 0, const float* mask = nullptr, int ldm = 0,
@@ -205,8 +253,7 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
     gemm<false, false>((int)R, 128, 128, h1, 128, w[2], 128, h2, 128, epi(b[2], 1), 1, s);
     // layer 3 on [h2 | x0] (the skip concat after layer index 2): two accumulating GEMMs, ReLU after the second
     gemm<false, false>((int)R, 128, 128, h2, 128, w[3], 128 + K0, h3, 128, epi(b[3], 0), 1, s);
-    gemm<false, false>((int)R, 128, K0, x0, K0, w[3] + 128, 128 + K0, h3, 128, epi(nullptr, 0, 1), 1, s);
-    hipLaunchKernelGGL(k_view_mean, dim3(blocks(R * 128)), dim3(256), 0, s, h3, 1, R * 128, 1, 1, h3);          // ReLU in place
+    gemm<false, false>((int)R, 128, K0, x0, K0, w[3] + 128, 128 + K0, h3, 128, epi(nullptr, 1, 1), 1, s);      // C = relu(C + ..)
     gemm<false, false>((int)R, 128, 128, h3, 128, w[6], 128, bott, 128, epi(b[6], 0), 1, s);                     // bottleneck, per view
     hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
     gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
@@ -294,8 +341,7 @@ void launch_vanilla_train_forward(const float* const* w, const float* const* b, 
     for (int i = 1; i < 8; ++i) {
         if (i == 5) {              // the skip concat after layer index 4: layer 5 reads [h4 | x0]
             gemm<false, false>(M, 256, 256, h[4], 256, w[5], 319, h[5], 256, epi(b[5], 0), 1, s);
-            gemm<false, false>(M, 256, 63, x0, 63, w[5] + 256, 319, h[5], 256, epi(nullptr, 0, 1), 1, s);
-            hipLaunchKernelGGL(k_view_mean, dim3(blocks(R * 256)), dim3(256), 0, s, h[5], 1, R * 256, 1, 1, h[5]);   // ReLU in place
+            gemm<false, false>(M, 256, 63, x0, 63, w[5] + 256, 319, h[5], 256, epi(nullptr, 1, 1), 1, s);   // C = relu(C + ..)
         } else {
             gemm<false, false>(M, 256, 256, h[i - 1], 256, w[i], 256, h[i], 256, epi(b[i], 1), 1, s);
         }
@@ -303,8 +349,7 @@ void launch_vanilla_train_forward(const float* const* w, const float* const* b, 
     gemm<false, false>(M, 1, 256, h[7], 256, w[10], 256, raw_sigma, 1, epi(b[10], 0), 1, s);
     gemm<false, false>(M, 256, 256, h[7], 256, w[9], 256, bott, 256, epi(b[9], 0), 1, s);
     gemm<false, false>(M, 128, 256, bott, 256, w[8], 283, v, 128, epi(b[8], 0), 1, s);
-    gemm<false, false>(M, 128, 27, cond, 27, w[8] + 256, 283, v, 128, epi(nullptr, 0, 1), 1, s);
-    hipLaunchKernelGGL(k_view_mean, dim3(blocks(R * 128)), dim3(256), 0, s, v, 1, R * 128, 1, 1, v);                   // ReLU in place
+    gemm<false, false>(M, 128, 27, cond, 27, w[8] + 256, 283, v, 128, epi(nullptr, 1, 1), 1, s);                   // C = relu(C + ..)
     gemm<false, false>(M, 3, 128, v, 128, w[11], 128, raw_rgb, 3, epi(b[11], 0), 1, s);
 }
 
