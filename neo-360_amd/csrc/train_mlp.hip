@@ -18,6 +18,8 @@
 //   k_view_mean / k_view_bcast / k_colsum / k_relu_mask: the few elementwise / reduction pieces in between.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "mfma_tile.h"
 
@@ -25,6 +27,9 @@ namespace neo {
 
 namespace {
 
+#ifndef NEO_SGEMM_ABLATE
+#define NEO_SGEMM_ABLATE 0     // timing experiments only (wrong results; tools/build_variant.py): 1 no MFMAs, 2 no operand loads in the pipelined loop
+#endif
 constexpr int GTM = 128;      // C tile: rows of op(A)
 constexpr int GTN = 64;       //         rows of op(B)
 constexpr int GK = 32;        // K step
@@ -102,15 +107,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
         for (int e = 0; e < 4; ++e) v[e] = tile[(8 * c + 4 * L.half + e) * pitch_t + row];
         return v;
     };
-    if (kbeg < kend) {
-        fetch(kbeg);
-        stage(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
-        const bool more = k0 + GK < kend;
-        if (more) fetch(k0 + GK);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < GK / 8; ++c) {
             const f32x4 a = frag(Bs[buf], BT, PRB, wn * 32 + L.l31, c);                    // D rows = n
@@ -118,10 +115,105 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
             const f32x4 b1 = frag(As[buf], AT, PRA, wm * 64 + 32 + L.l31, c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (NEO_SGEMM_ABLATE & 1) { acc[0][e] += a[e] * b0[e]; acc[1][e] += a[e] * b1[e]; continue; }
                 acc[0] = NEO_MFMA(a[e], b0[e], acc[0]);
                 acc[1] = NEO_MFMA(a[e], b1[e], acc[1]);
             }
         }
+    };
+    int kdone = kbeg;            // K steps [kbeg, kdone) are accumulated when the guarded loop below starts
+    // ---- interior tiles: every full K step through a branch-free pipeline, operands requested TWO steps ahead (two register
+    //      sets; a step's loads have two multiply phases to arrive from HBM), pointers advanced instead of recomputed ----
+    const int nfull = (kend - kbeg) / GK;
+    if (m0 + GTM <= M && n0 + GTN <= N && nfull >= 1) {
+        const float* pa[4];
+        const float* pb[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx4 = tid + 256 * j;
+            pa[j] = AT ? A + (long)(kbeg + idx4 / (GTM / 4)) * lda + m0 + (idx4 % (GTM / 4)) * 4
+                       : A + (long)(m0 + (idx4 >> 3)) * lda + kbeg + (idx4 & 7) * 4;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx4 = tid + 256 * j;
+            pb[j] = BT ? B + (long)(kbeg + idx4 / (GTN / 4)) * ldb + n0 + (idx4 % (GTN / 4)) * 4
+                       : B + (long)(n0 + (idx4 >> 3)) * ldb + kbeg + (idx4 & 7) * 4;
+        }
+        const long sa_step = AT ? (long)GK * lda : GK, sb_step = BT ? (long)GK * ldb : GK;
+        f32x4 qa[2][4], qb[2][2];
+        auto fetch_q = [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (!(NEO_SGEMM_ABLATE & 2)) qa[S][j] = *reinterpret_cast<const f4u*>(pa[j]); pa[j] += sa_step; }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { if (!(NEO_SGEMM_ABLATE & 2)) qb[S][j] = *reinterpret_cast<const f4u*>(pb[j]); pb[j] += sb_step; }
+        };
+        auto stage_q = [&](auto sc, int buf) {
+            constexpr int S = decltype(sc)::value;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) put(As[buf], AT, tid + 256 * j, GTM, PRA, qa[S][j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) put(Bs[buf], BT, tid + 256 * j, GTN, PRB, qb[S][j]);
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        int i = 0;
+        fetch_q(S0());
+        stage_q(S0(), 0);                                  // step 0 -> LDS buffer 0
+        if (nfull >= 5) {
+            fetch_q(S0());                                 // step 1
+            fetch_q(S1());                                 // step 2
+            __syncthreads();
+            // invariant at the top: LDS buffer 0 = step i, set 0 = step i + 1, set 1 = step i + 2 (both in flight)
+            for (; i + 4 < nfull; i += 2) {
+                compute(0);
+                stage_q(S0(), 1);                          // waits for set 0 only: set 1's loads stay in flight
+                fetch_q(S0());                             // step i + 3
+                __syncthreads();
+                compute(1);
+                stage_q(S1(), 0);
+                fetch_q(S1());                             // step i + 4
+                __syncthreads();
+            }
+        } else {
+            if (nfull >= 2) fetch_q(S0());
+            if (nfull >= 3) fetch_q(S1());
+            __syncthreads();
+        }
+        // drain: 1..4 steps left; buffer 0 = step i, set 0 = step i + 1, set 1 = step i + 2 where they exist, step i + 3 unrequested
+        const int left = nfull - i;
+        compute(0);
+        if (left >= 2) {
+            stage_q(S0(), 1);
+            if (left >= 4) fetch_q(S0());
+            __syncthreads();
+            compute(1);
+        }
+        if (left >= 3) {
+            stage_q(S1(), 0);
+            __syncthreads();
+            compute(0);
+        }
+        if (left >= 4) {
+            stage_q(S0(), 1);
+            __syncthreads();
+            compute(1);
+        }
+        __syncthreads();                                   // every wave is done with the LDS tiles before the tail step reuses them
+        kdone = kbeg + nfull * GK;
+    }
+    // ---- everything else (edge tiles, the partial last K step): guarded loads, one step ahead ----
+    if (kdone < kend) {
+        fetch(kdone);
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kdone; k0 < kend; k0 += GK, buf ^= 1) {
+        const bool more = k0 + GK < kend;
+        if (more) fetch(k0 + GK);
+        compute(buf);
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
