@@ -15,11 +15,13 @@ net = models.NeRF_TP(num_src_views=NV).to(dev)
 net.precision = PREC
 net.poll_flags = os.environ.get("POLL", "1") != "0"       # POLL=0: timing ablations produce garbage operands
 SCALE = float(os.environ.get("SCALE", 1.0))      # 0: all-zero weights and features (power / clock envelope experiments)
-net.load_state_dict({k: v * SCALE for k, v in synth.nerf_tp_state(0).items()})
+SCALE_W = float(os.environ.get("SCALE_W", SCALE))   # weights only / features only: which operands carry the power
+SCALE_F = float(os.environ.get("SCALE_F", SCALE))
+net.load_state_dict({k: v * SCALE_W for k, v in synth.nerf_tp_state(0).items()})
 H, W, focal = 480, 640, 512.0
 g = torch.Generator(device=dev); g.manual_seed(0)
-planes = [torch.randn(NV, 128, 120, 160, device=dev, generator=g) * (0.1 * SCALE) for _ in range(3)]
-latent = torch.randn(NV, 512, 240, 320, device=dev, generator=g) * (0.1 * SCALE)
+planes = [torch.randn(NV, 128, 120, 160, device=dev, generator=g) * (0.1 * SCALE_F) for _ in range(3)]
+latent = torch.randn(NV, 512, 240, 320, device=dev, generator=g) * (0.1 * SCALE_F)
 net.set_scene(planes[0], planes[1], planes[2], latent, (float(W), float(H)))
 c2w = synth.look_at_origin(40.0)
 ro, vd, rd, _ = ops.get_ray_directions_and_rays(H, W, focal, c2w)

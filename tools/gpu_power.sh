@@ -1,6 +1,6 @@
 # power / clock envelope of the split-fp16 kernels: same instruction stream with random and with all-zero operands
 # usage: gpu_power.sh vanilla|neo360
-mkdir -p gpurun_out/r02l; L=gpurun_out/r02l/power_$1.log; : > $L
+D=${POWER_OUT:-gpurun_out/r02l}; mkdir -p $D; L=$D/power_$1.log; : > $L
 rocm-smi --showmaxpower 2>/dev/null | grep -i "max" >> $L
 sample() { for i in $(seq 8); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Current Socket Graphics Package Power" | tr -s ' \t' ' ' | tr '\n' ' '; echo; sleep 0.5; done; }
 for mode in random zero; do
