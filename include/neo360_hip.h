@@ -265,23 +265,27 @@ int neo_distloss(neo_ctx* ctx, const float* w, const float* m, int R, int N, flo
                  float* grad_w, void* stream);
 
 /* NeRFPPMLP for TRAINING (the module the reference's training step differentiates, neo360/model.py:110-158 under
- * :697-820) on materialised rows, as the reference forms them: x0 (NV*P, 21 input_ch + 640) = [pos_enc | local 512 |
- * world 128] and cond (NV*P, 27) = view-direction encodings, view-major rows (row = v P + p).  w / b [host]: nine DEVICE
+ * :697-820) on the rows the reference forms: [pos_enc | local 512 | world 128] per point-view, given as the three dense
+ * tensors they are concatenated from (x_enc (NV*P, 21 input_ch), local_feat (NV*P, 512), world_feat (NV*P, 128): the
+ * concatenation, 3.3 GB for a reference chunk level, is never materialised), and cond (NV*P, 27) = view-direction
+ * encodings; view-major rows (row = v P + p).  w / b [host]: nine DEVICE
  * pointers each, order and nn.Linear (out, in) layout of neo_tp_upload_mlp (pts_linears.0..3, views_linear.0, .1,
  * bottleneck, density, rgb).  forward: raw_rgb (P,3), raw_sigma (P,1) (pre-activation, as the module returns them); the
  * activations the backward needs are written to `tape`, a CALLER-owned device buffer of neo_tp_mlp_train_tape_floats(NV, P)
  * floats (a training step runs the four MLPs of both levels forward before the first backward: one tape per call).
- * backward (with the tape, x0, cond and weights of that forward; g_* = upstream gradients):
+ * backward (with the tape, inputs, cond and weights of that forward; g_* = upstream gradients):
  * gw / gb [host]: nine device pointers each to gradient buffers of the weights' / biases' shapes, ZEROED by the caller
- * (partial sums are accumulated atomically); g_x0 (NV*P, K0) = gradient of the input rows (overwritten; may be NULL) -
- * its local / world columns feed neo_tp_gather_backward.  Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32).  At most
+ * (partial sums are accumulated atomically); g_x_enc / g_local / g_world = gradients of the three input tensors
+ * (overwritten; each may be NULL) - the latter two feed neo_tp_gather_backward.  Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32).  At most
  * 4.19 M rows per call. */
 long neo_tp_mlp_train_tape_floats(int NV, long P);
-int neo_tp_mlp_train_forward(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x0,
-                             const float* cond, int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, void* stream);
-int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w, const float* x0, const float* cond, int NV,
-                              long P, const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
-                              float* const* gb, float* g_x0, void* stream);
+int neo_tp_mlp_train_forward(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x_enc,
+                             const float* local_feat, const float* world_feat, const float* cond, int NV, long P, float* tape,
+                             float* raw_rgb, float* raw_sigma, void* stream);
+int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w, const float* x_enc, const float* local_feat,
+                              const float* world_feat, const float* cond, int NV, long P, const float* tape,
+                              const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc,
+                              float* g_local, float* g_world, void* stream);
 
 /* The vanilla NeRFMLP for training (vanilla_nerf/model.py:100-125 under the training step :255-283), same contract:
  * x0 (R, 63) encoded points, cond (R, 27) = each row's view-direction encoding (the ray's, tiled over its samples);

@@ -2,6 +2,7 @@
 // backward of the compositing, stand-alone feature lookups with their backward, the distortion loss, and the
 // training-mode forward of NeRF_TP (out_depth=False tuple, randomized sampling, white background honoured).
 #include "ctx.h"
+#include "train_kernels.h"
 
 using namespace neo_host;
 
@@ -217,33 +218,36 @@ int neo_tp_render_train(neo_ctx* ctx, const float* rays_o, const float* rays_d, 
 
 long neo_tp_mlp_train_tape_floats(int NV, long P) { return NV >= 1 && P >= 0 ? (long)neo::tp_train_tape_floats(NV, P) : 0; }
 
-int neo_tp_mlp_train_forward(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x0,
-                             const float* cond, int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, void* stream) {
+int neo_tp_mlp_train_forward(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x_enc,
+                             const float* local_feat, const float* world_feat, const float* cond, int NV, long P, float* tape,
+                             float* raw_rgb, float* raw_sigma, void* stream) {
     ENTER(ctx);
     REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (inside the sphere) or 4 (outside)");
     REQUIRE(NV >= 1 && P >= 0, "bad shape");
     if (P == 0) return NEO_OK;
     REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
-    REQUIRE(w && b && x0 && cond && tape && raw_rgb && raw_sigma, "null pointer");
+    REQUIRE(w && b && x_enc && local_feat && world_feat && cond && tape && raw_rgb && raw_sigma, "null pointer");
     for (int i = 0; i < 9; ++i) REQUIRE(w[i] && b[i], "null weight / bias pointer");
-    neo::launch_tp_train_forward(input_ch * 21, w, b, x0, cond, NV, P, tape, raw_rgb, raw_sigma,
+    neo::launch_tp_train_forward(input_ch * 21, w, b, x_enc, local_feat, world_feat, cond, NV, P, tape, raw_rgb, raw_sigma,
                                  static_cast<hipStream_t>(stream));
     return check_launch();
 }
 
-int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w, const float* x0, const float* cond, int NV,
-                              long P, const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
-                              float* const* gb, float* g_x0, void* stream) {
+int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w, const float* x_enc, const float* local_feat,
+                              const float* world_feat, const float* cond, int NV, long P, const float* tape,
+                              const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc,
+                              float* g_local, float* g_world, void* stream) {
     ENTER(ctx);
     REQUIRE(NV >= 1 && P >= 0, "bad shape");
     if (P == 0) return NEO_OK;
     REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (inside the sphere) or 4 (outside)");
     REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
-    REQUIRE(w && x0 && cond && tape && g_rgb && g_sigma && gw && gb, "null pointer");
+    REQUIRE(w && x_enc && local_feat && world_feat && cond && tape && g_rgb && g_sigma && gw && gb, "null pointer");
     for (int i = 0; i < 9; ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
     if (ctx->train_scratch.reserve(neo::tp_train_scratch_floats(NV, P) * sizeof(float))) return NEO_ERR_NOMEM;
-    neo::launch_tp_train_backward(input_ch * 21, w, x0, cond, NV, P, tape, ctx->train_scratch.as<float>(),
-                                  g_rgb, g_sigma, gw, gb, g_x0, static_cast<hipStream_t>(stream));
+    neo::launch_tp_train_backward(input_ch * 21, w, x_enc, local_feat, world_feat, cond, NV, P, tape,
+                                  ctx->train_scratch.as<float>(), g_rgb, g_sigma, gw, gb, g_x_enc, g_local, g_world,
+                                  static_cast<hipStream_t>(stream));
     return check_launch();
 }
 

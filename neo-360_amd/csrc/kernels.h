@@ -179,22 +179,7 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
                       const float* far, int R, int N, int chunk, uint32_t* flags, float* out, const float* dirsum,
                       hipStream_t s);
 
-// train_mlp.hip — NeRFPPMLP forward-with-tape + backward on materialised rows (exact fp32 MFMA GEMMs)
-size_t tp_train_tape_floats(int NV, long P);
-size_t tp_train_scratch_floats(int NV, long P);
-void launch_tp_train_forward(int pe, const float* const* w, const float* const* b, const float* x0, const float* cond, int NV,
-                             long P, float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s);
-void launch_tp_train_backward(int pe, const float* const* w, const float* x0, const float* cond, int NV, long P,
-                              const float* tape, float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw,
-                              float* const* gb, float* g_x0, hipStream_t s);
-
-size_t vanilla_train_tape_floats(long R);
-size_t vanilla_train_scratch_floats(long R);
-void launch_vanilla_train_forward(const float* const* w, const float* const* b, const float* x0, const float* cond, long R,
-                                  float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s);
-void launch_vanilla_train_backward(const float* const* w, const float* x0, const float* cond, long R, const float* tape,
-                                   float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
-                                   float* g_x0, float* g_cond, hipStream_t s);
+// (train_mlp.hip's launchers are declared in train_kernels.h)
 
 // mlp_pix_h.hip — PixelNeRF baseline decoder evaluator (split-fp16 arithmetic only)
 size_t pix_wpack_h_bytes();

@@ -1,0 +1,33 @@
+// Launchers of train_mlp.hip: the training-side MLPs (forward that keeps the activations + backward) on exact fp32 MFMA GEMMs.
+// Kept apart from kernels.h so that work on the training path leaves the evaluators' sources (and the hash bench.py stamps the
+// counter profiles with) untouched.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace neo {
+
+// NeRFPPMLP (neo360/model.py:110-158): rows R = NV * P view-major; the input rows are the three tensors x_enc (R, pe),
+// local (R, 512), world (R, 128) - never concatenated; cond (R, 27).  w / b order as neo_tp_upload_mlp.
+size_t tp_train_tape_floats(int NV, long P);
+size_t tp_train_scratch_floats(int NV, long P);
+void launch_tp_train_forward(int pe, const float* const* w, const float* const* b, const float* x_enc, const float* local,
+                             const float* world, const float* cond, int NV, long P, float* tape, float* raw_rgb,
+                             float* raw_sigma, hipStream_t s);
+void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc, const float* local, const float* world,
+                              const float* cond, int NV, long P, const float* tape, float* scratch, const float* g_rgb,
+                              const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc, float* g_local,
+                              float* g_world, hipStream_t s);
+
+// vanilla NeRFMLP (vanilla_nerf/model.py:100-125): rows R = rays x samples; x0 (R, 63), cond (R, 27).  w / b order as
+// neo_vanilla_upload_mlp.
+size_t vanilla_train_tape_floats(long R);
+size_t vanilla_train_scratch_floats(long R);
+void launch_vanilla_train_forward(const float* const* w, const float* const* b, const float* x0, const float* cond, long R,
+                                  float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s);
+void launch_vanilla_train_backward(const float* const* w, const float* x0, const float* cond, long R, const float* tape,
+                                   float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
+                                   float* g_x0, float* g_cond, hipStream_t s);
+
+}  // namespace neo

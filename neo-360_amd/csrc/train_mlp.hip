@@ -22,6 +22,7 @@
 
 #include "kernels.h"
 #include "mfma_tile.h"
+#include "train_kernels.h"
 
 namespace neo {
 
@@ -50,20 +51,34 @@ struct GemmEpi {
     float scale;              // result multiplied by this first (1 / NV of the view means)
 };
 
+// Up to four A operands whose K ranges are concatenated ([h2 | x_enc | local | world] of the NeRFPPMLP skip layer without
+// materialising the concatenation): n = 0 -> the plain (A, lda, K) of the launch; else segment i covers the next k[i]
+// columns of the reduction index, B advancing along its K axis.  Split-K is not combined with segments.
+struct GemmSegs {
+    const float* a[4];
+    long lda[4];
+    int k[4];
+    int n;
+};
+
 // C[M][N] (+)= op(A) . op(B)^T on 128 x 64 tiles: 4 waves of 64 (m) x 32 (n) = two accumulators sharing the n fragment.
 // Operands travel global -> registers (16-B loads along the stored-fast index, guarded element-wise at the edges) -> LDS
 // (double-buffered: the next K-step is staged into the other buffer while this one is multiplied, one barrier per step).
 template <bool AT, bool BT>
-__global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const float* __restrict__ A, long lda,
-                                                  const float* __restrict__ B, long ldb, float* __restrict__ C, long ldc,
-                                                  GemmEpi ep, int k_per_split) {
+__global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const float* __restrict__ A_in, long lda_in,
+                                                  const float* __restrict__ B_in, long ldb, float* __restrict__ C, long ldc,
+                                                  GemmEpi ep, int k_per_split, GemmSegs sg) {
     __shared__ __attribute__((aligned(16))) float As[2][AS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[2][BS_FLOATS];
     LaneCtx L;
     L.init();
     const int tid = threadIdx.x;
     const int m0 = blockIdx.y * GTM, n0 = blockIdx.x * GTN;
-    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    // the operand range being accumulated (one per segment)
+    const float* A = A_in;
+    const float* B = B_in;
+    long lda = lda_in;
+    int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
     const int wm = L.wv & 1, wn = L.wv >> 1;            // this wave: rows m0 + 64 wm .. + 63, columns n0 + 32 wn .. + 31
     f32x16 acc[2];
 #pragma unroll
@@ -121,6 +136,17 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
             }
         }
     };
+    const int nseg = sg.n > 0 ? sg.n : 1;
+    int koff = 0;
+    for (int si = 0; si < nseg; ++si) {
+    if (sg.n > 0) {
+        A = sg.a[si];
+        lda = sg.lda[si];
+        B = BT ? B_in + (long)koff * ldb : B_in + koff;
+        kbeg = 0;
+        kend = sg.k[si];
+        koff += sg.k[si];
+    }
     int kdone = kbeg;            // K steps [kbeg, kdone) are accumulated when the guarded loop below starts
     // ---- interior tiles: every full K step through a branch-free pipeline, operands requested TWO steps ahead (two register
     //      sets; a step's loads have two multiply phases to arrive from HBM), pointers advanced instead of recomputed ----
@@ -217,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
         if (more) stage(buf ^ 1);
         __syncthreads();
     }
+    }   // segments
     // ---- epilogue: lane = row m (l31), registers 4 g + e = columns n = 8 g + 4 half + e: 16 B per lane and g ----
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -310,7 +337,19 @@ void gemm(int M, int N, int K, const float* A, long lda, const float* B, long ld
     kps = ((kps + GK - 1) / GK) * GK;
     const int nz = (K + kps - 1) / kps;
     hipLaunchKernelGGL((k_sgemm<AT, BT>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
-                       ldb, C, ldc, ep, kps);
+                       ldb, C, ldc, ep, kps, GemmSegs{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0});
+}
+
+// C[M][N] = [A0 | A1 | ..][M][K0 + K1 + ..] . B[N][K0 + K1 + ..]^T  (B = a weight matrix (out, in), K fastest; dense segments)
+struct Seg { const float* a; int k; };
+void gemm_cat(int M, int N, const Seg* segs, int nseg, const float* B, long ldb, float* C, long ldc, const GemmEpi& ep,
+              hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    GemmSegs sg{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, {0, 0, 0, 0}, nseg};
+    int K = 0;
+    for (int i = 0; i < nseg; ++i) { sg.a[i] = segs[i].a; sg.lda[i] = segs[i].k; sg.k[i] = segs[i].k; K += segs[i].k; }
+    hipLaunchKernelGGL((k_sgemm<false, false>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, 1), dim3(256), 0, s, M, N, K,
+                       segs[0].a, (long)segs[0].k, B, ldb, C, ldc, ep, K, sg);
 }
 
 inline GemmEpi epi(const float* bias = nullptr, int relu = 0, int accumulate = 0, const float* mask = nullptr, int ldm = 0,
@@ -334,18 +373,22 @@ size_t tp_train_scratch_floats(int NV, long P) {
 }
 
 // w / b order as neo_tp_upload_mlp: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
-void launch_tp_train_forward(int pe, const float* const* w, const float* const* b, const float* x0, const float* cond, int NV,
-                             long P, float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s) {
+// the input rows [x_enc (pe) | local (512) | world (128)] are never concatenated: the two layers that read them take the three
+// tensors as segments of one reduction (gemm_cat)
+void launch_tp_train_forward(int pe, const float* const* w, const float* const* b, const float* x_enc, const float* local,
+                             const float* world, const float* cond, int NV, long P, float* tape, float* raw_rgb,
+                             float* raw_sigma, hipStream_t s) {
     const long R = (long)NV * P;
     const int K0 = pe + 640;
     float* h0 = tape; float* h1 = h0 + R * 128; float* h2 = h1 + R * 128; float* h3 = h2 + R * 128;
     float* bott = h3 + R * 128; float* y0 = bott + R * 128; float* hm = y0 + R * 64; float* ym = hm + P * 128; float* y1 = ym + P * 64;
-    gemm<false, false>((int)R, 128, K0, x0, K0, w[0], K0, h0, 128, epi(b[0], 1), 1, s);
+    const Seg in0[3] = {{x_enc, pe}, {local, 512}, {world, 128}};
+    gemm_cat((int)R, 128, in0, 3, w[0], K0, h0, 128, epi(b[0], 1), s);
     gemm<false, false>((int)R, 128, 128, h0, 128, w[1], 128, h1, 128, epi(b[1], 1), 1, s);
     gemm<false, false>((int)R, 128, 128, h1, 128, w[2], 128, h2, 128, epi(b[2], 1), 1, s);
-    // layer 3 on [h2 | x0] (the skip concat after layer index 2): two accumulating GEMMs, ReLU after the second
-    gemm<false, false>((int)R, 128, 128, h2, 128, w[3], 128 + K0, h3, 128, epi(b[3], 0), 1, s);
-    gemm<false, false>((int)R, 128, K0, x0, K0, w[3] + 128, 128 + K0, h3, 128, epi(nullptr, 1, 1), 1, s);      // C = relu(C + ..)
+    // layer 3 on [h2 | x_enc | local | world] (the skip concat after layer index 2): one reduction over four segments
+    const Seg in3[4] = {{h2, 128}, {x_enc, pe}, {local, 512}, {world, 128}};
+    gemm_cat((int)R, 128, in3, 4, w[3], 128 + K0, h3, 128, epi(b[3], 1), s);
     gemm<false, false>((int)R, 128, 128, h3, 128, w[6], 128, bott, 128, epi(b[6], 0), 1, s);                     // bottleneck, per view
     hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
     gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
@@ -357,10 +400,12 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
     gemm<false, false>((int)P, 3, 64, y1, 64, w[8], 64, raw_rgb, 3, epi(b[8], 0), 1, s);
 }
 
-// gw / gb: nine weight / bias gradients, ZEROED by the caller (split-K partials are accumulated atomically); g_x0 may be null
-void launch_tp_train_backward(int pe, const float* const* w, const float* x0, const float* cond, int NV, long P,
-                              const float* tape, float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw,
-                              float* const* gb, float* g_x0, hipStream_t s) {
+// gw / gb: nine weight / bias gradients, ZEROED by the caller (split-K partials are accumulated atomically); each of the
+// three input gradients (R x pe, R x 512, R x 128) may be null
+void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc, const float* local, const float* world,
+                              const float* cond, int NV, long P, const float* tape, float* scratch, const float* g_rgb,
+                              const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc, float* g_local,
+                              float* g_world, hipStream_t s) {
     const long R = (long)NV * P;
     const int K0 = pe + 640;
     const float* h0 = tape; const float* h1 = h0 + R * 128; const float* h2 = h1 + R * 128; const float* h3 = h2 + R * 128;
@@ -370,6 +415,9 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x0, co
     float* ga = scratch; float* gb2 = ga + R * 128; float* gy0 = gb2 + R * 128;                 // R-sized
     float* g_hm = gy0 + R * 64; float* g_y1 = g_hm + P * 128; float* g_ym = g_y1 + P * 64;       // P-sized
     const int SP = (int)((P + 8191) / 8192), SR = (int)((R + 8191) / 8192);                     // split-K of the weight gradients
+    const float* in[3] = {x_enc, local, world};
+    float* g_in[3] = {g_x_enc, g_local, g_world};
+    const int kin[3] = {pe, 512, 128}, off[3] = {0, pe, pe + 512};
     // rgb head
     gemm<true, true>(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, epi(nullptr, 0, 2), SP, s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_rgb, P, 3, gb[8]);
@@ -396,9 +444,11 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x0, co
     hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, h3, R * 128);                   // g_z3
     // layer 3 on [h2 | x0]
     gemm<true, true>(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, epi(nullptr, 0, 2), SR, s);
-    gemm<true, true>(128, K0, (int)R, gb2, 128, x0, K0, gw[3] + 128, 128 + K0, epi(nullptr, 0, 2), SR, s);
+    for (int i = 0; i < 3; ++i) {
+        gemm<true, true>(128, kin[i], (int)R, gb2, 128, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, epi(nullptr, 0, 2), SR, s);
+        if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, gb2, 128, w[3] + 128 + off[i], 128 + K0, g_in[i], kin[i], epi(), 1, s);
+    }
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[3]);
-    if (g_x0) gemm<false, true>((int)R, K0, 128, gb2, 128, w[3] + 128, 128 + K0, g_x0, K0, epi(), 1, s);
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[3], 128 + K0, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);    // g_z2 = (g_z3 W3a) relu'(h2)
     // layer 2
     gemm<true, true>(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, epi(nullptr, 0, 2), SR, s);
@@ -409,9 +459,11 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x0, co
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[1]);
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, ga, 128, epi(nullptr, 0, 0, h0, 128), 1, s);         // g_z0
     // layer 0
-    gemm<true, true>(128, K0, (int)R, ga, 128, x0, K0, gw[0], K0, epi(nullptr, 0, 2), SR, s);
+    for (int i = 0; i < 3; ++i) {
+        gemm<true, true>(128, kin[i], (int)R, ga, 128, in[i], kin[i], gw[0] + off[i], K0, epi(nullptr, 0, 2), SR, s);
+        if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, ga, 128, w[0] + off[i], K0, g_in[i], kin[i], epi(nullptr, 0, 1), 1, s);
+    }
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[0]);
-    if (g_x0) gemm<false, true>((int)R, K0, 128, ga, 128, w[0], K0, g_x0, K0, epi(nullptr, 0, 1), 1, s);
 }
 
 // ---- vanilla NeRFMLP (vanilla_nerf/model.py:100-125) ---------------------------------------------------------------------

@@ -193,46 +193,46 @@ class _TrainMLP(torch.autograd.Function):
             if tuple(w.shape) != want[i] or tuple(b.shape) != (want[i][0],):
                 raise ValueError("NeRFPPMLP layer %d: weight %s / bias %s, expected %s / (%d,)"
                                  % (i, tuple(w.shape), tuple(b.shape), want[i], want[i][0]))
-        x0 = torch.cat([f32(x_enc, "x_enc").reshape(-1, x_enc.shape[-1]), f32(local_feat, "local_feat"),
-                        f32(world_feat, "world_feat")], dim=-1).contiguous()
+        # the three input tensors go to the library as they are: the (NV*P, 703) concatenation the reference forms is never built
+        xe = f32(x_enc, "x_enc").reshape(-1, pe)
+        lf, wf = f32(local_feat, "local_feat"), f32(world_feat, "world_feat")
         cond = f32(cond_rows, "cond_rows")
-        c = _ctx(x0, lib_ctx)
+        c = _ctx(xe, lib_ctx)
         wd = [f32(w.detach(), "weight") for w in ws]
         bd = [f32(b.detach(), "bias") for b in bs]
         tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        raw_rgb = torch.empty(npts, 3, device=x0.device)
-        raw_sigma = torch.empty(npts, 1, device=x0.device)
+        raw_rgb = torch.empty(npts, 3, device=xe.device)
+        raw_sigma = torch.empty(npts, 1, device=xe.device)
         # the activations live in a tensor owned by THIS autograd node: a training step runs several MLP forwards
         # (inside / outside the sphere, coarse / fine) before the first backward
-        tape = torch.empty(c.lib.neo_tp_mlp_train_tape_floats(nv, npts), device=x0.device)
-        _lib.check(c.lib.neo_tp_mlp_train_forward(c.handle, input_ch, tab(wd), tab(bd), ptr(x0), ptr(cond), nv, npts,
-                                                  ptr(tape), ptr(raw_rgb), ptr(raw_sigma), c.stream()))
-        ctx_.save_for_backward(x0, cond, tape, *wd)
+        tape = torch.empty(c.lib.neo_tp_mlp_train_tape_floats(nv, npts), device=xe.device)
+        _lib.check(c.lib.neo_tp_mlp_train_forward(c.handle, input_ch, tab(wd), tab(bd), ptr(xe), ptr(lf), ptr(wf), ptr(cond), nv,
+                                                  npts, ptr(tape), ptr(raw_rgb), ptr(raw_sigma), c.stream()))
+        ctx_.save_for_backward(xe, lf, wf, cond, tape, *wd)
         ctx_.meta = (c, input_ch, nv, npts, x_enc.shape, [tuple(w.shape) for w in ws], [tuple(b.shape) for b in bs])
         return raw_rgb, raw_sigma
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx_, g_rgb, g_sigma):
-        x0, cond, tape, *wd = ctx_.saved_tensors
+        xe, lf, wf, cond, tape, *wd = ctx_.saved_tensors
         c, input_ch, nv, npts, xshape, wshapes, bshapes = ctx_.meta
         if ctx_.needs_input_grad[4]:
             raise NotImplementedError("nerfpp_mlp: no gradient for cond_rows (the reference's view directions are data)")
-        dev = x0.device
+        dev = xe.device
         g_rgb = f32(g_rgb.contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(npts, 3, device=dev)
         g_sigma = f32(g_sigma.contiguous(), "g_sigma") if g_sigma is not None else torch.zeros(npts, 1, device=dev)
         gw = [torch.zeros(s, device=dev) for s in wshapes]
         gb = [torch.zeros(s, device=dev) for s in bshapes]
-        need_x = any(ctx_.needs_input_grad[3:7])
-        g_x0 = torch.empty_like(x0) if need_x else None
+        # only the input gradients somebody asked for are computed (each its own dense tensor, no slicing afterwards)
+        gx = torch.empty_like(xe) if ctx_.needs_input_grad[3] else None
+        gworld = torch.empty_like(wf) if ctx_.needs_input_grad[5] else None
+        glocal = torch.empty_like(lf) if ctx_.needs_input_grad[6] else None
         tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-        _lib.check(c.lib.neo_tp_mlp_train_backward(c.handle, input_ch, tab(wd), ptr(x0), ptr(cond), nv, npts, ptr(tape),
-                                                   ptr(g_rgb), ptr(g_sigma), tab(gw), tab(gb), ptr(g_x0), c.stream()))
-        pe = input_ch * 21
-        gx = g_x0[:, :pe].reshape(xshape) if need_x and ctx_.needs_input_grad[3] else None
-        gworld = g_x0[:, pe + 512:] if need_x and ctx_.needs_input_grad[5] else None
-        glocal = g_x0[:, pe:pe + 512] if need_x and ctx_.needs_input_grad[6] else None
-        return (None, None, None, gx, None, gworld, glocal, *gw, *gb)
+        _lib.check(c.lib.neo_tp_mlp_train_backward(c.handle, input_ch, tab(wd), ptr(xe), ptr(lf), ptr(wf), ptr(cond), nv, npts,
+                                                   ptr(tape), ptr(g_rgb), ptr(g_sigma), tab(gw), tab(gb), ptr(gx), ptr(glocal),
+                                                   ptr(gworld), c.stream()))
+        return (None, None, None, gx.reshape(xshape) if gx is not None else None, None, gworld, glocal, *gw, *gb)
 
 
 def nerfpp_mlp(mlp, x_enc, cond_rows, world_feat, local_feat, nv, ctx=None):
