@@ -33,6 +33,7 @@ CHUNK = 1024
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA (= fp32 vector peak)
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
 PEAK_HBM_BYTES = 8.0e12               # MI355X_MICROARCH.md: HBM3E spec peak
+PEAK_CLOCK_MHZ = 2400.0               # the clock the MFMA peaks above are quoted at (256 CUs x 2.4 GHz)
 # torch threads of the CPU leg = the fastest setting of a sweep on the GPU box's host (2 x EPYC 9575F, 128 physical cores):
 # NeO-360 is fastest on 8 threads (26.5 rays/s; 16: 21.5, 32: 8.4, 64: 6.3, 128: 2.5 - profiles/r03_cpu_threads_neo360.log:
 # the gathers are memory-bound and the container's threads migrate), the dense vanilla / mip360 MLPs on 32
@@ -202,6 +203,8 @@ def cpu_baseline(workload, state, scene, rays_cpu, extra, kw, n):
             break
     dt = statistics.median(times)
     base = dict(value=n / dt, unit="rays/s", cores=physical_cores(), threads=torch.get_num_threads(), kind="port",
+                threads_choice="best-of-sweep (fastest torch thread count of a sweep on this host type: profiles/r03_cpu_threads_neo360.log, "
+                               "profiles/cpu_threads_r01.log; all 128 cores are 10x slower on the gather-bound NeO-360 oracle)",
                 sample="first %d rays of the same 640x480 frame as %s, same weights / features, "
                        "torch fp32 CPU oracle (validated equal to the reference: tests/golden, tests/test_oracle_fullsize.py, "
                        "tests/test_oracle_vs_reference.py) on %d of the host's %d physical cores (%d logical); median of %d "
@@ -298,10 +301,10 @@ class Runner:
 
     def step(self):
         return self.render.render_frame_sharded(self.net, self.shard_rays(), self.world, self.rank, chunk=CHUNK,
-                                                n_rays=self.R, **self.kw)
+                                                n_rays=self.R, always_gather=self.dist is not None, **self.kw)
 
     def fence(self):
-        if self.world > 1:
+        if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize()
 
@@ -310,14 +313,19 @@ class Runner:
             self.step()
         self.fence()
         self.ctx.set_timing(True)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            frame = self.step()
-        self.fence()
-        dt = time.perf_counter() - t0
+        # socket power / shader clock sampled from a thread of this process during the timed steps (neo360_amd.telemetry):
+        # the split kernels run at the power limit, so the sustained clock belongs next to every throughput number
+        from neo360_amd import telemetry
+        with telemetry.Sampler(self.dev.index or 0) as tel:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                frame = self.step()
+            self.fence()
+            dt = time.perf_counter() - t0
+        self.telemetry = tel.summary()
         kern = self.ctx.read_timing()
         self.ctx.set_timing(False)
-        if self.world > 1:
+        if self.dist is not None:
             tmax = torch.tensor([dt], device=self.dev, dtype=torch.float64)
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -341,6 +349,13 @@ class Runner:
                 "hbm_frac": (traffic / (avg_ms * 1e-3) / PEAK_HBM_BYTES) if traffic and avg_ms > 0 else None,
                 "mfma_busy": pmc.get("mfma_busy_frac"), "pmc_source": pmc.get("source"), "pmc_stale": pmc.get("stale"),
                 "kernel_source_sha16": kernel_source_hash(self.workload)}
+        tel = getattr(self, "telemetry", None) or {}
+        roof.update({k: tel.get(k) for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_w_max", "power_limit_w",
+                                             "telemetry_samples", "telemetry")})
+        if tel.get("sclk_mhz_mean"):
+            # the peak is quoted at the 2.4 GHz boost clock; at the clock this run sustained the same pipe peaks lower
+            roof["peak_at_measured_clock"] = peak * tel["sclk_mhz_mean"] / PEAK_CLOCK_MHZ
+            roof["frac_at_measured_clock"] = achieved / roof["peak_at_measured_clock"]
         if self.split:
             # every algorithmic multiply costs three fp16 products: the ceiling for ALGORITHMIC flops on this arithmetic
             roof["frac_of_split_ceiling"] = achieved / (PEAK_F16_MFMA_TFLOPS / 3.0)
@@ -393,7 +408,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)
     dist = None
-    if world > 1:
+    # one process per GPU over RCCL; a launch under torch.distributed.run with ONE rank (RANK set, world 1) initialises the
+    # process group as well, so the collective path of the N-GPU job (barrier, max-reduce, tile all-gather) also runs on a
+    # one-GPU box (tools/gpu_r04*.sh keeps that line in profiles/); plain `python bench.py` stays collective-free
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -478,8 +496,10 @@ def main():
                 r2.net.close()
                 del r2, f2
                 torch.cuda.empty_cache()
+        if dist is not None:
+            out["config"]["collective"] = "RCCL process group of %d rank%s (barrier, max-reduce of the step time, all_gather_into_tensor of the tiles)" % (world, "" if world == 1 else "s")
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

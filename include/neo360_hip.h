@@ -62,6 +62,11 @@ int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream);
 int neo_ctx_post_flags(neo_ctx* ctx, void* stream);
 int neo_ctx_take_flags(neo_ctx* ctx, int wait, void* stream, uint32_t* flags, int* pending);
 int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits);
+/* One context may be driven from several streams: its scratch (workspaces, per-launch tables, projected maps) is shared,
+ * so every rendering / evaluator / backward call on a stream other than the previous call's first waits - on the
+ * device, hipStreamWaitEvent, never on the host - for an event recorded behind that previous call.  stream_waits:
+ * how many such cross-stream waits this context has inserted (0 for the usual one-stream caller). */
+int neo_ctx_stream_waits(neo_ctx* ctx, uint64_t* cross_stream_waits);
 
 /* Arithmetic of the per-point MLP GEMMs of every renderer (vanilla, NeRF_TP, Mip-NeRF 360, PixelNeRF).
  * 1 (the context default, and the default of the Python modules, "f16x3"): fp16 MFMA with every fp32

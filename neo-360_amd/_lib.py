@@ -40,6 +40,7 @@ SIGNATURES = {
     "neo_ctx_post_flags": (_i, [_vp, _vp]),
     "neo_ctx_take_flags": (_i, [_vp, _i, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_i)]),
     "neo_ctx_sync_count": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "neo_ctx_stream_waits": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "neo_ctx_set_precision": (_i, [_vp, _i]),
     "neo_linspace_host": (None, [_f, _f, _i, c_float_p]),
     "neo_raygen": (_i, [_vp, _i, _i, _f, c_float_p, _vp, _vp, _vp, _vp, _vp]),
@@ -102,6 +103,11 @@ _lib = None
 
 class NeoError(RuntimeError):
     pass
+
+
+class NeoRangeError(NeoError):
+    """The range guard of the split-fp16 arithmetic tripped (device flag bit 1): the results of that call are invalid.
+    render.render_rays_test catches exactly this and re-renders the frame on the exact fp32 kernels."""
 
 
 def load():

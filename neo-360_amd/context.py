@@ -89,6 +89,12 @@ class Context:
         _lib.check(self.lib.neo_ctx_sync_count(self.handle, ctypes.byref(n)))
         return n.value
 
+    def stream_waits(self):
+        """Cross-stream ordering waits this context has inserted (calls arriving on a stream other than the previous call's)."""
+        n = ctypes.c_uint64(0)
+        _lib.check(self.lib.neo_ctx_stream_waits(self.handle, ctypes.byref(n)))
+        return n.value
+
     def set_precision(self, mode):
         """'f32' (exact fp32 MFMA) or 'f16x3' (fp16 MFMA, hi/lo-split operands, fp32-equivalent)."""
         code = {"f32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]

@@ -85,6 +85,20 @@ const float* neo_ctx::get_edges(int n, float near, float far, hipStream_t s) {
     return buf.as<float>();
 }
 
+int neo_ctx::order_begin(hipStream_t s) {
+    if (order_valid && s != order_stream) {
+        if (hipStreamWaitEvent(s, order_ev, 0) != hipSuccess) return neo_host::fail(NEO_ERR_HIP, "hipStreamWaitEvent failed");
+        order_waits += 1;
+    }
+    return NEO_OK;
+}
+void neo_ctx::order_end(hipStream_t s) {
+    if (!order_ev && hipEventCreateWithFlags(&order_ev, hipEventDisableTiming) != hipSuccess) { order_ev = nullptr; return; }
+    if (hipEventRecord(order_ev, s) == hipSuccess) { order_stream = s; order_valid = true; }
+}
+
+neo_order_scope::~neo_order_scope() { c->order_end(s); }
+
 void neo_ctx::span_begin(hipStream_t s) {
     if (!timing) return;
     hipEvent_t a, b;
@@ -155,6 +169,7 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     for (auto& ev : ctx->flag_ev) if (ev) (void)hipEventDestroy(ev);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     if (ctx->flag_host) (void)hipHostFree(ctx->flag_host);
     if (ctx->flags) (void)hipFree(ctx->flags);
     delete ctx;
@@ -238,9 +253,28 @@ int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits) {
     return NEO_OK;
 }
 
+int neo_ctx_stream_waits(neo_ctx* ctx, uint64_t* cross_stream_waits) {
+    ENTER(ctx);
+    REQUIRE(cross_stream_waits != nullptr, "null out pointer");
+    *cross_stream_waits = ctx->order_waits;
+    return NEO_OK;
+}
+
 int neo_ctx_set_precision(neo_ctx* ctx, int mode) {
     ENTER(ctx);
     REQUIRE(mode == 0 || mode == 1, "precision mode must be 0 (fp32 MFMA) or 1 (fp16 MFMA, hi/lo-split operands)");
+    if (mode == 1 && ctx->precision != 1) {
+        // entering the split arithmetic: the one-time range checks of packed weights and feature maps run again at the
+        // next split launch (a frame that tripped the guard and was re-rendered exactly must trip it again, not pass
+        // because "already checked")
+        for (auto& sl : ctx->vanilla) sl.range_checked = 0;
+        for (auto& sl : ctx->tp) sl.range_checked = 0;
+        for (auto& sl : ctx->mip) sl.range_checked = 0;
+        for (auto& sl : ctx->pix) sl.range_checked = 0;
+        ctx->enc.range_checked = 0;
+        ctx->planes_checked = ctx->latent_checked = 0;
+        ctx->pix_latent_checked = false;
+    }
     ctx->precision = mode;
     return NEO_OK;
 }
@@ -431,6 +465,7 @@ int neo_vanilla_render(neo_ctx* ctx, const float* rays_o, const float* viewdirs,
     const float* t0 = ctx->get_edges(n_coarse, near, far, s);
     const float* u = ctx->get_quantiles(n_fine, s);
     if (!t0 || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
     if (ctx->ws[0].reserve(static_cast<size_t>(R) * N0 * 16)) return NEO_ERR_NOMEM;
     if (ctx->ws[1].reserve(static_cast<size_t>(R) * N0 * 4)) return NEO_ERR_NOMEM;
     if (ctx->ws[2].reserve(static_cast<size_t>(R) * N1 * 4)) return NEO_ERR_NOMEM;

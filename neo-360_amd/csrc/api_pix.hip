@@ -154,6 +154,7 @@ int neo_pix_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const
     const float* t0 = ctx->get_edges(n_coarse, near, far, s);
     const float* u = ctx->get_quantiles(n_fine, s);
     if (!t0 || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
     if (ctx->ws[0].reserve(static_cast<size_t>(R) * N0 * 16)) return NEO_ERR_NOMEM;
     if (ctx->ws[1].reserve(static_cast<size_t>(R) * N0 * 4)) return NEO_ERR_NOMEM;
     if (ctx->ws[2].reserve(static_cast<size_t>(R) * N1 * 4)) return NEO_ERR_NOMEM;

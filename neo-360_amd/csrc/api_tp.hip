@@ -32,6 +32,7 @@ void fill_views(const float* poses, int nv, neo::TpViews& v) {
 int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
               const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N, int chunk,
               float* out, hipStream_t s) {
+    ORDERED(ctx, s);      // context scratch (tp_dirsum, projected maps, ws[]) is shared by all streams
     if (ctx->precision == 1) {
         // range guard of the split arithmetic: tri-planes are summed over three maps before they are split
         if (ctx->planes_checked != ctx->scene_epoch) {
@@ -207,6 +208,7 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const 
     if (!edges || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
 
     // workspaces
+    ORDERED(ctx, s);
     auto& W = ctx->ws;
     const size_t r = static_cast<size_t>(R);
     if (W[0].reserve(r * 4) || W[1].reserve(r * N0 * 4) || W[2].reserve(r * N0 * 4) || W[3].reserve(r * N1 * 16) ||

@@ -147,6 +147,7 @@ int neo_tp_render_train(neo_ctx* ctx, const float* rays_o, const float* rays_d, 
     const float* edges = ctx->get_edges(n_coarse, 0.0f, 1.0f, s);
     const float* u_det = ctx->get_quantiles(n_fine, s);
     if (!edges || !u_det) return fail(NEO_ERR_HIP, "constant table upload failed");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
     auto& W = ctx->ws;
     const size_t r = static_cast<size_t>(R);
     const size_t nu = seed ? r * (N0 > n_fine ? N0 : n_fine) * 4 : 4;
@@ -244,6 +245,7 @@ int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w,
     REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
     REQUIRE(w && x_enc && local_feat && world_feat && cond && tape && g_rgb && g_sigma && gw && gb, "null pointer");
     for (int i = 0; i < 9; ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
     if (ctx->train_scratch.reserve(neo::tp_train_scratch_floats(NV, P) * sizeof(float))) return NEO_ERR_NOMEM;
     neo::launch_tp_train_backward(input_ch * 21, w, x_enc, local_feat, world_feat, cond, NV, P, tape,
                                   ctx->train_scratch.as<float>(), g_rgb, g_sigma, gw, gb, g_x_enc, g_local, g_world,
@@ -273,6 +275,7 @@ int neo_vanilla_mlp_train_backward(neo_ctx* ctx, const float* const* w, const fl
     if (R == 0) return NEO_OK;
     REQUIRE(w && x0 && cond && tape && g_rgb && g_sigma && gw && gb, "null pointer");
     for (int i = 0; i < 12; ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
     if (ctx->train_scratch.reserve(neo::vanilla_train_scratch_floats(R) * sizeof(float))) return NEO_ERR_NOMEM;
     neo::launch_vanilla_train_backward(w, x0, cond, R, tape, ctx->train_scratch.as<float>(), g_rgb, g_sigma, gw, gb, g_x0, g_cond,
                                        static_cast<hipStream_t>(stream));

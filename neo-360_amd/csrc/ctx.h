@@ -15,6 +15,8 @@
 
 #include "kernels.h"
 
+struct neo_ctx;
+
 namespace neo_host {
 
 std::string& last_error();
@@ -104,6 +106,17 @@ inline int check_launch() {
 
 }  // namespace neo_host
 
+// Orders this call behind the previous call of the same context when the stream differs (neo_ctx::order_begin) and
+// records the ordering event when the enclosing scope ends, on every exit path.
+struct neo_order_scope {
+    neo_ctx* c;
+    hipStream_t s;
+    ~neo_order_scope();
+};
+#define ORDERED(ctx, s)                                   \
+    if (int rc_ = (ctx)->order_begin(s)) return rc_;      \
+    neo_order_scope order_scope_{(ctx), (s)}
+
 extern "C" void neo_linspace_host(float start, float end, int steps, float* out);
 
 struct neo_ctx {
@@ -151,6 +164,15 @@ struct neo_ctx {
     uint32_t flag_carry = 0;                     // reads retired by post() while making room
     bool flag_unposted = false;                  // the last post() found the ring full and posted nothing
     uint64_t blocking_waits = 0;                 // stream / event synchronisations issued by the flag calls
+    // Context-owned scratch (tp_dirsum, train_scratch, ws[]) is rewritten by every launch on whatever stream the caller
+    // passes: launches of one context are therefore ORDERED across streams - a call on a stream other than the previous
+    // call's first waits (device-side, hipStreamWaitEvent) for the event recorded behind that call.
+    hipStream_t order_stream = nullptr;
+    hipEvent_t order_ev = nullptr;
+    bool order_valid = false;
+    uint64_t order_waits = 0;                    // cross-stream waits inserted (tests)
+    int order_begin(hipStream_t s);
+    void order_end(hipStream_t s);
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
     double timed_points = 0.0, timed_flops = 0.0;

@@ -13,6 +13,8 @@ Inference path only (`randomized=False`, no autograd), as SURVEY.md §8b scopes 
 import ctypes
 import math
 import os
+import warnings
+import weakref
 
 import torch
 import torch.nn as nn
@@ -158,8 +160,21 @@ class _HipModule(nn.Module):
         return ctx
 
     def close(self):
-        """Release the library contexts (packed weights, scene features, workspaces) now."""
+        """Release the library contexts (packed weights, scene features, workspaces) now.  Deferred reads of the
+        assertion word that nobody looked at (`poll_flags='deferred'` and no later call / `check_flags()`) are taken
+        here; a tripped assertion or range guard becomes a RuntimeWarning instead of vanishing."""
         for ctx in self._ctx_cache.values():
+            if ctx.handle and self._flag_mode() == "deferred":
+                try:
+                    flags = ctx.take_flags(wait=True)
+                except Exception:
+                    flags = 0
+                if flags:
+                    warnings.warn("%s.close(): unread device assertions of earlier calls (flags=%d: %s); results of those "
+                                  "calls were invalid - call check_flags() before consuming outputs"
+                                  % (type(self).__name__, flags, " + ".join(
+                                      n for b, n in ((1, "ray missed the unit sphere"), (2, "split-fp16 range guard")) if flags & b)),
+                                  RuntimeWarning, stacklevel=2)
             ctx.close()
         self._ctx_cache.clear()
 
@@ -171,7 +186,7 @@ class _HipModule(nn.Module):
         if flags & 1:
             raise AssertionError("1.0 - p_norm_sq should be greater than 0" + where)
         if flags & 2:
-            raise _lib.NeoError(
+            raise _lib.NeoRangeError(
                 "split-fp16 arithmetic (precision 'f16x3') met an operand outside the fp16 range (|x| >= 65504 or "
                 "non-finite weights / features / activations): results of that call are invalid; use precision 'f32'" + where)
 
@@ -346,8 +361,10 @@ class NeRF_TP(_HipModule):
         (neo360/model.py:267-269).  Re-laid out channels-last on the device, once.
         preproject (None = keep `self.preproject`): see that attribute."""
         src = _source if _source is not None else (plane_xz, plane_xy, plane_yz, latent)
-        self._scene_fp = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in src)
-        self._scene_wh = (float(image_wh[0]), float(image_wh[1]))
+        # the device copy is about to change: until the upload below has succeeded NO tensor set matches it
+        # (ADVICE r3: a failing upload must not leave a fingerprint that names the new tensors next to the old copy)
+        self._scene_src = None
+        self._scene_ctx = None
         if preproject is not None:
             self.preproject = bool(preproject)
         planes = [f32(p, "plane") for p in (plane_xz, plane_xy, plane_yz)]
@@ -360,12 +377,19 @@ class NeRF_TP(_HipModule):
                                             ctx.stream()))
         torch.cuda.current_stream(latent.device).synchronize()   # inputs may be freed by the caller
         self._scene_ctx = ctx
+        self._scene_wh = (float(image_wh[0]), float(image_wh[1]))
+        # identity (weak references, compared with `is`) + versions: a (data_ptr, version, shape) fingerprint alone
+        # matches a NEW tensor the caching allocator placed at a freed map's address (a training loop's fresh encoder
+        # output at version 0 and the same shape) and the previous step's device copy would be gathered silently.
+        # Weak, not strong: an inference caller's 0.5 GB of NCHW maps must stay freeable; a dead reference matches nothing.
+        self._scene_src = (tuple(weakref.ref(t) for t in src), tuple(t._version for t in src))
 
     def scene_matches(self, maps):
-        """True when the device-side scene is a copy of exactly these four tensors at their current version."""
-        fp = getattr(self, "_scene_fp", None)
-        return (self._scene_ctx is not None and fp is not None
-                and fp == tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in maps))
+        """True when the device-side scene is a copy of exactly these four tensor OBJECTS at their current version."""
+        held = getattr(self, "_scene_src", None)
+        maps = tuple(maps)
+        return (self._scene_ctx is not None and held is not None and len(maps) == len(held[0])
+                and all(a is r() for a, r in zip(maps, held[0])) and tuple(t._version for t in maps) == held[1])
 
     def scene_image_wh(self, rays=None):
         """(W,H) of the source images: from the last set_scene, else from rays["src_imgs"]."""

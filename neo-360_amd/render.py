@@ -6,10 +6,11 @@ is reproduced — plus the single-frame replacement of the reference's only coll
 (LitModel.alter_gather_cat, models/interface.py:30-50) and its PSNR (:53-61).
 """
 import math
+import warnings
 
 import torch
 
-from . import models
+from . import _lib, models
 from .parallel import gather_tiles, shard_bounds
 
 _WHOLE = ("src_imgs", "src_poses", "src_focal", "src_c")
@@ -27,31 +28,64 @@ def _slice(batch, lo, hi):
     return out
 
 
-@torch.no_grad()
-def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0, train_frac=1.0, check=True):
-    """Fine-level rgb / depth of every ray in `batch` (one image), as the reference's
-    render_rays_test returns them: dict(rgb (R,3), depth (R,)) plus `target` /
-    `instance_mask` passed through when present.  check=True waits for the frame and raises what the device-side
-    assertions reported (a ray that missed the unit sphere, the split-fp16 range guard); check=False leaves that to
-    a later `model.check_flags()` (a loop over frames that never wants to block)."""
+def _render_once(model, batch, chunk, white_bkgd, near, far, train_frac):
     if isinstance(model, models.NeRF_TP):
         res = model(batch, False, white_bkgd, near, far, out_depth=True, chunk=chunk)
-        out = dict(rgb=res[1][0], depth=res[1][5], fg_rgb=res[1][1], bg_rgb=res[1][2], acc=res[1][3])
-    elif isinstance(model, models.PixelNeRF):
+        return dict(rgb=res[1][0], depth=res[1][5], fg_rgb=res[1][1], bg_rgb=res[1][2], acc=res[1][3])
+    if isinstance(model, models.PixelNeRF):
         res = model(batch, False, white_bkgd, near, far, chunk=chunk)      # vanilla_nerf/model_pixel.py:356-383
-        out = dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
-    elif isinstance(model, models.MipNeRF360):
+        return dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
+    if isinstance(model, models.MipNeRF360):
         # mipnerf360/model.py:471-505: train_frac = global_step / max_steps of the trainer; near/far as given
         rend, hist = model(batch, train_frac, False, False, near, far)
         w = hist[-1]["weights"]
-        out = dict(rgb=rend[-1]["rgb"], acc=w.sum(-1), depth=torch.zeros_like(w[:, 0]))   # the reference returns rgb only
-    elif isinstance(model, models.NeRF):
+        return dict(rgb=rend[-1]["rgb"], acc=w.sum(-1), depth=torch.zeros_like(w[:, 0]))   # the reference returns rgb only
+    if isinstance(model, models.NeRF):
         res = model(batch, False, white_bkgd, near, far)     # chunking does not change vanilla results
-        out = dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
-    else:
-        raise TypeError("unsupported renderer %r" % type(model))
+        return dict(rgb=res[1][0], depth=res[1][2], acc=res[1][1])
+    raise TypeError("unsupported renderer %r" % type(model))
+
+
+_warned_downgrade = set()
+
+
+@torch.no_grad()
+def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0, train_frac=1.0, check=True,
+                     on_range="retry_f32"):
+    """Fine-level rgb / depth of every ray in `batch` (one image), as the reference's
+    render_rays_test returns them: dict(rgb (R,3), depth (R,)) plus `target` /
+    `instance_mask` passed through when present.  check=True waits for the frame and raises what the device-side
+    assertions reported (a ray that missed the unit sphere); check=False leaves that to
+    a later `model.check_flags()` (a loop over frames that never wants to block).
+
+    on_range: what happens when the range guard of the split-fp16 arithmetic trips for this frame (an operand beyond the
+    fp16 range: a trained checkpoint or an un-normalised encoder; the reference is plain fp32 and never fails,
+    neo360/model.py:343-407).  "retry_f32" (default): the frame is rendered again on the exact fp32-MFMA kernels of the
+    same library - bitwise the frame `model.precision = "f32"` returns - and a RuntimeWarning says so once per module;
+    "raise": the NeoRangeError goes to the caller.  Needs check=True (the guard is read when the frame is complete)."""
+    if on_range not in ("retry_f32", "raise"):
+        raise ValueError("on_range must be 'retry_f32' or 'raise', got %r" % (on_range,))
+    out = _render_once(model, batch, chunk, white_bkgd, near, far, train_frac)
     if check:
-        model.check_flags()      # the deferred reads of the assertion word: raise before the frame is handed out
+        try:
+            model.check_flags()      # the deferred reads of the assertion word: raise before the frame is handed out
+        except _lib.NeoRangeError:
+            if on_range != "retry_f32" or isinstance(model, models.PixelNeRF):     # PixelNeRF has no exact-fp32 evaluator
+                raise
+            if id(model) not in _warned_downgrade:
+                _warned_downgrade.add(id(model))
+                warnings.warn("%s: an operand left the fp16 range of the split arithmetic (precision 'f16x3'); this frame "
+                              "(and any later one that trips the guard) is re-rendered on the exact fp32 kernels "
+                              "(~6x slower). Set model.precision = 'f32' to skip the failed attempt."
+                              % type(model).__name__, RuntimeWarning, stacklevel=2)
+            prev = model.precision
+            model.precision = "f32"
+            try:
+                out = _render_once(model, batch, chunk, white_bkgd, near, far, train_frac)
+                model.check_flags()
+            finally:
+                model.precision = prev
+            out["precision_used"] = "f32"
     for k in ("target", "instance_mask"):
         if k in batch:
             out[k] = batch[k]
@@ -60,12 +94,14 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
 
 @torch.no_grad()
 def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False, near=0.2, far=3.0, group=None,
-                         gather=True, train_frac=1.0, n_rays=None, out=None, reuse=False, check=True):
+                         gather=True, train_frac=1.0, n_rays=None, out=None, reuse=False, check=True, always_gather=False):
     """This rank renders its contiguous range of whole chunks; `gather=True` reassembles
     the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather.
     `batch` holds the whole frame's rays, or - with n_rays = R given - only this rank's shard
     (rays [shard_bounds(R, world, rank)), e.g. from ops.get_ray_directions_and_rays(ray_range=...)).
-    The gathered frame is a fresh tensor unless `out=` / `reuse=True` are given (parallel.gather_tiles)."""
+    The gathered frame is a fresh tensor unless `out=` / `reuse=True` are given (parallel.gather_tiles).
+    always_gather: run the collective at world == 1 too (a one-rank process group: the RCCL call path of the N-GPU job
+    on a one-GPU box; bench.py under `torchrun --nproc-per-node 1`)."""
     if n_rays is None:
         R = batch["rays_o"].shape[0]
         lo, hi = shard_bounds(R, world, rank, unit=chunk)
@@ -77,7 +113,7 @@ def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False
         mine = batch
     part = render_rays_test(model, mine, chunk, white_bkgd, near, far, train_frac, check=check)
     tile = torch.cat([part["rgb"], part["depth"][:, None], part["acc"][:, None]], dim=1)
-    if world == 1 or not gather:
+    if not gather or (world == 1 and not always_gather):
         return tile
     return gather_tiles(tile, R, world, unit=chunk, group=group, out=out, reuse=reuse)
 

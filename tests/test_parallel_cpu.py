@@ -123,3 +123,31 @@ def test_sharded_frame_equals_whole_frame_gloo(n, world, chunk):
         ret = mgr.dict()
         mp.spawn(_sharded_worker, args=(world, port, n, chunk, ret), nprocs=world, join=True)
         assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _world1_worker(rank, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from neo360_amd import render
+        g = torch.Generator().manual_seed(5)
+        n = 700
+        batch = dict(rays_o=torch.randn(n, 3, generator=g), rays_d=torch.randn(n, 3, generator=g),
+                     viewdirs=torch.randn(n, 3, generator=g), src_poses=torch.randn(3, 4, 4, generator=g),
+                     src_focal=torch.ones(3), src_c=torch.zeros(3, 2), src_imgs=torch.zeros(3, 3, 4, 4))
+        net = _FakePixelNeRF()
+        plain = render.render_frame_sharded(net, batch, 1, 0, chunk=256)                       # no collective at world 1
+        coll = render.render_frame_sharded(net, batch, 1, 0, chunk=256, always_gather=True)   # one-rank all-gather
+        ret[0] = bool(torch.equal(plain, coll)) and coll.data_ptr() != plain.data_ptr()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_always_gather_runs_the_collective_at_world_one():
+    """bench.py under `torchrun --nproc-per-node 1` (tests/test_gpu_multirank.py runs it on RCCL): same frame."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_world1_worker, args=(port, ret), nprocs=1, join=True)
+        assert ret.get(0) is True
