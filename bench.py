@@ -69,7 +69,7 @@ def physical_cores():
 
 # the translation unit of each workload's dominant kernel (split arithmetic) + the headers it is built from
 KERNEL_SOURCES = {
-    "neo360": ("mlp_tp_hp.hip", "tp_hp_layout.h", "tp_common.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+    "neo360": ("mlp_tp_hp.hip", "mlp_tp_hpp.hip", "tp_hp_layout.h", "tp_common.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
     "vanilla": ("mlp_vanilla_h.hip", "mfma_tile.h", "common.h", "kernels.h"),
     "mip360": ("mlp_mip_h.hip", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
     "mip360_128": ("mlp_mip_h.hip", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
@@ -94,8 +94,9 @@ def kernel_source_hash(workload="neo360"):
 # (12 k-steps of 16 inside the sphere, 14 outside, x 256 outputs) + L1, L2, L3 (3 x 128 x 128); once per point the
 # view-mean tail (bottleneck 128 x 128, view layers 160 x 64 and 64 x 64).  The 512-channel latent does not appear:
 # it is pre-projected once per scene (scene_setup_ms).
-def executed_flop_per_point_tp_hp(nv, outside):
-    per_view = (14 if outside else 12) * 16 * 256 + 3 * 128 * 128
+def executed_flop_per_point_tp_hp(nv, outside, planes_projected=False):
+    # planes_projected (mlp_tp_hpp.hip): the 8 world k-steps are gone as well (tri-planes pre-projected once per scene)
+    per_view = ((14 if outside else 12) - (8 if planes_projected else 0)) * 16 * 256 + 3 * 128 * 128
     macs = nv * per_view + 128 * 128 + 160 * 64 + 64 * 64
     return macs * 3 * 2.0
 
@@ -254,7 +255,7 @@ class Runner:
         self.net.precision = precision
         self.kernel_name = kernel + ("_h" if self.split else "")
         if workload == "neo360" and self.split and getattr(self.net, "preproject", False):
-            self.kernel_name = "k_tp_mlp_hp"
+            self.kernel_name = "k_tp_mlp_hpp" if self.net.preproject == 2 and self.net.preproject is not True else "k_tp_mlp_hp"
         self.c2w = synth.look_at_origin(40.0)
         self.R = H * W
         self.lo, self.hi = shard_bounds(self.R, world, rank, unit=CHUNK)
@@ -360,9 +361,10 @@ class Runner:
             # every algorithmic multiply costs three fp16 products: the ceiling for ALGORITHMIC flops on this arithmetic
             roof["frac_of_split_ceiling"] = achieved / (PEAK_F16_MFMA_TFLOPS / 3.0)
             roof["split_ceiling"] = PEAK_F16_MFMA_TFLOPS / 3.0
-        if self.workload == "neo360" and self.split and self.kernel_name == "k_tp_mlp_hp":
+        if self.workload == "neo360" and self.split and self.kernel_name in ("k_tp_mlp_hp", "k_tp_mlp_hpp"):
             # what the matrix pipe really executed (a frame's launches hold inside- and outside-sphere points 1:1)
-            ex = 0.5 * (executed_flop_per_point_tp_hp(3, False) + executed_flop_per_point_tp_hp(3, True))
+            pl = self.kernel_name == "k_tp_mlp_hpp"
+            ex = 0.5 * (executed_flop_per_point_tp_hp(3, False, pl) + executed_flop_per_point_tp_hp(3, True, pl))
             roof["executed_tflops"] = points * ex / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
             roof["frac_executed"] = roof["executed_tflops"] / PEAK_F16_MFMA_TFLOPS
             roof["executed_flop_per_point"] = ex

@@ -193,7 +193,10 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
  * (scene, MLP slot) through the local columns of pts_linears.0 and of pts_linears.3's skip half
  * (W . bilerp(F) = bilerp(W . F): neo360/model.py:110-158 is linear in the latent up to the first ReLU), and
  * the evaluator gathers the 256-channel result; costs 1 KB per latent texel and slot of context memory.
- * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order). */
+ * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order).
+ * enable == 2: the three tri-planes are pre-projected the same way through the world columns (the 128-channel plane
+ * sum of encoder_tp_fusion_conv.py:180-206 enters pts_linears.0 / .3 linearly too, model.py:123-137): no per-point world
+ * GEMM stage, four 256-channel maps are gathered, blended and added; 1 KB per plane texel and slot on top. */
 int neo_tp_set_preproject(neo_ctx* ctx, int enable);
 
 /* `predict` + the feature lookups for one region at given sample positions

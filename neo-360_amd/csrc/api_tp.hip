@@ -57,9 +57,27 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             // ray alone: summed once per ray here instead of once per sample and view inside the evaluator
             if (ctx->tp_dirsum.reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
             neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum.as<float>(), s);
-            ctx->span_begin(s);
-            neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
-                                  chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
+            if (ctx->preproject == 2) {
+                // the tri-planes through this slot's [W0_world | W3_world] (chunks 64..79 of the fp32 fragment stream)
+                if (sl.projpl_weights != sl.weights_epoch || sl.projpl_scene != ctx->scene_epoch) {
+                    const long texels = static_cast<long>(sc.nv) * sc.Hp * sc.Wp;
+                    for (int j = 0; j < 3; ++j) {
+                        if (sl.proj_pl[j].reserve(neo::tp_proj_bytes(texels))) return NEO_ERR_NOMEM;
+                        neo::launch_tp_preproject(sc.plane[j], texels, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch),
+                                                  sl.proj_pl[j].as<float>(), s, 256, 128, 64);
+                    }
+                    sl.projpl_weights = sl.weights_epoch;
+                    sl.projpl_scene = ctx->scene_epoch;
+                }
+                const neo::TpPlaneProj pp{{sl.proj_pl[0].as<float>(), sl.proj_pl[1].as<float>(), sl.proj_pl[2].as<float>()}};
+                ctx->span_begin(s);
+                neo::launch_tp_mlp_hpp(sl.input_ch, mh, sl.proj.as<float>(), pp, sc, views, rays_o, rays_d, viewdirs, tvals, far,
+                                       R, N, chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
+            } else {
+                ctx->span_begin(s);
+                neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
+                                      chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
+            }
         } else {
             guard_split_weights(sl, sl.wpack_h.p, neo::tp_wpack_h_bytes(sl.input_ch), ctx->flags, s);
             if (ctx->latent_checked != ctx->scene_epoch) {
@@ -150,10 +168,16 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
 
 int neo_tp_set_preproject(neo_ctx* ctx, int enable) {
     ENTER(ctx);
-    ctx->preproject = enable != 0;
+    REQUIRE(enable >= 0 && enable <= 2, "preproject mode must be 0 (off), 1 (latent) or 2 (latent + tri-planes)");
+    ctx->preproject = enable;
     for (auto& sl : ctx->tp) sl.range_checked = 0;       // the other fragment set is checked at its first launch
     if (!ctx->preproject)
         for (auto& sl : ctx->tp) { sl.proj.release(); sl.proj_weights = sl.proj_scene = 0; }
+    if (ctx->preproject != 2)
+        for (auto& sl : ctx->tp) {
+            for (auto& b : sl.proj_pl) b.release();
+            sl.projpl_weights = sl.projpl_scene = 0;
+        }
     return NEO_OK;
 }
 

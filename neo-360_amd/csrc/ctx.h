@@ -60,6 +60,8 @@ struct MlpSlot {
     DevBuf wpack_h;      // fp16 hi/lo split fragments (precision mode 1)
     DevBuf wpack_hp;     // NeRF_TP: split fragments of the pre-projected evaluator (no local-latent k-steps)
     DevBuf proj;         // NeRF_TP: latent pre-projected through this slot's [W0_loc | W3_loc] (256 ch / texel)
+    DevBuf proj_pl[3];   // NeRF_TP, preproject mode 2: the tri-planes through [W0_world | W3_world] (256 ch / texel)
+    uint64_t projpl_weights = 0, projpl_scene = 0;   // (weights_epoch, scene_epoch) `proj_pl` was computed for; 0 = never
     uint64_t weights_epoch = 0;             // bumped by every upload
     uint64_t range_checked = 0;             // weights_epoch whose split fragments passed through the range check
     uint64_t proj_weights = 0, proj_scene = 0;   // (weights_epoch, scene_epoch) `proj` was computed for; 0 = never
@@ -67,7 +69,8 @@ struct MlpSlot {
     bool ready = false;
     void release() {
         wpack.release(); bias.release(); heads.release(); wpack_h.release(); wpack_hp.release(); proj.release();
-        proj_weights = proj_scene = 0;
+        for (auto& b : proj_pl) b.release();
+        proj_weights = proj_scene = projpl_weights = projpl_scene = 0;
         ready = false;
     }
 };
@@ -136,7 +139,7 @@ struct neo_ctx {
     uint64_t scene_epoch = 0;          // bumped by every neo_tp_set_scene
     uint64_t planes_checked = 0, latent_checked = 0;   // scene_epoch whose maps passed the split range check
     neo_host::DevBuf tp_dirsum;        // (rays, 32): view-summed direction encodings of the current launch (k_tp_mlp_hp)
-    int preproject = 1;                // split path: gather the latent pre-projected through the first-layer weights
+    int preproject = 1;                // split path: 1 gather the latent pre-projected through the first-layer weights; 2 the tri-planes too
     // PixelNeRF scene latent: its own buffer / descriptor / ready flag (a context may hold both decoders)
     neo_host::DevBuf pix_latent;
     neo::TpScene pix_scene{};

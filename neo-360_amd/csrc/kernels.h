@@ -169,8 +169,9 @@ size_t tp_wpack_hp_bytes(int input_ch);
 size_t tp_proj_bytes(long texels);    // pre-projected map: 256 fp32 channels per latent texel
 void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipStream_t s);
 // G (texels, 256) = latent_cl (texels, 512) . [W0_loc | W3_loc]^T from the fp32 fragment pack's stage X
+// (in_ch = 128, first_chunk = 64: a tri-plane through the world columns [W0_world | W3_world], mlp_tp_hpp.hip)
 void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
-                          hipStream_t s, int channels = 256);
+                          hipStream_t s, int channels = 256, int in_ch = 512, int first_chunk = 0);
 // dirsum (R, 32): per ray the SUM over the source views of its view-direction encoding in each view's camera frame
 // (27 features + 5 zeros), built by launch_tp_dirsum before every evaluator launch
 void launch_tp_dirsum(const float* viewdirs, int R, const TpViews& views, int nv, float* dirsum, hipStream_t s);
@@ -178,6 +179,14 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
                       const float* rays_o, const float* rays_d, const float* viewdirs, const float* tvals,
                       const float* far, int R, int N, int chunk, uint32_t* flags, float* out, const float* dirsum,
                       hipStream_t s);
+
+// mlp_tp_hpp.hip — the same evaluator with the three TRI-PLANES pre-projected as well (through [W0_world | W3_world]):
+// no world GEMM stage per point-view; 4 maps x 1 KB taps are blended and added to the L0 / L3-skip accumulators
+struct TpPlaneProj { const float* p[3]; };      // xz, xy, yz: (NV * Hp * Wp, 256) fp32, channel order hp::proj_index
+void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj, const TpPlaneProj& pp, const TpScene& sc,
+                       const TpViews& views, const float* rays_o, const float* rays_d, const float* viewdirs,
+                       const float* tvals, const float* far, int R, int N, int chunk, uint32_t* flags, float* out,
+                       const float* dirsum, hipStream_t s);
 
 // (train_mlp.hip's launchers are declared in train_kernels.h)
 

@@ -53,6 +53,9 @@
 #ifndef NEO_TP_ZSKIP
 #define NEO_TP_ZSKIP 1        // skip a view's latent / tri-plane gather pipeline when no row of the tile has a non-zero tap weight in it
 #endif
+#ifndef NEO_TP_DPF
+#define NEO_TP_DPF 1          // 1: a gather item's tap offsets / weights are read from LDS ONE ITEM AHEAD of their use (the ISA of the plain form waits out a full LDS round trip twice per item: ds_read offsets -> s_waitcnt -> 4 loads, ds_read weights -> s_waitcnt -> blend)
+#endif
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
 // tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
@@ -215,6 +218,26 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             const uint32_t lane_b = 16u * col4;
             f32x4 taps[RING][4];
             f32x4 wsum;                                    // running sum over the three planes of one row group
+#if NEO_TP_DPF
+            int4 d_off[2];                                 // tap byte offsets of the item that is REQUESTED next (slot = item & 1)
+            f32x4 d_w[2];                                  // tap weights of the item that is BLENDED next
+            // item -> its descriptor row in LDS (offsets and weights share the layout)
+            auto desc_index = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 16) return (rg + 16 * (i % 4)) * 4;
+                else return (((i - 16) % 3) * TM + rg + 16 * (((i - 16) % 12) / 3)) * 4;
+            };
+            auto fetch_off = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 16) d_off[i & 1] = *reinterpret_cast<const int4*>(loc_off + desc_index(ic));
+                else if constexpr (i < 40) d_off[i & 1] = *reinterpret_cast<const int4*>(pl_off + desc_index(ic));
+            };
+            auto fetch_w = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 16) d_w[i & 1] = *reinterpret_cast<const f32x4*>(loc_w + desc_index(ic));
+                else if constexpr (i < 40) d_w[i & 1] = *reinterpret_cast<const f32x4*>(pl_w + desc_index(ic));
+            };
+#endif
             // item i: 0..15 = pre-projected latent (chunk i / 4, row group i % 4); 16..39 = tri-planes
             // (stage (i - 16) / 12, row group ((i - 16) % 12) / 3, plane (i - 16) % 3)
             constexpr int NI = 40;
@@ -222,17 +245,27 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 constexpr int i = decltype(ic)::value;
                 if constexpr ((i < 16 && (NEO_TP_ABLATE & 1)) || (i >= 16 && (NEO_TP_ABLATE & 2))) {
                 } else if constexpr (i < 16) {
-                    constexpr int c = i / 4, q = i % 4;
+                    constexpr int c = i / 4;
+                    [[maybe_unused]] constexpr int q = i % 4;
+#if NEO_TP_DPF
+                    const int4 off = d_off[i & 1];
+#else
                     const int row = rg + 16 * q;
                     const int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
+#endif
                     taps[i % RING][0] = tp::load_tap(proj, (uint32_t)off.x + lane_b + 256u * c);
                     taps[i % RING][1] = tp::load_tap(proj, (uint32_t)off.y + lane_b + 256u * c);
                     taps[i % RING][2] = tp::load_tap(proj, (uint32_t)off.z + lane_b + 256u * c);
                     taps[i % RING][3] = tp::load_tap(proj, (uint32_t)off.w + lane_b + 256u * c);
                 } else if constexpr (i < NI) {
-                    constexpr int w = i - 16, s2 = w / 12, q = (w % 12) / 3, j = w % 3;
+                    constexpr int w = i - 16, s2 = w / 12, j = w % 3;
+                    [[maybe_unused]] constexpr int q = (w % 12) / 3;
+#if NEO_TP_DPF
+                    const int4 off = d_off[i & 1];
+#else
                     const int row = rg + 16 * q;
                     const int4 off = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
+#endif
                     taps[i % RING][0] = tp::load_tap(sc.plane[j], (uint32_t)off.x + lane_b + 256u * s2);
                     taps[i % RING][1] = tp::load_tap(sc.plane[j], (uint32_t)off.y + lane_b + 256u * s2);
                     taps[i % RING][2] = tp::load_tap(sc.plane[j], (uint32_t)off.z + lane_b + 256u * s2);
@@ -253,12 +286,20 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 } else if constexpr (i < 16) {
                     constexpr int c = i / 4, q = i % 4;
                     const int row = rg + 16 * q;
+#if NEO_TP_DPF
+                    const f32x4 val = blend4(taps[i % RING], d_w[i & 1]);
+#else
                     const f32x4 val = blend4(taps[i % RING], *reinterpret_cast<const f32x4*>(loc_w + row * 4));
+#endif
                     *reinterpret_cast<f32x4*>(fbuf(c & 1) + row * 64 + ((col4 ^ (row & 15)) << 2)) = val;
                 } else {
                     constexpr int w = i - 16, s2 = w / 12, q = (w % 12) / 3, j = w % 3;
                     const int row = rg + 16 * q;
+#if NEO_TP_DPF
+                    const f32x4 val = blend4(taps[i % RING], d_w[i & 1]);
+#else
                     const f32x4 val = blend4(taps[i % RING], *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4));
+#endif
                     if constexpr (j == 0) wsum = val; else wsum = wsum + val;
                     if constexpr (j == 2) write_x(xbuf(s2), row, wsum);
                 }
@@ -378,9 +419,20 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             const bool any_latent = !NEO_TP_ZSKIP || zm[0] != 0ull;
             const bool any_plane = !NEO_TP_ZSKIP || (zm[1] | zm[2] | zm[3]) != 0ull;
             if (any_latent) {
+#if NEO_TP_DPF
+                static_for<0, RING - 1>([&](auto ic) { fetch_off(ic); issue(ic); });
+                fetch_off(std::integral_constant<int, RING - 1>());
+                fetch_w(std::integral_constant<int, 0>());
+#else
                 static_for<0, RING - 1>([&](auto ic) { issue(ic); });
+#endif
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
+#if NEO_TP_DPF
+                    // descriptors one item ahead: offsets of the item requested in the NEXT pass, weights of the item blended in it
+                    if constexpr (i + RING < 16) fetch_off(std::integral_constant<int, i + RING>());
+                    if constexpr (i + 1 < 16) fetch_w(std::integral_constant<int, i + 1>());
+#endif
                     if constexpr (i + RING - 1 < 16) issue(std::integral_constant<int, i + RING - 1>());
                     if constexpr (i == 4 || i == 8 || i == 12) consume_chunk(std::integral_constant<int, i / 4 - 1>());
                     finish(ic);
@@ -395,9 +447,19 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 #define NEO_TP_PLANE_MMA_INSIDE 1     // 1: world stage 0 is multiplied between the gather items of stage 1 and the tri-plane pipeline always runs (measured best); 0: tri-plane pipeline skipped when no tap carries weight, stage 0 multiplied afterwards
 #endif
             if (any_plane || NEO_TP_PLANE_MMA_INSIDE) {
+#if NEO_TP_DPF
+                static_for<16, 16 + RING - 1>([&](auto ic) { fetch_off(ic); issue(ic); });
+                fetch_off(std::integral_constant<int, 16 + RING - 1>());
+                fetch_w(std::integral_constant<int, 16>());
+#else
                 static_for<16, 16 + RING - 1>([&](auto ic) { issue(ic); });
+#endif
                 static_for<16, NI>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
+#if NEO_TP_DPF
+                    if constexpr (i + RING < NI) fetch_off(std::integral_constant<int, i + RING>());
+                    if constexpr (i + 1 < NI) fetch_w(std::integral_constant<int, i + 1>());
+#endif
                     if constexpr (i + RING - 1 < NI) issue(std::integral_constant<int, i + RING - 1>());
                     if constexpr (NEO_TP_PLANE_MMA_INSIDE && i >= 28 && (i - 28) % 3 == 0)
                         mma_k(xbuf(0), std::integral_constant<int, (i - 28) / 3>());
@@ -866,9 +928,12 @@ __global__ void k_tp_dirsum(const float* __restrict__ viewdirs, int R, TpViews v
 // One workgroup = 64 texels (2 M-tiles), wave w = N-tiles 2w, 2w+1.  B fragments come straight from global memory
 // (16 B per lane at a 2 KB row pitch: every line is consumed over four consecutive chunks); the kernel is bound by
 // the 64-cycle fp32 MFMA (60 GFLOP per MLP at 640x480 sources: ~1 ms).
-template <int NTW>      // N-tiles per wave: 2 -> 256 outputs per texel (NeRF_TP: [W0_loc | W3_loc]), 1 -> 128 (PixelNeRF: W0_loc)
+// The same kernel projects a tri-plane through the WORLD columns (in_ch = 128, chunks c0 = 64..79 of the stream: packed k =
+// [local 512 | world 128 | pe]) for mlp_tp_hpp.hip.
+template <int NTW, int NC>      // N-tiles per wave: 2 -> 256 outputs per texel (NeRF_TP: [W0 | W3 skip]), 1 -> 128 (PixelNeRF: W0_loc); NC = in_ch / 8
 __global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restrict__ F, const f32x4* __restrict__ wx, int KC,
-                                                           long T, float* __restrict__ G) {
+                                                           long T, float* __restrict__ G, int c0) {
+    constexpr int in_ch = NC * 8;
     LaneCtx L;
     L.init();
     const long t0 = (long)blockIdx.x * 64;
@@ -884,13 +949,13 @@ __global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restric
     for (int mt = 0; mt < 2; ++mt) {
         long t = t0 + mt * 32 + L.l31;
         if (t >= T) t = T - 1;
-        frow[mt] = F + t * 512 + 4 * L.half;
+        frow[mt] = F + t * in_ch + 4 * L.half;
     }
 #pragma unroll 2
-    for (int c = 0; c < 64; ++c) {
+    for (int c = 0; c < NC; ++c) {
         f32x4 a[NTW], b[2];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) a[nt] = wx[((NTW * L.wv + nt) * KC + c) * 64 + L.lane];
+        for (int nt = 0; nt < NTW; ++nt) a[nt] = wx[((NTW * L.wv + nt) * KC + c0 + c) * 64 + L.lane];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) b[mt] = *reinterpret_cast<const f32x4*>(frow[mt] + 8 * c);
 #pragma unroll
@@ -978,14 +1043,16 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipS
 }
 
 void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,
-                          hipStream_t s, int channels) {
+                          hipStream_t s, int channels, int in_ch, int first_chunk) {
     if (texels <= 0) return;
-    if (channels == 128)
-        hipLaunchKernelGGL(k_tp_preproject<1>, dim3((unsigned)((texels + 63) / 64)), dim3(256), 0, s, latent_cl,
-                           reinterpret_cast<const f32x4*>(wpack_f32_stage_x), kc_x, texels, proj);
-    else
-        hipLaunchKernelGGL(k_tp_preproject<2>, dim3((unsigned)((texels + 63) / 64)), dim3(256), 0, s, latent_cl,
-                           reinterpret_cast<const f32x4*>(wpack_f32_stage_x), kc_x, texels, proj);
+    const dim3 grid((unsigned)((texels + 63) / 64));
+    const f32x4* wx = reinterpret_cast<const f32x4*>(wpack_f32_stage_x);
+    if (channels == 128 && in_ch == 512)
+        hipLaunchKernelGGL((k_tp_preproject<1, 64>), grid, dim3(256), 0, s, latent_cl, wx, kc_x, texels, proj, first_chunk);
+    else if (in_ch == 512)
+        hipLaunchKernelGGL((k_tp_preproject<2, 64>), grid, dim3(256), 0, s, latent_cl, wx, kc_x, texels, proj, first_chunk);
+    else          // in_ch == 128: a tri-plane through the world columns
+        hipLaunchKernelGGL((k_tp_preproject<2, 16>), grid, dim3(256), 0, s, latent_cl, wx, kc_x, texels, proj, first_chunk);
 }
 
 void launch_tp_dirsum(const float* viewdirs, int R, const TpViews& views, int nv, float* dirsum, hipStream_t s) {

@@ -1,0 +1,602 @@
+// NeO-360 decoder point evaluator, split-fp16 arithmetic, with ALL FOUR gathered maps pre-projected through the first-layer
+// weights once per (scene, MLP): the pixel-aligned latent (as mlp_tp_hp.hip) AND the three tri-planes.
+//
+// NeRFPPMLP (neo360/model.py:110-158) consumes the 128-channel tri-plane sum (encoder_tp_fusion_conv.py:180-206: three
+// grid_samples, summed) only through two linear maps - the world columns of pts_linears.0 and of the skip half of
+// pts_linears.3 (model.py:123-137) - exactly like the 512-channel latent.  Bilinear interpolation is linear, so
+//        W_world . sum_j bilerp(P_j) = sum_j bilerp(W_world . P_j)
+// and G_j = P_j . [W0_world | W3_world]^T (256 channels per texel, k_tp_preproject on chunks 64..79 of the fp32 fragment
+// stream) is gathered instead of P_j.  Per point-view that removes the world GEMM stage - 8 of the 12 (inside) / 14
+// (outside) streamed k-steps: 32,768 of 98,304 executed MACs with their hi/lo splits, LDS plane stores, B-fragment reads
+// and weight fragments - and replaces 3 x 512 B taps by 3 x 1 KB taps (24 more gather items per tile-view).
+//
+// Per 64-point tile and source view: descriptors and the pos_enc features (into their OWN LDS tile) first; then ONE flat
+// software pipeline over 64 gather items (4 chunks of 64 output channels x 4 row groups x 4 maps), a ring of RING tap
+// register sets deep with the tap descriptors read from LDS one item ahead; the four maps' blends of a (chunk, row group)
+// are summed in registers, travel through the 16 KB fp32 transposition tile and are ADDED to the L0 / L3-skip accumulators.
+// The only matrix work left before the L0 epilogue - the pos_enc k-steps (4 inside / 6 outside the sphere) - is issued
+// between the gather items.  L1, L2, L3, view-mean linearity and the heads are those of mlp_tp_hp.hip.
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "tp_hp_layout.h"
+
+#ifndef NEO_TPP_WPS
+#define NEO_TPP_WPS 2          // workgroups per CU
+#endif
+#ifndef NEO_TPP_RING
+#define NEO_TPP_RING 3         // tap register sets (16 VGPRs each); prefetch distance = RING - 1 items
+#endif
+#ifndef NEO_TPP_XD
+#define NEO_TPP_XD 2           // pos_enc weight fragments requested this many k-steps ahead
+#endif
+#ifndef NEO_TPP_LD
+#define NEO_TPP_LD 4           // L1..L3 weight stream prefetch distance (k-steps)
+#endif
+#ifndef NEO_TPP_TD
+#define NEO_TPP_TD 6           // tail weight stream prefetch distance
+#endif
+#ifndef NEO_TPP_ZSKIP
+#define NEO_TPP_ZSKIP 1        // gather only the maps in which some row of the tile has a weighted tap (latent / planes)
+#endif
+#ifndef NEO_TPP_MMA_INSIDE
+#define NEO_TPP_MMA_INSIDE 2   // pos_enc k-steps: 1 between the gather items of every pipeline variant, 2 only inside the all-maps pipeline (after the pipeline otherwise), 0 always after the pipeline
+#endif
+#define TPP_SYNC() __syncthreads()
+
+namespace neo {
+
+namespace {
+
+using namespace hp;
+constexpr int RING = NEO_TPP_RING;
+
+// LDS carve (4-byte words): tp_common.h's carve [0, tp::LDS_WORDS) | biases + head weights | pos_enc stage 0
+constexpr int PP_OFF_BIAS = tp::LDS_WORDS;
+constexpr int PP_OFF_XPE0 = PP_OFF_BIAS + 768 + 336;
+constexpr int PP_LDS_WORDS = PP_OFF_XPE0 + TM * 64;          // [64][64] halves x 2 planes = 16 KB; total 74,560 B: 2 workgroups per CU
+
+template <int PE_C>
+__global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, const float* __restrict__ proj, TpPlaneProj pp,
+                                                               TpScene sc, TpViews views, const float* __restrict__ rays_o,
+                                                               const float* __restrict__ rays_d,
+                                                               const float* __restrict__ viewdirs,
+                                                               const float* __restrict__ tvals,
+                                                               const float* __restrict__ far_arr, int R, int N, int chunk,
+                                                               uint32_t* __restrict__ flags, float4* __restrict__ out,
+                                                               const float* __restrict__ dirsum) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* hbase = reinterpret_cast<_Float16*>(smem + tp::OFF_ACT);
+    const HT act{hbase, hbase + TM * 128};                                   // [64][128] x 2 planes (32 KB)
+    auto fbuf = [&](int b) { return smem + tp::OFF_ACT + b * (TM * 64); };   // the same 32 KB as two fp32 [64][64] tiles
+    _Float16* xb0 = reinterpret_cast<_Float16*>(smem + PP_OFF_XPE0);
+    const HT xpe0{xb0, xb0 + TM * 64};                                       // pos_enc features 0..63, [64][64] x 2 planes
+    _Float16* dbase = reinterpret_cast<_Float16*>(smem + tp::OFF_DIR);
+    const HT dsm{dbase, dbase + TM * 32};                                    // [64][32] x 2 planes: view loop = pos_enc features 64..95
+    const HT xpe1 = dsm;                                                     //   (outside the sphere); tail = mean direction encoding
+    const tp::Scratch S = tp::carve(smem);
+    int* loc_off = S.loc_off;
+    float* loc_w = S.loc_w;
+    int* pl_off = S.pl_off;
+    float* pl_w = S.pl_w;
+
+    LaneCtx L;
+    L.init();
+    int tid = threadIdx.x;
+    const long P = (long)R * N;
+    const long tile0 = tp::xcd_tile(blockIdx.x, (P + TM - 1) / TM) * TM;
+    if (tile0 >= P) return;       // surplus workgroup of the rounded-up grid (uniform exit before any barrier)
+    const h8* wp = reinterpret_cast<const h8*>(m.wpack);
+    constexpr int KSX = ks_x(PE_C);              // k-steps per N-tile in the packed streamed stage: 8 world (unused here) + pos_enc
+    constexpr int KSP = pe_ksteps(PE_C);         // pos_enc k-steps: 4 (63 -> 64 features) / 6 (84 -> 96)
+    constexpr int NPE = PE_C == 3 ? 1 : 2;
+
+    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
+    float* dens_w = smem + tp::OFF_DENSW;
+    if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
+    float* lbias_w = smem + PP_OFF_BIAS;
+    for (int i = tid; i < 768; i += 256) lbias_w[i] = m.bias[i];
+    for (int i = tid; i < HD_RB + 3; i += 256) lbias_w[768 + i] = m.heads[i];
+    const float* lbias = lbias_w;
+    const float* lheads = lbias_w + 768;
+    TPP_SYNC();
+
+    // view means by linearity (mlp_tp_h.hip): only sum_v relu(L3_v) is accumulated per view; sum_v dir_enc_v comes ready-made
+    // per ray from k_tp_dirsum and is only needed in the tail
+    f32x16 hsum[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; }
+    const int vnt = L.wv & 1, vmt = L.wv >> 1;
+
+#pragma unroll 1
+    for (int v = 0; v < sc.nv; ++v) {
+        // per-lane indices re-derived from an opaque lane id inside the loop: keeps the swizzled LDS addresses of the
+        // loop body from being hoisted (and spilled) as loop invariants
+        asm volatile("" : "+v"(tid));
+        L.lane = tid & 63;
+        L.half = L.lane >> 5;
+        L.l31 = L.lane & 31;
+        L.key = L.lane & 15;
+        const float* rot = views.rot[v];
+        const float* trn = views.trans[v];
+        tp::view_descriptors<PROJ_TEXEL_BYTES, false, PROJ_TEXEL_BYTES>(S, L, sc, rot, trn, v, [](int, int, float) {});
+        // ---- pos_enc of this view's camera-frame point into its own tile: row = tid % 64, wave q takes chunks q and 4 + q of
+        //      stage 0 (and chunk q of stage 1).  The camera-frame point is computed here with the arithmetic of
+        //      view_descriptors (same expression, no contraction), so no barrier separates it from the descriptors. ----
+        {
+            const int row = tid & 63, q = tid >> 6;
+            const float ex = S.pe_world[row * 4], ey = S.pe_world[row * 4 + 1], ez = S.pe_world[row * 4 + 2];
+            f32x4 xv;
+            xv[0] = (rot[0] * ex + rot[1] * ey + rot[2] * ez) + trn[0];
+            xv[1] = (rot[3] * ex + rot[4] * ey + rot[5] * ez) + trn[1];
+            xv[2] = (rot[6] * ex + rot[7] * ey + rot[8] * ez) + trn[2];
+            xv[3] = S.pe_world[row * 4 + 3];
+            // a chunk = 8 features = 4 (sin, cos) PAIRS of the pair order (launch_tp_pack_hp): pair p = 4 chunk + jj = octave * C +
+            // coordinate; both features of a pair come out of one argument reduction (common.h:sincos_pair)
+            auto pe_chunk = [&](auto ldh, const HT& buf, int pstage, int hf) __attribute__((always_inline)) {
+                constexpr int LDH = decltype(ldh)::value;
+                const int chs = hf * 4 + q;                    // chunk inside this stage (wave-uniform)
+                const int ch = pstage * 8 + chs;               // chunk of the whole encoding
+                float f[8];
+                if (ch * 4 < 10 * PE_C) {                      // pairs (C = 3: chunk 7 holds pairs 28, 29 and the identity features)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if (PE_C == 3 && jj >= 2 && ch == 7) {  // pairs 30, 31 do not exist: positions 60..63 = x, y, z, 0
+                            f[2 * jj] = jj == 2 ? xv[0] : xv[2];
+                            f[2 * jj + 1] = jj == 2 ? xv[1] : 0.0f;
+                            range_see(L, f[2 * jj]); range_see(L, f[2 * jj + 1]);
+                            continue;
+                        }
+                        float x;
+                        int oct;
+                        if constexpr (PE_C == 4) {
+                            x = xv[jj];
+                            oct = ch;
+                        } else {
+                            const int p = ch * 4 + jj;         // wave-uniform: scalar arithmetic
+                            oct = p / 3;
+                            const int a = p - 3 * oct;
+                            x = a == 0 ? xv[0] : a == 1 ? xv[1] : xv[2];
+                        }
+                        sincos_pair(ldexpf(x, oct), f[2 * jj], f[2 * jj + 1]);
+                    }
+                } else {                                        // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = 0.0f;
+                    if (ch * 4 == 10 * PE_C) {
+                        range_see(L, xv[0]); range_see(L, xv[1]); range_see(L, xv[2]); range_see(L, xv[3]);
+                        f[0] = xv[0]; f[1] = xv[1]; f[2] = xv[2]; f[3] = xv[3];
+                    }
+                }
+                h8 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    h2 h, l;
+                    split2(f[e], f[e + 1], h, l);
+                    vh[e] = h[0]; vh[e + 1] = h[1];
+                    vl[e] = l[0]; vl[e + 1] = l[1];
+                }
+                const int o = chunk_off<LDH>(row, chs);
+                *reinterpret_cast<h8*>(buf.hi + o) = vh;
+                *reinterpret_cast<h8*>(buf.lo + o) = vl;
+            };
+            pe_chunk(std::integral_constant<int, 64>(), xpe0, 0, 0);
+            pe_chunk(std::integral_constant<int, 64>(), xpe0, 0, 1);
+            if constexpr (NPE == 2) pe_chunk(std::integral_constant<int, 32>(), xpe1, 1, 0);      // features 64..95 (84..95 padding)
+        }
+        TPP_SYNC();
+#if NEO_TPP_ZSKIP
+        // Which maps carry any weight for this tile (samples outside a feature map blend to exactly zero: grid_sample's zero
+        // padding).  Outside the unit sphere the far samples project outside every source image (71 % of the fine tile-views
+        // have no weighted latent tap) and often outside the tri-plane volume as well (21 %): profiles/r03_tile_footprint.json.
+        bool any_latent, any_plane;
+        {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(loc_w + L.lane * 4);
+            any_latent = __ballot(w0[0] != 0.0f || w0[1] != 0.0f || w0[2] != 0.0f || w0[3] != 0.0f) != 0ull;
+            unsigned long long zp = 0ull;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const f32x4 wj = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + L.lane) * 4);
+                zp |= __ballot(wj[0] != 0.0f || wj[1] != 0.0f || wj[2] != 0.0f || wj[3] != 0.0f);
+            }
+            any_plane = zp != 0ull;
+        }
+#else
+        const bool any_latent = true, any_plane = true;
+#endif
+
+        // ---- [L0 | L3 skip half] pre-activations: bias + four pre-projected maps (adds) + pos_enc GEMM ----
+        f32x16 accx[2][2];
+        bias_tile(accx[0][0], lbias + B_0, L.wv, L);
+        accx[0][1] = accx[0][0];
+        bias_tile(accx[1][0], lbias + B_3, L.wv, L);
+        accx[1][1] = accx[1][0];
+        {
+            const int col4 = tid & 15, rg = tid >> 4;
+            const uint32_t lane_b = 16u * col4;
+            f32x4 taps[RING][4];
+            f32x4 wsum;                                    // running sum over the maps of one (chunk, row group)
+            int4 d_off[2];                                 // tap byte offsets of the item REQUESTED next (slot = item & 1)
+            f32x4 d_w[2];                                  // tap weights of the item BLENDED next
+            // pos_enc weight fragments: k-steps 8..8+KSP-1 of N-tiles wv (L0) and 4 + wv (L3 skip) of the packed streamed stage
+            constexpr int XD = NEO_TPP_XD, XS = XD + 1;
+            h8 wh[XS][2], wl[XS][2];
+            const char* wxb = reinterpret_cast<const char*>(wp + hoff_x());
+            uint32_t wx_off[2];
+            wx_off[0] = (uint32_t)((L.wv * KSX + 8) * 2 * 64 + L.lane) * 16u;
+            wx_off[1] = (uint32_t)(((4 + L.wv) * KSX + 8) * 2 * 64 + L.lane) * 16u;
+            auto load_wk = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int kp = decltype(kc)::value;
+                if constexpr (kp < KSP) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        wh[kp % XS][nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * kp));
+                        wl[kp % XS][nt] = *reinterpret_cast<const h8*>(wxb + (wx_off[nt] + 2048u * kp + 1024u));
+                    }
+                }
+            };
+            auto mma_k = [&](auto kc) __attribute__((always_inline)) {
+                constexpr int kp = decltype(kc)::value;
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    if constexpr (kp < 4) {
+                        const int o = chunk_off<64>(mt * 32 + L.l31, (kp << 1) + L.half);
+                        bh[mt] = *reinterpret_cast<const h8*>(xpe0.hi + o);
+                        bl[mt] = *reinterpret_cast<const h8*>(xpe0.lo + o);
+                    } else {
+                        const int o = chunk_off<32>(mt * 32 + L.l31, ((kp - 4) << 1) + L.half);
+                        bh[mt] = *reinterpret_cast<const h8*>(xpe1.hi + o);
+                        bl[mt] = *reinterpret_cast<const h8*>(xpe1.lo + o);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        accx[nt][mt] = NEO_MFMA_H(wl[kp % XS][nt], bh[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[kp % XS][nt], bl[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H(wh[kp % XS][nt], bh[mt], accx[nt][mt]);
+                    }
+                load_wk(std::integral_constant<int, kp + XD>());
+            };
+            // chunk c of the summed projected maps -> accumulators (this wave's pieces: 2 per M-tile)
+            auto consume_chunk = [&](auto cc) __attribute__((always_inline)) {
+                constexpr int c = decltype(cc)::value;
+                const float* buf = fbuf(c & 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int row = mt * 32 + L.l31;
+                        const int piece = L.wv * 4 + gg * 2 + L.half;
+                        const f32x4 val = *reinterpret_cast<const f32x4*>(buf + row * 64 + ((piece ^ (row & 15)) << 2));
+                        constexpr int g0 = 2 * (c & 1);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += val[e];
+                    }
+            };
+            // The pipeline for a compile-time set of maps: MASK bit 0 = latent, bit 1 = the three planes.  G maps per
+            // (chunk, row group); item i: group i / G (chunk = group / 4, row group = group % 4), member i % G.
+            auto pipeline = [&](auto mc) __attribute__((always_inline)) {
+                constexpr int MASK = decltype(mc)::value;
+                constexpr int G = (MASK & 1) + 3 * ((MASK >> 1) & 1);
+                constexpr int NI = 16 * G;
+                // pos_enc k-step kp is issued before item mma_item(kp)
+                auto mma_here = [&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr ((NEO_TPP_MMA_INSIDE == 1 || (NEO_TPP_MMA_INSIDE == 2 && MASK == 3)) && NI > 0) {
+                        static_for<0, KSP>([&](auto kc) {
+                            constexpr int kp = decltype(kc)::value;
+                            if constexpr (i == ((2 * kp + 1) * NI) / (2 * KSP) + (NI >= 48 ? 2 : 0)) mma_k(kc);
+                        });
+                    }
+                };
+                if constexpr (NI > 0) {
+                    auto map_of = [](int i) constexpr { return (MASK & 1) ? i % G : i % G + 1; };      // 0 latent, 1..3 planes
+                    auto desc_index = [&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int mp = map_of(i), q = (i / G) % 4;
+                        if constexpr (mp == 0) return (rg + 16 * q) * 4;
+                        else return ((mp - 1) * TM + rg + 16 * q) * 4;
+                    };
+                    auto fetch_off = [&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value;
+                        if constexpr (i < NI) {
+                            if constexpr (map_of(i) == 0) d_off[i & 1] = *reinterpret_cast<const int4*>(loc_off + desc_index(ic));
+                            else d_off[i & 1] = *reinterpret_cast<const int4*>(pl_off + desc_index(ic));
+                        }
+                    };
+                    auto fetch_w = [&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value;
+                        if constexpr (i < NI) {
+                            if constexpr (map_of(i) == 0) d_w[i & 1] = *reinterpret_cast<const f32x4*>(loc_w + desc_index(ic));
+                            else d_w[i & 1] = *reinterpret_cast<const f32x4*>(pl_w + desc_index(ic));
+                        }
+                    };
+                    auto issue = [&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value;
+                        if constexpr (i < NI) {
+                            constexpr int mp = map_of(i), c = i / (4 * G);
+                            const float* base = mp == 0 ? proj : pp.p[mp == 0 ? 0 : mp - 1];
+                            const int4 off = d_off[i & 1];
+                            taps[i % RING][0] = tp::load_tap(base, (uint32_t)off.x + lane_b + 256u * c);
+                            taps[i % RING][1] = tp::load_tap(base, (uint32_t)off.y + lane_b + 256u * c);
+                            taps[i % RING][2] = tp::load_tap(base, (uint32_t)off.z + lane_b + 256u * c);
+                            taps[i % RING][3] = tp::load_tap(base, (uint32_t)off.w + lane_b + 256u * c);
+                        }
+                    };
+                    auto finish = [&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int k = i % G, c = i / (4 * G), q = (i / G) % 4;
+                        const f32x4 val = blend4(taps[i % RING], d_w[i & 1]);
+                        if constexpr (k == 0) wsum = val; else wsum = wsum + val;
+                        if constexpr (k == G - 1) {
+                            const int row = rg + 16 * q;
+                            *reinterpret_cast<f32x4*>(fbuf(c & 1) + row * 64 + ((col4 ^ (row & 15)) << 2)) = wsum;
+                        }
+                    };
+                    static_for<0, RING - 1>([&](auto ic) { fetch_off(ic); issue(ic); });
+                    fetch_off(std::integral_constant<int, RING - 1>());
+                    fetch_w(std::integral_constant<int, 0>());
+                    static_for<0, NI>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        // descriptors one item ahead: offsets of the item requested in the NEXT pass, weights of the item blended in it
+                        fetch_off(std::integral_constant<int, i + RING>());
+                        fetch_w(std::integral_constant<int, i + 1>());
+                        issue(std::integral_constant<int, i + RING - 1>());
+                        if constexpr (i % (4 * G) == 0 && i > 0) consume_chunk(std::integral_constant<int, i / (4 * G) - 1>());
+                        mma_here(ic);
+                        finish(ic);
+                        __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
+                        if constexpr (i % (4 * G) == 4 * G - 1) TPP_SYNC();
+                    });
+                    consume_chunk(std::integral_constant<int, 3>());
+                }
+                if constexpr (NEO_TPP_MMA_INSIDE == 1 && NI == 0) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
+            };
+            static_for<0, XD>([&](auto kc) { load_wk(kc); });
+            if (any_latent && any_plane) pipeline(std::integral_constant<int, 3>());
+            else if (any_plane) pipeline(std::integral_constant<int, 2>());
+            else if (any_latent) pipeline(std::integral_constant<int, 1>());
+            else pipeline(std::integral_constant<int, 0>());
+            if constexpr (NEO_TPP_MMA_INSIDE == 0) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
+            if constexpr (NEO_TPP_MMA_INSIDE == 2)
+                if (!(any_latent && any_plane)) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
+        }
+        TPP_SYNC();          // the transposition tiles alias the activation tile: every wave has consumed the last chunk
+        // ---- L0 epilogue; L1, L2, L3 as ONE weight stream of 24 k-steps (N-tile = wave) requested LD k-steps ahead
+        //      across the layer boundaries: the weights of the next layer do not wait for the barriers ----
+        {
+            constexpr int LD = NEO_TPP_LD, LS = LD + 1;
+            h8 lwh[LS], lwl[LS];
+            const char* lwb = reinterpret_cast<const char*>(wp);
+            const uint32_t lw_off = (uint32_t)(L.wv * 8 * 128 + L.lane) * 16u;
+            auto load_l = [&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g < 24) {
+                    constexpr int layer = g / 8, ks = g % 8;
+                    constexpr uint32_t base = (uint32_t)(layer == 0 ? hoff_1(PE_C) : layer == 1 ? hoff_2(PE_C) : hoff_3a(PE_C)) * 16u;
+                    lwh[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks));
+                    lwl[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks + 1024u));
+                }
+            };
+            static_for<0, LD>([&](auto gc) { load_l(gc); });
+            f32x16 acc[2];
+            store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
+            store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
+            TPP_SYNC();
+            static_for<0, 24>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int layer = g / 8, ks = g % 8;
+                if constexpr (ks == 0) {
+                    if constexpr (layer < 2) {
+                        bias_tile(acc[0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
+                        acc[1] = acc[0];
+                    } else {
+                        acc[0] = accx[1][0];
+                        acc[1] = accx[1][1];
+                    }
+                }
+                load_l(std::integral_constant<int, g + LD>());
+                h8 bh[2], bl[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<128>(mt * 32 + L.l31, (ks << 1) + L.half);
+                    bh[mt] = *reinterpret_cast<const h8*>(act.hi + o);
+                    bl[mt] = *reinterpret_cast<const h8*>(act.lo + o);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[mt] = NEO_MFMA_H(lwl[g % LS], bh[mt], acc[mt]);
+                    acc[mt] = NEO_MFMA_H(lwh[g % LS], bl[mt], acc[mt]);
+                    acc[mt] = NEO_MFMA_H(lwh[g % LS], bh[mt], acc[mt]);
+                }
+                if constexpr (ks == 7) {
+                    if constexpr (layer < 2) {
+                        TPP_SYNC();
+                        store_tile_h<true>(acc[0], act, L.wv, 0, L);
+                        store_tile_h<true>(acc[1], act, L.wv, 1, L);
+                        TPP_SYNC();
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            hsum[0][r] += relu1(acc[0][r]);
+                            hsum[1][r] += relu1(acc[1][r]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+        TPP_SYNC();           // every wave is done reading this view's tiles
+    }
+
+    // ---- view mean of the trunk -> density head (x * (1 / nv): see mlp_tp_hp.hip) ----
+    const float inv_nv = 1.0f / (float)sc.nv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hsum[0][r] = hsum[0][r] * inv_nv; hsum[1][r] = hsum[1][r] * inv_nv; }
+    store_tile_h<false>(hsum[0], act, L.wv, 0, L);
+    store_tile_h<false>(hsum[1], act, L.wv, 1, L);
+    {
+        // view mean of the direction encoding straight from the per-ray table of this launch (k_tp_dirsum: the sum over
+        // the views of the ray whose direction this point carries, quirk Q1) -> hi/lo planes; 8 features per thread
+        const int p = tid >> 2, f0 = (tid & 3) << 3;
+        const int dray = __float_as_int(S.vdir_world[p * 4 + 3]);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(dirsum + (long)dray * 32 + f0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(dirsum + (long)dray * 32 + f0 + 4);
+        h8 vh, vl;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const float a = (j < 4 ? s0[j] : s1[j - 4]) * inv_nv, b = (j < 4 ? s0[j + 1] : s1[j - 3]) * inv_nv;
+            h2 h, l;
+            split2(a, b, h, l);
+            vh[j] = h[0]; vh[j + 1] = h[1];
+            vl[j] = l[0]; vl[j + 1] = l[1];
+        }
+        const int o = chunk_off<32>(p, tid & 3);
+        *reinterpret_cast<h8*>(dsm.hi + o) = vh;
+        *reinterpret_cast<h8*>(dsm.lo + o) = vl;
+    }
+    TPP_SYNC();
+    float raw_sigma;
+    {
+        float sg = density_partial(act, dens_w, L);
+        sg += __shfl_xor(sg, 1, 64);
+        sg += __shfl_xor(sg, 2, 64);
+        raw_sigma = sg + lheads[HD_DB];
+    }
+    // ---- tail GEMMs as one weight stream of 22 k-steps, TD ahead across the stage boundaries:
+    //      bottleneck of the view mean (N-tile wave, 8 k-steps, both M-tiles), view layer 0 on [mean bottleneck | mean dir enc]
+    //      (N-tile vnt, M-tile vmt, 8 + 2 k-steps), 64 x 64 (4 k-steps) ----
+    {
+        const char* twb = reinterpret_cast<const char*>(wp);
+        constexpr int TD = NEO_TPP_TD, TS = TD + 1;
+        h8 twh[TS], twl[TS];
+        auto load_t = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 22) {
+                constexpr int stage = g < 8 ? 0 : g < 18 ? 1 : 2;
+                constexpr int ks = stage == 0 ? g : stage == 1 ? g - 8 : g - 18;
+                constexpr int KS = stage == 0 ? 8 : stage == 1 ? 10 : 4;
+                constexpr uint32_t base = (uint32_t)(stage == 0 ? hoff_b(PE_C) : stage == 1 ? hoff_v0(PE_C) : hoff_v1(PE_C)) * 16u;
+                const int nt = stage == 0 ? L.wv : vnt;
+                const uint32_t off = base + (uint32_t)((nt * KS + ks) * 128 + L.lane) * 16u;
+                twh[g % TS] = *reinterpret_cast<const h8*>(twb + off);
+                twl[g % TS] = *reinterpret_cast<const h8*>(twb + off + 1024u);
+            }
+        };
+        static_for<0, TD>([&](auto gc) { load_t(gc); });
+        f32x16 acc2[2], y;
+        static_for<0, 22>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            load_t(std::integral_constant<int, g + TD>());
+            if constexpr (g < 8) {
+                if constexpr (g == 0) {
+                    bias_tile(acc2[0], lbias + B_B, L.wv, L);
+                    acc2[1] = acc2[0];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int o = chunk_off<128>(mt * 32 + L.l31, (g << 1) + L.half);
+                    const h8 bh = *reinterpret_cast<const h8*>(act.hi + o);
+                    const h8 bl = *reinterpret_cast<const h8*>(act.lo + o);
+                    acc2[mt] = NEO_MFMA_H(twl[g % TS], bh, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bl, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bh, acc2[mt]);
+                }
+                if constexpr (g == 7) {
+                    TPP_SYNC();
+                    store_tile_h<false>(acc2[0], act, L.wv, 0, L);
+                    store_tile_h<false>(acc2[1], act, L.wv, 1, L);
+                    TPP_SYNC();
+                }
+            } else {
+                constexpr bool v0 = g < 18;
+                constexpr int ks = v0 ? g - 8 : g - 18;
+                if constexpr (ks == 0) bias_tile(y, lbias + (v0 ? B_V0 : B_V1), vnt, L);
+                h8 bh, bl;
+                if constexpr (v0 && ks >= 8) {
+                    const int o = chunk_off<32>(vmt * 32 + L.l31, ((ks - 8) << 1) + L.half);
+                    bh = *reinterpret_cast<const h8*>(dsm.hi + o);
+                    bl = *reinterpret_cast<const h8*>(dsm.lo + o);
+                } else {
+                    const int o = chunk_off<128>(vmt * 32 + L.l31, (ks << 1) + L.half);
+                    bh = *reinterpret_cast<const h8*>(act.hi + o);
+                    bl = *reinterpret_cast<const h8*>(act.lo + o);
+                }
+                y = NEO_MFMA_H(twl[g % TS], bh, y);
+                y = NEO_MFMA_H(twh[g % TS], bl, y);
+                y = NEO_MFMA_H(twh[g % TS], bh, y);
+                if constexpr (g == 17) {
+                    TPP_SYNC();
+                    store_tile_h<true>(y, act, vnt, vmt, L);
+                    TPP_SYNC();
+                }
+                if constexpr (g == 21) {
+                    TPP_SYNC();
+                    store_tile_h<true>(y, act, vnt, vmt, L);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    TPP_SYNC();
+    {
+        const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
+        const float* wr = lheads + HD_RW;
+        float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int chunk_i = part * 2 + ((c + part) & 1);
+            const int o = chunk_off<128>(pt, chunk_i);
+            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = (float)vh[e] + (float)vl[e];
+                r += h * wr[chunk_i * 8 + e];
+                g += h * wr[64 + chunk_i * 8 + e];
+                b += h * wr[128 + chunk_i * 8 + e];
+            }
+        }
+        r += __shfl_xor(r, 1, 64); r += __shfl_xor(r, 2, 64);
+        g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
+        b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
+        range_commit(L, m.flags);
+        const long gi = tile0 + pt;
+        if (part == 0 && gi < P) {
+            out[gi] = make_float4(colour_act(r + lheads[HD_RB]), colour_act(g + lheads[HD_RB + 1]),
+                                  colour_act(b + lheads[HD_RB + 2]), density_act(raw_sigma));
+        }
+    }
+}
+
+}  // namespace
+
+void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj, const TpPlaneProj& pp, const TpScene& sc,
+                       const TpViews& views, const float* rays_o, const float* rays_d, const float* viewdirs,
+                       const float* tvals, const float* far, int R, int N, int chunk, uint32_t* flags, float* out,
+                       const float* dirsum, hipStream_t s) {
+    const long P = (long)R * N;
+    if (P <= 0) return;
+    const size_t lds = (size_t)PP_LDS_WORDS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hpp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hpp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long tiles = tp::xcd_grid((P + TM - 1) / TM);
+    if (input_ch == 3)
+        hipLaunchKernelGGL(k_tp_mlp_hpp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, pp, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), dirsum);
+    else
+        hipLaunchKernelGGL(k_tp_mlp_hpp<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, proj, pp, sc, views, rays_o, rays_d,
+                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out), dirsum);
+}
+
+}  // namespace neo

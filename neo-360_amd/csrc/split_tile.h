@@ -100,9 +100,52 @@ __device__ __forceinline__ float relu1(float x) {
     return __builtin_bit_cast(float, xi > 0 ? xi : 0);
 }
 
-// D tile (N-tile nt, M-tile mt) -> (ReLU) -> split -> the two planes of an activation tile with LDH halves per row
+// D tile (N-tile nt, M-tile mt) -> (ReLU) -> split -> the two planes of an activation tile with LDH halves per row.
+// D holds outputs 8g + 4 half + e (e < 4) of point l31 in 4 consecutive registers: lanes l and l + 32 hold the two 8-byte
+// halves of one 16-byte chunk.  The 8-byte form (ds_write_b64: lane groups of 16 CONSECUTIVE lanes, banks (a/4) mod 32)
+// is 2-way bank-conflicted - the 16 rows of a group map onto 8 distinct slot residues.  NEO_SPLIT_STORE128:
+// v_permlane32_swap exchanges the halves of a PAIR of chunks (2gp, 2gp + 1), lanes 0-31 then own chunk 2gp and lanes 32-63
+// chunk 2gp + 1 of their point: one ds_write_b128 per plane and chunk pair (lane groups of 8 consecutive lanes = 8 rows with
+// 8 distinct slot residues under the XOR swizzle: conflict-free), as mlp_vanilla_h.hip does since round 2.  Same bits in LDS.
+#ifndef NEO_SPLIT_STORE128
+#define NEO_SPLIT_STORE128 1
+#endif
+typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void swap_halves32(su32x2& x, su32x2& y) {      // x[lanes 32-63] <-> y[lanes 0-31]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const su32x2 r = __builtin_amdgcn_permlane32_swap(x[i], y[i], false, false);   // builtin: the compiler inserts the wait states
+        x[i] = r[0];
+        y[i] = r[1];
+    }
+}
 template <bool RELU, int LDH = 128>
 __device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, int nt, int mt, const LaneCtx& L) {
+#if NEO_SPLIT_STORE128
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+        h4 vh[2], vl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = acc[4 * (2 * gp + u) + e];
+                v[e] = RELU ? relu1(x) : x;
+            }
+            range_see4(L, v);
+            split4(v, vh[u], vl[u]);
+        }
+        su32x2 xh = __builtin_bit_cast(su32x2, vh[0]), yh = __builtin_bit_cast(su32x2, vh[1]);
+        su32x2 xl = __builtin_bit_cast(su32x2, vl[0]), yl = __builtin_bit_cast(su32x2, vl[1]);
+        swap_halves32(xh, yh);      // lanes < 32: (xh | yh) = chunk 2gp; lanes >= 32: chunk 2gp + 1
+        swap_halves32(xl, yl);
+        const int o = chunk_off<LDH>(mt * 32 + L.l31, nt * 4 + 2 * gp + L.half);
+        *reinterpret_cast<su32x4*>(act.hi + o) = su32x4{xh[0], xh[1], yh[0], yh[1]};
+        *reinterpret_cast<su32x4*>(act.lo + o) = su32x4{xl[0], xl[1], yl[0], yl[1]};
+    }
+#else
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 v;
@@ -118,6 +161,7 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, i
         *reinterpret_cast<h4*>(act.hi + o) = vh;
         *reinterpret_cast<h4*>(act.lo + o) = vl;
     }
+#endif
 }
 
 

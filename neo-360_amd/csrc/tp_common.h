@@ -208,7 +208,9 @@ __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile
 // pre-projected map of mlp_tp_hp.hip).
 // DIRS = false: the view-direction encoding is not computed here (mlp_tp_hp.hip takes the per-ray sum over the views
 // from a table built once per launch, k_tp_dirsum).
-template <int LOC_TEXEL_BYTES = 2048, bool DIRS = true, class PutDir>
+// PL_TEXEL_BYTES: bytes per tri-plane texel the plane taps address (128 fp32 channels, or 256 for the pre-projected
+// planes of mlp_tp_hpp.hip).
+template <int LOC_TEXEL_BYTES = 2048, bool DIRS = true, int PL_TEXEL_BYTES = 128 * 4, class PutDir>
 __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx& L, const TpScene& sc,
                                                  const float* rot, const float* trn, int v, PutDir put_dir) {
     int* loc_off = S.loc_off; float* loc_w = S.loc_w; int* pl_off = S.pl_off; float* pl_w = S.pl_w;
@@ -248,7 +250,7 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 t = bilinear_taps(ga, gb, sc.Wp, sc.Hp);
                 dst_off = pl_off + (L.wv - 1) * TM * 4; dst_w = pl_w + (L.wv - 1) * TM * 4;
                 base = v * sc.Hp * sc.Wp;
-                texel_bytes = 128 * 4;
+                texel_bytes = PL_TEXEL_BYTES;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

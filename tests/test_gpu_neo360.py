@@ -76,7 +76,7 @@ def test_sharp_density(golden):
                               golden("g4_neo_sharp_noise"), "sharp")
 
 
-@pytest.mark.parametrize("preproject", [True, False])
+@pytest.mark.parametrize("preproject", [True, 2, False])
 def test_reference_sample_counts_1024(golden, preproject):
     """One reference-sized chunk: 1024 rays, 128 coarse + 256 fine, fg + bg, 3 views; both split evaluators
     (latent pre-projected through the first-layer weights = default, and the reference's operation order)."""
@@ -93,7 +93,7 @@ def test_preprojection_is_a_reassociation(golden):
     """Per-point outputs of the pre-projected evaluator vs the evaluator that gathers the 512-channel latent and
     multiplies it per point: identical up to fp32 reassociation (W.bilerp(F) = bilerp(W.F)), on every slot."""
     from neo360_amd import ops
-    a, b = _net(32, 64, preproject=True), _net(32, 64, preproject=False)
+    a, b, c = _net(32, 64, preproject=True), _net(32, 64, preproject=False), _net(32, 64, preproject=2)
     batch = _batch(256)
     far, _ = ops.intersect_sphere(batch["rays_o"], batch["rays_d"])
     t_fg = torch.linspace(0.03, 0.97, 65, device=DEV)[None, :] * far.reshape(-1, 1)
@@ -102,17 +102,23 @@ def test_preprojection_is_a_reassociation(golden):
         ya, yb = a.eval_mlp(slot, batch, tv, far=far), b.eval_mlp(slot, batch, tv, far=far)
         assert max_abs(ya[..., :3], yb[..., :3]) < 5e-6, slot
         assert max_abs(ya[..., 3], yb[..., 3]) < 2e-5, slot          # softplus densities reach O(10)
+        # the same reassociation applied to the three tri-planes (world columns): mlp_tp_hpp.hip
+        yc = c.eval_mlp(slot, batch, tv, far=far)
+        assert max_abs(yc[..., :3], yb[..., :3]) < 5e-6, slot
+        assert max_abs(yc[..., 3], yb[..., 3]) < 2e-5, slot
     # new weights invalidate the projection
     sd = synth.nerf_tp_state(3)
-    a.load_state_dict(sd); b.load_state_dict(sd)
+    a.load_state_dict(sd); b.load_state_dict(sd); c.load_state_dict(sd)
     ya, yb = a.eval_mlp(1, batch, t_fg, far=far), b.eval_mlp(1, batch, t_fg, far=far)
     assert max_abs(ya, yb) < 2e-5
+    assert max_abs(c.eval_mlp(1, batch, t_fg, far=far), yb) < 2e-5
     # and so does a new scene
     sc = cases.small_scene(seed=11)
-    for net in (a, b):
+    for net in (a, b, c):
         net.set_scene(sc["plane_xz"].to(DEV), sc["plane_xy"].to(DEV), sc["plane_yz"].to(DEV), sc["latent"].to(DEV), sc["image_wh"])
     ya, yb = a.eval_mlp(3, batch, t_bg, far=far), b.eval_mlp(3, batch, t_bg, far=far)
     assert max_abs(ya, yb) < 2e-5
+    assert c.preproject == 2 and max_abs(c.eval_mlp(3, batch, t_bg, far=far), yb) < 2e-5
 
 
 @pytest.mark.parametrize("nv", [1, 2, 5])

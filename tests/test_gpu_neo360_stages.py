@@ -19,10 +19,11 @@ R, NC, NF = 96, 128, 256
 _ORACLE_L0 = {}          # level-0 oracle outputs are the same for every kernel variant: evaluated once per session
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f16x3-noproj", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3-pp2", "f16x3-noproj", "f32"])
 def setup(request):
-    """All four point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent
-    (default), split-fp16 in the reference's operation order, exact fp32 MFMA."""
+    """All point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent (default),
+    with the tri-planes pre-projected as well ("pp2", mlp_tp_hpp.hip), split-fp16 in the reference's operation order,
+    exact fp32 MFMA."""
     params = synth.nerf_tp_state(0)
     scene = cases.small_scene()
     net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
@@ -31,7 +32,7 @@ def setup(request):
     net.load_state_dict(params)
     net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
                   scene["latent"].to(DEV), scene["image_wh"],
-                  preproject=not request.param.endswith("noproj"))
+                  preproject=2 if request.param.endswith("pp2") else not request.param.endswith("noproj"))
     batch = cases.neo_batch(cases.strided_rays(R))
     return params, scene, net, batch, {k: v.to(DEV) for k, v in batch.items()}
 

@@ -1,4 +1,6 @@
-"""Micro-benchmark of the NeO-360 point-evaluator kernel alone (env: PREC=f16x3|f32, R, N, SLOT, REPS).
+"""Micro-benchmark of the NeO-360 point-evaluator kernel alone (env: PREC=f16x3|f32, R, N, SLOT or SLOTS=1,3,0,2, REPS,
+PP=0|1|2 pre-projection mode).  SLOTS runs several slots in one process (N = 385 for the fine slots 1 / 3, 129 for 0 / 2) and
+prints socket power / shader clock sampled during each timed loop (neo360_amd.telemetry).
 Same synthetic scene as bench.py --workload neo360 (3 source views, 240x320 latent, 120x160 planes)."""
 import os, sys, time
 import torch
@@ -13,6 +15,8 @@ SLOT, REPS = int(os.environ.get("SLOT", 1)), int(os.environ.get("REPS", 3))
 NV = 3
 net = models.NeRF_TP(num_src_views=NV).to(dev)
 net.precision = PREC
+if os.environ.get("PP") is not None:
+    net.preproject = {"0": False, "1": True, "2": 2}[os.environ["PP"]]
 net.poll_flags = os.environ.get("POLL", "1") != "0"       # POLL=0: timing ablations produce garbage operands
 SCALE = float(os.environ.get("SCALE", 1.0))      # 0: all-zero weights and features (power / clock envelope experiments)
 SCALE_W = float(os.environ.get("SCALE_W", SCALE))   # weights only / features only: which operands carry the power
@@ -30,10 +34,6 @@ poses, sfocal, centre = synth.source_views(NV, W, H)
 rays = {"rays_o": ro[sel].contiguous(), "rays_d": rd[sel].contiguous(), "viewdirs": vd[sel].contiguous(),
         "src_poses": poses.to(dev), "src_focal": sfocal.to(dev), "src_c": centre.to(dev)}
 far, _ = ops.intersect_sphere(rays["rays_o"], rays["rays_d"])
-if SLOT < 2:
-    t = torch.linspace(0.02, 0.98, N, device=dev)[None, :] * far.reshape(-1, 1)
-else:
-    t = torch.linspace(0.98, 0.02, N, device=dev)[None, :].expand(R, N).contiguous()
 _eval = net.eval_mlp
 def eval_mlp(*a, **k):
     try:
@@ -43,18 +43,31 @@ def eval_mlp(*a, **k):
             raise
         return torch.zeros(1, device=dev)
 net.eval_mlp = eval_mlp
-for _ in range(1):
-    net.eval_mlp(SLOT, rays, t, far=far)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(REPS):
-    out = net.eval_mlp(SLOT, rays, t, far=far)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / REPS
-pe = 63 if SLOT < 2 else 84
-macs = NV * ((pe + 640) * 128 + 2 * 128 * 128 + (pe + 640 + 128) * 128 + 128 * 128 + 155 * 64) + 128 + 64 * 64 + 64 * 3
-print("%s %s slot %d R=%d N=%d  %.2f ms  %.1f algorithmic TFLOP/s  checksum %.6f" % (
-    os.environ.get("TAG", ""), PREC, SLOT, R, N, dt * 1e3, R * N * macs * 2 / dt / 1e12, float(out.double().sum())))
+from neo360_amd import telemetry
+SLOTS = [int(x) for x in os.environ["SLOTS"].split(",")] if os.environ.get("SLOTS") else [SLOT]
+for SLOT in SLOTS:
+    if os.environ.get("SLOTS"):
+        N = 385 if SLOT in (1, 3) else 129
+    if SLOT < 2:
+        t = torch.linspace(0.02, 0.98, N, device=dev)[None, :] * far.reshape(-1, 1)
+    else:
+        t = torch.linspace(0.98, 0.02, N, device=dev)[None, :].expand(R, N).contiguous()
+    for _ in range(2):
+        net.eval_mlp(SLOT, rays, t, far=far)
+    torch.cuda.synchronize()
+    with telemetry.Sampler(0, period_s=0.02) as tel:
+        t0 = time.perf_counter()
+        for _ in range(REPS):
+            out = net.eval_mlp(SLOT, rays, t, far=far)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / REPS
+    ts = tel.summary()
+    pe = 63 if SLOT < 2 else 84
+    macs = NV * ((pe + 640) * 128 + 2 * 128 * 128 + (pe + 640 + 128) * 128 + 128 * 128 + 155 * 64) + 128 + 64 * 64 + 64 * 3
+    print("%s %s pp=%s slot %d R=%d N=%d  %.3f ms  %.1f algorithmic TFLOP/s  checksum %.6f  sclk %s MHz  power %s W (%s samples)" % (
+        os.environ.get("TAG", ""), PREC, int(net.preproject), SLOT, R, N, dt * 1e3, R * N * macs * 2 / dt / 1e12, float(out.double().sum()),
+        ("%.0f" % ts["sclk_mhz_mean"]) if ts.get("sclk_mhz_mean") else "?", ("%.0f" % ts["power_w_mean"]) if ts.get("power_w_mean") else "?",
+        ts.get("telemetry_samples", 0)), flush=True)
 if os.environ.get("TRACE"):
     # variant built with -DNEO_TP_TRACE=1: per-phase s_memtime sums of wave 0 of every workgroup
     import ctypes
