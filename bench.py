@@ -255,7 +255,7 @@ class Runner:
         self.net.precision = precision
         self.kernel_name = kernel + ("_h" if self.split else "")
         if workload == "neo360" and self.split and getattr(self.net, "preproject", False):
-            self.kernel_name = "k_tp_mlp_hpp" if self.net.preproject == 2 and self.net.preproject is not True else "k_tp_mlp_hp"
+            self.kernel_name = "k_tp_mlp_hpp" if self.net.preproject in (2, 3) and self.net.preproject is not True else "k_tp_mlp_hp"
         self.c2w = synth.look_at_origin(40.0)
         self.R = H * W
         self.lo, self.hi = shard_bounds(self.R, world, rank, unit=CHUNK)

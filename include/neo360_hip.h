@@ -196,7 +196,9 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
  * enable == 0: the latent itself is gathered and multiplied per point (the reference's operation order).
  * enable == 2: the three tri-planes are pre-projected the same way through the world columns (the 128-channel plane
  * sum of encoder_tp_fusion_conv.py:180-206 enters pts_linears.0 / .3 linearly too, model.py:123-137): no per-point world
- * GEMM stage, four 256-channel maps are gathered, blended and added; 1 KB per plane texel and slot on top. */
+ * GEMM stage, four 256-channel maps are gathered, blended and added; 1 KB per plane texel and slot on top.
+ * enable == 3: as 2 for slots 1..3, as 1 for slot 0 (the coarse level inside the sphere: its widely spaced samples share
+ * no texels, the larger taps cost more than the GEMM stage they replace). */
 int neo_tp_set_preproject(neo_ctx* ctx, int enable);
 
 /* `predict` + the feature lookups for one region at given sample positions

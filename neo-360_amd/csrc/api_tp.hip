@@ -57,7 +57,11 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             // ray alone: summed once per ray here instead of once per sample and view inside the evaluator
             if (ctx->tp_dirsum.reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
             neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum.as<float>(), s);
-            if (ctx->preproject == 2) {
+            // mode 2: every slot; mode 3: every slot but the coarse one inside the sphere (slot 0), whose widely spaced samples
+            // share no texels - there the 24 extra 1 KB gather items cost more than the world GEMM stage they replace
+            // (profiles/r04_tp_hp_experiments.log: 4.03 vs 3.82 ms; the other three launches gain 0 / 0 / 7 %)
+            const int slot_index = static_cast<int>(&sl - ctx->tp);
+            if (ctx->preproject == 2 || (ctx->preproject == 3 && slot_index != 0)) {
                 // the tri-planes through this slot's [W0_world | W3_world] (chunks 64..79 of the fp32 fragment stream)
                 if (sl.projpl_weights != sl.weights_epoch || sl.projpl_scene != ctx->scene_epoch) {
                     const long texels = static_cast<long>(sc.nv) * sc.Hp * sc.Wp;
@@ -168,12 +172,12 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
 
 int neo_tp_set_preproject(neo_ctx* ctx, int enable) {
     ENTER(ctx);
-    REQUIRE(enable >= 0 && enable <= 2, "preproject mode must be 0 (off), 1 (latent) or 2 (latent + tri-planes)");
+    REQUIRE(enable >= 0 && enable <= 3, "preproject mode must be 0 (off), 1 (latent), 2 (latent + tri-planes) or 3 (2 except slot 0)");
     ctx->preproject = enable;
     for (auto& sl : ctx->tp) sl.range_checked = 0;       // the other fragment set is checked at its first launch
     if (!ctx->preproject)
         for (auto& sl : ctx->tp) { sl.proj.release(); sl.proj_weights = sl.proj_scene = 0; }
-    if (ctx->preproject != 2)
+    if (ctx->preproject < 2)
         for (auto& sl : ctx->tp) {
             for (auto& b : sl.proj_pl) b.release();
             sl.projpl_weights = sl.projpl_scene = 0;

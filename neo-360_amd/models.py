@@ -330,11 +330,12 @@ class NeRF_TP(_HipModule):
         # split path: gather the latent pre-projected through each MLP's first-layer weights (256 instead of 512
         # channels per tap, 51 % fewer MACs per point-view; see csrc/mlp_tp_hp.hip).  False: the reference's order.
         # 2: the tri-planes are pre-projected through the world columns as well (csrc/mlp_tp_hpp.hip): no world GEMM stage.
-        self.preproject = {"0": False, "1": True, "2": 2}.get(os.environ.get("NEO360_TP_PREPROJECT", "1"), True)
+        # 3: mode 2 for every MLP but fg_coarse (mode 1 there).
+        self.preproject = {"0": False, "1": True, "2": 2, "3": 3}.get(os.environ.get("NEO360_TP_PREPROJECT", "1"), True)
 
     def _context(self, device):
         ctx = super()._context(device)
-        mode = 2 if (self.preproject == 2 and self.preproject is not True) else int(bool(self.preproject))
+        mode = int(self.preproject) if (self.preproject in (2, 3) and self.preproject is not True) else int(bool(self.preproject))
         if getattr(ctx, "_preproject", None) != mode:
             _lib.check(ctx.lib.neo_tp_set_preproject(ctx.handle, mode))
             ctx._preproject = mode
@@ -367,7 +368,7 @@ class NeRF_TP(_HipModule):
         self._scene_src = None
         self._scene_ctx = None
         if preproject is not None:
-            self.preproject = 2 if (preproject == 2 and preproject is not True) else bool(preproject)
+            self.preproject = int(preproject) if (preproject in (2, 3) and preproject is not True) else bool(preproject)
         planes = [f32(p, "plane") for p in (plane_xz, plane_xy, plane_yz)]
         latent = f32(latent, "latent")
         ctx = self._context(latent.device)

@@ -44,6 +44,24 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_optional():
+    """Like `golden`, but None for a fixture that has not been generated (the per-ray flip sizes are evidence the rule
+    uses when it is there; without it the coarser fixture-wide bound applies)."""
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            path = os.path.join(GOLDEN, name + ".npz")
+            if not os.path.exists(path):
+                return None
+            with np.load(path) as z:
+                cache[name] = {k: torch.from_numpy(z[k]) for k in z.files}
+        return cache[name]
+
+    return load
+
+
+@pytest.fixture(scope="session")
 def built_lib():
     """The in-tree HIP library (built on demand; hipcc cross-compiles without a GPU)."""
     from neo360_amd import build
@@ -112,43 +130,63 @@ FLIP_MARGIN = 1e-6      # ~16 ulps of a cdf in [0,1]: what faithful fp32 evaluat
                         # GPU-vs-reference coarse weights 5e-7, profiles/r03_full_chunk_anatomy.log)
 
 
-def check_vs_reference_noise(got, g, noise, label, tol=1e-4):
+FLIP_PRONE_MAX_FRAC = 0.10   # a fixture with more flip-prone rays than this would make the exemption the rule: fail instead
+ABOVE_TOL_MAX_FRAC = 0.005   # rays that may exceed 1e-4 at all (observed over 9 fixtures: <= 0.2 %, profiles/r04_parity_report.json)
+
+
+def check_vs_reference_noise(got, g, noise, label, tol=1e-4, flip=None):
     """End-to-end NeO-360 contract, separated by how well the REFERENCE determines each ray.  Evidence, all produced by
-    the reference itself in the build container (tests/golden/make_golden.py:g4_neo_noise):
+    the reference itself in the build container (tests/golden/make_golden.py:g4_neo_noise, g4_neo_flip):
       noise_<k>   per ray and output |ref32 - ref64| (its decoder run in fp32 = the fixture g, and by its own fp64 twin;
-                  for the full-size fixture also the maximum over fp32 runs with every weight moved within +-1 ulp);
+                  for the full-size fixtures also the maximum over fp32 runs with every weight moved within +-1 ulp);
       margin_bg1  per ray min_ij |u_j - cdf_i| inside its inverse-CDF sampler for the background fine level.  There the
                   bins DEscend (neo360/model.py:319-331), bin0 / bin1 are always the first / last bin, and the sampler
                   is DISCONTINUOUS at every u_j = cdf_i: one of the 256 new samples crosses the whole range.  A ray with
                   margin < 1e-6 flips under any re-evaluation of the coarse level that is not bit-identical - which rays
                   do flip differs from one realisation to the next (fp64 twin, ulp trials and the GPU each flip a
-                  different handful of the ~6 % flip-prone rays), so no finite set of twins can list them, the margin does.
+                  different handful of the ~6 % flip-prone rays), so no finite set of twins can list them, the margin does;
+      flip_<k>    (fixture <name>_flip) per ray and output what crossing that ray's near-threshold quantiles DOES: the
+                  reference's fp32 forward with its sampler's quantiles shifted by +-2e-6, max |shifted - fixture|.
     Rule:
       * a ray with noise < 1e-5 and margin >= 1e-6 must meet 1e-4 on every output - no exceptions;
       * a ray the reference disagrees with itself on (n >= 1e-5) must land within 1e-4 + 3 n;
-      * a flip-prone ray (margin < 1e-6) must land within 1e-4 + 3 max(n, F), F = the largest self-disagreement the
-        reference shows on ANY ray of the fixture for that output (the size of a flip, ~1e-4), and at most 2 % of the
-        rays may exceed 1e-4 at all.
+      * a flip-prone ray (margin < 1e-6) must land within 1e-4 + 3 max(n, f): n its own self-noise, f ITS OWN flip size
+        (without a flip fixture: the largest self-disagreement of the fixture, the round-3 rule);
+      * at most 10 % of a fixture's rays may be flip-prone and at most 0.5 % of its rays may exceed 1e-4 at all.
     Records max / p99 / counts per output in the parity report."""
     rec = {}
     nrays = int(noise["noise_rgb1"].numel())
-    flip = (noise["margin_bg1"] < FLIP_MARGIN) if "margin_bg1" in noise else torch.zeros(nrays, dtype=torch.bool)
+    has_margin = "margin_bg1" in noise
+    flipm = (noise["margin_bg1"] < FLIP_MARGIN) if has_margin else torch.zeros(nrays, dtype=torch.bool)
+    assert int(flipm.sum()) <= FLIP_PRONE_MAX_FRAC * nrays, (label, "flip-prone rays", int(flipm.sum()), nrays)
+    strict_ok = True
     for k in NEO_KEYS:
         err = per_ray_abs(got[k] - g[k])
         n = noise["noise_" + k]
-        well = (n < 1e-5) & ~flip
+        well = (n < 1e-5) & ~flipm
         F = float(n.max())
-        bound = tol + 3.0 * torch.where(flip, torch.clamp(n, min=F), n)
-        rec[k] = dict(max=float(err.max()), p99=float(err.quantile(0.99)), max_well_conditioned=float(err[well].max()),
-                      self_noise_rays=int((n >= 1e-5).sum()), flip_prone_rays=int(flip.sum()),
-                      rays_above_1e_4=int((err >= tol).sum()), reference_self_noise_max=F, rays=int(err.numel()))
-        assert float(err[well].max()) < tol, (label, k, "well-conditioned ray above 1e-4", float(err[well].max()))
+        if flip is not None:
+            f = flip["flip_" + k]
+            bound = tol + 3.0 * torch.where(flipm, torch.maximum(n, f), n)
+        else:
+            bound = tol + 3.0 * torch.where(flipm, torch.clamp(n, min=F), n)
+        worst_well = float(err[well].max()) if bool(well.any()) else 0.0
+        # the round-2 rule (no margin exemption: n < 1e-5 => 1e-4, else 1e-4 + 3 n), recorded, not asserted
+        strict_ok = strict_ok and bool((err <= torch.where(n < 1e-5, torch.full_like(n, tol), tol + 3.0 * n)).all())
+        rec[k] = dict(max=float(err.max()), p99=float(err.quantile(0.99)), max_well_conditioned=worst_well,
+                      self_noise_rays=int((n >= 1e-5).sum()), flip_prone_rays=int(flipm.sum()),
+                      rays_above_1e_4=int((err >= tol).sum()), reference_self_noise_max=F, rays=int(err.numel()),
+                      flip_bound="per-ray" if flip is not None else "fixture-max")
+        assert worst_well < tol, (label, k, "well-conditioned ray above 1e-4", worst_well)
         bad = ~well
         if bool(bad.any()):
             excess = err[bad] - bound[bad]
-            assert float(excess.max()) <= 0.0, (label, k, "ill-conditioned ray beyond the reference's own noise",
+            assert float(excess.max()) <= 0.0, (label, k, "ill-conditioned ray beyond the reference's own noise / flip size",
                                                 float(err[bad].max()), F)
-        assert int((err >= tol).sum()) <= max(1, int(0.02 * err.numel())), (label, k, "too many rays above 1e-4")
+        assert int((err >= tol).sum()) <= max(1, int(ABOVE_TOL_MAX_FRAC * err.numel())), (label, k, "too many rays above 1e-4",
+                                                                                         int((err >= tol).sum()))
+    rec["passes_rule_without_margin_exemption"] = strict_ok
+    rec["rays_above_1e_4_any_output"] = int(torch.stack([per_ray_abs(got[k] - g[k]) >= tol for k in NEO_KEYS]).any(dim=0).sum())
     mse = float(((got["rgb1"].clamp(0, 1) - g["rgb1"].clamp(0, 1)) ** 2).mean())
     rec["psnr_db_vs_reference"] = float("inf") if mse == 0 else -10.0 * __import__("math").log10(mse)
     record_parity(label, **rec)

@@ -76,21 +76,42 @@ def full_scene(seed=0, nv=NV):
     return sc
 
 
-def full_strip_index(n):
+def full_strip_index(n, stride=601, start_row=230):
     """n rays of the 640x480 frame: a stride-601 walk starting at the image centre row (hits every region of the
     frame; as ONE reference chunk when n = 1024)."""
     W, H = FULL_WH
-    return (torch.arange(n, dtype=torch.int64) * 601 + 230 * W) % (H * W)
+    return (torch.arange(n, dtype=torch.int64) * stride + start_row * W) % (H * W)
 
 
-def full_batch(n, nv=NV):
+def full_batch(n, nv=NV, stride=601, start_row=230, **camera):
     """Rays of the bench camera (look_at_origin(40 deg), focal 0.8 W; fp64 NumPy ray generation so the fixture does
-    not depend on either ray generator) + the bench's source cameras."""
+    not depend on either ray generator) + the bench's source cameras.  camera: azimuth / radius / height of another
+    target pose on the test orbit (crop_rays)."""
     W, H = FULL_WH
-    rays = take(crop_rays(H, W), full_strip_index(n))
+    rays = take(crop_rays(H, W, **camera), full_strip_index(n, stride, start_row))
     poses, focal, centre = synth.source_views(nv, W, H)
     rays.update(src_poses=poses, src_focal=focal, src_c=centre, src_imgs=torch.zeros(nv, 3, H, W))
     return rays
+
+
+# More reference chunks of the C3 scene at full size (fixtures g4_neo_full_<tag>, VERDICT r3 task 6: the parity rule for
+# ill-conditioned rays was calibrated on ONE chunk from ONE camera): another strip of the bench frame, two other target
+# poses (one close to the unit sphere, one low), and five source views at full map size.
+FULL_B = {
+    "b1": dict(nv=NV, stride=389, start_row=57),
+    "b2": dict(nv=NV, stride=601, start_row=230, azimuth=130.0, radius=0.6, height=0.45),
+    "b3": dict(nv=NV, stride=463, start_row=311, azimuth=250.0, radius=0.78, height=0.1),
+    "b4": dict(nv=5, stride=601, start_row=140),
+}
+
+
+def full_case(tag, n=1024):
+    """(scene, batch) of fixture g4_neo_full_<tag>; tag None / "" = the round-3 chunk (g4_neo_full)."""
+    if not tag:
+        return full_scene(), full_batch(n)
+    kw = dict(FULL_B[tag])
+    nv = kw.pop("nv")
+    return full_scene(nv=nv), full_batch(n, nv=nv, **kw)
 
 
 def aabb_cases(seed=3, n=4096):

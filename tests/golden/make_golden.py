@@ -260,7 +260,11 @@ def g4_vanilla():
 
 
 def _neo_inputs(n_rays, nv, full):
-    """(scene, batch): the small fixture scene, or the BASELINE C3 configuration at full size (cases.full_*)."""
+    """(scene, batch): the small fixture scene, or the BASELINE C3 configuration at full size (cases.full_*);
+    full = "b1".."b4": the additional full-size chunks of cases.FULL_B (their own pose / strip / view count)."""
+    if isinstance(full, str):
+        assert cases.FULL_B[full]["nv"] == nv
+        return cases.full_case(full, n_rays)
     if full:
         return cases.full_scene(nv=nv), cases.full_batch(n_rays, nv=nv)
     return cases.small_scene(nv=nv), cases.neo_batch(cases.strided_rays(n_rays), nv=nv)
@@ -322,7 +326,7 @@ class _MarginProbe:
         self.h.sorted_piecewise_constant_pdf = self.orig
 
 
-def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=False, ulp_trials=0):
+def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=False, ulp_trials=0, nv=cases.NV):
     """The reference's OWN rounding noise on the rays of fixture g4_neo_<tag>: the same call evaluated by the
     reference in fp32 and by its fp64 twin (module.double(), fp64 rays / latent; the tri-planes stay fp32 because
     index_grid casts its coordinates with .float(), encoder_tp_fusion_conv.py:128-130).  Stored per ray:
@@ -335,10 +339,12 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=Fa
     The fp64 twin samples that sensitivity once per ray; on a chaotic ray (descending-bin inversion,
     neo360/model.py:319-331) one sample can land near zero by luck, so the stored noise is the MAXIMUM over the twin
     and the trials."""
-    scene, batch = _neo_inputs(n_rays, cases.NV, full)
+    scene, batch = _neo_inputs(n_rays, nv, full)
     state = synth.nerf_tp_state(0, density_gain=gain)
     per_ray = ("rays_o", "rays_d", "viewdirs")
     keys = ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")
+    _ref_tp = ref_nerf_tp
+    ref_nerf_tp_nv = lambda st, sc: _ref_tp(st, sc, nv=nv)
 
     def run(net, b):
         acc = {k: [] for k in keys}
@@ -350,7 +356,7 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=Fa
             acc["fgacc1"].append(res[1][3]); acc["lam1"].append(res[1][4]); acc["depth1"].append(res[1][5])
         return {k: torch.cat(v, 0) for k, v in acc.items()}
 
-    net32 = ref_nerf_tp(state, scene)
+    net32 = ref_nerf_tp_nv(state, scene)
     net32.num_coarse_samples, net32.num_fine_samples = n_coarse, n_fine
     with _MarginProbe(ref.load("models.neo360.helper")) as probe:
         r32 = run(net32, batch)
@@ -361,7 +367,7 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=Fa
     del net32
     scene64 = dict(scene)
     scene64["latent"] = scene["latent"].double()
-    net64 = ref_nerf_tp(state, scene64).double()
+    net64 = ref_nerf_tp_nv(state, scene64).double()
     net64.num_coarse_samples, net64.num_fine_samples = n_coarse, n_fine
     b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
     r64 = run(net64, b64)
@@ -376,7 +382,7 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=Fa
                 st[name] = (w.double() * (1.0 + eta.double())).float()
             else:
                 st[name] = w
-        net_t = ref_nerf_tp(st, scene)
+        net_t = ref_nerf_tp_nv(st, scene)
         net_t.num_coarse_samples, net_t.num_fine_samples = n_coarse, n_fine
         rt = run(net_t, batch)
         del net_t
@@ -401,6 +407,78 @@ def g4_neo_noise(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=Fa
     for k in keys:
         out["refit_" + k] = np.float32(np.abs(fx[k] - r32[k].numpy()).max())
     save("g4_neo_%s_noise" % tag, **out)
+
+
+class _ShiftedQuantiles:
+    """While active, the reference's inverse-CDF sampler (neo360/helper.py:174-215) draws its deterministic quantiles
+    u = linspace(0, 1 - 2^-32, n) SHIFTED by `delta` (clamped to the same range): every threshold u_j = cdf_i that lies
+    within |delta| of a quantile is crossed - in one direction - exactly as an fp32 re-evaluation of the coarse level
+    with a cdf error of that size and sign would cross it."""
+
+    def __init__(self, helper_module, delta):
+        self.h, self.delta = helper_module, float(delta)
+        self.orig = helper_module.sorted_piecewise_constant_pdf
+
+    def __enter__(self):
+        me = self
+
+        def wrapped(bins, weights, num_samples, randomized, float_min_eps=2 ** -32):
+            real = torch.linspace
+
+            def shifted(start, end, steps, **kw):
+                return torch.clamp(real(start, end, steps, **kw) + me.delta, float(start), float(end))
+
+            torch.linspace = shifted
+            try:
+                return me.orig(bins, weights, num_samples, randomized, float_min_eps)
+            finally:
+                torch.linspace = real
+
+        self.h.sorted_piecewise_constant_pdf = wrapped
+        return self
+
+    def __exit__(self, *a):
+        self.h.sorted_piecewise_constant_pdf = self.orig
+
+
+def g4_neo_flip(tag, n_rays, chunk, n_coarse=128, n_fine=256, gain=1.0, full=False, nv=cases.NV, delta=2e-6):
+    """PER-RAY size of a sampler flip on the rays of fixture g4_neo_<tag>, measured on the reference itself: its fp32
+    forward with the fine-level quantiles shifted by +delta and by -delta (delta = 2 x the flip margin the tests use,
+    conftest.FLIP_MARGIN): flip_<k>[ray] = max over the two runs of |shifted - fixture| (max over channels).  On a ray whose
+    margin is below the flip margin this is what crossing its near-threshold quantile(s) does to each output; on all
+    other rays it is the (tiny) effect of moving 256 samples by 2e-6 of the range.  conftest.check_vs_reference_noise
+    bounds a flip-prone ray by ITS OWN flip size instead of the largest one of the fixture."""
+    scene, batch = _neo_inputs(n_rays, nv, full)
+    state = synth.nerf_tp_state(0, density_gain=gain)
+    per_ray = ("rays_o", "rays_d", "viewdirs")
+    keys = ("rgb0", "rgb1", "fg1", "bg1", "fgacc1", "lam1", "depth0", "depth1")
+    net = ref_nerf_tp(state, scene, nv=nv)
+    net.num_coarse_samples, net.num_fine_samples = n_coarse, n_fine
+
+    def run():
+        acc = {k: [] for k in keys}
+        for i in range(0, n_rays, chunk):
+            part = {k: (v[i:i + chunk] if k in per_ray else v) for k, v in batch.items()}
+            res = net(part, False, False, 0.0, 0.0, out_depth=True)
+            acc["rgb0"].append(res[0][0]); acc["depth0"].append(res[0][5])
+            acc["rgb1"].append(res[1][0]); acc["fg1"].append(res[1][1]); acc["bg1"].append(res[1][2])
+            acc["fgacc1"].append(res[1][3]); acc["lam1"].append(res[1][4]); acc["depth1"].append(res[1][5])
+        return {k: torch.cat(v, 0) for k, v in acc.items()}
+
+    fx = np.load(os.path.join(HERE, "g4_neo_%s.npz" % tag))
+    per_ray_max = lambda d: (d.amax(dim=-1) if d.dim() == 2 and d.shape[-1] == 3 else d.reshape(n_rays))
+    out = {"flip_" + k: torch.zeros(n_rays, dtype=torch.float64) for k in keys}
+    helper = ref.load("models.neo360.helper")
+    for d in (delta, -delta):
+        with _ShiftedQuantiles(helper, d):
+            r = run()
+        for k in keys:
+            out["flip_" + k] = torch.maximum(out["flip_" + k], per_ray_max((r[k].double() - torch.from_numpy(fx[k]).double()).abs()))
+    out = {k: v.float() for k, v in out.items()}
+    out["delta"] = np.float64(delta)
+    print("flip sizes (%s): bg1 max %.2e, rays with bg1 flip >= 1e-5: %d; rgb1 max %.2e" % (
+        tag, float(out["flip_bg1"].max()), int((out["flip_bg1"] >= 1e-5).sum()), float(out["flip_rgb1"].max())))
+    save("g4_neo_%s_flip" % tag, **out)
 
 
 # ---------------------------------------------------------------------------------
@@ -621,6 +699,17 @@ def main(which):
         # and the reference's fp64 twin on the same rays.  ~10 GB of RAM, a few minutes.
         "g4n_full": lambda: g4_neo("full", 1024, 1024, full=True),
         "g4n_full_noise": lambda: g4_neo_noise("full", 1024, 1024, full=True, ulp_trials=2),
+        # four more full-size chunks (cases.FULL_B): another strip, two other target poses, five source views; each with
+        # its fp64 twin, two +-1 ulp trials and the cdf margins (VERDICT r3 task 6)
+        **{"g4n_full_%s" % t: (lambda t=t: g4_neo("full_" + t, 1024, 1024, full=t, nv=cases.FULL_B[t]["nv"])) for t in cases.FULL_B},
+        **{"g4n_full_%s_noise" % t: (lambda t=t: g4_neo_noise("full_" + t, 1024, 1024, full=t, ulp_trials=2, nv=cases.FULL_B[t]["nv"]))
+           for t in cases.FULL_B},
+        # per-ray flip sizes (quantiles shifted by +-2e-6 inside the reference's sampler) for every fixture that has a noise twin
+        "g4n_1024_flip": lambda: g4_neo_flip("1024", 1024, 1024),
+        "g4n_1500_flip": lambda: g4_neo_flip("1500", 1500, 1024),
+        "g4n_sharp_flip": lambda: g4_neo_flip("sharp", 256, 256, 32, 64, gain=8.0),
+        "g4n_full_flip": lambda: g4_neo_flip("full", 1024, 1024, full=True),
+        **{"g4n_full_%s_flip" % t: (lambda t=t: g4_neo_flip("full_" + t, 1024, 1024, full=t, nv=cases.FULL_B[t]["nv"])) for t in cases.FULL_B},
         "g6": g6_mip360,
         "g7": g7_pixelnerf,
         "g8": g8_training,

@@ -66,14 +66,35 @@ def _outputs(res):
                 lam1=cat(1, 4), depth1=cat(1, 5))
 
 
+_NV5 = {}
+
+
+def _net_nv5():
+    """Five source views at full map size (fixture g4_neo_full_b4; the reference builds NeRF_TP(num_src_views=5) for the
+    5-view render names, neo360/model.py:606-616)."""
+    if "net" not in _NV5:
+        net = models.NeRF_TP(num_coarse_samples=128, num_fine_samples=256, num_src_views=5).to(DEV)
+        net.load_state_dict(synth.nerf_tp_state(0))
+        sc = cases.full_scene(nv=5)
+        net.set_scene(sc["plane_xz"].to(DEV), sc["plane_xy"].to(DEV), sc["plane_yz"].to(DEV), sc["latent"].to(DEV), sc["image_wh"])
+        _NV5["net"] = net
+    return _NV5["net"]
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-def test_neo360_full_size_chunk_vs_reference(neo_full, golden, precision):
-    """One reference chunk (1024 rays spread over the 640x480 frame) at the full C3 configuration against the
-    reference's own outputs, same rule as the small-scene 1024-ray test: 1e-4 on EVERY output (depth included) of
-    every ray the reference determines to better than 1e-5; the remaining rays within 1e-4 + 3 x the reference's own
-    fp32-vs-fp64 disagreement on that ray."""
+@pytest.mark.parametrize("tag", ["", "b1", "b2", "b3", "b4"])
+def test_neo360_full_size_chunk_vs_reference(neo_full, golden, golden_optional, precision, tag):
+    """Reference chunks (1024 rays spread over the 640x480 frame) at the full C3 configuration against the reference's own
+    outputs: the round-3 chunk ("") and four more (cases.FULL_B: another strip, two other target poses, five source
+    views).  Same rule as the small-scene 1024-ray test: 1e-4 on EVERY output (depth included) of every ray the reference
+    determines to better than 1e-5; a ray the reference disagrees with itself on within 1e-4 + 3 x that disagreement; a
+    flip-prone ray within 1e-4 + 3 x ITS OWN flip size (conftest.check_vs_reference_noise)."""
     state, net, scene, batch = neo_full
-    cb = cases.full_batch(1024)
+    name = "g4_neo_full" + ("_" + tag if tag else "")
+    g, noise = golden(name), golden(name + "_noise")
+    if tag == "b4":
+        net = _net_nv5()
+    _, cb = cases.full_case(tag) if tag else (None, cases.full_batch(1024))
     gb = {k: v.to(DEV) for k, v in cb.items()}
     old = net.precision
     net.precision = precision
@@ -82,11 +103,13 @@ def test_neo360_full_size_chunk_vs_reference(neo_full, golden, precision):
         net.check_flags()
     finally:
         net.precision = old
-    check_vs_reference_noise(got, golden("g4_neo_full"), golden("g4_neo_full_noise"), "neo360_full_size_C3/%s" % precision)
-    # the library's ray generator gives the same rays as the fixture's fp64 NumPy ones (o exact, d to fp32 rounding):
-    # the chunk is a subset of the frame the benchmark renders
-    idx = cases.full_strip_index(1024).to(DEV)
-    assert torch.equal(batch["rays_o"][idx], gb["rays_o"]) and max_abs(batch["rays_d"][idx], gb["rays_d"]) < 3e-7
+    check_vs_reference_noise(got, g, noise, "neo360_full_size_C3%s/%s" % ("_" + tag if tag else "", precision),
+                             flip=golden_optional(name + "_flip"))
+    if not tag:
+        # the library's ray generator gives the same rays as the fixture's fp64 NumPy ones (o exact, d to fp32 rounding):
+        # the chunk is a subset of the frame the benchmark renders
+        idx = cases.full_strip_index(1024).to(DEV)
+        assert torch.equal(batch["rays_o"][idx], gb["rays_o"]) and max_abs(batch["rays_d"][idx], gb["rays_d"]) < 3e-7
 
 
 def test_mip360_full_frame_and_strip():

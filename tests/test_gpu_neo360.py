@@ -65,28 +65,29 @@ def test_internal_chunking_equals_callers(golden):
     assert max_abs(res[1][0].cpu(), g["rgb1"]) < TOL and max_abs(res[1][5].cpu(), g["depth1"]) < TOL
 
 
-def _check_vs_reference_noise(got, g, noise, label):
-    check_vs_reference_noise(got, g, noise, "neo360_e2e/" + label)
+def _check_vs_reference_noise(got, g, noise, label, flip=None):
+    check_vs_reference_noise(got, g, noise, "neo360_e2e/" + label, flip=flip)
 
 
-def test_sharp_density(golden):
+def test_sharp_density(golden, golden_optional):
     """Density head x8 (trained-like, peaky weights): hierarchical resampling is ill-conditioned there in the
     reference itself (fixture g4_neo_sharp_noise: depth1 differs by up to 4.4e-4 between its fp32 and fp64 runs)."""
     _check_vs_reference_noise(_render(_net(32, 64, gain=8.0), 256, 256), golden("g4_neo_sharp"),
-                              golden("g4_neo_sharp_noise"), "sharp")
+                              golden("g4_neo_sharp_noise"), "sharp", flip=golden_optional("g4_neo_sharp_flip"))
 
 
 @pytest.mark.parametrize("preproject", [True, 2, False])
-def test_reference_sample_counts_1024(golden, preproject):
+def test_reference_sample_counts_1024(golden, golden_optional, preproject):
     """One reference-sized chunk: 1024 rays, 128 coarse + 256 fine, fg + bg, 3 views; both split evaluators
     (latent pre-projected through the first-layer weights = default, and the reference's operation order)."""
     _check_vs_reference_noise(_render(_net(128, 256, preproject=preproject), 1024, 1024), golden("g4_neo_1024"),
-                              golden("g4_neo_1024_noise"), "1024 preproject=%s" % preproject)
+                              golden("g4_neo_1024_noise"), "1024 preproject=%s" % preproject,
+                              flip=golden_optional("g4_neo_1024_flip"))
 
 
-def test_reference_sample_counts_1500_two_chunks(golden):
+def test_reference_sample_counts_1500_two_chunks(golden, golden_optional):
     _check_vs_reference_noise(_render(_net(128, 256), 1500, 1024), golden("g4_neo_1500"),
-                              golden("g4_neo_1500_noise"), "1500")
+                              golden("g4_neo_1500_noise"), "1500", flip=golden_optional("g4_neo_1500_flip"))
 
 
 def test_preprojection_is_a_reassociation(golden):

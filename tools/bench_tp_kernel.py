@@ -16,7 +16,7 @@ NV = 3
 net = models.NeRF_TP(num_src_views=NV).to(dev)
 net.precision = PREC
 if os.environ.get("PP") is not None:
-    net.preproject = {"0": False, "1": True, "2": 2}[os.environ["PP"]]
+    net.preproject = {"0": False, "1": True, "2": 2, "3": 3}[os.environ["PP"]]
 net.poll_flags = os.environ.get("POLL", "1") != "0"       # POLL=0: timing ablations produce garbage operands
 SCALE = float(os.environ.get("SCALE", 1.0))      # 0: all-zero weights and features (power / clock envelope experiments)
 SCALE_W = float(os.environ.get("SCALE_W", SCALE))   # weights only / features only: which operands carry the power
