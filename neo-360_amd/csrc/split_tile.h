@@ -108,7 +108,7 @@ __device__ __forceinline__ float relu1(float x) {
 // chunk 2gp + 1 of their point: one ds_write_b128 per plane and chunk pair (lane groups of 8 consecutive lanes = 8 rows with
 // 8 distinct slot residues under the XOR swizzle: conflict-free), as mlp_vanilla_h.hip does since round 2.  Same bits in LDS.
 #ifndef NEO_SPLIT_STORE128
-#define NEO_SPLIT_STORE128 1
+#define NEO_SPLIT_STORE128 0
 #endif
 typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned su32x4 __attribute__((ext_vector_type(4)));

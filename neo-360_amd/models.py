@@ -456,7 +456,6 @@ class NeRF_TP(_HipModule):
         self._raise_flags(ctx.poll_flags())       # also clears the word: a miss here must not fail a later forward()
         return out
 
-    @torch.no_grad()
     def _forward_train(self, rays, randomized, white_bkgd, chunk=None, seed=None):
         """out_depth=False: per level (comp_rgb, fg_weights, bg_weights, fg_sdist, bg_sdist, bg_acc)
         (neo360/model.py:531-579), forward values only.  randomized=True draws the stratified level-0 jitter and the
@@ -501,15 +500,45 @@ class NeRF_TP(_HipModule):
             out.append((t["rgb"], t["fg_w"], t["bg_w"], fg_sd, bg_sd, t["bg_acc"]))
         return out
 
-    @torch.no_grad()
+    def _maps_for_grad(self, rays):
+        """The four scene tensors a differentiable call gathers from (and sends gradients to): an attached encoder is run
+        WITH autograd on this batch, as the reference's forward does (neo360/model.py:281-300); otherwise the very tensors
+        given to `set_scene`, if the caller still holds them."""
+        enc = getattr(self, "encoder", None)
+        if enc is not None:
+            src = rays["src_imgs"]
+            planes = enc(src, rays["src_poses"], rays["src_focal"], rays["src_c"])
+            self._scene_wh = (float(src.shape[-1]), float(src.shape[-2]))
+            return planes[0], planes[1], planes[2], enc.spatial_encoder.latent
+        held = getattr(self, "_scene_src", None)
+        maps = tuple(r() for r in held[0]) if held is not None else ()
+        if len(maps) != 4 or any(m is None for m in maps):
+            raise _lib.NeoError("a differentiable forward needs the scene tensors: attach an encoder module, or keep the four "
+                                "tensors passed to set_scene(...) alive (the module holds only weak references to them)")
+        return maps
+
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def forward(self, rays, randomized, white_bkgd, near, far, out_depth=False, chunk=None, seed=None):
         """out_depth=True (evaluation, neo360/model.py:521-527): per level (comp_rgb, fg_rgb, bg_rgb, fg_acc, bg_lambda,
         comp_depth), randomized=False.  out_depth=False (the training call, :531-579): per level (comp_rgb, fg_weights,
-        bg_weights, fg_sdist, bg_sdist, bg_acc), randomized as asked (`_forward_train`).  `near`/`far` are ignored
+        bg_weights, fg_sdist, bg_sdist, bg_acc), randomized as asked.  `near`/`far` are ignored
         exactly as in the reference (:277-278).  All rays of the call form ONE reference chunk unless `chunk` is given
-        (whole-frame rendering, see render.py)."""
+        (whole-frame rendering, see render.py).
+        The training call is DIFFERENTIABLE when autograd is on and a parameter requires grad (the reference's
+        training_step, model.py:697-820): it then runs on the operators of training.py (lookups, NeRFPPMLP with a native
+        backward, compositing) instead of the fused no-grad kernels; same return tuple, same samples for one seed."""
         if not out_depth:
-            return self._forward_train(rays, randomized, white_bkgd, chunk, seed)
+            if self._wants_grad():
+                from . import training
+                return training.tp_render_train(self, rays, randomized, white_bkgd, self._maps_for_grad(rays), chunk, seed)
+            with torch.no_grad():
+                return self._forward_train(rays, randomized, white_bkgd, chunk, seed)
+        with torch.no_grad():
+            return self._forward_eval(rays, randomized, white_bkgd, chunk)
+
+    def _forward_eval(self, rays, randomized, white_bkgd, chunk=None):
         self._check_mode(randomized)
         rays_o = f32(rays["rays_o"], "rays_o")
         rays_d = f32(rays["rays_d"], "rays_d")

@@ -303,3 +303,112 @@ def nerf_mlp(mlp, x_enc, dir_enc, ctx=None):
     layers = mlp.ordered_layers()
     params = [l.weight for l in layers] + [l.bias for l in layers]
     return _TrainVanillaMLP.apply(ctx, x_enc, dir_enc, *params)
+
+
+# ---- the module-level training call (neo360/model.py:697-820 calls self.model(batch, randomized=True, ...)) ------------------
+
+def _world_to_camera(pts, c2w):
+    """(P,3) world points, (NV,4,4) camera-to-world -> (NV,P,3): rot = c2w[:3,:3]^T, trans = -rot t (neo360/util.py:52-70)."""
+    rot = c2w[:, :3, :3].transpose(1, 2)
+    trans = -torch.bmm(rot, c2w[:, :3, 3:])
+    return torch.matmul(rot[:, None], pts[None, :, :, None])[..., 0] + trans[:, None, :, 0]
+
+
+def _outside_points(o, d, inv_r):
+    """Inverted-sphere parameterisation of the samples outside the unit sphere (neo360/helper.py:401-451), torch ops on the
+    device: the ray's sphere exit point rotated about (o x p_sphere) by asin|p_mid| - asin(|p_mid| / r), re-normalised, 1/r
+    appended.  (R,N) -> (R,N,4).  Sample positions carry no gradient (helper.py:224 detaches them)."""
+    shape = list(inv_r.shape) + [3]
+    o, d = o[:, None, :].expand(shape), d[:, None, :].expand(shape)
+    d1 = -(d * o).sum(-1, keepdim=True) / (d ** 2).sum(-1, keepdim=True)
+    p_mid = o + d1 * d
+    r_mid = torch.norm(p_mid, dim=-1, keepdim=True)
+    d2 = torch.sqrt(1.0 - r_mid * r_mid) * (1.0 / torch.norm(d, dim=-1, keepdim=True))
+    p_sph = o + (d1 + d2) * d
+    axis = torch.cross(o, p_sph, dim=-1)
+    axis = axis / torch.norm(axis, dim=-1, keepdim=True)
+    ang = torch.asin(r_mid) - torch.asin(r_mid * inv_r[..., None])
+    turned = (p_sph * torch.cos(ang) + torch.cross(axis, p_sph, dim=-1) * torch.sin(ang)
+              + axis * (axis * p_sph).sum(-1, keepdim=True) * (1.0 - torch.cos(ang)))
+    turned = turned / (torch.norm(turned, dim=-1, keepdim=True) + 1e-10)
+    return torch.cat((turned, inv_r.unsqueeze(-1)), dim=-1)
+
+
+def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed=None):
+    """NeRF_TP.forward(out_depth=False) WITH autograd: per level (comp_rgb, fg_weights, bg_weights, fg_sdist, bg_sdist,
+    bg_acc) exactly as the fused call returns them (neo360/model.py:531-579), built from the differentiable operators of
+    this file - level-0 samples (sample_level0), lookups (gather_features: gradients reach the four feature maps and,
+    through them, an encoder), encodings, NeRFPPMLP with its native backward (nerfpp_mlp: gradients reach all four
+    MLPs' parameters), the reference's activations, compositing (composite), hierarchical resampling on detached weights
+    (helper.py:224) - so the reference's training_step (model.py:697-820: rgb loss on both levels + eff_distloss on the
+    weights) runs unchanged on `loss.backward()`.  maps = (plane_xz, plane_xy, plane_yz, latent) NCHW tensors (the
+    encoder's outputs, or the tensors given to set_scene).  randomized draws come from the library's counter-based
+    generator with the stream ids of the fused call (0 / 1 level-0 jitter fg / bg, 2 / 3 level-1 quantiles), so both
+    paths see the same samples for one seed.  All rays form ONE reference chunk unless `chunk` is given."""
+    from . import ops
+    rays_o, rays_d, viewdirs = f32(rays["rays_o"], "rays_o"), f32(rays["rays_d"], "rays_d"), f32(rays["viewdirs"], "viewdirs")
+    B = rays_o.shape[0]
+    if chunk is not None and int(chunk) < B:
+        parts = []
+        for i in range(0, B, int(chunk)):
+            sub = {k: (v[i:i + int(chunk)] if k in ("rays_o", "rays_d", "viewdirs") else v) for k, v in rays.items()}
+            parts.append(tp_render_train(module, sub, randomized, white_bkgd, maps, None,
+                                         None if seed is None else int(seed) + i))
+        return [tuple(torch.cat([p[lv][j] for p in parts], dim=0) for j in range(6)) for lv in range(2)]
+    if module.density_noise != 0.0 and randomized:
+        raise NotImplementedError("density_noise (neo360/model.py:381-384) is not part of the accelerated path")
+    dev = rays_o.device
+    c = module._context(dev)
+    poses = f32(rays["src_poses"], "src_poses")
+    NV = poses.shape[0]
+    n0, n1 = module.num_coarse_samples, module.num_fine_samples
+    with torch.no_grad():
+        far, _ = ops.intersect_sphere(rays_o, rays_d, ctx=c)                                   # model.py:278
+        if randomized:
+            seed = int(seed) if seed is not None else int(torch.randint(1, 2 ** 62, (1,)).item())
+            seed = seed or 1
+            u_fg, u_bg = rand_uniform(seed, 0, B, n0 + 1, ctx=c), rand_uniform(seed, 1, B, n0 + 1, ctx=c)
+        else:
+            u_fg = u_bg = None
+        fg_t, bg_s = sample_level0(far, n0, u_fg, u_bg, ctx=c)
+        rot = poses[:, :3, :3].transpose(1, 2)
+        dir_cam = torch.matmul(rot[:, None], viewdirs[None, :, :, None])[..., 0]              # (NV,B,3): model.py:339-341
+        d_enc = ops.pos_enc(dir_cam, 0, module.deg_view, ctx=c)                                # (NV,B,27)
+    mlps = module._mlps()
+    out = []
+    for level in range(2):
+        N = fg_t.shape[1]
+        with torch.no_grad():
+            cond = d_enc.repeat(1, N, 1).reshape(-1, d_enc.shape[-1])      # row (v, j) carries ray j mod B (model.py:357-360, quirk Q1)
+            fg_p = rays_o[:, None, :] + fg_t[..., None] * rays_d[:, None, :]
+            bg_p4 = _outside_points(rays_o, rays_d, bg_s)
+            bg_lin = rays_o[:, None, :] + (far * (1.0 - bg_s) + 3.0 * bg_s)[..., None] * rays_d[:, None, :]
+            fg_x = ops.pos_enc(_world_to_camera(fg_p.reshape(-1, 3), poses), module.min_deg_point, module.max_deg_point, ctx=c)
+            bg_cam = torch.cat((_world_to_camera(bg_p4[..., :3].reshape(-1, 3), poses),
+                                bg_p4[..., 3].reshape(1, -1, 1).expand(NV, -1, -1)), dim=-1)     # model.py:454-464
+            bg_x = ops.pos_enc(bg_cam, module.min_deg_point, module.max_deg_point, ctx=c)
+        res = {}
+        for name, mlp, look, x_enc in (("fg", mlps[level], fg_p, fg_x), ("bg", mlps[2 + level], bg_lin, bg_x)):
+            world, local = gather_features(module, look.reshape(-1, 3), maps[0], maps[1], maps[2], maps[3], rays)
+            raw_rgb, raw_sigma = nerfpp_mlp(mlp, x_enc, cond, world, local, NV, ctx=c)
+            rgb = (torch.sigmoid(raw_rgb) * (1.0 + 2.0 * 0.001) - 0.001).reshape(B, N, 3)     # model.py:383-385
+            sigma = torch.nn.functional.softplus(raw_sigma + (-1.0)).reshape(B, N, 1)          # model.py:380-381
+            res[name] = (rgb, sigma)
+        fg_c, _, fg_w, lam, _ = composite(1, res["fg"][0], res["fg"][1], fg_t, rays_d, far, white_bkgd, ctx=c)
+        bg_c, bg_acc, bg_w, _, _ = composite(2, res["bg"][0], res["bg"][1], bg_s, None, None, white_bkgd, ctx=c)
+        rgb = fg_c + lam * bg_c
+        fg_sd = 0.5 * (fg_t[..., 1:] + fg_t[..., :-1])                                          # model.py:564-571
+        fg_sd = torch.cat([fg_sd, (fg_sd[:, -1] + (fg_sd[:, -1] - fg_sd[:, -2])).unsqueeze(-1)], dim=-1)
+        bg_sd = torch.cat([0.5 * (bg_s[..., 1:] + bg_s[..., :-1]), bg_s[..., -1:]], dim=-1)
+        out.append((rgb, fg_w, bg_w, fg_sd, bg_sd, bg_acc))
+        if level == 0:
+            with torch.no_grad():
+                if randomized:
+                    fg_t = resample_u(fg_t, fg_w, rand_uniform(seed, 2, B, n1, ctx=c), False, ctx=c)
+                    bg_s = resample_u(bg_s, bg_w, rand_uniform(seed, 3, B, n1, ctx=c), True, ctx=c)
+                else:
+                    fg_t = ops.resample(fg_t, fg_w.detach(), n1, False, ctx=c)
+                    bg_s = ops.resample(bg_s, bg_w.detach(), n1, True, ctx=c)
+    flags = c.poll_flags()
+    module._raise_flags(flags)
+    return out

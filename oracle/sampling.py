@@ -135,14 +135,14 @@ def vanilla_level1(bins, weights, rays_o, dirs, t_prev, n_new):
 
 def neo_fg_level1(bins, weights, rays_o, rays_d, t_prev, n_new):
     """neo360/helper.py:218-231 (in_sphere=True)."""
-    t = merge_sorted(t_prev, piecewise_constant_samples(bins, weights, n_new))
+    t = merge_sorted(t_prev, piecewise_constant_samples(bins, weights, n_new).detach())      # helper.py:224: .detach()
     return t, points_on_rays(t, rays_o, rays_d)
 
 
 def neo_bg_level1(bins, weights, rays_o, rays_d, s_prev, n_new, far, far_uncontracted=3.0):
     """neo360/helper.py:218-249 (in_sphere=False): merged set sorted ascending,
     linear depth from the ascending set, then both flipped to descending."""
-    s_asc = merge_sorted(s_prev, piecewise_constant_samples(bins, weights, n_new))
+    s_asc = merge_sorted(s_prev, piecewise_constant_samples(bins, weights, n_new).detach())  # helper.py:224: .detach()
     t_lin = far * (1.0 - s_asc) + far_uncontracted * s_asc
     s_desc = torch.flip(s_asc, dims=[-1])
     t_lin = torch.flip(t_lin, dims=[-1])

@@ -64,7 +64,7 @@ def resample_randomized(t_prev, weights, u, descending=False):
     """sample_pdf with randomized=True (helper.py:218-231): bins = midpoints of t_prev, pdf weights = weights[:,1:-1]
     (the callers' slicing, model.py:308-318), draws u (R, n_new); merged and sorted (descending for the bg branch)."""
     mids = 0.5 * (t_prev[..., 1:] + t_prev[..., :-1])
-    new = sampling.piecewise_constant_samples(mids, weights[..., 1:-1], u.shape[-1], u=u)
+    new = sampling.piecewise_constant_samples(mids, weights[..., 1:-1], u.shape[-1], u=u).detach()      # helper.py:224
     merged = torch.sort(torch.cat([t_prev, new], dim=-1), dim=-1).values
     return torch.flip(merged, dims=[-1]) if descending else merged
 

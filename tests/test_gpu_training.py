@@ -465,3 +465,102 @@ def test_training_mlps_reject_wrong_shapes():
     # empty batches are no-ops, not errors
     r, s = training.nerf_mlp(vm, torch.zeros(0, 5, 63, device=DEV), torch.zeros(0, 27, device=DEV))
     assert r.shape == (0, 5, 3) and s.shape == (0, 5, 1)
+
+
+def test_module_training_call_is_differentiable():
+    """`NeRF_TP(batch, randomized, white_bkgd, near, far)` - the call of the reference's training_step
+    (neo360/model.py:725-732 inside :697-820) - under autograd: same return tuple and forward values as the fused no-grad call,
+    and the gradients of the reference's loss (rgb L2 on both levels + eff_distloss on the fine weights, :1246-1260) with
+    respect to EVERY parameter of the four MLPs, the three tri-planes and the latent against fp64 autograd of
+    oracle.neo360.render.  Rays whose fine-level samples differ between the fp32 pipeline and the fp64 oracle (the
+    reference's inverse-CDF sampler is discontinuous, see conftest.check_vs_reference_noise) are masked out of the loss on
+    both sides - the comparison is about derivatives, not about which side of a threshold a quantile falls."""
+    sc = cases.small_scene()
+    R = 256
+    sd = synth.nerf_tp_state(0)
+    net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
+    net.load_state_dict(sd)
+    batch = cases.neo_batch(cases.strided_rays(R))
+    gb = {k: v.to(DEV) for k, v in batch.items()}
+    target = synth.uniform(77, "module_target", (R, 3), 0.0, 1.0)
+    interval = 1.0 / (NC + 1 + NF)
+    names = ("rgb", "fg_w", "bg_w", "fg_sd", "bg_sd", "bg_acc")
+
+    def loss_of(levels, tgt, mask, dist):
+        l = sum((((lv[0] - tgt) ** 2).sum(-1) * mask).sum() / mask.sum() for lv in levels)
+        fine = levels[1]
+        return l + 0.01 * (dist(fine[1] * mask[:, None], fine[3], interval) + dist(fine[2] * mask[:, None], fine[4], interval))
+
+    gm = {k: sc[k].to(DEV).clone().requires_grad_(True) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")}
+    net.set_scene(gm["plane_xz"], gm["plane_xy"], gm["plane_yz"], gm["latent"], sc["image_wh"])
+    # ---- forward values: fused no-grad call vs the differentiable call ----
+    fused = net(gb, False, False, 0.0, 0.0, out_depth=False)
+    with torch.enable_grad():
+        for p in net.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        diff = net(gb, False, False, 0.0, 0.0, out_depth=False)
+        assert diff[1][0].requires_grad and diff[1][1].requires_grad
+        for lv in (0, 1):
+            for nm, a, b in zip(names, diff[lv], fused[lv]):
+                assert a.shape == b.shape, (nm, lv)
+                err = (a.detach() - b).abs()
+                if lv == 1 and nm in ("fg_w", "bg_w", "fg_sd", "bg_sd"):
+                    assert float(err.median()) < 1e-6 and float(err.quantile(0.999)) < 1e-3, (nm, lv)
+                else:
+                    assert float(err.max()) < 1e-4, (nm, lv, float(err.max()))
+        # ---- oracle, fp64, autograd ----
+        dbl = lambda d: {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in d.items()}
+        cm = {k: v.clone().double().requires_grad_(True) for k, v in sc.items() if isinstance(v, torch.Tensor)}
+        cm["image_wh"] = sc["image_wh"]
+        pp = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        want = oracle.neo360.render(pp, dbl(batch), cm, n_coarse=NC, n_fine=NF, white_bkgd=False, out_depth=False)
+        # rays on which both pipelines drew the same fine-level samples
+        same = ((diff[1][3].detach().cpu().double() - want[1][3].detach()).abs().amax(-1) < 1e-4) & \
+               ((diff[1][4].detach().cpu().double() - want[1][4].detach()).abs().amax(-1) < 1e-4)
+        assert int(same.sum()) >= int(0.9 * R), int(same.sum())
+        mask_c = same.double()
+        loss_c = loss_of(want, target.double(), mask_c, T.eff_distloss)
+        pnames = sorted(pp)
+        g_c = torch.autograd.grad(loss_c, [pp[k] for k in pnames] + [cm[k] for k in ("plane_xz", "plane_xy", "plane_yz", "latent")])
+        # ---- library ----
+        loss_g = loss_of(diff, target.to(DEV), same.to(DEV).float(), training.eff_distloss)
+        params = dict(net.named_parameters())
+        g_g = torch.autograd.grad(loss_g, [params[k] for k in pnames] + [gm[k] for k in ("plane_xz", "plane_xy", "plane_yz", "latent")])
+    assert abs(float(loss_g) - float(loss_c)) < 1e-5 * max(1.0, abs(float(loss_c))), (float(loss_g), float(loss_c))
+    worst, worst_name = 0.0, ""
+    for nm, a, b in zip(pnames + ["plane_xz", "plane_xy", "plane_yz", "latent"], g_g, g_c):
+        scale = float(b.abs().max()) + 1e-15
+        err = float((a.detach().cpu().double() - b).abs().max()) / scale
+        if err > worst:
+            worst, worst_name = err, nm
+        # 5e-3 of the tensor's largest entry, as test_training_step_end_to_end_gradients: a ReLU unit within an ulp of its kink
+        # contributes one row differently
+        assert a.shape == b.shape and err < 5e-3, (nm, err)
+    from conftest import record_parity
+    record_parity("train_module_call_differentiable", max_rel_grad_err_vs_fp64=worst, worst_tensor=worst_name,
+                  rays_compared=int(same.sum()), rays=R, loss_abs_err=abs(float(loss_g) - float(loss_c)))
+    for p in net.parameters():
+        p.requires_grad_(False)
+
+
+def test_module_training_call_same_samples_for_one_seed():
+    """randomized=True: the differentiable call and the fused call draw the same stratified / inverse-CDF samples for a seed."""
+    net = _train_net()
+    sc = cases.small_scene()
+    maps = [sc[k].to(DEV) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")]
+    net.set_scene(*maps, sc["image_wh"])
+    gb = {k: v.to(DEV) for k, v in cases.neo_batch(cases.strided_rays(NR)).items()}
+    fused = net(gb, True, False, 0.0, 0.0, out_depth=False, seed=SEED)
+    with torch.enable_grad():
+        for p in net.parameters():
+            p.requires_grad_(True)
+        diff = net(gb, True, False, 0.0, 0.0, out_depth=False, seed=SEED)
+    assert torch.equal(diff[0][3], fused[0][3]) and torch.equal(diff[0][4], fused[0][4])          # level-0 rows: bit-identical
+    assert float((diff[1][3] - fused[1][3]).abs().median()) < 1e-6                                   # level 1: same draws on ~equal weights
+    assert max_abs(diff[0][0].detach(), fused[0][0]) < 1e-4
+    del maps
+    import gc
+    gc.collect()
+    with torch.enable_grad(), pytest.raises(Exception, match="scene tensors"):
+        net(gb, True, False, 0.0, 0.0, out_depth=False, seed=SEED)                                     # the maps are gone
