@@ -189,7 +189,8 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
                      const float* latent, int Cl, int Hf, int Wf, float image_w,
                      float image_h, void* stream);
 
-/* Split-fp16 arithmetic only.  enable != 0 (default): the 512-channel latent is pre-projected once per
+/* Both arithmetic modes (the exact fp32 evaluator gathers the same projected maps since round 4; in it modes 2 and 3 both
+ * project the planes for every slot).  enable != 0 (default): the 512-channel latent is pre-projected once per
  * (scene, MLP slot) through the local columns of pts_linears.0 and of pts_linears.3's skip half
  * (W . bilerp(F) = bilerp(W . F): neo360/model.py:110-158 is linear in the latent up to the first ReLU), and
  * the evaluator gathers the 256-channel result; costs 1 KB per latent texel and slot of context memory.

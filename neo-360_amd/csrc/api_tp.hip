@@ -28,11 +28,40 @@ void fill_views(const float* poses, int nv, neo::TpViews& v) {
     }
 }
 
+// The maps a slot gathers in pre-projection modes, recomputed (exact fp32 MFMA, k_tp_preproject: ~1 ms per map) only when the
+// scene or the slot's weights changed since they were made: the latent through [W0_loc | W3_loc], and - planes = true - the three
+// tri-planes through [W0_world | W3_world] (chunks 64..79 of the fp32 fragment stream).  Shared by both arithmetic modes.
+int ensure_projections(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, bool planes, hipStream_t s, long plane_base[3]) {
+    const long t_lat = static_cast<long>(sc.nv) * sc.Hf * sc.Wf, t_pl = static_cast<long>(sc.nv) * sc.Hp * sc.Wp;
+    for (int j = 0; j < 3; ++j) plane_base[j] = t_lat + j * t_pl;
+    const size_t need = neo::tp_proj_bytes(t_lat + (planes ? 3 * t_pl : 0)) + neo::tp_proj_pad_bytes();
+    REQUIRE(need <= 4294967295UL, "projected maps too large for 32-bit byte offsets");
+    if (need > sl.proj.cap) {          // growing re-allocates: everything in the buffer has to be made again
+        if (sl.proj.reserve(need)) return NEO_ERR_NOMEM;
+        sl.proj_weights = sl.proj_scene = sl.projpl_weights = sl.projpl_scene = 0;
+    }
+    if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->scene_epoch) {
+        neo::launch_tp_preproject(sc.latent, t_lat, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch), sl.proj.as<float>(), s);
+        sl.proj_weights = sl.weights_epoch;
+        sl.proj_scene = ctx->scene_epoch;
+    }
+    if (planes && (sl.projpl_weights != sl.weights_epoch || sl.projpl_scene != ctx->scene_epoch)) {
+        for (int j = 0; j < 3; ++j)
+            neo::launch_tp_preproject(sc.plane[j], t_pl, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch),
+                                      sl.proj.as<float>() + plane_base[j] * 256, s, 256, 128, 64);
+        sl.projpl_weights = sl.weights_epoch;
+        sl.projpl_scene = ctx->scene_epoch;
+    }
+    return NEO_OK;
+}
+
 // one region's evaluator launch in the context's arithmetic mode
 int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpViews& views, const float* rays_o,
               const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N, int chunk,
               float* out, hipStream_t s) {
     ORDERED(ctx, s);      // context scratch (tp_dirsum, projected maps, ws[]) is shared by all streams
+    const int slot_index = static_cast<int>(&sl - ctx->tp);
+    long plane_base[3] = {0, 0, 0};          // first texel of each projected tri-plane inside sl.proj
     if (ctx->precision == 1) {
         // range guard of the split arithmetic: tri-planes are summed over three maps before they are split
         if (ctx->planes_checked != ctx->scene_epoch) {
@@ -41,47 +70,24 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             ctx->planes_checked = ctx->scene_epoch;
         }
         if (ctx->preproject) {
-            // latent pre-projected through this slot's [W0_loc | W3_loc]: recomputed (exact fp32 MFMA, ~1 ms) only
-            // when the scene or the slot's weights changed since the last launch
-            if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->scene_epoch) {
-                const long texels = static_cast<long>(sc.nv) * sc.Hf * sc.Wf;
-                if (sl.proj.reserve(neo::tp_proj_bytes(texels))) return NEO_ERR_NOMEM;
-                neo::launch_tp_preproject(sc.latent, texels, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch),
-                                          sl.proj.as<float>(), s);
-                sl.proj_weights = sl.weights_epoch;
-                sl.proj_scene = ctx->scene_epoch;
-            }
+            // mode 2: planes projected for every slot; mode 3: for every slot but the coarse one inside the sphere (slot 0), whose
+            // widely spaced samples share no texels - there the 24 extra 1 KB gather items cost more than the world GEMM stage
+            // they replace (profiles/r04_tp_hp_experiments.log: 4.03 vs 3.82 ms; the other three launches gain 0 / 0 / 7 %)
+            const bool planes = ctx->preproject == 2 || (ctx->preproject == 3 && slot_index != 0);
+            if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base)) return rc;
             guard_split_weights(sl, sl.wpack_hp.p, neo::tp_wpack_hp_bytes(sl.input_ch), ctx->flags, s);
             neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
             // the view-direction encodings enter the MLP only through their mean over the views, and they depend on the
             // ray alone: summed once per ray here instead of once per sample and view inside the evaluator
             if (ctx->tp_dirsum.reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
             neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum.as<float>(), s);
-            // mode 2: every slot; mode 3: every slot but the coarse one inside the sphere (slot 0), whose widely spaced samples
-            // share no texels - there the 24 extra 1 KB gather items cost more than the world GEMM stage they replace
-            // (profiles/r04_tp_hp_experiments.log: 4.03 vs 3.82 ms; the other three launches gain 0 / 0 / 7 %)
-            const int slot_index = static_cast<int>(&sl - ctx->tp);
-            if (ctx->preproject == 2 || (ctx->preproject == 3 && slot_index != 0)) {
-                // the tri-planes through this slot's [W0_world | W3_world] (chunks 64..79 of the fp32 fragment stream)
-                if (sl.projpl_weights != sl.weights_epoch || sl.projpl_scene != ctx->scene_epoch) {
-                    const long texels = static_cast<long>(sc.nv) * sc.Hp * sc.Wp;
-                    for (int j = 0; j < 3; ++j) {
-                        if (sl.proj_pl[j].reserve(neo::tp_proj_bytes(texels))) return NEO_ERR_NOMEM;
-                        neo::launch_tp_preproject(sc.plane[j], texels, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch),
-                                                  sl.proj_pl[j].as<float>(), s, 256, 128, 64);
-                    }
-                    sl.projpl_weights = sl.weights_epoch;
-                    sl.projpl_scene = ctx->scene_epoch;
-                }
-                const neo::TpPlaneProj pp{{sl.proj_pl[0].as<float>(), sl.proj_pl[1].as<float>(), sl.proj_pl[2].as<float>()}};
-                ctx->span_begin(s);
-                neo::launch_tp_mlp_hpp(sl.input_ch, mh, sl.proj.as<float>(), pp, sc, views, rays_o, rays_d, viewdirs, tvals, far,
+            ctx->span_begin(s);
+            if (planes)
+                neo::launch_tp_mlp_hpp(sl.input_ch, mh, sl.proj.as<float>(), plane_base, sc, views, rays_o, rays_d, viewdirs, tvals, far,
                                        R, N, chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
-            } else {
-                ctx->span_begin(s);
+            else
                 neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
                                       chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
-            }
         } else {
             guard_split_weights(sl, sl.wpack_h.p, neo::tp_wpack_h_bytes(sl.input_ch), ctx->flags, s);
             if (ctx->latent_checked != ctx->scene_epoch) {
@@ -93,9 +99,18 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             neo::launch_tp_mlp_h(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
         }
     } else {
+        // exact fp32 MFMA; with pre-projection on, the same algorithm as the split default in the reference's arithmetic: the
+        // projected maps are gathered and added, their GEMM stages are not executed per point (the matrix work dominates this
+        // kernel at 1/16 of the fp16 rate, so the planes are projected in modes 2 AND 3, for every slot)
         neo::TpMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};
+        const bool planes = ctx->preproject >= 2;
+        if (ctx->preproject)
+            if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base)) return rc;
+        const float* pbase = sl.proj.as<float>();
+        const neo::TpPlaneProj pp{{pbase + plane_base[0] * 256, pbase + plane_base[1] * 256, pbase + plane_base[2] * 256}};
         ctx->span_begin(s);
-        neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+        neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s,
+                           ctx->preproject ? sl.proj.as<float>() : nullptr, planes ? &pp : nullptr);
     }
     ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(sl.input_ch, sc.nv));
     return NEO_OK;
@@ -172,15 +187,16 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
 
 int neo_tp_set_preproject(neo_ctx* ctx, int enable) {
     ENTER(ctx);
+    (void)hipDeviceSynchronize();        // projected maps may be released below: nothing of this context may still read them
     REQUIRE(enable >= 0 && enable <= 3, "preproject mode must be 0 (off), 1 (latent), 2 (latent + tri-planes) or 3 (2 except slot 0)");
     ctx->preproject = enable;
     for (auto& sl : ctx->tp) sl.range_checked = 0;       // the other fragment set is checked at its first launch
     if (!ctx->preproject)
         for (auto& sl : ctx->tp) { sl.proj.release(); sl.proj_weights = sl.proj_scene = 0; }
     if (ctx->preproject < 2)
-        for (auto& sl : ctx->tp) {
-            for (auto& b : sl.proj_pl) b.release();
-            sl.projpl_weights = sl.projpl_scene = 0;
+        for (auto& sl : ctx->tp) {           // the plane part goes with the next (smaller) allocation; mark it stale now
+            if (ctx->preproject) sl.proj.release();
+            sl.proj_weights = sl.proj_scene = sl.projpl_weights = sl.projpl_scene = 0;
         }
     return NEO_OK;
 }

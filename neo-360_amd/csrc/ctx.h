@@ -59,9 +59,9 @@ struct MlpSlot {
     DevBuf wpack, bias, heads;
     DevBuf wpack_h;      // fp16 hi/lo split fragments (precision mode 1)
     DevBuf wpack_hp;     // NeRF_TP: split fragments of the pre-projected evaluator (no local-latent k-steps)
-    DevBuf proj;         // NeRF_TP: latent pre-projected through this slot's [W0_loc | W3_loc] (256 ch / texel)
-    DevBuf proj_pl[3];   // NeRF_TP, preproject mode 2: the tri-planes through [W0_world | W3_world] (256 ch / texel)
-    uint64_t projpl_weights = 0, projpl_scene = 0;   // (weights_epoch, scene_epoch) `proj_pl` was computed for; 0 = never
+    DevBuf proj;         // NeRF_TP: ONE buffer [latent through this slot's [W0_loc | W3_loc] | the three tri-planes through
+                         // [W0_world | W3_world] (preproject modes 2, 3) | padding], 256 fp32 channels = 1 KB per texel
+    uint64_t projpl_weights = 0, projpl_scene = 0;   // (weights_epoch, scene_epoch) the plane part was computed for; 0 = never
     uint64_t weights_epoch = 0;             // bumped by every upload
     uint64_t range_checked = 0;             // weights_epoch whose split fragments passed through the range check
     uint64_t proj_weights = 0, proj_scene = 0;   // (weights_epoch, scene_epoch) `proj` was computed for; 0 = never
@@ -69,7 +69,6 @@ struct MlpSlot {
     bool ready = false;
     void release() {
         wpack.release(); bias.release(); heads.release(); wpack_h.release(); wpack_hp.release(); proj.release();
-        for (auto& b : proj_pl) b.release();
         proj_weights = proj_scene = projpl_weights = projpl_scene = 0;
         ready = false;
     }

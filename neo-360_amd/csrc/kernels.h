@@ -99,9 +99,13 @@ size_t tp_heads_floats();
 void launch_tp_pack(int input_ch, const float* const* w, const float* const* b, float* wpack, float* bias,
                     float* heads, hipStream_t s);
 void launch_channels_last(const float* src, int NV, int C, int H, int W, float* dst, hipStream_t s);
+struct TpPlaneProj;
+// proj != null: the latent pre-projected through [W0_loc | W3_loc] is gathered instead of the latent (k_tp_preproject);
+// pp != null as well: the three tri-planes pre-projected through [W0_world | W3_world] likewise
 void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
                    const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
-                   int chunk, uint32_t* flags, float* out, hipStream_t s);
+                   int chunk, uint32_t* flags, float* out, hipStream_t s, const float* proj = nullptr,
+                   const TpPlaneProj* pp = nullptr);
 
 // weight re-packing into MFMA fragment order (defined in mlp_tp.hip)
 struct PackSegs { int k0[3], len[3], col[3]; };
@@ -183,8 +187,11 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
 // mlp_tp_hpp.hip — the same evaluator with the three TRI-PLANES pre-projected as well (through [W0_world | W3_world]):
 // no world GEMM stage per point-view; 4 maps x 1 KB taps are blended and added to the L0 / L3-skip accumulators
 struct TpPlaneProj { const float* p[3]; };      // xz, xy, yz: (NV * Hp * Wp, 256) fp32, channel order hp::proj_index
-void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj, const TpPlaneProj& pp, const TpScene& sc,
-                       const TpViews& views, const float* rays_o, const float* rays_d, const float* viewdirs,
+// proj_all: ONE buffer [projected latent | projected xz | xy | yz] (+ >= 4 KB of padding: the gather pipeline reads one
+// chunk past its last item); plane_base_texels[j]: first texel (1 KB each) of plane j in it; total size < 4 GB.
+size_t tp_proj_pad_bytes();
+void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj_all, const long plane_base_texels[3],
+                       const TpScene& sc, const TpViews& views, const float* rays_o, const float* rays_d, const float* viewdirs,
                        const float* tvals, const float* far, int R, int N, int chunk, uint32_t* flags, float* out,
                        const float* dirsum, hipStream_t s);
 

@@ -18,7 +18,13 @@
 // the streamed input; the L3 half stays in accumulator registers until L3's turn.
 //
 // Work per point-view: 255,424 MAC (fg) / 260,800 MAC (bg); + 4,416 MAC per point.
+//
+// PROJ (round 4, VERDICT r3 task 9): the exact-fp32 evaluator on the PRE-PROJECTED maps of mlp_tp_hp.hip / mlp_tp_hpp.hip -
+// the same algorithm in the reference's arithmetic.  PROJ = 1: the 512-channel latent is gathered as G = F . [W0_loc | W3_loc]^T
+// (k_tp_preproject, exact fp32 MFMA) and ADDED to the [L0 | L3 skip] accumulators, the eight local stages of the streamed
+// GEMM (131,072 MACs per point-view) are not executed; PROJ = 2: the three tri-planes likewise (32,768 more).
 #include "tp_common.h"
+#include "tp_hp_layout.h"
 
 namespace neo {
 
@@ -132,8 +138,8 @@ __device__ __forceinline__ void gemm1(f32x16& acc, const f32x4* __restrict__ wp,
     }
 }
 
-template <int PE_C>
-__global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpViews views,
+template <int PE_C, int PROJ>
+__global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, const float* __restrict__ proj, TpPlaneProj pp, TpScene sc, TpViews views,
                                                     const float* __restrict__ rays_o,
                                                     const float* __restrict__ rays_d,
                                                     const float* __restrict__ viewdirs,
@@ -181,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
         L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
-        tp::view_descriptors(S, L, sc, rot, trn, v, [&](int p, int f, float val) { dsm[swz_index<DIR_LD, 7>(p, f)] = val; });
+        tp::view_descriptors<(PROJ >= 1 ? hp::PROJ_TEXEL_BYTES : 2048), true, (PROJ == 2 ? hp::PROJ_TEXEL_BYTES : 128 * 4)>(
+            S, L, sc, rot, trn, v, [&](int p, int f, float val) { dsm[swz_index<DIR_LD, 7>(p, f)] = val; });
         __syncthreads();
 
         // ---- streamed-input GEMM: [L0 | L3 skip half] (256 outputs) over 703 / 724 features ----
@@ -253,14 +260,67 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, TpScene sc, TpVie
                     *reinterpret_cast<f32x4*>(buf + row * XB_LD + ((ch ^ (row & 15)) << 2)) = vv;
                 }
             };
-            // prologue: stage 0
-            issue_local(0, 0);
-            finish_local(act, 0);
-            issue_local(0, 1);
-            finish_local(act, 1);
+            // ---- pre-projected maps: 4 chunks of 64 output channels x 4 row groups; the maps' blends of a (chunk, row group)
+            //      are summed in registers (latent, then xz, xy, yz), go through an fp32 transposition tile (gather layout ->
+            //      MFMA D layout, hp::proj_index) and are added to the accumulators: the structure of mlp_tp_hpp.hip ----
+            if constexpr (PROJ >= 1) {
+                constexpr int NM = PROJ == 2 ? 4 : 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float* fb = act + (c & 1) * (TM * XB_LD);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = rg + 16 * q;
+                        f32x4 sum;
+#pragma unroll
+                        for (int mp = 0; mp < NM; ++mp) {
+                            const float* base = mp == 0 ? proj : pp.p[mp == 0 ? 0 : mp - 1];
+                            const int di = mp == 0 ? row * 4 : ((mp - 1) * TM + row) * 4;
+                            const int4 off = *reinterpret_cast<const int4*>((mp == 0 ? loc_off : pl_off) + di);
+                            f32x4 t4[4];
+                            t4[0] = tp::load_tap(base, (uint32_t)off.x + lane_b + 256u * c);
+                            t4[1] = tp::load_tap(base, (uint32_t)off.y + lane_b + 256u * c);
+                            t4[2] = tp::load_tap(base, (uint32_t)off.z + lane_b + 256u * c);
+                            t4[3] = tp::load_tap(base, (uint32_t)off.w + lane_b + 256u * c);
+                            const f32x4 val = blend4(t4, *reinterpret_cast<const f32x4*>((mp == 0 ? loc_w : pl_w) + di));
+                            if (mp == 0) sum = val; else sum = sum + val;
+                        }
+                        write_x(fb, row, sum);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int gg = 0; gg < 2; ++gg) {
+                            const int row = mt * 32 + L.l31;
+                            const int piece = L.wv * 4 + gg * 2 + L.half;
+                            const f32x4 val = *reinterpret_cast<const f32x4*>(fb + row * XB_LD + ((piece ^ (row & 15)) << 2));
+                            const int g0 = 2 * (c & 1);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += val[e];
+                        }
+                }
+                __syncthreads();      // the transposition tiles are the streamed-input tiles: chunk 3 has been consumed
+            }
+            constexpr int S0 = PROJ == 0 ? 0 : PROJ == 1 ? 8 : 10;       // first streamed stage: 0 local, 8 world, 10 pos_enc
+            // prologue: stage S0
+            if constexpr (PROJ == 0) {
+                issue_local(0, 0);
+                finish_local(act, 0);
+                issue_local(0, 1);
+                finish_local(act, 1);
+            } else if constexpr (PROJ == 1) {
+                issue_plane(0, 0, 0);
+                finish_planes(act, 0, 0);
+                issue_plane(0, 0, 1);
+                finish_planes(act, 0, 1);
+            } else {
+                finish_pe(act, 0, 0);
+                finish_pe(act, 0, 1);
+            }
             __syncthreads();
 #pragma unroll 1
-            for (int s = 0; s < NST; ++s) {
+            for (int s = S0; s < NST; ++s) {
                 float* cur = act + (s & 1) * (TM * XB_LD);
                 float* nxt = act + ((s + 1) & 1) * (TM * XB_LD);
                 const int sn = s + 1;
@@ -484,17 +544,23 @@ void launch_channels_last(const float* src, int NV, int C, int H, int W, float* 
 
 void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
                    const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
-                   int chunk, uint32_t* flags, float* out, hipStream_t s) {
+                   int chunk, uint32_t* flags, float* out, hipStream_t s, const float* proj, const TpPlaneProj* pp) {
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = LDS_FLOATS * sizeof(float);
-    const long tiles = tp::xcd_grid((P + TM - 1) / TM);
-    if (input_ch == 3)
-        hipLaunchKernelGGL(k_tp_mlp<3>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
-                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
-    else
-        hipLaunchKernelGGL(k_tp_mlp<4>, dim3((unsigned)tiles), dim3(256), lds, s, m, sc, views, rays_o, rays_d,
-                           viewdirs, tvals, far, R, N, chunk, flags, reinterpret_cast<float4*>(out));
+    const dim3 grid((unsigned)tp::xcd_grid((P + TM - 1) / TM));
+    const TpPlaneProj planes = pp ? *pp : TpPlaneProj{{nullptr, nullptr, nullptr}};
+    float4* o4 = reinterpret_cast<float4*>(out);
+    const int mode = !proj ? 0 : pp ? 2 : 1;      // gather the latent itself | the projected latent | projected latent + planes
+#define NEO_TP_F32_LAUNCH(C, PR)                                                                                          \
+    hipLaunchKernelGGL((k_tp_mlp<C, PR>), grid, dim3(256), lds, s, m, proj, planes, sc, views, rays_o, rays_d, viewdirs, \
+                       tvals, far, R, N, chunk, flags, o4)
+    if (input_ch == 3) {
+        if (mode == 0) NEO_TP_F32_LAUNCH(3, 0); else if (mode == 1) NEO_TP_F32_LAUNCH(3, 1); else NEO_TP_F32_LAUNCH(3, 2);
+    } else {
+        if (mode == 0) NEO_TP_F32_LAUNCH(4, 0); else if (mode == 1) NEO_TP_F32_LAUNCH(4, 1); else NEO_TP_F32_LAUNCH(4, 2);
+    }
+#undef NEO_TP_F32_LAUNCH
 }
 
 }  // namespace neo

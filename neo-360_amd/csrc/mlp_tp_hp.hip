@@ -1006,6 +1006,7 @@ extern "C" void neo_debug_tp_trace(unsigned long long* host16, int reset) {
 
 size_t tp_wpack_hp_bytes(int input_ch) { return (size_t)hpack_h8(input_ch) * 16; }
 size_t tp_proj_bytes(long texels) { return (size_t)texels * PROJ_TEXEL_BYTES; }
+size_t tp_proj_pad_bytes() { return 8192; }
 
 void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipStream_t s) {
     // w order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb

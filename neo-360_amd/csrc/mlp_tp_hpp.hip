@@ -10,12 +10,19 @@
 // (outside) streamed k-steps: 32,768 of 98,304 executed MACs with their hi/lo splits, LDS plane stores, B-fragment reads
 // and weight fragments - and replaces 3 x 512 B taps by 3 x 1 KB taps (24 more gather items per tile-view).
 //
-// Per 64-point tile and source view: descriptors and the pos_enc features (into their OWN LDS tile) first; then ONE flat
-// software pipeline over 64 gather items (4 chunks of 64 output channels x 4 row groups x 4 maps), a ring of RING tap
-// register sets deep with the tap descriptors read from LDS one item ahead; the four maps' blends of a (chunk, row group)
-// are summed in registers, travel through the 16 KB fp32 transposition tile and are ADDED to the L0 / L3-skip accumulators.
+// Per 64-point tile and source view: descriptors and the pos_enc features (into their OWN LDS tile) first; then a software
+// pipeline over gather items - one item = (chunk of 64 output channels, group of 16 rows, map): 4 taps x 256 B per row - a
+// ring of RING tap register sets deep with the tap descriptors read from LDS one item ahead; the maps' blends of a
+// (chunk, row group) are summed in registers, travel through the 16 KB fp32 transposition tile and are ADDED to the L0 / L3-skip
+// accumulators.  The four projected maps live in ONE buffer (one base pointer, 32-bit byte offsets).
+// WORK LIST (default): a sample outside a map blends to exactly zero (grid_sample zero padding), and outside the unit
+// sphere that is the normal case - so per tile-view the kernel lists the (row group, map) pairs in which ANY row carries a
+// weight (6 of 16 on average outside the sphere, 14 inside: tools/footprint_study.py) and the pipeline runs over that list,
+// padded to a multiple of RING with zero-weight entries so the ring slots stay compile-time constants; every load of the
+// loop is unconditional, so its s_waitcnt bookkeeping stays exact.  NEO_TPP_WORKLIST=0: the round-4 first version, four
+// compile-time pipelines (all maps / planes / latent / none) chosen per tile-view.
 // The only matrix work left before the L0 epilogue - the pos_enc k-steps (4 inside / 6 outside the sphere) - is issued
-// between the gather items.  L1, L2, L3, view-mean linearity and the heads are those of mlp_tp_hp.hip.
+// between the chunks.  L1, L2, L3, view-mean linearity and the heads are those of mlp_tp_hp.hip.
 #include <hip/hip_fp16.h>
 
 #include <algorithm>
@@ -31,13 +38,16 @@
 #define NEO_TPP_RING 3         // tap register sets (16 VGPRs each); prefetch distance = RING - 1 items
 #endif
 #ifndef NEO_TPP_XD
-#define NEO_TPP_XD 2           // pos_enc weight fragments requested this many k-steps ahead
+#define NEO_TPP_XD 1           // pos_enc weight fragments requested this many k-steps ahead (a k-step sits between two chunks of the gather: one ahead is a whole chunk of time)
 #endif
 #ifndef NEO_TPP_LD
 #define NEO_TPP_LD 4           // L1..L3 weight stream prefetch distance (k-steps)
 #endif
 #ifndef NEO_TPP_TD
 #define NEO_TPP_TD 6           // tail weight stream prefetch distance
+#endif
+#ifndef NEO_TPP_WORKLIST
+#define NEO_TPP_WORKLIST 1     // gather pipeline over the list of (row group, map) pairs that carry weight (0: whole-map variants)
 #endif
 #ifndef NEO_TPP_ZSKIP
 #define NEO_TPP_ZSKIP 1        // gather only the maps in which some row of the tile has a weighted tap (latent / planes)
@@ -54,13 +64,26 @@ namespace {
 using namespace hp;
 constexpr int RING = NEO_TPP_RING;
 
-// LDS carve (4-byte words): tp_common.h's carve [0, tp::LDS_WORDS) | biases + head weights | pos_enc stage 0
-constexpr int PP_OFF_BIAS = tp::LDS_WORDS;
+// LDS carve (4-byte words).  Tap descriptors: 5 blocks of [64 rows][4 taps] - block 0 the latent, 1..3 the planes, block 4
+// all zeros (offset 0, weight 0: the padding entries of the work list) - byte offsets first, weights DESC_W words later.
+constexpr int PP_OFF_DESC = tp::OFF_DIR + TM * 32;           // after the activation tile (8192) and the direction tile (2048)
+constexpr int DESC_BLOCK = TM * 4, DESC_W = 5 * DESC_BLOCK;  // words
+constexpr int PP_OFF_LIST = PP_OFF_DESC + 2 * DESC_W;        // [4 waves][LIST_MAX] int4 records
+constexpr int LIST_MAX = 18;
+constexpr int PP_OFF_CAM = PP_OFF_LIST + 4 * LIST_MAX * 4;
+constexpr int PP_OFF_PE = PP_OFF_CAM + TM * 4;
+constexpr int PP_OFF_FEAT = PP_OFF_PE + TM * 4;
+constexpr int PP_OFF_VDIR = PP_OFF_FEAT + TM * 4;
+constexpr int PP_OFF_DENSW = PP_OFF_VDIR + TM * 4;
+constexpr int PP_OFF_BIAS = PP_OFF_DENSW + 128;
 constexpr int PP_OFF_XPE0 = PP_OFF_BIAS + 768 + 336;
-constexpr int PP_LDS_WORDS = PP_OFF_XPE0 + TM * 64;          // [64][64] halves x 2 planes = 16 KB; total 74,560 B: 2 workgroups per CU
+constexpr int PP_LDS_WORDS = PP_OFF_XPE0 + TM * 64;          // [64][64] halves x 2 planes = 16 KB; total 77,760 B: 2 workgroups per CU
+static_assert(PP_LDS_WORDS * 4 <= 81920, "two workgroups per CU");
+
+struct TpPlaneBase { int texels[3]; };      // first texel of each projected tri-plane inside the one projected-maps buffer
 
 template <int PE_C>
-__global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, const float* __restrict__ proj, TpPlaneProj pp,
+__global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, const float* __restrict__ proj, TpPlaneBase plb,
                                                                TpScene sc, TpViews views, const float* __restrict__ rays_o,
                                                                const float* __restrict__ rays_d,
                                                                const float* __restrict__ viewdirs,
@@ -77,10 +100,18 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
     _Float16* dbase = reinterpret_cast<_Float16*>(smem + tp::OFF_DIR);
     const HT dsm{dbase, dbase + TM * 32};                                    // [64][32] x 2 planes: view loop = pos_enc features 64..95
     const HT xpe1 = dsm;                                                     //   (outside the sphere); tail = mean direction encoding
-    const tp::Scratch S = tp::carve(smem);
-    int* loc_off = S.loc_off;
+    tp::Scratch S;
+    S.loc_off = reinterpret_cast<int*>(smem + PP_OFF_DESC);
+    S.pl_off = S.loc_off + DESC_BLOCK;
+    S.loc_w = smem + PP_OFF_DESC + DESC_W;
+    S.pl_w = S.loc_w + DESC_BLOCK;
+    S.cam_enc = smem + PP_OFF_CAM;
+    S.pe_world = smem + PP_OFF_PE;
+    S.feat_world = smem + PP_OFF_FEAT;
+    S.vdir_world = smem + PP_OFF_VDIR;
+    [[maybe_unused]] int* loc_off = S.loc_off;
     float* loc_w = S.loc_w;
-    int* pl_off = S.pl_off;
+    [[maybe_unused]] int* pl_off = S.pl_off;
     float* pl_w = S.pl_w;
 
     LaneCtx L;
@@ -95,8 +126,12 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
     constexpr int NPE = PE_C == 3 ? 1 : 2;
 
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
-    float* dens_w = smem + tp::OFF_DENSW;
+    float* dens_w = smem + PP_OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
+    if (tid < DESC_BLOCK) {                            // the all-zero descriptor block (offset 0 = the buffer's first texel, weight 0)
+        S.loc_off[4 * DESC_BLOCK + tid] = 0;
+        S.loc_w[4 * DESC_BLOCK + tid] = 0.0f;
+    }
     float* lbias_w = smem + PP_OFF_BIAS;
     for (int i = tid; i < 768; i += 256) lbias_w[i] = m.bias[i];
     for (int i = tid; i < HD_RB + 3; i += 256) lbias_w[768 + i] = m.heads[i];
@@ -122,7 +157,8 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
         L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
-        tp::view_descriptors<PROJ_TEXEL_BYTES, false, PROJ_TEXEL_BYTES>(S, L, sc, rot, trn, v, [](int, int, float) {});
+        tp::view_descriptors<PROJ_TEXEL_BYTES, false, PROJ_TEXEL_BYTES>(S, L, sc, rot, trn, v, [](int, int, float) {},
+                                                                        L.wv == 0 ? 0 : plb.texels[L.wv == 0 ? 0 : L.wv - 1]);
         // ---- pos_enc of this view's camera-frame point into its own tile: row = tid % 64, wave q takes chunks q and 4 + q of
         //      stage 0 (and chunk q of stage 1).  The camera-frame point is computed here with the arithmetic of
         //      view_descriptors (same expression, no contraction), so no barrier separates it from the descriptors. ----
@@ -188,7 +224,9 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             if constexpr (NPE == 2) pe_chunk(std::integral_constant<int, 32>(), xpe1, 1, 0);      // features 64..95 (84..95 padding)
         }
         TPP_SYNC();
-#if NEO_TPP_ZSKIP
+#if NEO_TPP_WORKLIST
+        // (the work list below decides per (row group, map) what is gathered)
+#elif NEO_TPP_ZSKIP
         // Which maps carry any weight for this tile (samples outside a feature map blend to exactly zero: grid_sample's zero
         // padding).  Outside the unit sphere the far samples project outside every source image (71 % of the fine tile-views
         // have no weighted latent tap) and often outside the tri-plane volume as well (21 %): profiles/r03_tile_footprint.json.
@@ -219,8 +257,11 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             const uint32_t lane_b = 16u * col4;
             f32x4 taps[RING][4];
             f32x4 wsum;                                    // running sum over the maps of one (chunk, row group)
-            int4 d_off[2];                                 // tap byte offsets of the item REQUESTED next (slot = item & 1)
-            f32x4 d_w[2];                                  // tap weights of the item BLENDED next
+            int4 d_off[RING];                              // tap byte offsets of the item REQUESTED next (slot = item & 1; work list: entry % 3)
+            [[maybe_unused]] f32x4 d_w[2];                 // tap weights of the item BLENDED next
+#if NEO_TPP_WORKLIST
+            f32x4 d_w3[RING];                              // (work-list pipeline: slot = entry % 3, like the taps)
+#endif
             // pos_enc weight fragments: k-steps 8..8+KSP-1 of N-tiles wv (L0) and 4 + wv (L3 skip) of the packed streamed stage
             constexpr int XD = NEO_TPP_XD, XS = XD + 1;
             h8 wh[XS][2], wl[XS][2];
@@ -279,6 +320,111 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += val[e];
                     }
             };
+#if NEO_TPP_WORKLIST
+            static_assert(RING == 3 && LIST_MAX % RING == 0, "the work-list pipeline is written for a ring of three");
+            // ---- the work list of this tile-view.  Every wave builds its own copy (identical in all four: no barrier). ----
+            int n_p;                                         // entries incl. padding: a multiple of RING, 6..18 (wave-uniform)
+            const int4* list;
+            {
+                int4* mylist = reinterpret_cast<int4*>(smem + PP_OFF_LIST) + L.wv * LIST_MAX;
+                unsigned am = 0;                             // bit 4 q + m: a row of group q (rows 16 q .. 16 q + 15) has a weighted tap in map m
+#pragma unroll
+                for (int mp = 0; mp < 4; ++mp) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(loc_w + (mp * TM + L.lane) * 4);
+                    const unsigned long long z = __ballot(w[0] != 0.0f || w[1] != 0.0f || w[2] != 0.0f || w[3] != 0.0f);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) am |= (((z >> (16 * q)) & 0xFFFFull) != 0ull ? 1u : 0u) << (4 * q + mp);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)                  // an empty group keeps ONE entry: the latent's all-zero weights blend
+                    if (((am >> (4 * q)) & 0xFu) == 0u) am |= 1u << (4 * q);      // to the zeros the group's rows must receive
+                const int n = __builtin_popcount(am);
+                n_p = ((n + RING - 1) / RING) * RING;
+                int mine = -1;                               // lane i: the i-th set bit of am
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    if (((am >> b) & 1u) && __builtin_popcount(am & ((1u << b) - 1u)) == L.lane) mine = b;
+                if (L.lane < n_p) {
+                    int4 rec;                                // x: byte offset of the group's first descriptor row; y: 16 q;
+                    if (mine >= 0) {                         // z: 0.0f for the first map of a group, 1.0f after (wsum * z + blend); w: last map
+                        const int q = mine >> 2, mp = mine & 3;
+                        const unsigned grp = (am >> (4 * q)) & 0xFu;
+                        rec.x = (mp * TM + 16 * q) * 16;
+                        rec.y = 16 * q;
+                        rec.z = (grp & ((1u << mp) - 1u)) == 0u ? 0 : 0x3f800000;
+                        rec.w = (grp >> (mp + 1)) == 0u ? 1 : 0;
+                    } else {
+                        rec.x = 4 * DESC_BLOCK * 4;          // padding: the all-zero block - adds 0.0, stores nothing
+                        rec.y = 0;
+                        rec.z = 0x3f800000;
+                        rec.w = 0;
+                    }
+                    mylist[L.lane] = rec;
+                }
+                list = mylist;
+            }
+            const char* dbase = reinterpret_cast<const char*>(S.loc_off) + rg * 16;     // this thread's row inside a 16-row group
+            float* fstore = fbuf(0) + rg * 64 + ((col4 ^ rg) << 2);                     // its 16 B inside a group's rows of the transposition tile
+            auto wrap = [&](int idx) __attribute__((always_inline)) { return idx >= n_p ? idx - n_p : idx; };
+            int rx[RING];                                    // record offsets: rx[e % 3] (see the step)
+            int4 fin[RING];                                  // blend records
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wsum[e] = 0.0f;
+            // prologue: entries 0 and 1 of chunk 0 requested, descriptors of entry 2 and weights of entry 0 on their way
+            static_for<0, XD>([&](auto kc) { load_wk(kc); });
+            {
+                const int r0 = list[0].x, r1 = list[1].x, r2 = list[2].x;
+                fin[0] = list[0];
+                rx[0] = list[3].x; rx[1] = r1; rx[2] = r2;
+                const int4 o0 = *reinterpret_cast<const int4*>(dbase + r0);
+                const int4 o1 = *reinterpret_cast<const int4*>(dbase + r1);
+                d_off[2] = *reinterpret_cast<const int4*>(dbase + r2);
+                d_w3[0] = *reinterpret_cast<const f32x4*>(dbase + r0 + DESC_W * 4);
+                taps[0][0] = tp::load_tap(proj, (uint32_t)o0.x + lane_b); taps[0][1] = tp::load_tap(proj, (uint32_t)o0.y + lane_b);
+                taps[0][2] = tp::load_tap(proj, (uint32_t)o0.z + lane_b); taps[0][3] = tp::load_tap(proj, (uint32_t)o0.w + lane_b);
+                taps[1][0] = tp::load_tap(proj, (uint32_t)o1.x + lane_b); taps[1][1] = tp::load_tap(proj, (uint32_t)o1.y + lane_b);
+                taps[1][2] = tp::load_tap(proj, (uint32_t)o1.z + lane_b); taps[1][3] = tp::load_tap(proj, (uint32_t)o1.w + lane_b);
+            }
+            // One step = one list entry e of chunk c (ring slot j = e % 3: n_p is a multiple of 3, so slots are static):
+            //   weights of entry e + 1, records of e + 4 / e + 1, tap offsets of e + 3 are read from LDS (used in the NEXT step);
+            //   the taps of entry e + 2 are requested; entry e is blended, added to the group's running sum, and the sum stored
+            //   when e is its group's last map.  Indices past the list wrap into the next chunk (same list, next 256 B).
+            auto step = [&](auto cc, auto jc, int k) __attribute__((always_inline)) {
+                constexpr int c = decltype(cc)::value, j = decltype(jc)::value;
+                constexpr int j1 = (j + 1) % RING, j2 = (j + 2) % RING;
+                const int e = k + j;
+                d_w3[j1] = *reinterpret_cast<const f32x4*>(dbase + rx[j1] + DESC_W * 4);        // rx[j1] still is entry e + 1's
+                rx[j1] = list[wrap(e + 4)].x;
+                fin[j1] = list[wrap(e + 1)];
+                d_off[j] = *reinterpret_cast<const int4*>(dbase + rx[j]);                         // entry e + 3
+                {
+                    const float* base = proj + 64 * (e + 2 >= n_p ? c + 1 : c);                   // chunk = 64 fp32 channels (scalar select)
+                    const int4 off = d_off[j2];
+                    taps[j2][0] = tp::load_tap(base, (uint32_t)off.x + lane_b);
+                    taps[j2][1] = tp::load_tap(base, (uint32_t)off.y + lane_b);
+                    taps[j2][2] = tp::load_tap(base, (uint32_t)off.z + lane_b);
+                    taps[j2][3] = tp::load_tap(base, (uint32_t)off.w + lane_b);
+                }
+                const f32x4 val = blend4(taps[j], d_w3[j]);
+                const float keep = __int_as_float(fin[j].z);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wsum[t] = __builtin_fmaf(wsum[t], keep, val[t]);
+                if (fin[j].w) *reinterpret_cast<f32x4*>(fstore + (c & 1) * (TM * 64) + fin[j].y * 64) = wsum;
+                __builtin_amdgcn_sched_barrier(0);          // keep the ring RING entries deep: no hoisting of later entries' loads
+            };
+            static_for<0, 4>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                // this chunk's share of the pos_enc k-steps (KSP = 4: one per chunk; 6: 2, 1, 2, 1)
+                static_for<0, KSP>([&](auto kc) {
+                    constexpr int kp = decltype(kc)::value;
+                    if constexpr ((KSP == 4 ? kp : (kp < 2 ? 0 : kp < 3 ? 1 : kp < 5 ? 2 : 3)) == c) mma_k(kc);
+                });
+#pragma unroll 1
+                for (int k = 0; k < n_p; k += RING) static_for<0, RING>([&](auto jc) { step(cc, jc, k); });
+                TPP_SYNC();
+                consume_chunk(cc);
+            });
+#else
             // The pipeline for a compile-time set of maps: MASK bit 0 = latent, bit 1 = the three planes.  G maps per
             // (chunk, row group); item i: group i / G (chunk = group / 4, row group = group % 4), member i % G.
             auto pipeline = [&](auto mc) __attribute__((always_inline)) {
@@ -321,7 +467,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         constexpr int i = decltype(ic)::value;
                         if constexpr (i < NI) {
                             constexpr int mp = map_of(i), c = i / (4 * G);
-                            const float* base = mp == 0 ? proj : pp.p[mp == 0 ? 0 : mp - 1];
+                            const float* base = proj;          // one buffer: the descriptors carry each map's base
                             const int4 off = d_off[i & 1];
                             taps[i % RING][0] = tp::load_tap(base, (uint32_t)off.x + lane_b + 256u * c);
                             taps[i % RING][1] = tp::load_tap(base, (uint32_t)off.y + lane_b + 256u * c);
@@ -366,6 +512,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             if constexpr (NEO_TPP_MMA_INSIDE == 0) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
             if constexpr (NEO_TPP_MMA_INSIDE == 2)
                 if (!(any_latent && any_plane)) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
+#endif
         }
         TPP_SYNC();          // the transposition tiles alias the activation tile: every wave has consumed the last chunk
         // ---- L0 epilogue; L1, L2, L3 as ONE weight stream of 24 k-steps (N-tile = wave) requested LD k-steps ahead
@@ -577,12 +724,14 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
 
 }  // namespace
 
-void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj, const TpPlaneProj& pp, const TpScene& sc,
-                       const TpViews& views, const float* rays_o, const float* rays_d, const float* viewdirs,
+void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj_all, const long plane_base_texels[3],
+                       const TpScene& sc, const TpViews& views, const float* rays_o, const float* rays_d, const float* viewdirs,
                        const float* tvals, const float* far, int R, int N, int chunk, uint32_t* flags, float* out,
                        const float* dirsum, hipStream_t s) {
     const long P = (long)R * N;
     if (P <= 0) return;
+    const float* proj = proj_all;
+    const TpPlaneBase pp{{(int)plane_base_texels[0], (int)plane_base_texels[1], (int)plane_base_texels[2]}};
     const size_t lds = (size_t)PP_LDS_WORDS * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -211,8 +211,11 @@ __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile
 // PL_TEXEL_BYTES: bytes per tri-plane texel the plane taps address (128 fp32 channels, or 256 for the pre-projected
 // planes of mlp_tp_hpp.hip).
 template <int LOC_TEXEL_BYTES = 2048, bool DIRS = true, int PL_TEXEL_BYTES = 128 * 4, class PutDir>
+// pl_base_texels: added to this wave's tri-plane texel indices (mlp_tp_hpp.hip keeps the four projected maps in ONE buffer
+// and addresses them from one base pointer; 0 for every other caller).
 __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx& L, const TpScene& sc,
-                                                 const float* rot, const float* trn, int v, PutDir put_dir) {
+                                                 const float* rot, const float* trn, int v, PutDir put_dir,
+                                                 int pl_base_texels = 0) {
     int* loc_off = S.loc_off; float* loc_w = S.loc_w; int* pl_off = S.pl_off; float* pl_w = S.pl_w;
     float* cam_enc = S.cam_enc; const float* pe_world = S.pe_world; const float* feat_world = S.feat_world;
     const float* vdir_world = S.vdir_world;
@@ -249,7 +252,7 @@ __device__ __forceinline__ void view_descriptors(const Scratch& S, const LaneCtx
                 const float gb = L.wv == 2 ? cy_ : cz_;
                 t = bilinear_taps(ga, gb, sc.Wp, sc.Hp);
                 dst_off = pl_off + (L.wv - 1) * TM * 4; dst_w = pl_w + (L.wv - 1) * TM * 4;
-                base = v * sc.Hp * sc.Wp;
+                base = v * sc.Hp * sc.Wp + pl_base_texels;
                 texel_bytes = PL_TEXEL_BYTES;
             }
 #pragma unroll

@@ -19,11 +19,12 @@ R, NC, NF = 96, 128, 256
 _ORACLE_L0 = {}          # level-0 oracle outputs are the same for every kernel variant: evaluated once per session
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f16x3-pp2", "f16x3-noproj", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3-pp2", "f16x3-noproj", "f32", "f32-pp2", "f32-noproj"])
 def setup(request):
     """All point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent (default),
     with the tri-planes pre-projected as well ("pp2", mlp_tp_hpp.hip), split-fp16 in the reference's operation order,
-    exact fp32 MFMA."""
+    exact fp32 MFMA on the projected latent (default), on projected latent + planes ("f32-pp2") and in the reference's
+    operation order ("f32-noproj")."""
     params = synth.nerf_tp_state(0)
     scene = cases.small_scene()
     net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
