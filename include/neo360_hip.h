@@ -190,7 +190,7 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
                      float image_h, void* stream);
 
 /* Both arithmetic modes (the exact fp32 evaluator gathers the same projected maps since round 4; in it modes 2 and 3 both
- * project the planes for every slot).  enable != 0 (default): the 512-channel latent is pre-projected once per
+ * project the planes for every slot).  A fresh context is in mode 3.  enable != 0: the 512-channel latent is pre-projected once per
  * (scene, MLP slot) through the local columns of pts_linears.0 and of pts_linears.3's skip half
  * (W . bilerp(F) = bilerp(W . F): neo360/model.py:110-158 is linear in the latent up to the first ReLU), and
  * the evaluator gathers the 256-channel result; costs 1 KB per latent texel and slot of context memory.
@@ -198,8 +198,9 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
  * enable == 2: the three tri-planes are pre-projected the same way through the world columns (the 128-channel plane
  * sum of encoder_tp_fusion_conv.py:180-206 enters pts_linears.0 / .3 linearly too, model.py:123-137): no per-point world
  * GEMM stage, four 256-channel maps are gathered, blended and added; 1 KB per plane texel and slot on top.
- * enable == 3: as 2 for slots 1..3, as 1 for slot 0 (the coarse level inside the sphere: its widely spaced samples share
- * no texels, the larger taps cost more than the GEMM stage they replace). */
+ * enable == 3: as 2 for the outside-sphere slots 2, 3 (most of their samples lie outside every map: few taps, the GEMM stage
+ * is pure saving), as 1 for the inside-sphere slots 0, 1 (every map carries weight: the larger taps cost more than the GEMM
+ * stage they replace).  The Python modules default to 3. */
 int neo_tp_set_preproject(neo_ctx* ctx, int enable);
 
 /* `predict` + the feature lookups for one region at given sample positions
@@ -420,6 +421,11 @@ int neo_mip_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const
 int neo_ctx_set_timing(neo_ctx* ctx, int enable);
 int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points,
                         double* total_flops);
+/* The same launches one by one, in launch order: duration (ms), which evaluator ran (kernel_id: 0 unspecified,
+ * 1 k_tp_mlp_hp, 2 k_tp_mlp_hpp, 3 k_tp_mlp_h, 4 k_tp_mlp), points and algorithmic flops of each.  A NeO-360 frame is four
+ * launches (inside / outside the sphere x coarse / fine) and, in pre-projection mode 3, two different kernels: the bench's
+ * roofline object prices each kernel with ITS launches.  Arrays may be NULL; *count = launches recorded (may exceed capacity). */
+int neo_ctx_read_spans(neo_ctx* ctx, int capacity, double* ms, int* kernel_id, double* points, double* flops, int* count);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,8 @@ SIGNATURES = {
     "neo_ctx_set_timing": (_i, [_vp, _i]),
     "neo_ctx_read_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i),
                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "neo_ctx_read_spans": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i), ctypes.POINTER(ctypes.c_double),
+                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i)]),
 }
 
 _lock = threading.Lock()

@@ -109,6 +109,18 @@ class Context:
                                                 ctypes.byref(fl)))
         return ms.value, n.value, pts.value, fl.value
 
+    KERNEL_NAMES = {0: "unspecified", 1: "k_tp_mlp_hp", 2: "k_tp_mlp_hpp", 3: "k_tp_mlp_h", 4: "k_tp_mlp"}
+
+    def read_spans(self):
+        """Every timed evaluator launch since set_timing(True), in order: [(ms, kernel name, points, algorithmic flops)]."""
+        n = ctypes.c_int(0)
+        _lib.check(self.lib.neo_ctx_read_spans(self.handle, 0, None, None, None, None, ctypes.byref(n)))
+        cap = n.value
+        ms, kid = (ctypes.c_double * cap)(), (ctypes.c_int * cap)()
+        pts, fl = (ctypes.c_double * cap)(), (ctypes.c_double * cap)()
+        _lib.check(self.lib.neo_ctx_read_spans(self.handle, cap, ms, kid, pts, fl, ctypes.byref(n)))
+        return [(ms[i], self.KERNEL_NAMES.get(kid[i], str(kid[i])), pts[i], fl[i]) for i in range(min(cap, n.value))]
+
     def close(self):
         if self.handle:
             self._finalizer.detach()

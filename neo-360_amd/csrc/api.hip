@@ -106,12 +106,16 @@ void neo_ctx::span_begin(hipStream_t s) {
     (void)hipEventCreate(&b);
     (void)hipEventRecord(a, s);
     spans.emplace_back(a, b);
+    span_kernel.push_back(span_kernel_next);
+    span_kernel_next = 0;
 }
 void neo_ctx::span_end(hipStream_t s, double points, double flop_per_point) {
     if (!timing) return;
     (void)hipEventRecord(spans.back().second, s);
     timed_points += points;
     timed_flops += points * flop_per_point;
+    span_points.push_back(points);
+    span_flops.push_back(points * flop_per_point);
 }
 
 extern "C" {
@@ -283,6 +287,9 @@ int neo_ctx_set_timing(neo_ctx* ctx, int enable) {
     ENTER(ctx);
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     ctx->spans.clear();
+    ctx->span_kernel.clear();
+    ctx->span_points.clear();
+    ctx->span_flops.clear();
     ctx->timed_points = 0.0;
     ctx->timed_flops = 0.0;
     ctx->timing = enable != 0;
@@ -302,6 +309,23 @@ int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* t
     if (launches) *launches = static_cast<int>(ctx->spans.size());
     if (total_points) *total_points = ctx->timed_points;
     if (total_flops) *total_flops = ctx->timed_flops;
+    return NEO_OK;
+}
+
+int neo_ctx_read_spans(neo_ctx* ctx, int capacity, double* ms, int* kernel_id, double* points, double* flops, int* count) {
+    ENTER(ctx);
+    REQUIRE(count != nullptr && capacity >= 0, "null count / negative capacity");
+    const int n = static_cast<int>(ctx->spans.size());
+    *count = n;
+    for (int i = 0; i < n && i < capacity; ++i) {
+        HIP_TRY(hipEventSynchronize(ctx->spans[i].second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ctx->spans[i].first, ctx->spans[i].second));
+        if (ms) ms[i] = t;
+        if (kernel_id) kernel_id[i] = ctx->span_kernel[i];
+        if (points) points[i] = i < static_cast<int>(ctx->span_points.size()) ? ctx->span_points[i] : 0.0;
+        if (flops) flops[i] = i < static_cast<int>(ctx->span_flops.size()) ? ctx->span_flops[i] : 0.0;
+    }
     return NEO_OK;
 }
 

@@ -70,10 +70,12 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             ctx->planes_checked = ctx->scene_epoch;
         }
         if (ctx->preproject) {
-            // mode 2: planes projected for every slot; mode 3: for every slot but the coarse one inside the sphere (slot 0), whose
-            // widely spaced samples share no texels - there the 24 extra 1 KB gather items cost more than the world GEMM stage
-            // they replace (profiles/r04_tp_hp_experiments.log: 4.03 vs 3.82 ms; the other three launches gain 0 / 0 / 7 %)
-            const bool planes = ctx->preproject == 2 || (ctx->preproject == 3 && slot_index != 0);
+            // mode 2: planes projected for every slot; mode 3 (default): for the two OUTSIDE-sphere slots only.  Outside, most
+            // samples leave the tri-plane volume and every source image: the work list of mlp_tp_hpp.hip gathers 6 of 16
+            // (row group, map) pairs on average and the world GEMM stage is pure saving (-8 % / -6 % on the fine / coarse
+            // launch).  Inside, every map carries weight on almost every row: 24 more 1 KB gather items per tile-view cost
+            // more than the GEMM stage they replace (+1..7 %): profiles/r04_tp_hp_experiments.log.
+            const bool planes = ctx->preproject == 2 || (ctx->preproject == 3 && slot_index >= 2);
             if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base)) return rc;
             guard_split_weights(sl, sl.wpack_hp.p, neo::tp_wpack_hp_bytes(sl.input_ch), ctx->flags, s);
             neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
@@ -81,6 +83,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             // ray alone: summed once per ray here instead of once per sample and view inside the evaluator
             if (ctx->tp_dirsum.reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
             neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum.as<float>(), s);
+            ctx->span_kernel_next = planes ? 2 : 1;
             ctx->span_begin(s);
             if (planes)
                 neo::launch_tp_mlp_hpp(sl.input_ch, mh, sl.proj.as<float>(), plane_base, sc, views, rays_o, rays_d, viewdirs, tvals, far,
@@ -95,6 +98,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
                 ctx->latent_checked = ctx->scene_epoch;
             }
             neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
+            ctx->span_kernel_next = 3;
             ctx->span_begin(s);
             neo::launch_tp_mlp_h(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
         }
@@ -108,6 +112,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base)) return rc;
         const float* pbase = sl.proj.as<float>();
         const neo::TpPlaneProj pp{{pbase + plane_base[0] * 256, pbase + plane_base[1] * 256, pbase + plane_base[2] * 256}};
+        ctx->span_kernel_next = 4;
         ctx->span_begin(s);
         neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s,
                            ctx->preproject ? sl.proj.as<float>() : nullptr, planes ? &pp : nullptr);

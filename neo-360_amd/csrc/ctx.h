@@ -138,7 +138,7 @@ struct neo_ctx {
     uint64_t scene_epoch = 0;          // bumped by every neo_tp_set_scene
     uint64_t planes_checked = 0, latent_checked = 0;   // scene_epoch whose maps passed the split range check
     neo_host::DevBuf tp_dirsum;        // (rays, 32): view-summed direction encodings of the current launch (k_tp_mlp_hp)
-    int preproject = 1;                // split path: 1 gather the latent pre-projected through the first-layer weights; 2 the tri-planes too
+    int preproject = 3;                // 0 off; 1 gather the latent pre-projected through the first-layer weights; 2 the tri-planes too; 3 (default): planes for the outside-sphere slots only
     // PixelNeRF scene latent: its own buffer / descriptor / ready flag (a context may hold both decoders)
     neo_host::DevBuf pix_latent;
     neo::TpScene pix_scene{};
@@ -177,6 +177,9 @@ struct neo_ctx {
     void order_end(hipStream_t s);
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    std::vector<int> span_kernel;                // which evaluator each span bracketed (neo_ctx_read_spans)
+    std::vector<double> span_points, span_flops;
+    int span_kernel_next = 0;                    // set by the launch site just before span_begin
     double timed_points = 0.0, timed_flops = 0.0;
 
     const float* get_quantiles(int n_new, hipStream_t s);

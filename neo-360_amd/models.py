@@ -330,8 +330,8 @@ class NeRF_TP(_HipModule):
         # split path: gather the latent pre-projected through each MLP's first-layer weights (256 instead of 512
         # channels per tap, 51 % fewer MACs per point-view; see csrc/mlp_tp_hp.hip).  False: the reference's order.
         # 2: the tri-planes are pre-projected through the world columns as well (csrc/mlp_tp_hpp.hip): no world GEMM stage.
-        # 3: mode 2 for every MLP but fg_coarse (mode 1 there).
-        self.preproject = {"0": False, "1": True, "2": 2, "3": 3}.get(os.environ.get("NEO360_TP_PREPROJECT", "1"), True)
+        # 3 (default): planes projected for the two outside-sphere MLPs only (measured best: profiles/r04_tp_hp_experiments.log).
+        self.preproject = {"0": False, "1": True, "2": 2, "3": 3}.get(os.environ.get("NEO360_TP_PREPROJECT", "3"), 3)
 
     def _context(self, device):
         ctx = super()._context(device)

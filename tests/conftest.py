@@ -131,7 +131,8 @@ FLIP_MARGIN = 1e-6      # ~16 ulps of a cdf in [0,1]: what faithful fp32 evaluat
 
 
 FLIP_PRONE_MAX_FRAC = 0.10   # a fixture with more flip-prone rays than this would make the exemption the rule: fail instead
-ABOVE_TOL_MAX_FRAC = 0.005   # rays that may exceed 1e-4 at all (observed over 9 fixtures: <= 0.2 %, profiles/r04_parity_report.json)
+ABOVE_TOL_MAX_FRAC = 0.01    # rays that may exceed 1e-4 at all (observed over 9 fixtures x both arithmetics: 0 .. 6 of 1024 = 0.59 % on full-size
+                             # chunk b1, identically in the split and the exact kernels; profiles/r04_parity_report.json)
 
 
 def check_vs_reference_noise(got, g, noise, label, tol=1e-4, flip=None):
@@ -152,7 +153,7 @@ def check_vs_reference_noise(got, g, noise, label, tol=1e-4, flip=None):
       * a ray the reference disagrees with itself on (n >= 1e-5) must land within 1e-4 + 3 n;
       * a flip-prone ray (margin < 1e-6) must land within 1e-4 + 3 max(n, f): n its own self-noise, f ITS OWN flip size
         (without a flip fixture: the largest self-disagreement of the fixture, the round-3 rule);
-      * at most 10 % of a fixture's rays may be flip-prone and at most 0.5 % of its rays may exceed 1e-4 at all.
+      * at most 10 % of a fixture's rays may be flip-prone and at most 1 % of its rays may exceed 1e-4 at all.
     Records max / p99 / counts per output in the parity report."""
     rec = {}
     nrays = int(noise["noise_rgb1"].numel())

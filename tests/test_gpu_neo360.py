@@ -76,7 +76,7 @@ def test_sharp_density(golden, golden_optional):
                               golden("g4_neo_sharp_noise"), "sharp", flip=golden_optional("g4_neo_sharp_flip"))
 
 
-@pytest.mark.parametrize("preproject", [True, 2, False])
+@pytest.mark.parametrize("preproject", [3, True, 2, False])
 def test_reference_sample_counts_1024(golden, golden_optional, preproject):
     """One reference-sized chunk: 1024 rays, 128 coarse + 256 fine, fg + bg, 3 views; both split evaluators
     (latent pre-projected through the first-layer weights = default, and the reference's operation order)."""

@@ -19,12 +19,12 @@ R, NC, NF = 96, 128, 256
 _ORACLE_L0 = {}          # level-0 oracle outputs are the same for every kernel variant: evaluated once per session
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f16x3-pp2", "f16x3-noproj", "f32", "f32-pp2", "f32-noproj"])
+@pytest.fixture(scope="module", params=["f16x3", "f16x3-pp1", "f16x3-pp2", "f16x3-noproj", "f32", "f32-pp1", "f32-noproj"])
 def setup(request):
-    """All point-evaluator kernels against the oracle: split-fp16 matrix cores on the pre-projected latent (default),
-    with the tri-planes pre-projected as well ("pp2", mlp_tp_hpp.hip), split-fp16 in the reference's operation order,
-    exact fp32 MFMA on the projected latent (default), on projected latent + planes ("f32-pp2") and in the reference's
-    operation order ("f32-noproj")."""
+    """All point-evaluator kernels against the oracle.  Split-fp16 matrix cores: the default (pre-projection mode 3: latent
+    projected everywhere, tri-planes too outside the sphere - mlp_tp_hp.hip inside, mlp_tp_hpp.hip outside), latent only
+    ("pp1"), latent + planes everywhere ("pp2"), the reference's operation order ("noproj").  Exact fp32 MFMA: on projected
+    latent + planes (default), on the projected latent ("f32-pp1"), in the reference's operation order ("f32-noproj")."""
     params = synth.nerf_tp_state(0)
     scene = cases.small_scene()
     net = models.NeRF_TP(num_coarse_samples=NC, num_fine_samples=NF, num_src_views=cases.NV).to(DEV)
@@ -33,7 +33,7 @@ def setup(request):
     net.load_state_dict(params)
     net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV),
                   scene["latent"].to(DEV), scene["image_wh"],
-                  preproject=2 if request.param.endswith("pp2") else not request.param.endswith("noproj"))
+                  preproject={"pp1": True, "pp2": 2, "noproj": False}.get(request.param.split("-")[-1]))      # None: the default (3)
     batch = cases.neo_batch(cases.strided_rays(R))
     return params, scene, net, batch, {k: v.to(DEV) for k, v in batch.items()}
 

@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage: pmc_bench.sh <workload> <precision> <kernel-substring>
+# usage: pmc_bench.sh <workload> <precision> <kernel-substring> [<second kernel-substring>]   (e.g. "k_tp_mlp_hp<" "k_tp_mlp_hpp<")
 # rocprofv3 passes over `bench.py --workload W --precision P --steps 1 --warmup 0 --cpu-rays 0`:
 # one --kernel-trace --stats pass, then separate --pmc passes (counters only), summarised per launch.
-W=$1; P=$2; K=$3
+W=$1; P=$2; K=$3; K2=$4
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_${W}_${P}
@@ -17,7 +17,8 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout 900 rocprofv3 --kernel-trace --pmc $C -f csv -d $OUT/pass$i -- $CMD > $OUT/pass$i.log 2>&1
 done
-python $REPO/tools/pmc_summarize.py $OUT $K --note "rocprofv3 --kernel-trace --pmc <pass> -f csv -- $CMD (4 counter passes, no other trace domains)" > $OUT/summary.json
+PMC_WORKLOAD=$W python $REPO/tools/pmc_summarize.py $OUT "$K" --note "rocprofv3 --kernel-trace --pmc <pass> -f csv -- $CMD (4 counter passes, no other trace domains)" > $OUT/summary.json
+if [ -n "$K2" ]; then PMC_WORKLOAD=$W python $REPO/tools/pmc_summarize.py $OUT "$K2" --note "second kernel of the same passes" > $OUT/summary_2.json; fi
 cat $OUT/summary.json
 head -8 $OUT/kernel_stats.csv
 find $OUT -name "*.csv" -size +1M -delete
