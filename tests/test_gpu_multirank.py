@@ -141,7 +141,8 @@ def test_bench_under_torchrun_one_rank():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 1 and out["unit"] == "rays/s" and out["value"] > 1e4
     assert "RCCL process group of 1 rank" in out["config"]["collective"]
-    assert out["roofline"]["launches"] == 4                      # fg / bg x coarse / fine of the one timed frame
+    assert out["roofline"]["all_evaluator_launches"]["launches"] == 4      # inside / outside the sphere x coarse / fine of the one timed frame
+    assert sum(k["launches"] for k in out["roofline"]["kernels"].values()) == 4
     path = os.path.join(ROOT, "gpurun_out", "bench_torchrun_world1.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
