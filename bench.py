@@ -269,7 +269,8 @@ class Runner:
     def _time_scene_setup(self):
         """Once-per-scene work that the per-frame numbers do not contain: channels-last re-layout of the feature maps
         (set_scene), weight upload + fragment packing, and the pre-projection of the latent through each of the four
-        MLPs' first-layer weights (k_tp_preproject; the 131,072 MACs per point-view the evaluator no longer executes)."""
+        MLPs' first-layer weights (k_tp_preproject; the 131,072 MACs per point-view the evaluator no longer executes) and -
+        pre-projection mode 3, the default - of the three tri-planes through the world columns for the two outside-sphere MLPs."""
         sc, net = self.scene, self.net
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -288,7 +289,8 @@ class Runner:
         return {"set_scene_ms": (t1 - t0) * 1e3, "pack_and_preproject_ms": max(0.0, (t2 - t1) - (t3 - t2)) * 1e3,
                 "total_ms": ((t1 - t0) + max(0.0, (t2 - t1) - (t3 - t2))) * 1e3,
                 "note": "once per scene / per weight update, not part of ms_per_step: channels-last re-layout of 3 tri-planes + latent, "
-                        "weight upload + fragment packing, 4 x k_tp_preproject (exact fp32 MFMA)"}
+                        "weight upload + fragment packing, k_tp_preproject (exact fp32 MFMA) x 4 for the latent + x 6 for the tri-planes "
+                        "of the two outside-sphere MLPs (pre-projection mode 3)"}
 
     def shard_rays(self):
         # only this rank's rays are generated, into the previous frame's tensors
