@@ -92,12 +92,12 @@ def kernel_source_hash(workload="neo360"):
 # MFMA products k_tp_mlp_hp really issues per point (NV source views; each algorithmic multiply = 3 fp16 products
 # a_hi b_hi + a_hi b_lo + a_lo b_hi; padded k-steps counted): per view the streamed [world | pos_enc] stage
 # (12 k-steps of 16 inside the sphere, 14 outside, x 256 outputs) + L1, L2, L3 (3 x 128 x 128); once per point the
-# view-mean tail (bottleneck 128 x 128, view layers 160 x 64 and 64 x 64).  The 512-channel latent does not appear:
-# it is pre-projected once per scene (scene_setup_ms).
+# view-mean tail (view layer 0 with the bottleneck folded in, 160 x 64, and view layer 1, 64 x 64).  The 512-channel latent does
+# not appear: it is pre-projected once per scene (scene_setup_ms).
 def executed_flop_per_point_tp_hp(nv, outside, planes_projected=False):
     # planes_projected (mlp_tp_hpp.hip): the 8 world k-steps are gone as well (tri-planes pre-projected once per scene)
     per_view = ((14 if outside else 12) - (8 if planes_projected else 0)) * 16 * 256 + 3 * 128 * 128
-    macs = nv * per_view + 128 * 128 + 160 * 64 + 64 * 64
+    macs = nv * per_view + 160 * 64 + 64 * 64          # the bottleneck (128 x 128) is folded into view layer 0 at pack time (round 4)
     return macs * 3 * 2.0
 
 

@@ -441,7 +441,10 @@ int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, 
     if (sl.wpack_h.reserve(neo::vanilla_wpack_h_bytes())) return NEO_ERR_NOMEM;
     neo::launch_vanilla_pack(weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
                              static_cast<hipStream_t>(stream));
-    neo::launch_vanilla_pack_h(weights, sl.wpack_h.p, static_cast<hipStream_t>(stream));
+    if (sl.bias_hp.reserve(neo::vanilla_bias_floats() * sizeof(float)) || sl.fold_ws.reserve(neo::vanilla_fold_floats() * sizeof(float)))
+        return NEO_ERR_NOMEM;
+    neo::launch_vanilla_pack_h(weights, biases, sl.wpack_h.p, sl.fold_ws.as<float>(), sl.bias.as<float>(), sl.bias_hp.as<float>(),
+                               static_cast<hipStream_t>(stream));
     sl.weights_epoch += 1;
     sl.ready = true;
     return check_launch();
@@ -454,7 +457,7 @@ static int vanilla_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const
     if (ctx->precision == 1) guard_split_weights(sl, sl.wpack_h.p, neo::vanilla_wpack_h_bytes(), ctx->flags, s);
     ctx->span_begin(s);
     if (ctx->precision == 1) {
-        neo::VanillaMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
+        neo::VanillaMlpHDev mh{sl.wpack_h.p, sl.bias_hp.as<float>(), sl.heads.as<float>(), ctx->flags};
         neo::launch_vanilla_mlp_h(mh, rays_o, dirs, t, t_row_stride, R, N, out, s);
     } else {
         neo::VanillaMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>()};

@@ -78,7 +78,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             const bool planes = ctx->preproject == 2 || (ctx->preproject == 3 && slot_index >= 2);
             if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base)) return rc;
             guard_split_weights(sl, sl.wpack_hp.p, neo::tp_wpack_hp_bytes(sl.input_ch), ctx->flags, s);
-            neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
+            neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias_hp.as<float>(), sl.heads.as<float>(), ctx->flags};
             // the view-direction encodings enter the MLP only through their mean over the views, and they depend on the
             // ray alone: summed once per ray here instead of once per sample and view inside the evaluator
             if (ctx->tp_dirsum.reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
@@ -150,7 +150,10 @@ int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* 
     neo::launch_tp_pack(input_ch, weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
                         static_cast<hipStream_t>(stream));
     neo::launch_tp_pack_h(input_ch, weights, sl.wpack_h.p, static_cast<hipStream_t>(stream));
-    neo::launch_tp_pack_hp(input_ch, weights, sl.wpack_hp.p, static_cast<hipStream_t>(stream));
+    if (sl.bias_hp.reserve(neo::tp_bias_floats() * sizeof(float)) || sl.fold_ws.reserve(neo::tp_fold_floats() * sizeof(float)))
+        return NEO_ERR_NOMEM;
+    neo::launch_tp_pack_hp(input_ch, weights, biases, sl.wpack_hp.p, sl.fold_ws.as<float>(), sl.bias.as<float>(),
+                           sl.bias_hp.as<float>(), static_cast<hipStream_t>(stream));
     sl.weights_epoch += 1;
     sl.input_ch = input_ch;
     sl.ready = true;

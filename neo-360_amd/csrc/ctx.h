@@ -59,6 +59,7 @@ struct MlpSlot {
     DevBuf wpack, bias, heads;
     DevBuf wpack_h;      // fp16 hi/lo split fragments (precision mode 1)
     DevBuf wpack_hp;     // NeRF_TP: split fragments of the pre-projected evaluator (no local-latent k-steps)
+    DevBuf bias_hp, fold_ws;   // NeRF_TP pre-projected evaluators: their bias block (view layer 0 with the bottleneck folded in) + pack scratch
     DevBuf proj;         // NeRF_TP: ONE buffer [latent through this slot's [W0_loc | W3_loc] | the three tri-planes through
                          // [W0_world | W3_world] (preproject modes 2, 3) | padding], 256 fp32 channels = 1 KB per texel
     uint64_t projpl_weights = 0, projpl_scene = 0;   // (weights_epoch, scene_epoch) the plane part was computed for; 0 = never
@@ -69,6 +70,7 @@ struct MlpSlot {
     bool ready = false;
     void release() {
         wpack.release(); bias.release(); heads.release(); wpack_h.release(); wpack_hp.release(); proj.release();
+        bias_hp.release(); fold_ws.release();
         proj_weights = proj_scene = projpl_weights = projpl_scene = 0;
         ready = false;
     }

@@ -67,7 +67,14 @@ struct VanillaMlpHDev {
     uint32_t* flags;      // context assertion word (bit 1: split range guard)
 };
 size_t vanilla_wpack_h_bytes();
-void launch_vanilla_pack_h(const float* const* weights, void* wpack_h, hipStream_t s);
+// pack_h.hip: [W_v[:, :nb] . W_b | W_v[:, nb:]] and b_v + W_v[:, :nb] . b_b - a linear bottleneck folded into the layer that consumes it
+void launch_fold_bottleneck(const float* wv, const float* wb, const float* bb, const float* bv, int n_out, int nb, int nin,
+                            int extra, float* wfold, float* bfold, hipStream_t s);
+// biases / fold_ws: the split kernel folds the (linear) bottleneck into the view layer at pack time: bias_h = its own copy of the
+// bias block with the view layer's entry replaced, fold_ws = vanilla_fold_floats() floats of scratch
+size_t vanilla_fold_floats();
+void launch_vanilla_pack_h(const float* const* weights, const float* const* biases, void* wpack_h, float* fold_ws,
+                           const float* bias_src, float* bias_h, hipStream_t s);
 void launch_vanilla_mlp_h(const VanillaMlpHDev& m, const float* rays_o, const float* dirs, const float* t,
                           int t_row_stride, int R, int N, float* out, hipStream_t s);
 void launch_vanilla_mlp(const VanillaMlpDev& m, const float* rays_o, const float* dirs, const float* t,
@@ -171,7 +178,11 @@ void launch_tp_mlp_h(int input_ch, const TpMlpHDev& m, const TpScene& sc, const 
 int tp_kc_x(int input_ch);            // k-chunks per N-tile of stage X in the fp32 fragment pack (mlp_tp.hip)
 size_t tp_wpack_hp_bytes(int input_ch);
 size_t tp_proj_bytes(long texels);    // pre-projected map: 256 fp32 channels per latent texel
-void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipStream_t s);
+// fold_ws: tp_fold_floats() floats of scratch (the folded view-layer-0 matrix, tp_hp_layout.h NEO_TP_FOLDB); bias_src: the shared
+// 768-float bias block; bias_hp: the pre-projected evaluators' own copy of it (view layer 0's bias folded)
+size_t tp_fold_floats();
+void launch_tp_pack_hp(int input_ch, const float* const* w, const float* const* b, void* wpack_hp, float* fold_ws,
+                       const float* bias_src, float* bias_hp, hipStream_t s);
 // G (texels, 256) = latent_cl (texels, 512) . [W0_loc | W3_loc]^T from the fp32 fragment pack's stage X
 // (in_ch = 128, first_chunk = 64: a tri-plane through the world columns [W0_world | W3_world], mlp_tp_hpp.hip)
 void launch_tp_preproject(const float* latent_cl, long texels, const float* wpack_f32_stage_x, int kc_x, float* proj,

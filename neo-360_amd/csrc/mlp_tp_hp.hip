@@ -743,7 +743,59 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         sg += __shfl_xor(sg, 2, 64);
         raw_sigma = sg + lheads[HD_DB];
     }
-#if NEO_TP_TSTREAM
+#if NEO_TP_FOLDB
+    // ---- tail GEMMs as one weight stream of 14 k-steps, TD ahead across the stage boundary: view layer 0 WITH THE BOTTLENECK FOLDED
+    //      IN (tp_hp_layout.h) on [mean trunk | mean dir enc] (N-tile vnt, M-tile vmt, 8 + 2 k-steps), then 64 x 64 (4 k-steps) ----
+    {
+        const char* twb = reinterpret_cast<const char*>(wp);
+        constexpr int TD = NEO_TP_TSTREAM ? NEO_TP_TSTREAM : 6, TS = TD + 1;
+        h8 twh[TS], twl[TS];
+        auto load_t = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 14) {
+                constexpr bool v0 = g < 10;
+                constexpr int ks = v0 ? g : g - 10;
+                constexpr int KS = v0 ? 10 : 4;
+                constexpr uint32_t base = (uint32_t)(v0 ? hoff_v0(PE_C) : hoff_v1(PE_C)) * 16u;
+                const uint32_t off = base + (uint32_t)((vnt * KS + ks) * 128 + L.lane) * 16u;
+                twh[g % TS] = *reinterpret_cast<const h8*>(twb + off);
+                twl[g % TS] = *reinterpret_cast<const h8*>(twb + off + 1024u);
+            }
+        };
+        static_for<0, TD>([&](auto gc) { load_t(gc); });
+        f32x16 y;
+        static_for<0, 14>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            load_t(std::integral_constant<int, g + TD>());
+            constexpr bool v0 = g < 10;
+            constexpr int ks = v0 ? g : g - 10;
+            if constexpr (ks == 0) bias_tile(y, lbias + (v0 ? B_V0 : B_V1), vnt, L);
+            h8 bh, bl;
+            if constexpr (v0 && ks >= 8) {
+                const int o = chunk_off<32>(vmt * 32 + L.l31, ((ks - 8) << 1) + L.half);
+                bh = *reinterpret_cast<const h8*>(dsm.hi + o);
+                bl = *reinterpret_cast<const h8*>(dsm.lo + o);
+            } else {
+                const int o = chunk_off<128>(vmt * 32 + L.l31, (ks << 1) + L.half);
+                bh = *reinterpret_cast<const h8*>(act.hi + o);
+                bl = *reinterpret_cast<const h8*>(act.lo + o);
+            }
+            y = NEO_MFMA_H(twl[g % TS], bh, y);
+            y = NEO_MFMA_H(twh[g % TS], bl, y);
+            y = NEO_MFMA_H(twh[g % TS], bh, y);
+            if constexpr (g == 9) {
+                TP_SYNC();          // every wave has read the view-mean trunk (density head, view layer 0)
+                store_tile_h<true>(y, act, vnt, vmt, L);
+                TP_SYNC();
+            }
+            if constexpr (g == 13) {
+                TP_SYNC();
+                store_tile_h<true>(y, act, vnt, vmt, L);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+#elif NEO_TP_TSTREAM
     // ---- tail GEMMs as one weight stream of 22 k-steps, TD ahead across the stage boundaries:
     //      bottleneck of the view mean (N-tile cw, 8 k-steps, both M-tiles), view layer 0 on [mean bottleneck | mean dir enc]
     //      (N-tile vnt, M-tile vmt, 8 + 2 k-steps), 64 x 64 (4 k-steps) ----
@@ -1008,8 +1060,20 @@ size_t tp_wpack_hp_bytes(int input_ch) { return (size_t)hpack_h8(input_ch) * 16;
 size_t tp_proj_bytes(long texels) { return (size_t)texels * PROJ_TEXEL_BYTES; }
 size_t tp_proj_pad_bytes() { return 8192; }
 
-void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipStream_t s) {
-    // w order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
+size_t tp_fold_floats() { return 64 * 155; }
+
+void launch_tp_pack_hp(int input_ch, const float* const* w, const float* const* b, void* wpack_hp, float* fold_ws,
+                       const float* bias_src, float* bias_hp, hipStream_t s) {
+    // w / b order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
+    // biases of the pre-projected evaluators = the shared bias block with view layer 0's entry replaced by the folded one
+    (void)hipMemcpyAsync(bias_hp, bias_src, 768 * sizeof(float), hipMemcpyDeviceToDevice, s);
+#if NEO_TP_FOLDB
+    launch_fold_bottleneck(w[4], w[6], b[6], b[4], 64, 128, 128, 27, fold_ws, bias_hp + B_V0, s);
+    const float* w_v0 = fold_ws;
+#else
+    (void)fold_ws; (void)b;
+    const float* w_v0 = w[4];
+#endif
     _Float16* base = reinterpret_cast<_Float16*>(wpack_hp);
     const int pe = input_ch * 21;
     const int x0w = pe + 512 + 128;
@@ -1037,7 +1101,7 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, void* wpack_hp, hipS
     pack_h(w[6], 128, 128, 8, 0, p128, base + (long)hoff_b(input_ch) * 8, s);
     PackSegs v0 = none;
     v0.len[0] = 155;
-    pack_h(w[4], 155, 64, 10, 0, v0, base + (long)hoff_v0(input_ch) * 8, s);
+    pack_h(w_v0, 155, 64, 10, 0, v0, base + (long)hoff_v0(input_ch) * 8, s);
     PackSegs v1 = none;
     v1.len[0] = 64;
     pack_h(w[5], 64, 64, 4, 0, v1, base + (long)hoff_v1(input_ch) * 8, s);

@@ -49,6 +49,12 @@
 #ifndef NEO_TPP_WORKLIST
 #define NEO_TPP_WORKLIST 1     // gather pipeline over the list of (row group, map) pairs that carry weight (0: whole-map variants)
 #endif
+#ifndef NEO_TPP_SKIPEMPTY
+#define NEO_TPP_SKIPEMPTY 3    // work list: a tile-view in which NO tap of any map carries weight (21 % of the fine tile-views outside the sphere) skips the gather and the adds.  1: the whole gather under one branch, pos_enc k-steps in front of it; 3: zero-trip gather loops, k-steps stay between the chunks; 0: off
+#endif
+#ifndef NEO_TPP_PE_WCACHE
+#define NEO_TPP_PE_WCACHE 0    // outside the sphere the 4th encoded coordinate is 1 / r, the same in every source view: its 10 (sin, cos) pairs are computed for view 0 only
+#endif
 #ifndef NEO_TPP_ZSKIP
 #define NEO_TPP_ZSKIP 1        // gather only the maps in which some row of the tile has a weighted tap (latent / planes)
 #endif
@@ -189,6 +195,9 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         float x;
                         int oct;
                         if constexpr (PE_C == 4) {
+                            // coordinate 3 = 1 / r does not depend on the source view: its pairs are computed for view 0 and stay
+                            // in the tile (the later views store only the first 12 bytes of a chunk)
+                            if (NEO_TPP_PE_WCACHE && jj == 3 && v > 0) { f[6] = 0.0f; f[7] = 0.0f; continue; }
                             x = xv[jj];
                             oct = ch;
                         } else {
@@ -216,8 +225,16 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                     vl[e] = l[0]; vl[e + 1] = l[1];
                 }
                 const int o = chunk_off<LDH>(row, chs);
-                *reinterpret_cast<h8*>(buf.hi + o) = vh;
-                *reinterpret_cast<h8*>(buf.lo + o) = vl;
+                if (NEO_TPP_PE_WCACHE && PE_C == 4 && v > 0 && ch * 4 < 10 * PE_C) {      // an octave chunk of a later view: x, y, z pairs only
+                    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 ph = __builtin_bit_cast(u32x4, vh), pl = __builtin_bit_cast(u32x4, vl);
+                    *reinterpret_cast<u32x3*>(buf.hi + o) = u32x3{ph[0], ph[1], ph[2]};
+                    *reinterpret_cast<u32x3*>(buf.lo + o) = u32x3{pl[0], pl[1], pl[2]};
+                } else {
+                    *reinterpret_cast<h8*>(buf.hi + o) = vh;
+                    *reinterpret_cast<h8*>(buf.lo + o) = vl;
+                }
             };
             pe_chunk(std::integral_constant<int, 64>(), xpe0, 0, 0);
             pe_chunk(std::integral_constant<int, 64>(), xpe0, 0, 1);
@@ -324,6 +341,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             static_assert(RING == 3 && LIST_MAX % RING == 0, "the work-list pipeline is written for a ring of three");
             // ---- the work list of this tile-view.  Every wave builds its own copy (identical in all four: no barrier). ----
             int n_p;                                         // entries incl. padding: a multiple of RING, 6..18 (wave-uniform)
+            bool any_w;                                      // some tap of some map carries weight in this tile-view (wave-uniform, the same in all four waves)
             const int4* list;
             {
                 int4* mylist = reinterpret_cast<int4*>(smem + PP_OFF_LIST) + L.wv * LIST_MAX;
@@ -335,6 +353,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
 #pragma unroll
                     for (int q = 0; q < 4; ++q) am |= (((z >> (16 * q)) & 0xFFFFull) != 0ull ? 1u : 0u) << (4 * q + mp);
                 }
+                any_w = !NEO_TPP_SKIPEMPTY || am != 0u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)                  // an empty group keeps ONE entry: the latent's all-zero weights blend
                     if (((am >> (4 * q)) & 0xFu) == 0u) am |= 1u << (4 * q);      // to the zeros the group's rows must receive
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             for (int e = 0; e < 4; ++e) wsum[e] = 0.0f;
             // prologue: entries 0 and 1 of chunk 0 requested, descriptors of entry 2 and weights of entry 0 on their way
             static_for<0, XD>([&](auto kc) { load_wk(kc); });
-            {
+            if (any_w) {
                 const int r0 = list[0].x, r1 = list[1].x, r2 = list[2].x;
                 fin[0] = list[0];
                 rx[0] = list[3].x; rx[1] = r1; rx[2] = r2;
@@ -412,16 +431,34 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 if (fin[j].w) *reinterpret_cast<f32x4*>(fstore + (c & 1) * (TM * 64) + fin[j].y * 64) = wsum;
                 __builtin_amdgcn_sched_barrier(0);          // keep the ring RING entries deep: no hoisting of later entries' loads
             };
+#if NEO_TPP_SKIPEMPTY == 1
+            // the pos_enc k-steps in one block, outside any branch (an MFMA on the 64 accumulator registers inside a branch makes
+            // the allocator spill them: profiles/r03_tp_hp_experiments.log); the first two entries' taps are already on their way
+            static_for<0, KSP>([&](auto kc) { mma_k(kc); });
+            if (any_w)
+#elif NEO_TPP_SKIPEMPTY == 2
+            if (!any_w) static_for<0, KSP>([&](auto kc) { mma_k(kc); });       // (experiment: MFMAs in both branches -> 86 / 106 spills)
+            else
+#elif NEO_TPP_SKIPEMPTY == 3
+            // an empty tile-view runs the same code with a zero-trip gather loop and without the adds: the pos_enc k-steps keep
+            // their places between the chunks and stay outside any branch (the barriers stay too: four cheap ones per view)
+            if (!any_w) n_p = 0;
+#endif
             static_for<0, 4>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
+#if NEO_TPP_SKIPEMPTY != 1
                 // this chunk's share of the pos_enc k-steps (KSP = 4: one per chunk; 6: 2, 1, 2, 1)
                 static_for<0, KSP>([&](auto kc) {
                     constexpr int kp = decltype(kc)::value;
                     if constexpr ((KSP == 4 ? kp : (kp < 2 ? 0 : kp < 3 ? 1 : kp < 5 ? 2 : 3)) == c) mma_k(kc);
                 });
+#endif
 #pragma unroll 1
                 for (int k = 0; k < n_p; k += RING) static_for<0, RING>([&](auto jc) { step(cc, jc, k); });
                 TPP_SYNC();
+#if NEO_TPP_SKIPEMPTY == 3
+                if (any_w)
+#endif
                 consume_chunk(cc);
             });
 #else
@@ -616,6 +653,59 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
         sg += __shfl_xor(sg, 2, 64);
         raw_sigma = sg + lheads[HD_DB];
     }
+#if NEO_TP_FOLDB
+    // ---- tail GEMMs as one weight stream of 14 k-steps, TD ahead across the stage boundary: view layer 0 WITH THE BOTTLENECK FOLDED
+    //      IN (tp_hp_layout.h) on [mean trunk | mean dir enc] (N-tile vnt, M-tile vmt, 8 + 2 k-steps), then 64 x 64 (4 k-steps) ----
+    {
+        const char* twb = reinterpret_cast<const char*>(wp);
+        constexpr int TD = NEO_TPP_TD, TS = TD + 1;
+        h8 twh[TS], twl[TS];
+        auto load_t = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 14) {
+                constexpr bool v0 = g < 10;
+                constexpr int ks = v0 ? g : g - 10;
+                constexpr int KS = v0 ? 10 : 4;
+                constexpr uint32_t base = (uint32_t)(v0 ? hoff_v0(PE_C) : hoff_v1(PE_C)) * 16u;
+                const uint32_t off = base + (uint32_t)((vnt * KS + ks) * 128 + L.lane) * 16u;
+                twh[g % TS] = *reinterpret_cast<const h8*>(twb + off);
+                twl[g % TS] = *reinterpret_cast<const h8*>(twb + off + 1024u);
+            }
+        };
+        static_for<0, TD>([&](auto gc) { load_t(gc); });
+        f32x16 y;
+        static_for<0, 14>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            load_t(std::integral_constant<int, g + TD>());
+            constexpr bool v0 = g < 10;
+            constexpr int ks = v0 ? g : g - 10;
+            if constexpr (ks == 0) bias_tile(y, lbias + (v0 ? B_V0 : B_V1), vnt, L);
+            h8 bh, bl;
+            if constexpr (v0 && ks >= 8) {
+                const int o = chunk_off<32>(vmt * 32 + L.l31, ((ks - 8) << 1) + L.half);
+                bh = *reinterpret_cast<const h8*>(dsm.hi + o);
+                bl = *reinterpret_cast<const h8*>(dsm.lo + o);
+            } else {
+                const int o = chunk_off<128>(vmt * 32 + L.l31, (ks << 1) + L.half);
+                bh = *reinterpret_cast<const h8*>(act.hi + o);
+                bl = *reinterpret_cast<const h8*>(act.lo + o);
+            }
+            y = NEO_MFMA_H(twl[g % TS], bh, y);
+            y = NEO_MFMA_H(twh[g % TS], bl, y);
+            y = NEO_MFMA_H(twh[g % TS], bh, y);
+            if constexpr (g == 9) {
+                TPP_SYNC();          // every wave has read the view-mean trunk (density head, view layer 0)
+                store_tile_h<true>(y, act, vnt, vmt, L);
+                TPP_SYNC();
+            }
+            if constexpr (g == 13) {
+                TPP_SYNC();
+                store_tile_h<true>(y, act, vnt, vmt, L);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+#else
     // ---- tail GEMMs as one weight stream of 22 k-steps, TD ahead across the stage boundaries:
     //      bottleneck of the view mean (N-tile wave, 8 k-steps, both M-tiles), view layer 0 on [mean bottleneck | mean dir enc]
     //      (N-tile vnt, M-tile vmt, 8 + 2 k-steps), 64 x 64 (4 k-steps) ----
@@ -691,6 +781,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             __builtin_amdgcn_sched_barrier(0);
         });
     }
+#endif
     TPP_SYNC();
     {
         const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;

@@ -111,6 +111,9 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 #ifndef NEO_VH_XLAYER
 #define NEO_VH_XLAYER 1        // the next stage's first weight fragments are requested before this stage's barrier
 #endif
+#ifndef NEO_VH_FOLDB
+#define NEO_VH_FOLDB 1         // the linear bottleneck is folded into the view layer at pack time (launch_vanilla_pack_h): no bottleneck stage
+#endif
 #ifndef NEO_VH_PREFETCH
 #define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
 #endif
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
             if (XL) ring_prime(ring, wp + woff, KS, nt0, 16, L);
             gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L, ring, XL);
         }
-        if (XL) {          // next stage: L(s+1) (its stream is 20 k-steps long for s + 1 == 5), or the bottleneck after L7
+        if (XL && (!NEO_VH_FOLDB || s < 7)) {          // next stage: L(s+1) (its stream is 20 k-steps long for s + 1 == 5), or the bottleneck after L7
             const int nwoff = s < 7 ? stage_w_off(1) + s * (8 * 16 * 128) + (s + 1 > 5 ? 8 * 4 * 128 : 0) : stage_w_off(8);
             ring_prime(ring, wp + nwoff, s + 1 == 5 ? 20 : 16, nt0, 0, L);
         }
@@ -410,13 +413,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
         for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o, 64);
         raw_sigma = s + m.heads[HD_DB];
     }
+#if !NEO_VH_FOLDB
     // ---- bottleneck: 256 -> 256, no activation ----
     init_bias<NTW, MT>(acc, m.bias + stage_b_off(8), nt0, L);
     gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L, ring, XL);
     VH_SYNC();
     store_act<NTW, MT, false>(acc, act, nt0, 0, L);
     VH_SYNC();
-    // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU (4 N-tiles: split over M as well when NW = 8) ----
+#endif
+    // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU (4 N-tiles: split over M as well when NW = 8); with the bottleneck
+    //      folded in (NEO_VH_FOLDB) its first 256 inputs are the trunk's last activations themselves ----
     {
         constexpr int MTV = NW == 8 ? 1 : MT;
         const int ntv = L.wv & 3, mtv = NW == 8 ? (L.wv >> 2) : 0;
@@ -485,12 +491,23 @@ __global__ void k_pack_stage_h(const float* __restrict__ W, int n_out, int k_in,
 }  // namespace
 
 size_t vanilla_wpack_h_bytes() { return (size_t)WPACK_H8 * 16; }
+size_t vanilla_fold_floats() { return 128 * 283; }
 
-void launch_vanilla_pack_h(const float* const* weights, void* wpack_h, hipStream_t s) {
+// weights / biases order: pts_linears.0..7, views_linear.0, bottleneck_layer, density_layer, rgb_layer
+void launch_vanilla_pack_h(const float* const* weights, const float* const* biases, void* wpack_h, float* fold_ws,
+                           const float* bias_src, float* bias_h, hipStream_t s) {
     _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
+    (void)hipMemcpyAsync(bias_h, bias_src, (size_t)stage_b_off(NUM_STAGES) * sizeof(float), hipMemcpyDeviceToDevice, s);
+#if NEO_VH_FOLDB
+    // bottleneck_layer (256 -> 256, NO activation) feeds views_linear.0 only (vanilla_nerf/model.py:113-121):
+    // W_v [W_b h + b_b | d] + b_v = (W_v[:, :256] W_b) h + W_v[:, 256:] d + (W_v[:, :256] b_b + b_v).  The product is formed once
+    // per upload (fp64 accumulation) and packed as the view layer; the kernel skips the bottleneck stage (65,536 of 593,408 MACs).
+    launch_fold_bottleneck(weights[8], weights[9], biases[9], biases[8], 128, 256, 256, 27, fold_ws, bias_h + stage_b_off(9), s);
+#endif
     for (int st = 0; st < NUM_STAGES; ++st) {
         const int total = (ST_N[st] / 32) * ST_KS[st] * 512;
-        hipLaunchKernelGGL(k_pack_stage_h, dim3((total + 255) / 256), dim3(256), 0, s, weights[ST_SRC[st]], ST_N[st],
+        const float* src = (NEO_VH_FOLDB && st == 9) ? fold_ws : weights[ST_SRC[st]];
+        hipLaunchKernelGGL(k_pack_stage_h, dim3((total + 255) / 256), dim3(256), 0, s, src, ST_N[st],
                            ST_KIN[st], ST_KS[st], base + (long)stage_w_off(st) * 8);
     }
 }

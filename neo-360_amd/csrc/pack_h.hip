@@ -64,7 +64,40 @@ __global__ void k_f32_range_check(const float* __restrict__ x, size_t n4, size_t
     if (bad) atomicOr(flags, FLAG_SPLIT_RANGE);
 }
 
+// Bottleneck folded into the layer that consumes it (tp_hp_layout.h NEO_TP_FOLDB; the same algebra for the vanilla NeRFMLP,
+// vanilla_nerf/model.py:113-121: bottleneck_layer has no activation and feeds views_linear.0 only):
+//   wfold (n_out, nin + extra) = [W_v[:, :nb] . W_b (nb, nin) | W_v[:, nb:nb + extra]],   bfold (n_out) = b_v + W_v[:, :nb] . b_b
+// fp64 accumulation, one thread per output element.
+__global__ void k_fold_bottleneck(const float* __restrict__ wv, const float* __restrict__ wb, const float* __restrict__ bb,
+                                  const float* __restrict__ bv, int n_out, int nb, int nin, int extra,
+                                  float* __restrict__ wfold, float* __restrict__ bfold) {
+    const int ldv = nb + extra, ldf = nin + extra;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)n_out * ldf) {
+        const int o = (int)(idx / ldf), i = (int)(idx % ldf);
+        if (i < nin) {
+            double acc = 0.0;
+            for (int j = 0; j < nb; ++j) acc += (double)wv[(long)o * ldv + j] * (double)wb[(long)j * nin + i];
+            wfold[idx] = (float)acc;
+        } else {
+            wfold[idx] = wv[(long)o * ldv + nb + (i - nin)];
+        }
+    } else if (idx < (long)n_out * ldf + n_out) {
+        const int o = (int)(idx - (long)n_out * ldf);
+        double acc = (double)bv[o];
+        for (int j = 0; j < nb; ++j) acc += (double)wv[(long)o * ldv + j] * (double)bb[j];
+        bfold[o] = (float)acc;
+    }
+}
+
 }  // namespace
+
+void launch_fold_bottleneck(const float* wv, const float* wb, const float* bb, const float* bv, int n_out, int nb, int nin,
+                            int extra, float* wfold, float* bfold, hipStream_t s) {
+    const long total = (long)n_out * (nin + extra) + n_out;
+    hipLaunchKernelGGL(k_fold_bottleneck, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wv, wb, bb, bv, n_out, nb, nin,
+                       extra, wfold, bfold);
+}
 
 void launch_half_range_check(const void* halves, size_t n, uint32_t* flags, hipStream_t s) {
     if (n == 0) return;

@@ -31,6 +31,15 @@ constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 324;
 
 constexpr int PROJ_TEXEL_BYTES = 1024;     // 256 fp32 channels per texel of the pre-projected map
 
+// Bottleneck folded into view layer 0 (round 4).  NeRFPPMLP's bottleneck layer has NO activation and feeds views_linear.0 only
+// (neo360/model.py:133-149), and the evaluators already apply it to the view MEAN of the trunk (linearity, mlp_tp_h.hip):
+//     W_v0 [W_b h + b_b | d] + b_v0  =  (W_v0[:, :128] W_b) h + W_v0[:, 128:] d + (W_v0[:, :128] b_b + b_v0).
+// The 64 x 128 product matrix and the bias are formed once per weight upload (k_fold_bottleneck, fp64 accumulation) and packed
+// into the slot of view layer 0: the tail loses its 128 x 128 GEMM (48 of its 90 MFMAs per wave), an epilogue and two barriers.
+#ifndef NEO_TP_FOLDB
+#define NEO_TP_FOLDB 1
+#endif
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
