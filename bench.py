@@ -414,7 +414,9 @@ class Runner:
         if self.workload == "neo360" and not self.split and getattr(self.net, "preproject", False):
             # the exact kernel on projected maps skips the projected stages' MACs: executed = algorithmic - skipped
             pl = self.net.preproject in (2, 3) and self.net.preproject is not True
-            skipped = 3 * (131072 + (32768 if pl else 0)) * 2.0            # per point: 3 views x (latent [+ planes]) MACs x 2
+            # per point: 3 views x (latent [+ planes] pre-projected; bottleneck 16,384 + view layer 0 9,920 moved out of the view loop
+            # by linearity) MACs, minus the folded view layer run once per tile (160 x 64), x 2
+            skipped = (3 * (131072 + (32768 if pl else 0) + 26304) - 10240) * 2.0
             ex = flops - points * skipped
             roof["executed_tflops"] = ex / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
             roof["frac_executed"] = roof["executed_tflops"] / PEAK_F32_MFMA_TFLOPS

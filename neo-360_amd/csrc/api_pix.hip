@@ -71,7 +71,8 @@ int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, cons
     if (sl.bias.reserve(neo::pix_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.heads.reserve(neo::pix_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.wpack.reserve(neo::pix_wproj_bytes())) return NEO_ERR_NOMEM;
-    neo::launch_pix_pack_h(weights, biases, sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(),
+    if (sl.fold_ws.reserve(neo::pix_fold_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_pix_pack_h(weights, biases, sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), sl.fold_ws.as<float>(),
                            static_cast<hipStream_t>(stream));
     neo::launch_pix_pack_proj(weights[0], sl.wpack.as<float>(), static_cast<hipStream_t>(stream));
     sl.input_ch = 3;

@@ -147,8 +147,9 @@ int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* 
     if (sl.heads.reserve(neo::tp_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.wpack_h.reserve(neo::tp_wpack_h_bytes(input_ch))) return NEO_ERR_NOMEM;
     if (sl.wpack_hp.reserve(neo::tp_wpack_hp_bytes(input_ch))) return NEO_ERR_NOMEM;
+    if (sl.fold_ws.reserve(neo::tp_fold_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     neo::launch_tp_pack(input_ch, weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(),
-                        static_cast<hipStream_t>(stream));
+                        static_cast<hipStream_t>(stream), sl.fold_ws.as<float>());
     neo::launch_tp_pack_h(input_ch, weights, sl.wpack_h.p, static_cast<hipStream_t>(stream));
     if (sl.bias_hp.reserve(neo::tp_bias_floats() * sizeof(float)) || sl.fold_ws.reserve(neo::tp_fold_floats() * sizeof(float)))
         return NEO_ERR_NOMEM;

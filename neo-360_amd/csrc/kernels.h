@@ -103,8 +103,9 @@ struct TpViews {                     // world -> camera per source view (neo360/
 size_t tp_wpack_floats(int input_ch);
 size_t tp_bias_floats();
 size_t tp_heads_floats();
+// fold_ws: tp_fold_floats() floats of scratch (stage V0F: view layer 0 with the bottleneck folded in)
 void launch_tp_pack(int input_ch, const float* const* w, const float* const* b, float* wpack, float* bias,
-                    float* heads, hipStream_t s);
+                    float* heads, hipStream_t s, float* fold_ws);
 void launch_channels_last(const float* src, int NV, int C, int H, int W, float* dst, hipStream_t s);
 struct TpPlaneProj;
 // proj != null: the latent pre-projected through [W0_loc | W3_loc] is gathered instead of the latent (k_tp_preproject);
@@ -212,8 +213,9 @@ void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj_all, 
 size_t pix_wpack_h_bytes();
 size_t pix_bias_floats();
 size_t pix_heads_floats();
+size_t pix_fold_floats();        // scratch of launch_pix_pack_h (the folded view-layer-0 matrix)
 void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack_h, float* bias, float* heads,
-                       hipStream_t s);
+                       float* fold_ws, hipStream_t s);
 size_t pix_wproj_bytes();        // fp32 MFMA fragments of pts_linears.0's latent columns (pre-projection, mlp_pix_h.hip)
 void launch_pix_pack_proj(const float* w0, float* wproj, hipStream_t s);
 void launch_pix_mlp_h(const TpMlpHDev& m, const float* proj /* null: gather the latent itself */, const TpScene& sc, const TpViews& views, const float* rays_o,

@@ -21,6 +21,10 @@
 #define NEO_GATHER_WAVES_PER_SIMD 3
 #endif
 
+#ifndef NEO_PIX_FOLDB
+#define NEO_PIX_FOLDB 1
+#endif
+
 namespace neo {
 
 namespace {
@@ -368,9 +372,13 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         sg += __shfl_xor(sg, 2, 64);
         sigma = fmaxf(sg + m.heads[HD_DB], 0.0f);
     }
-    // ---- bottleneck of the view mean (no activation), view layer 0 on [mean bottleneck | mean dir enc] -> 128 ----
+    // ---- bottleneck of the view mean (no activation), view layer 0 on [mean bottleneck | mean dir enc] -> 128.
+    //      NEO_PIX_FOLDB (default): the bottleneck is folded into view layer 0 at pack time (launch_pix_pack_h; the algebra of
+    //      tp_hp_layout.h NEO_TP_FOLDB: model_pixel.py's bottleneck_layer has no activation and feeds views_linear.0 only), so
+    //      view layer 0 reads the view-mean trunk itself ----
     f32x16 ysum[1][2];
     {
+#if !NEO_PIX_FOLDB
         f32x16 acc[1][2];
         bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
         acc[0][1] = acc[0][0];
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
         store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
         store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
         __syncthreads();
+#endif
         bias_tile(ysum[0][0], m.bias + B_V0, L.wv, L);
         ysum[0][1] = ysum[0][0];
         gemm2h<1, 128>(ysum, wp + PX_V0, 10, nts_1, 0, 0, 8, act, L);
@@ -440,8 +449,10 @@ size_t pix_wpack_h_bytes() { return (size_t)PX_TOTAL * 16; }
 size_t pix_bias_floats() { return BIAS_FLOATS; }
 size_t pix_heads_floats() { return HEADS_FLOATS; }
 
+size_t pix_fold_floats() { return 128 * 155; }
+
 void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack_h, float* bias, float* heads,
-                       hipStream_t s) {
+                       float* fold_ws, hipStream_t s) {
     // w order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
     _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
     const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -455,7 +466,7 @@ void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack
     pack_h(w[6], 128, 128, 8, 0, p128, base + (size_t)PX_B * 8, s);
     PackSegs v0 = none;
     v0.len[0] = 155;
-    pack_h(w[4], 155, 128, 10, 0, v0, base + (size_t)PX_V0 * 8, s);
+    pack_h(w[4], 155, 128, 10, 0, v0, base + (size_t)PX_V0 * 8, s);       // (re-packed from the folded matrix below when NEO_PIX_FOLDB)
     pack_h(w[5], 128, 128, 8, 0, p128, base + (size_t)PX_V1 * 8, s);
     auto cp = [&](const float* src, int n, float* dst) {
         hipLaunchKernelGGL(k_copy_n, dim3((n + 255) / 256), dim3(256), 0, s, src, n, dst);
@@ -463,6 +474,12 @@ void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack
     (void)hipMemsetAsync(heads, 0, HEADS_FLOATS * sizeof(float), s);
     cp(b[0], 128, bias + B_0); cp(b[1], 128, bias + B_1); cp(b[2], 128, bias + B_2); cp(b[3], 128, bias + B_3);
     cp(b[6], 128, bias + B_B); cp(b[4], 128, bias + B_V0); cp(b[5], 128, bias + B_V1);
+#if NEO_PIX_FOLDB
+    // after the plain copies: [W_v0[:, :128] . W_b | W_v0[:, 128:]] into fold_ws (packed above - stream order: the fold kernel is
+    // enqueued here, so the view layer is packed AGAIN below from the folded matrix), folded bias over B_V0
+    launch_fold_bottleneck(w[4], w[6], b[6], b[4], 128, 128, 128, 27, fold_ws, bias + B_V0, s);
+    pack_h(fold_ws, 155, 128, 10, 0, v0, base + (size_t)PX_V0 * 8, s);
+#endif
     cp(w[7], 128, heads + HD_DW); cp(b[7], 1, heads + HD_DB); cp(w[8], 384, heads + HD_RW); cp(b[8], 3, heads + HD_RB);
 }
 

@@ -55,9 +55,11 @@ __host__ __device__ constexpr int off_3a(int pe_c) { return off_2(pe_c) + 4 * 16
 __host__ __device__ constexpr int off_b(int pe_c) { return off_3a(pe_c) + 4 * 16 * 256; }
 __host__ __device__ constexpr int off_v0(int pe_c) { return off_b(pe_c) + 4 * 16 * 256; }
 __host__ __device__ constexpr int off_v1(int pe_c) { return off_v0(pe_c) + 2 * 20 * 256; }
-__host__ __device__ constexpr int wpack_floats(int pe_c) { return off_v1(pe_c) + 2 * 8 * 256; }
-// biases: b0 | b3 | b1 | b2 | bb | bv0 | bv1
-constexpr int B_0 = 0, B_3 = 128, B_1 = 256, B_2 = 384, B_B = 512, B_V0 = 640, B_V1 = 704, BIAS_FLOATS = 768;
+// stage V0F (round 4): views_linear.0 with the bottleneck folded in, [W_v0[:, :128] W_b | W_v0[:, 128:]] (tp_hp_layout.h NEO_TP_FOLDB)
+__host__ __device__ constexpr int off_v0f(int pe_c) { return off_v1(pe_c) + 2 * 8 * 256; }
+__host__ __device__ constexpr int wpack_floats(int pe_c) { return off_v0f(pe_c) + 2 * 20 * 256; }
+// biases: b0 | b3 | b1 | b2 | bb | bv0 | bv1 | bv0 folded
+constexpr int B_0 = 0, B_3 = 128, B_1 = 256, B_2 = 384, B_B = 512, B_V0 = 640, B_V1 = 704, B_V0F = 768, BIAS_FLOATS = 832;
 // heads: density w[128] | density b (4) | rgb w[3][64] | rgb b (4)
 constexpr int HD_DW = 0, HD_DB = 128, HD_RW = 132, HD_RB = 324, HEADS_FLOATS = 328;
 
@@ -165,6 +167,11 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, const float* __re
     const f32x4* wp = reinterpret_cast<const f32x4*>(m.wpack);
     constexpr int KCX = kc_x(PE_C);
     constexpr int NST = PE_C == 3 ? 11 : 12;   // streamed-input stages: 8 local, 2 world, 1-2 pos_enc
+    // FOLD (with the pre-projected maps, PROJ >= 1): everything after relu(L3_v) is linear up to the view mean, and the bottleneck
+    // has no activation: per view only sum_v relu(L3_v) and sum_v dir_enc_v are accumulated, and view layer 0 with the bottleneck
+    // folded in (stage V0F) runs ONCE per tile on the means - 26,304 of the 91,584 MACs per point-view leave the view loop.
+    // PROJ = 0 keeps the reference's operation order throughout.
+    constexpr bool FOLD = PROJ >= 1;
 
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     __syncthreads();
@@ -188,7 +195,12 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, const float* __re
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
         tp::view_descriptors<(PROJ >= 1 ? hp::PROJ_TEXEL_BYTES : 2048), true, (PROJ == 2 ? hp::PROJ_TEXEL_BYTES : 128 * 4)>(
-            S, L, sc, rot, trn, v, [&](int p, int f, float val) { dsm[swz_index<DIR_LD, 7>(p, f)] = val; });
+            S, L, sc, rot, trn, v, [&](int p, int f, float val) {
+                // FOLD: only the SUM over the views of the direction encoding is needed (the view branch is linear up to the
+                // view mean); every (point, feature) is written by one thread per view
+                float* d = dsm + swz_index<DIR_LD, 7>(p, f);
+                if (FOLD && v > 0) *d += val; else *d = val;
+            });
         __syncthreads();
 
         // ---- streamed-input GEMM: [L0 | L3 skip half] (256 outputs) over 703 / 724 features ----
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, const float* __re
             hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
             hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
         }
+        if constexpr (!FOLD) {
         store_tile<ACT_LD, 15, true>(acc[0][0], act, L.wv, 0, L);
         store_tile<ACT_LD, 15, true>(acc[0][1], act, L.wv, 1, L);
         __syncthreads();
@@ -386,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, const float* __re
             for (int r = 0; r < 16; ++r) ysum[r] += y[r];
         }
         __syncthreads();   // act / dsm / descriptors are rewritten by the next view
+        }                  // !FOLD
     }
 
     // ---- view mean of the trunk -> density head ----
@@ -410,10 +424,21 @@ __global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, const float* __re
         s += __shfl_xor(s, 2, 64);
         raw_sigma = s + m.heads[HD_DB];
     }
+    if constexpr (FOLD) {
+        // view layer 0 with the bottleneck folded in, once per tile, on [mean trunk (act) | mean direction encoding (dsm)]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsm[tid * 8 + j] = dsm[tid * 8 + j] / nvf;       // the sums -> means, in place (scaling is layout-blind)
+        __syncthreads();
+        bias_tile(ysum, m.bias + B_V0F, vnt, L);
+        gemm1<ACT_LD, 15>(ysum, wp + off_v0f(PE_C) / 4, 20, vnt, vmt, 0, 16, act, L);
+        gemm1<DIR_LD, 7>(ysum, wp + off_v0f(PE_C) / 4, 20, vnt, vmt, 16, 4, dsm, L);
+    }
     __syncthreads();
     // ---- view mean of the view branch -> ReLU -> 64x64 -> ReLU -> rgb head ----
+    if constexpr (!FOLD) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ysum[r] = ysum[r] / nvf;
+        for (int r = 0; r < 16; ++r) ysum[r] = ysum[r] / nvf;
+    }
     store_tile<ACT_LD, 15, true>(ysum, act, vnt, vmt, L);
     __syncthreads();
     {
@@ -502,7 +527,7 @@ size_t tp_bias_floats() { return BIAS_FLOATS; }
 size_t tp_heads_floats() { return HEADS_FLOATS; }
 
 void launch_tp_pack(int input_ch, const float* const* w, const float* const* b, float* wpack, float* bias,
-                    float* heads, hipStream_t s) {
+                    float* heads, hipStream_t s, float* fold_ws) {
     // w/b order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
     const int pe = input_ch * 21;                 // 63 or 84
     const int x0w = pe + 512 + 128;               // 703 or 724
@@ -531,6 +556,9 @@ void launch_tp_pack(int input_ch, const float* const* w, const float* const* b, 
     };
     cp(b[0], 128, bias + B_0); cp(b[3], 128, bias + B_3); cp(b[1], 128, bias + B_1); cp(b[2], 128, bias + B_2);
     cp(b[6], 128, bias + B_B); cp(b[4], 64, bias + B_V0); cp(b[5], 64, bias + B_V1);
+    // stage V0F: view layer 0 with the bottleneck folded in (fp64 accumulation, pack_h.hip), for the FOLD form of the kernel
+    launch_fold_bottleneck(w[4], w[6], b[6], b[4], 64, 128, 128, 27, fold_ws, bias + B_V0F, s);
+    pack_block(fold_ws, 155, 64, 20, 0, v0, wpack + off_v0f(input_ch), s);
     (void)hipMemsetAsync(heads, 0, HEADS_FLOATS * sizeof(float), s);
     cp(w[7], 128, heads + HD_DW); cp(b[7], 1, heads + HD_DB); cp(w[8], 192, heads + HD_RW); cp(b[8], 3, heads + HD_RB);
 }
