@@ -367,6 +367,8 @@ class NeRF_TP(_HipModule):
         # (a failing upload must not leave a fingerprint that names the new tensors next to the old copy)
         self._scene_src = None
         self._scene_ctx = None
+        self._scene_key = None        # whoever uploads through an attached encoder records its own key AFTER this call (_ensure_scene);
+                                      # an upload from anywhere else (a training step's gather_features) must not leave an eval key behind
         if preproject is not None:
             self.preproject = int(preproject) if (preproject in (2, 3) and preproject is not True) else bool(preproject)
         planes = [f32(p, "plane") for p in (plane_xz, plane_xy, plane_yz)]

@@ -31,7 +31,9 @@ def test_kernel_source_lists_cover_the_kernels_own_includes():
 
 def test_pmc_summary_is_dropped_when_its_stamp_is_stale(tmp_path, monkeypatch):
     prof = bench.pmc_profile("neo360", "f16x3")
-    src = os.path.join(bench.ROOT, "profiles", "r03_pmc_neo360_f16x3.json")
+    import glob
+    src = sorted(glob.glob(os.path.join(bench.ROOT, "profiles", "r[0-9][0-9]_pmc_neo360_f16x3.json")))[-1]     # newest round wins
+    assert os.path.relpath(src, bench.ROOT) == prof["source"]
     committed = json.load(open(src))
     if committed.get("kernel_source_sha16") == bench.kernel_source_hash("neo360"):
         assert prof.get("mfma_busy_frac") and not prof.get("stale")          # the committed summary belongs to this tree

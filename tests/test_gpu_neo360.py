@@ -217,6 +217,33 @@ def test_attached_encoder_runs_once_per_scene():
     assert enc.calls == 4 and max_abs(d, ref) > 1e-3
 
 
+def test_training_step_between_two_eval_frames_does_not_leave_a_stale_scene():
+    """An attached encoder, an eval frame of scene B, a DIFFERENTIABLE training call on scene A (which uploads A's encoder output
+    through gather_features), then scene B again: the second eval frame must be rendered from B's features, not from what the
+    training step left on the device (the eval-side cache key is dropped by every upload)."""
+    enc = _StubEncoder().to(DEV)
+    net = models.NeRF_TP(num_coarse_samples=16, num_fine_samples=24, num_src_views=cases.NV, encoder=enc).to(DEV)
+    net.load_state_dict(synth.nerf_tp_state(0), strict=False)
+    eval_b = _batch(48)                                                    # src_imgs = 0 -> k = 1
+    train_a = dict(_batch(32))
+    train_a["src_imgs"] = torch.full_like(eval_b["src_imgs"], 0.7)         # another scene
+    first = net(eval_b, False, False, 0.0, 0.0, out_depth=True)[1][0].clone()
+    calls = enc.calls
+    with torch.enable_grad():
+        for p in net.parameters():
+            p.requires_grad_(True)
+        out = net(train_a, True, False, 0.0, 0.0, out_depth=False, seed=5)
+        assert out[1][0].requires_grad and enc.calls == calls + 1          # the encoder ran WITH autograd for the training batch
+        out[1][0].sum().backward()
+        assert enc.gain.grad is not None and float(enc.gain.grad.abs()) > 0.0      # gradients reach the encoder through the lookups
+    for p in net.parameters():
+        p.requires_grad_(False)
+    enc.gain.grad = None
+    again = net(eval_b, False, False, 0.0, 0.0, out_depth=True)[1][0]
+    assert enc.calls == calls + 2                                          # re-encoded: the device scene was the training batch's
+    assert max_abs(again, first) < 1e-6
+
+
 def test_sphere_miss_raises():
     net = _net(32, 64)
     batch = _batch(8)
