@@ -71,8 +71,8 @@ def physical_cores():
 KERNEL_SOURCES = {
     "neo360": ("mlp_tp_hp.hip", "mlp_tp_hpp.hip", "tp_hp_layout.h", "tp_common.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
     "vanilla": ("mlp_vanilla_h.hip", "mfma_tile.h", "common.h", "kernels.h"),
-    "mip360": ("mlp_mip_h.hip", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
-    "mip360_128": ("mlp_mip_h.hip", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+    "mip360": ("mlp_mip_h.hip", "mip_gemm_h.h", "mip_layered.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+    "mip360_128": ("mlp_mip_h.hip", "mip_gemm_h.h", "mip_layered.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
     "pixelnerf": ("mlp_pix_h.hip", "tp_common.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
 }
 

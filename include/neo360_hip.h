@@ -397,6 +397,15 @@ int neo_mip_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d
                 const float* viewdirs, const float* radii, const float* tdist, int R, int n,
                 float* out, void* stream);
 
+/* Schedule of the NeRF MLP (8 x 1024, models/mipnerf360/model.py:30-120) in split-fp16 arithmetic.  mode 1: layer by
+ * layer - the encodings of a batch of 16384 intervals are written once as MFMA fragments, the eight trunk layers run as
+ * 256 x 256-tile GEMMs whose activations stay in L2 / Infinity Cache between layers (one weight fragment feeds 4 interval
+ * tiles), the fused evaluator adds the heads and the colour branch; 160 MB of context memory.  mode 0: the fused
+ * evaluator end to end (one weight fragment per 32 intervals).  mode -1 (a fresh context): layer by layer for calls of
+ * 8192 intervals or more.  Same arithmetic per product, a different fp32 summation order inside a layer only through
+ * the k-step order, which is the same: results agree to the last bits (tests/test_gpu_mip360.py). */
+int neo_mip_set_layered(neo_ctx* ctx, int mode);
+
 /* compute_alpha_weights(opaque_background=True) + volumetric_rendering (helper.py:246-274):
  * rgbdens (R,n,4), tdist (R,n+1) -> weights (R,n), rgb (R,3) = sum w c + max(0,1-acc)*bg. */
 int neo_mip_composite(neo_ctx* ctx, const float* rgbdens, const float* tdist, const float* rays_d,
@@ -422,7 +431,8 @@ int neo_ctx_set_timing(neo_ctx* ctx, int enable);
 int neo_ctx_read_timing(neo_ctx* ctx, double* total_ms, int* launches, double* total_points,
                         double* total_flops);
 /* The same launches one by one, in launch order: duration (ms), which evaluator ran (kernel_id: 0 unspecified,
- * 1 k_tp_mlp_hp, 2 k_tp_mlp_hpp, 3 k_tp_mlp_h, 4 k_tp_mlp), points and algorithmic flops of each.  A NeO-360 frame is four
+ * 1 k_tp_mlp_hp, 2 k_tp_mlp_hpp, 3 k_tp_mlp_h, 4 k_tp_mlp; Mip-NeRF 360: 5 proposal MLP (fused split evaluator), 6 NeRF MLP fused,
+ * 7 NeRF MLP layer by layer - one span covers all batches of the call -, 8 exact fp32), points and algorithmic flops of each.  A NeO-360 frame is four
  * launches (inside / outside the sphere x coarse / fine) and, in pre-projection mode 3, two different kernels: the bench's
  * roofline object prices each kernel with ITS launches.  Arrays may be NULL; *count = launches recorded (may exceed capacity). */
 int neo_ctx_read_spans(neo_ctx* ctx, int capacity, double* ms, int* kernel_id, double* points, double* flops, int* count);

@@ -84,6 +84,7 @@ SIGNATURES = {
     "neo_pix_upload_mlp": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "neo_pix_set_scene": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
     "neo_pix_set_preproject": (_i, [_vp, _i]),
+    "neo_mip_set_layered": (_i, [_vp, _i]),
     "neo_pix_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_pix_render": (_i, [_vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _f, _f, _f, _f, _f, _i, _i, _i,
                             _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -157,6 +157,7 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     for (auto& kv : ctx->centre_quantiles) kv.second.release();
     for (auto& sl : ctx->mip) sl.release();
     ctx->mip_basis.release();
+    for (auto& b : ctx->mip_lws) b.release();
     for (auto& kv : ctx->edges) kv.second.release();
     for (auto& b : ctx->ws) b.release();
     for (auto& sl : ctx->tp) sl.release();

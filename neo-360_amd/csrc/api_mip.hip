@@ -1,5 +1,6 @@
 // Mip-NeRF 360 entry points of the C ABI (models/mipnerf360/model.py:236-365).
 #include "ctx.h"
+#include "mip_layered.h"
 
 using namespace neo_host;
 
@@ -16,11 +17,28 @@ int mip_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* ray
     if (!sl.ready) return fail(NEO_ERR_STATE, "MipNeRF360 MLP slot %d has no weights", slot);
     const int* sh = ctx->mip_shape[slot];
     if (ctx->precision == 1) guard_split_weights(sl, sl.wpack_h.p, neo::mip_wpack_h_bytes(sh[0], sh[1], sh[2]), ctx->flags, s);
+    // NeRF MLP in split arithmetic: layer-by-layer trunk (mip_gemm_h.h) from 8192 intervals on (neo_mip_set_layered); a
+    // batch's activations live in context-owned buffers (grow-only, 160 MB)
+    const bool layered = ctx->precision == 1 && sh[0] == 1024 && sh[1] == 8 && sh[2] &&
+                         (ctx->mip_layered == 1 || (ctx->mip_layered < 0 && static_cast<long>(R) * n >= 8192));
+    const int cap = neo::MIP_LAYERED_BATCH;
+    if (layered && (ctx->mip_lws[0].reserve(neo::mip_layered_x0_bytes(cap)) || ctx->mip_lws[1].reserve(neo::mip_layered_y_bytes(cap)) ||
+                    ctx->mip_lws[2].reserve(neo::mip_layered_y_bytes(cap))))
+        return NEO_ERR_NOMEM;
+    // span ids (neo_ctx_read_spans): 5 fused split evaluator of a proposal MLP, 6 of the NeRF MLP, 7 the NeRF MLP layer by layer
+    // (k_mip_ipe_h + 8 x k_mip_gemm_h + the fused evaluator's tail per batch), 8 exact fp32 evaluator
+    ctx->span_kernel_next = ctx->precision != 1 ? 8 : layered ? 7 : (sh[0] == 1024 ? 6 : 5);
     ctx->span_begin(s);
     int rc;
     if (ctx->precision == 1) {      // split-fp16 matrix cores (fp32-equivalent), neo_ctx_set_precision
         neo::MipMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>(), ctx->flags};
-        rc = neo::launch_mip_mlp_h(sh[0], sh[1], sh[2], mh, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
+        if (layered) {
+            const neo::MipLayeredWs ws{static_cast<char*>(ctx->mip_lws[0].p), static_cast<char*>(ctx->mip_lws[1].p),
+                                       static_cast<char*>(ctx->mip_lws[2].p), cap};
+            rc = neo::launch_mip_mlp_h_layered(mh, ws, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
+        } else {
+            rc = neo::launch_mip_mlp_h(sh[0], sh[1], sh[2], mh, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
+        }
     } else {
         neo::MipMlpDev m{sl.wpack.as<float>(), sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>()};
         rc = neo::launch_mip_mlp(sh[0], sh[1], sh[2], m, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
@@ -87,7 +105,15 @@ int neo_mip_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d
     REQUIRE(R >= 0 && n >= 1, "bad shape");
     if (R == 0) return NEO_OK;
     REQUIRE(rays_o && rays_d && viewdirs && radii && tdist && out, "null pointer");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));          // the layer-by-layer path writes context-owned activation buffers
     return mip_mlp_launch(ctx, slot, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, static_cast<hipStream_t>(stream));
+}
+
+int neo_mip_set_layered(neo_ctx* ctx, int mode) {
+    ENTER(ctx);
+    REQUIRE(mode >= -1 && mode <= 1, "mode must be -1 (auto), 0 (fused evaluator) or 1 (layer by layer)");
+    ctx->mip_layered = mode;
+    return NEO_OK;
 }
 
 int neo_mip_composite(neo_ctx* ctx, const float* rgbdens, const float* tdist, const float* rays_d, int R, int n,

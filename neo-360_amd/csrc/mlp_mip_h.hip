@@ -11,6 +11,13 @@
 // accumulator tile.  Compiled without packed-fp32 VALU ops like mlp_tp_h.hip (build.py:EXTRA_FLAGS).
 //
 // Algorithmic work: PropMLP 325,888 MAC, NeRFMLP 8,672,000 MAC per interval.
+//
+// Round 4: the NeRF MLP also runs LAYER BY LAYER (launch_mip_mlp_h_layered): k_mip_ipe_h writes a batch's encodings as MFMA
+// fragments, eight k_mip_gemm_h launches (mip_gemm_h.h: 256 x 256 output tiles, weight fragment reused by 4 interval tiles
+// instead of 1) run the trunk with the activations in L2 / Infinity Cache between layers, and this file's evaluator in TAIL
+// mode (trunk output read back into its LDS tile) adds density head, bottleneck, view layer and rgb head.
+#include "mip_gemm_h.h"
+#include "mip_layered.h"
 #include "split_tile.h"
 
 #ifndef NEO_MIP_H_WAVES
@@ -65,78 +72,11 @@ __host__ __device__ inline int hd_db(int W) { return W; }
 __host__ __device__ inline int hd_rw(int W) { return W + 4; }
 __host__ __device__ inline int hd_rb(int W) { return W + 4 + 384; }
 
-// acc[nt] += W-stage k-steps [ks0, ks0+n) x tile k-steps [tks0, tks0+n); N-tiles nt0..nt0+NTW-1, the one M-tile.
-// wb = byte address of the stage's fragments (uniform); fragments are addressed SGPR base + 32-bit VGPR offset.
-template <int NTW, int LDH>
-__device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW], const char* __restrict__ wb, int KS, int nt0, int ks0,
-                                       int tks0, int n, const HT& tile, const LaneCtx& L) {
-    h8 ah[2][NTW], al[2][NTW];
-    uint32_t off[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) off[nt] = (uint32_t)(((nt0 + nt) * KS + ks0) * 128 + L.lane) * 16u;
-    auto load_w = [&](int slot, int s) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            ah[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s));
-            al[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s + 1024u));
-        }
-    };
-    load_w(0, 0);
-#pragma unroll 1
-    for (int s = 0; s < n; s += 2) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (s + u < n) {
-                if (s + u + 1 < n) load_w((u + 1) & 1, s + u + 1);
-                const int o = chunk_off<LDH>(L.l31, ((tks0 + s + u) << 1) + L.half);
-                const h8 bh = *reinterpret_cast<const h8*>(tile.hi + o);
-                const h8 bl = *reinterpret_cast<const h8*>(tile.lo + o);
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    acc[nt] = NEO_MFMA_H(al[u][nt], bh, acc[nt]);
-                    acc[nt] = NEO_MFMA_H(ah[u][nt], bl, acc[nt]);
-                    acc[nt] = NEO_MFMA_H(ah[u][nt], bh, acc[nt]);
-                }
-            }
-        }
-    }
-}
-
-// NWV waves per workgroup (8, or 16 for the 1024-wide MLP: 4 waves per SIMD, 128 VGPRs, two accumulator tiles each)
-template <int W, int DEPTH, bool RGB, int NWV>
-__global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) void k_mip_mlp_h(MipMlpHDev m, const float* __restrict__ rays_o,
-                                                                        const float* __restrict__ rays_d,
-                                                                        const float* __restrict__ viewdirs,
-                                                                        const float* __restrict__ radii,
-                                                                        const float* __restrict__ tdist, int R, int n,
-                                                                        float4* __restrict__ out) {
-    constexpr int NTW = W / (32 * NWV);      // N-tiles per wave for W-wide layers (NWV waves x NTW x 32 = W)
-    constexpr int NT = NWV * 64;             // threads
-    constexpr int FPT = 2048 / NT;           // encoding features per thread and stage (32 rows x 64 features)
-    constexpr int KSW = W / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* hb = reinterpret_cast<_Float16*>(smem);
-    const HT act{hb, hb + TMR * W};                                             // [32][W] x 2 planes
-    _Float16* xb = hb + 2 * TMR * W;
-    auto xbuf = [&](int b) { return HT{xb + b * (2 * TMR * 64), xb + b * (2 * TMR * 64) + TMR * 64}; };   // 2 x [32][64] x 2 planes
-    _Float16* db = xb + 4 * TMR * 64;
-    const HT dsm{db, db + TMR * 32};                                            // [32][32] x 2 planes (rgb branch)
-    float* lift = reinterpret_cast<float*>(db + 2 * TMR * 32);                  // [32][44]: 21 lifted means | 21 variances
-    float* rowz = lift + TMR * 44;                                              // [32][12]: contracted mean | covariance
-    LaneCtx L;
-    L.init();
-    int tid = threadIdx.x;
-    const long P = (long)R * n;
-    const long tile0 = (long)blockIdx.x * TMR;
-    constexpr int W_BOTT = woff_of(W, DEPTH - 1) + (W / 32) * ks_of(W, DEPTH - 1) * 128, W_VIEW = W_BOTT + 8 * (W / 16) * 128;
-    constexpr int B_BOTT = DEPTH * W, B_VIEW = B_BOTT + 256;
-    const char* wbase = reinterpret_cast<const char*>(m.wpack);
-
-    // ---- per-row Gaussian, contraction (identical arithmetic to mlp_mip.hip) ---------------------------
-    if (tid < TMR) {
-        long g = tile0 + tid;
-        if (g >= P) g = P - 1;
-        const int ray = (int)(g / n), i = (int)(g - (long)ray * n);
+// ---- per-interval set-up shared by the fused evaluator and the encoding producer of the layer-by-layer path ----
+// conical frustum -> Gaussian -> contraction of interval i of `ray`: rz[0..2] = contracted mean, rz[3..11] = covariance
+__device__ __forceinline__ void row_gaussian(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                             const float* __restrict__ radii, const float* __restrict__ tdist, int ray, int i,
+                                             int n, float* __restrict__ rz) {
         const float t0 = tdist[(long)ray * (n + 1) + i], t1 = tdist[(long)ray * (n + 1) + i + 1];
         float o[3], d[3];
 #pragma unroll
@@ -197,16 +137,19 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
             for (int b = 0; b < 3; ++b) cc[a][b] = tmp[a][0] * J[b][0] + tmp[a][1] * J[b][1] + tmp[a][2] * J[b][2];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            rowz[tid * 12 + a] = z[a];
+            rz[a] = z[a];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) rowz[tid * 12 + 3 + a * 3 + b] = cc[a][b];
+            for (int b = 0; b < 3; ++b) rz[3 + a * 3 + b] = cc[a][b];
         }
-        if (RGB) {
-            // view-direction encoding, append_identity=True (helper.py:92-99): [d | sin(d 2^k) | sin(d 2^k + pi/2)], k<4
+}
+
+// view-direction encoding of `ray` into row `row` of the [32][32] split tile, append_identity=True (helper.py:92-99):
+// [d | sin(d 2^k) | sin(d 2^k + pi/2)], k < 4, zero-padded to 32
+__device__ __forceinline__ void row_direnc(const float* __restrict__ viewdirs, int ray, int row, const HT& dsm) {
             auto put = [&](int f, float v) {
                 _Float16 h, l;
                 split(v, h, l);
-                const int o2 = chunk_off<32>(tid, f >> 3) + (f & 7);
+                const int o2 = chunk_off<32>(row, f >> 3) + (f & 7);
                 dsm.hi[o2] = h;
                 dsm.lo[o2] = l;
             };
@@ -224,13 +167,14 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
                 }
 #pragma unroll
             for (int f = 27; f < 32; ++f) put(f, 0.0f);
-        }
-    }
-    __syncthreads();
-    // ---- lift_and_diagonalize (helper.py:70-73): mean_j = z . b_j ; var_j = sum_i b_ij (cov b_j)_i ----
-    for (int idx = tid; idx < TMR * NB; idx += NT) {
+}
+
+// lift_and_diagonalize (helper.py:70-73): mean_j = z . b_j ; var_j = sum_i b_ij (cov b_j)_i  -> lift[row][44]
+__device__ __forceinline__ void lift_rows(const float* __restrict__ basis, const float* __restrict__ rowz, float* __restrict__ lift,
+                                          int tid, int nthreads) {
+    for (int idx = tid; idx < TMR * NB; idx += nthreads) {
         const int row = idx / NB, j = idx - row * NB;
-        const float b0 = m.basis[j], b1 = m.basis[NB + j], b2 = m.basis[2 * NB + j];
+        const float b0 = basis[j], b1 = basis[NB + j], b2 = basis[2 * NB + j];
         const float* rz = rowz + row * 12;
         const float mj = rz[0] * b0 + rz[1] * b1 + rz[2] * b2;
         float vj = 0.f;
@@ -240,6 +184,112 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
         lift[row * 44 + j] = mj;
         lift[row * 44 + NB + j] = vj;
     }
+}
+
+// integrated_pos_enc (helper.py:77-88), feature f < 504 of row `row`; 0 for the padding features
+__device__ __forceinline__ float ipe_feature(const float* __restrict__ lift, int row, int f) {
+    float val = 0.0f;
+    if (f < 504) {
+        const bool shifted = f >= 252;
+        const int g = shifted ? f - 252 : f;
+        const int k = g / NB, j = g - k * NB;
+        const float mean = lift[row * 44 + j], var = lift[row * 44 + NB + j];
+        const float arg = ldexpf(mean, k);
+        val = expf(-0.5f * ldexpf(var, 2 * k)) * sin_cw(shifted ? arg + HALF_PI_F32 : arg);
+    }
+    return val;
+}
+
+// acc[nt] += W-stage k-steps [ks0, ks0+n) x tile k-steps [tks0, tks0+n); N-tiles nt0..nt0+NTW-1, the one M-tile.
+// wb = byte address of the stage's fragments (uniform); fragments are addressed SGPR base + 32-bit VGPR offset.
+template <int NTW, int LDH>
+__device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW], const char* __restrict__ wb, int KS, int nt0, int ks0,
+                                       int tks0, int n, const HT& tile, const LaneCtx& L) {
+    h8 ah[2][NTW], al[2][NTW];
+    uint32_t off[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) off[nt] = (uint32_t)(((nt0 + nt) * KS + ks0) * 128 + L.lane) * 16u;
+    auto load_w = [&](int slot, int s) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            ah[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s));
+            al[slot][nt] = *reinterpret_cast<const h8*>(wb + (off[nt] + 2048u * s + 1024u));
+        }
+    };
+    load_w(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < n; s += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (s + u < n) {
+                if (s + u + 1 < n) load_w((u + 1) & 1, s + u + 1);
+                const int o = chunk_off<LDH>(L.l31, ((tks0 + s + u) << 1) + L.half);
+                const h8 bh = *reinterpret_cast<const h8*>(tile.hi + o);
+                const h8 bl = *reinterpret_cast<const h8*>(tile.lo + o);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    acc[nt] = NEO_MFMA_H(al[u][nt], bh, acc[nt]);
+                    acc[nt] = NEO_MFMA_H(ah[u][nt], bl, acc[nt]);
+                    acc[nt] = NEO_MFMA_H(ah[u][nt], bh, acc[nt]);
+                }
+            }
+        }
+    }
+}
+
+// NWV waves per workgroup (8, or 16 for the 1024-wide MLP: 4 waves per SIMD, 128 VGPRs, two accumulator tiles each)
+// TAIL: the trunk has been run by the layer-by-layer path; its output (fragment order, interval tile blockIdx.x of the
+// batch that starts at interval p0) is `yin`, this kernel adds the heads and the colour branch
+template <int W, int DEPTH, bool RGB, int NWV, bool TAIL = false>
+__global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) void k_mip_mlp_h(MipMlpHDev m, const float* __restrict__ rays_o,
+                                                                        const float* __restrict__ rays_d,
+                                                                        const float* __restrict__ viewdirs,
+                                                                        const float* __restrict__ radii,
+                                                                        const float* __restrict__ tdist, int R, int n,
+                                                                        float4* __restrict__ out,
+                                                                        const char* __restrict__ yin = nullptr, long p0 = 0) {
+    constexpr int NTW = W / (32 * NWV);      // N-tiles per wave for W-wide layers (NWV waves x NTW x 32 = W)
+    constexpr int NT = NWV * 64;             // threads
+    constexpr int FPT = 2048 / NT;           // encoding features per thread and stage (32 rows x 64 features)
+    constexpr int KSW = W / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* hb = reinterpret_cast<_Float16*>(smem);
+    const HT act{hb, hb + TMR * W};                                             // [32][W] x 2 planes
+    _Float16* xb = hb + 2 * TMR * W;
+    auto xbuf = [&](int b) { return HT{xb + b * (2 * TMR * 64), xb + b * (2 * TMR * 64) + TMR * 64}; };   // 2 x [32][64] x 2 planes
+    _Float16* db = xb + 4 * TMR * 64;
+    const HT dsm{db, db + TMR * 32};                                            // [32][32] x 2 planes (rgb branch)
+    float* lift = reinterpret_cast<float*>(db + 2 * TMR * 32);                  // [32][44]: 21 lifted means | 21 variances
+    float* rowz = lift + TMR * 44;                                              // [32][12]: contracted mean | covariance
+    LaneCtx L;
+    L.init();
+    int tid = threadIdx.x;
+    const long P = (long)R * n;
+    const long tile0 = p0 + (long)blockIdx.x * TMR;
+    constexpr int W_BOTT = woff_of(W, DEPTH - 1) + (W / 32) * ks_of(W, DEPTH - 1) * 128, W_VIEW = W_BOTT + 8 * (W / 16) * 128;
+    constexpr int B_BOTT = DEPTH * W, B_VIEW = B_BOTT + 256;
+    const char* wbase = reinterpret_cast<const char*>(m.wpack);
+
+    // ---- per-row Gaussian, contraction (identical arithmetic to mlp_mip.hip) ---------------------------
+    if (tid < TMR) {
+        long g = tile0 + tid;
+        if (g >= P) g = P - 1;
+        const int ray = (int)(g / n), i = (int)(g - (long)ray * n);
+        if (!TAIL) row_gaussian(rays_o, rays_d, radii, tdist, ray, i, n, rowz + tid * 12);
+        if (RGB) row_direnc(viewdirs, ray, tid, dsm);
+    }
+    __syncthreads();
+    if (!TAIL) lift_rows(m.basis, rowz, lift, tid, NT);
+    else {
+        // trunk output of the layer-by-layer path: fragment (k-step, plane, lane = (half, interval)) -> 16-byte chunk
+        // 2 ks + half of row `interval` in the swizzled tile; this workgroup's interval tile is blockIdx.x of the batch
+        const char* yt = yin + (size_t)blockIdx.x * (KSW * 2048);
+        for (int c = tid; c < KSW * 128; c += NT) {
+            const int ks = c >> 7, plane = (c >> 6) & 1, ln = c & 63;
+            const h8 v = *reinterpret_cast<const h8*>(yt + (size_t)c * 16);
+            *reinterpret_cast<h8*>((plane ? act.lo : act.hi) + chunk_off<W>(ln & 31, 2 * ks + (ln >> 5))) = v;
+        }
+    }
     __syncthreads();
 
     // integrated_pos_enc (helper.py:77-88): 64 features of stage s; thread = (row, 4 consecutive features)
@@ -248,16 +298,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
         _Float16 vh[FPT], vl[FPT];
 #pragma unroll
         for (int e = 0; e < FPT; ++e) {
-            const int f = s * 64 + q * FPT + e;
-            float val = 0.0f;
-            if (f < 504) {
-                const bool shifted = f >= 252;
-                const int g = shifted ? f - 252 : f;
-                const int k = g / NB, j = g - k * NB;
-                const float mean = lift[row * 44 + j], var = lift[row * 44 + NB + j];
-                const float arg = ldexpf(mean, k);
-                val = expf(-0.5f * ldexpf(var, 2 * k)) * sin_cw(shifted ? arg + HALF_PI_F32 : arg);
-            }
+            const float val = ipe_feature(lift, row, s * 64 + q * FPT + e);
             split(val, vh[e], vl[e]);
         }
         const int o = chunk_off<64>(row, (q * FPT) >> 3) + ((q * FPT) & 7);
@@ -279,7 +320,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
     f32x16 acc[NTW];
     // ---- trunk ----
 #pragma unroll 1
-    for (int layer = 0; layer < DEPTH; ++layer) {
+    for (int layer = TAIL ? DEPTH : 0; layer < DEPTH; ++layer) {
         // per-lane indices re-derived from an opaque lane id: keeps swizzled LDS addresses out of scratch
         asm volatile("" : "+v"(tid));
         L.lane = tid & 63;
@@ -385,6 +426,45 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
     }
 }
 
+// Encoding producer of the layer-by-layer path: one interval tile (32 intervals) of the batch that starts at interval p0 per
+// workgroup; the 504 features (+ 8 zeros) as fragments of 32 k-steps.  Thread (row, q) makes features 64 s + 8 q + 0..7 of
+// stage s = chunk q of that stage = k-step 4 s + q/2, fragment half q & 1: one 16-byte store per plane.  Same feature
+// order, same arithmetic as `produce` in the fused evaluator.
+__global__ __launch_bounds__(256) void k_mip_ipe_h(const float* __restrict__ basis, const float* __restrict__ rays_o,
+                                                   const float* __restrict__ rays_d, const float* __restrict__ radii,
+                                                   const float* __restrict__ tdist, int R, int n, long p0,
+                                                   char* __restrict__ x0) {
+    __shared__ float rowz[TMR * 12];
+    __shared__ float lift[TMR * 44];
+    const int tid = threadIdx.x;
+    const long P = (long)R * n;
+    if (tid < TMR) {
+        long g = p0 + (long)blockIdx.x * TMR + tid;
+        if (g >= P) g = P - 1;                                   // padding intervals repeat the last one (finite values)
+        const int ray = (int)(g / n), i = (int)(g - (long)ray * n);
+        row_gaussian(rays_o, rays_d, radii, tdist, ray, i, n, rowz + tid * 12);
+    }
+    __syncthreads();
+    lift_rows(basis, rowz, lift, tid, 256);
+    __syncthreads();
+    const int row = tid & 31, q = tid >> 5;
+    char* xt = x0 + (size_t)blockIdx.x * (32 * 2048) + (size_t)((q & 1) * 32 + row) * 16;
+#pragma unroll 1
+    for (int s = 0; s < 8; ++s) {
+        h8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 h, l;
+            split(ipe_feature(lift, row, s * 64 + q * 8 + e), h, l);
+            vh[e] = h;
+            vl[e] = l;
+        }
+        char* p = xt + (size_t)(s * 4 + (q >> 1)) * 2048;
+        *reinterpret_cast<h8*>(p) = vh;
+        *reinterpret_cast<h8*>(p + 1024) = vl;
+    }
+}
+
 template <int W>
 size_t lds_bytes() {
     return (size_t)(2 * TMR * W + 4 * TMR * 64 + 2 * TMR * 32) * sizeof(_Float16) + (size_t)(TMR * 44 + TMR * 12) * sizeof(float);
@@ -433,6 +513,42 @@ int launch_mip_mlp_h(int width, int depth, int rgb, const MipMlpHDev& m, const f
                            rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));
     else
         return -1;
+    return 0;
+}
+
+int launch_mip_mlp_h_layered(const MipMlpHDev& m, const MipLayeredWs& ws, const float* rays_o, const float* rays_d,
+                             const float* viewdirs, const float* radii, const float* tdist, int R, int n, float* out,
+                             hipStream_t s) {
+    constexpr int W = 1024, DEPTH = 8;
+    const long P = (long)R * n;
+    if (P <= 0) return 0;
+    if (!ws.x0 || !ws.ya || !ws.yb || ws.cap < 2048 || ws.cap % 2048) return -1;
+    auto tail = k_mip_mlp_h<W, DEPTH, true, NEO_MIP_H_WAVES, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<W>());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_gemm_h<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES);
+    const char* wbase = reinterpret_cast<const char*>(m.wpack);
+    char* bufs[2] = {ws.ya, ws.yb};
+    for (long p0 = 0; p0 < P; p0 += ws.cap) {
+        const long pb = P - p0 < ws.cap ? P - p0 : ws.cap;
+        const int n_it = (int)((pb + 2047) / 2048) * 64;            // the GEMM's grid wants whole groups of 64 interval tiles
+        hipLaunchKernelGGL(k_mip_ipe_h, dim3((unsigned)n_it), dim3(256), 0, s, m.basis, rays_o, rays_d, radii, tdist, R, n, p0, ws.x0);
+        for (int l = 0; l < DEPTH; ++l) {
+            MipGemmArgs a{};
+            a.w = wbase + (size_t)woff_of(W, l) * 16;
+            a.bias = m.bias + l * W;
+            a.x0 = l == 0 ? ws.x0 : bufs[(l + 1) & 1];
+            a.ks0 = l == 0 ? 32 : W / 16;
+            a.x1 = l == 5 ? ws.x0 : nullptr;                        // skip concat [h | encoding] (model.py:76-79)
+            a.ks1 = l == 5 ? 32 : 0;
+            a.y = bufs[l & 1];
+            a.n_it = n_it;
+            a.flags = m.flags;
+            hipLaunchKernelGGL(k_mip_gemm_h<true>, dim3(mip_gemm_grid(n_it)), dim3(MG_THREADS), MG_LDS_BYTES, s, a);
+        }
+        hipLaunchKernelGGL(tail, dim3((unsigned)((pb + TMR - 1) / TMR)), dim3(NEO_MIP_H_WAVES * 64), lds_bytes<W>(), s, m, rays_o,
+                           rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out),
+                           static_cast<const char*>(bufs[(DEPTH - 1) & 1]), p0);
+    }
     return 0;
 }
 

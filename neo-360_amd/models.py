@@ -771,6 +771,17 @@ class MipNeRF360(_HipModule):
         self.num_prop_samples, self.num_nerf_samples, self.num_levels = num_prop_samples, num_nerf_samples, num_levels
         self.mlps = nn.ModuleList([MipNeRF360MLP(4, 256, disable_rgb=True), MipNeRF360MLP(4, 256, disable_rgb=True),
                                    MipNeRF360MLP(8, 1024)])
+        # NeRF MLP schedule (neo_mip_set_layered): None = the library's choice (layer-by-layer GEMMs from 8192 intervals per
+        # call), True / False = always / never; $NEO360_MIP_LAYERED = 0 / 1 presets it (A/B runs of bench.py)
+        self.layered = {"0": False, "1": True}.get(os.environ.get("NEO360_MIP_LAYERED", ""), None)
+
+    def _context(self, device):
+        ctx = super()._context(device)
+        mode = -1 if self.layered is None else int(bool(self.layered))
+        if getattr(ctx, "_mip_layered", None) != mode:
+            _lib.check(ctx.lib.neo_mip_set_layered(ctx.handle, mode))
+            ctx._mip_layered = mode
+        return ctx
 
     def _sync_weights(self, ctx):
         for slot, mlp in enumerate(self.mlps):

@@ -14,9 +14,10 @@ DEV = "cuda"
 TOL = 1e-4
 
 
-def _net(gain=1.0, counts=(64, 32)):
+def _net(gain=1.0, counts=(64, 32), layered=None):
     net = models.MipNeRF360(num_prop_samples=counts[0], num_nerf_samples=counts[1]).to(DEV)
     net.load_state_dict(synth.mip360_state(0, density_gain=gain, weight_gain=0.5))
+    net.layered = layered          # NeRF MLP schedule: None = the library's choice, True = layer-by-layer GEMMs, False = fused
     return net
 
 
@@ -47,9 +48,11 @@ def test_resample_stage(golden):
     assert max_abs(s0.cpu(), want0) < 1e-6
 
 
-def test_mlp_stages_vs_oracle():
-    """cast_rays + contraction + IPE + MLP, both MLP shapes, on oracle-produced intervals."""
-    net = _net()
+@pytest.mark.parametrize("layered", [False, True])
+def test_mlp_stages_vs_oracle(layered):
+    """cast_rays + contraction + IPE + MLP, both MLP shapes, on oracle-produced intervals; the NeRF MLP in both schedules
+    (layered: 1600 intervals = one padded batch of 2048)."""
+    net = _net(layered=layered)
     params = synth.mip360_state(0, weight_gain=0.5)
     rays = cases.mip_rays(50)          # ragged: 50*64 = 3200 = 100 tiles; 50*32 = 1600 = 50 tiles
     basis = mip360.icosahedron_basis()
@@ -75,11 +78,12 @@ def test_composite_stage():
     assert max_abs(rgb.cpu(), want_rgb) < 2e-6
 
 
+@pytest.mark.parametrize("layered", [False, True])
 @pytest.mark.parametrize("tag,tf,gain,counts", [("a", 1.0, 1.0, (64, 32)), ("b", 0.3, 1.0, (64, 32)),
                                                 ("sharp", 1.0, 6.0, (64, 32)), ("c", 1.0, 1.0, (64, 128))])
-def test_end_to_end_vs_golden(golden, tag, tf, gain, counts):
+def test_end_to_end_vs_golden(golden, tag, tf, gain, counts, layered):
     g = golden("g6_mip360")
-    rend, hist = _net(gain, counts)(_to(cases.mip_rays(160)), tf, False, False, 0.2, 3.0)
+    rend, hist = _net(gain, counts, layered)(_to(cases.mip_rays(160)), tf, False, False, 0.2, 3.0)
     for lv in range(3):
         assert max_abs(rend[lv]["rgb"].cpu(), g["rgb%d_%s" % (lv, tag)]) < TOL
         assert max_abs(hist[lv]["sdist"].cpu(), g["sdist%d_%s" % (lv, tag)]) < TOL
@@ -87,6 +91,22 @@ def test_end_to_end_vs_golden(golden, tag, tf, gain, counts):
         assert max_abs(hist[lv]["density"].cpu(), g["dens%d_%s" % (lv, tag)]) < 2e-4
     assert max_abs(hist[2]["rgb"].cpu(), g["prgb2_%s" % tag]) < TOL
     assert float(hist[0]["rgb"].abs().max()) == 0.0          # proposal levels carry no colour
+
+
+@pytest.mark.parametrize("rays,n", [(77, 32), (600, 32), (130, 128)])
+def test_layered_schedule_equals_fused_evaluator(rays, n):
+    """The layer-by-layer NeRF MLP (encodings -> 8 GEMM launches -> heads) runs the SAME products in the same k order as
+    the fused evaluator: bitwise equal outputs.  77 x 32 = 2464 intervals (a padded batch, ragged last tile), 600 x 32 =
+    19200 (two batches, the second short), 130 x 128 = 16640 (one full batch + 256 intervals)."""
+    batch = _to(cases.mip_rays(rays))
+    s = torch.sort(synth.uniform(79, "mip_eq_%d_%d" % (rays, n), (rays, n + 1), 0.0, 1.0), dim=-1).values
+    tdist = (1 / (s * (1 / 3.0) + (1 - s) * (1 / 0.2))).to(DEV)
+    fused = _net(layered=False).eval_mlp(2, batch, tdist)
+    layer = _net(layered=True).eval_mlp(2, batch, tdist)
+    assert torch.isfinite(layer).all()
+    assert torch.equal(layer, fused), float((layer - fused).abs().max())
+    auto = _net().eval_mlp(2, batch, tdist)                    # the library's choice is one of the two
+    assert torch.equal(auto, fused)
 
 
 def test_randomized_refused_and_empty():
