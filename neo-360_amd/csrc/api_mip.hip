@@ -31,7 +31,8 @@ int mip_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* ray
     ctx->span_begin(s);
     int rc;
     if (ctx->precision == 1) {      // split-fp16 matrix cores (fp32-equivalent), neo_ctx_set_precision
-        neo::MipMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>(), ctx->flags};
+        neo::MipMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->mip_basis.as<float>(), ctx->flags,
+                           sl.bias_hp.as<float>()};
         if (layered) {
             const neo::MipLayeredWs ws{static_cast<char*>(ctx->mip_lws[0].p), static_cast<char*>(ctx->mip_lws[1].p),
                                        static_cast<char*>(ctx->mip_lws[2].p), cap};
@@ -71,7 +72,8 @@ int neo_mip_upload_mlp(neo_ctx* ctx, int slot, int width, int depth, int rgb, co
     if (sl.wpack_h.reserve(neo::mip_wpack_h_bytes(width, depth, rgb))) return NEO_ERR_NOMEM;
     neo::launch_mip_pack(width, depth, rgb, weights, biases, sl.wpack.as<float>(), sl.bias.as<float>(),
                          sl.heads.as<float>(), s);
-    neo::launch_mip_pack_h(width, depth, rgb, weights, sl.wpack_h.p, s);
+    if (rgb && (sl.fold_ws.reserve(neo::mip_fold_floats() * sizeof(float)) || sl.bias_hp.reserve(128 * sizeof(float)))) return NEO_ERR_NOMEM;
+    neo::launch_mip_pack_h(width, depth, rgb, weights, biases, sl.wpack_h.p, sl.fold_ws.as<float>(), sl.bias_hp.as<float>(), s);
     ctx->mip_shape[slot][0] = width;
     ctx->mip_shape[slot][1] = depth;
     ctx->mip_shape[slot][2] = rgb;

@@ -134,9 +134,14 @@ struct MipMlpHDev {       // split-fp16 fragments (mlp_mip_h.hip); bias / heads 
     const float* heads;
     const float* basis;
     uint32_t* flags;      // context assertion word (bit 1: split range guard)
+    const float* view_bias = nullptr;   // 128: views_linear.0's bias with the bottleneck folded in (b_v + W_v[:, :256] b_b); rgb MLP only
 };
 size_t mip_wpack_h_bytes(int width, int depth, int rgb);
-void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, void* wpack_h, hipStream_t s);
+size_t mip_fold_floats();     // scratch of launch_mip_pack_h (the folded view layer, fp32)
+// rgb MLP: the (linear) bottleneck is folded into views_linear.0 at pack time (pack_h.hip:launch_fold_bottleneck): the fragments
+// hold [W_v[:, :256] W_b | W_v[:, 256:]] (128 x (width + 27)), view_bias (128 floats) receives the folded bias
+void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, const float* const* b, void* wpack_h, float* fold_ws,
+                       float* view_bias, hipStream_t s);
 int launch_mip_mlp_h(int width, int depth, int rgb, const MipMlpHDev& m, const float* rays_o, const float* rays_d,
                      const float* viewdirs, const float* radii, const float* tdist, int R, int n, float* out,
                      hipStream_t s);

@@ -12,6 +12,11 @@
 //
 // Algorithmic work: PropMLP 325,888 MAC, NeRFMLP 8,672,000 MAC per interval.
 //
+// Colour branch (round 4): bottleneck_layer has no activation and feeds views_linear.0 only (model.py:100-108), so it is folded
+// into that layer at pack time - [W_v[:, :256] W_b | W_v[:, 256:]] h', one 128 x (1024 + 27) layer instead of 256 x 1024 +
+// 128 x 283 - and the layer's K range is split over the workgroup's 16 waves (4 N-tiles x 4 quarters, partial tiles added
+// through LDS): all waves stream weights, each for 16-18 k-steps, with a 4-deep fragment ring.
+//
 // Round 4: the NeRF MLP also runs LAYER BY LAYER (launch_mip_mlp_h_layered): k_mip_ipe_h writes a batch's encodings as MFMA
 // fragments, eight k_mip_gemm_h launches (mip_gemm_h.h: 256 x 256 output tiles, weight fragment reused by 4 interval tiles
 // instead of 1) run the trunk with the activations in L2 / Infinity Cache between layers, and this file's evaluator in TAIL
@@ -36,8 +41,8 @@ constexpr float EPS32 = 1.1920929e-07f;
 struct MipLayoutH {
     int w_layer[8];   // h8 offset of trunk layer i
     int ks_layer[8];  // 16-deep k-steps of layer i
-    int w_bott, w_view;
-    int b_layer[8], b_bott, b_view;
+    int w_view;       // views_linear.0 with the bottleneck folded in: 128 outputs, K = W + 27 -> W / 16 + 2 k-steps
+    int b_layer[8];
     int total_h8, total_b;
 };
 
@@ -53,10 +58,7 @@ __host__ __device__ inline MipLayoutH mip_layout_h(int W, int depth, int rgb) {
         ob += W;
     }
     if (rgb) {
-        L.w_bott = ow; ow += 8 * (W / 16) * 128;    // 256 outputs
-        L.b_bott = ob; ob += 256;
-        L.w_view = ow; ow += 4 * 18 * 128;          // 128 outputs, K = 256 + 27 -> 288 = 18 k-steps
-        L.b_view = ob; ob += 128;
+        L.w_view = ow; ow += 4 * (W / 16 + 2) * 128;
     }
     L.total_h8 = ow;
     L.total_b = ob;
@@ -237,6 +239,33 @@ __device__ __forceinline__ void gemm_h(f32x16 (&acc)[NTW], const char* __restric
     }
 }
 
+// one accumulator tile, N k-steps fully unrolled, weight fragments in a ring D deep (k-step k + D - 1 is requested before
+// k-step k is multiplied): the colour branch's short K ranges are latency-bound with one fragment in flight
+template <int LDH, int N, int D>
+__device__ __forceinline__ void gemm_ring(f32x16& acc, const char* __restrict__ wb, int KS, int nt, int ks0, int tks0,
+                                          const HT& tile, const LaneCtx& L) {
+    h8 ah[D], al[D];
+    const char* p = wb + (size_t)((uint32_t)((nt * KS + ks0) * 128 + L.lane) * 16u);
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) {
+        ah[i] = *reinterpret_cast<const h8*>(p + 2048 * i);
+        al[i] = *reinterpret_cast<const h8*>(p + 2048 * i + 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (k + D - 1 < N) {
+            ah[(k + D - 1) % D] = *reinterpret_cast<const h8*>(p + 2048 * (k + D - 1));
+            al[(k + D - 1) % D] = *reinterpret_cast<const h8*>(p + 2048 * (k + D - 1) + 1024);
+        }
+        const int o = chunk_off<LDH>(L.l31, ((tks0 + k) << 1) + L.half);
+        const h8 bh = *reinterpret_cast<const h8*>(tile.hi + o);
+        const h8 bl = *reinterpret_cast<const h8*>(tile.lo + o);
+        acc = NEO_MFMA_H(al[k % D], bh, acc);
+        acc = NEO_MFMA_H(ah[k % D], bl, acc);
+        acc = NEO_MFMA_H(ah[k % D], bh, acc);
+    }
+}
+
 // NWV waves per workgroup (8, or 16 for the 1024-wide MLP: 4 waves per SIMD, 128 VGPRs, two accumulator tiles each)
 // TAIL: the trunk has been run by the layer-by-layer path; its output (fragment order, interval tile blockIdx.x of the
 // batch that starts at interval p0) is `yin`, this kernel adds the heads and the colour branch
@@ -266,8 +295,7 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
     int tid = threadIdx.x;
     const long P = (long)R * n;
     const long tile0 = p0 + (long)blockIdx.x * TMR;
-    constexpr int W_BOTT = woff_of(W, DEPTH - 1) + (W / 32) * ks_of(W, DEPTH - 1) * 128, W_VIEW = W_BOTT + 8 * (W / 16) * 128;
-    constexpr int B_BOTT = DEPTH * W, B_VIEW = B_BOTT + 256;
+    constexpr int W_VIEW = woff_of(W, DEPTH - 1) + (W / 32) * ks_of(W, DEPTH - 1) * 128;
     const char* wbase = reinterpret_cast<const char*>(m.wpack);
 
     // ---- per-row Gaussian, contraction (identical arithmetic to mlp_mip.hip) ---------------------------
@@ -369,36 +397,56 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
     }
     float r = 0.f, g = 0.f, b = 0.f;
     if (RGB) {
-        // ---- bottleneck W -> 256 (no activation): one N-tile per wave ----
-        f32x16 ab[1];
-        if (L.wv < 8) {
-            bias_tile(ab[0], m.bias + B_BOTT, L.wv, L);
-            gemm_h<1, W>(ab, wbase + (size_t)W_BOTT * 16, KSW, L.wv, 0, 0, KSW, act, L);
-        }
-        __syncthreads();
-        if (L.wv < 8) store_tile_h<false, W>(ab[0], act, L.wv, 0, L);
-        __syncthreads();
-        // ---- view layer [bottleneck 256 | dir enc 27] -> 128, ReLU: waves 0..3 ----
-        if (L.wv < 4) {
-            bias_tile(ab[0], m.bias + B_VIEW, L.wv, L);
-            gemm_h<1, W>(ab, wbase + (size_t)W_VIEW * 16, 18, L.wv, 0, 0, 16, act, L);
-            gemm_h<1, 32>(ab, wbase + (size_t)W_VIEW * 16, 18, L.wv, 16, 0, 2, dsm, L);
-        }
-        __syncthreads();
-        if (L.wv < 4) store_tile_h<true, W>(ab[0], act, L.wv, 0, L);
-        __syncthreads();
-        // ---- rgb head: 16 lanes per row, 8 features each ----
-        const int row = (tid >> 4) & 31, part = tid & 15;     // (threads >= 512 repeat rows; only tid < 512 writes)
-        const float* wr = m.heads + hd_rw(W);
-        const int o = chunk_off<W>(row, part);
-        const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
-        const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
+        // ---- views_linear.0 with the bottleneck folded in: [h W | dir enc 27 -> 32] -> 128, ReLU.  Wave = (N-tile wv & 3,
+        // K quarter wv >> 2): quarter q multiplies k-steps [16 q, 16 q + 16) of h, quarter 3 the two direction k-steps as
+        // well; quarters 1..3 hand their partial tiles to quarter 0 through the (now dead) activation tile as fp32 ----
+        if constexpr (NWV == 16) {
+            constexpr int KSV = KSW + 2, KQ = KSW / 4;
+            const int vnt = L.wv & 3, kq = L.wv >> 2;
+            f32x16 ab[1];
+            if (kq == 0) bias_tile(ab[0], m.view_bias, vnt, L);
+            else
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float h = (float)vh[e] + (float)vl[e];
-            r += h * wr[part * 8 + e];
-            g += h * wr[128 + part * 8 + e];
-            b += h * wr[256 + part * 8 + e];
+                for (int e = 0; e < 16; ++e) ab[0][e] = 0.0f;
+            gemm_ring<W, KQ, 4>(ab[0], wbase + (size_t)W_VIEW * 16, KSV, vnt, kq * KQ, kq * KQ, act, L);
+            if (kq == 3) gemm_h<1, 32>(ab, wbase + (size_t)W_VIEW * 16, KSV, vnt, KSW, 0, 2, dsm, L);
+            __syncthreads();                                   // every read of the trunk output (density head too) is done
+            float* part = reinterpret_cast<float*>(hb);        // 12 partial tiles x 4 KB, D layout lane for lane
+            if (kq > 0) {
+                float* ps = part + ((kq - 1) * 4 + vnt) * 1024 + L.lane * 4;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<f32x4*>(ps + gq * 256) = f32x4{ab[0][4 * gq], ab[0][4 * gq + 1], ab[0][4 * gq + 2], ab[0][4 * gq + 3]};
+            }
+            __syncthreads();
+            const HT vt{xb, xb + TMR * 128};                   // [32][128] x 2 planes in the (idle) encoding stage buffers
+            if (kq == 0) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float* ps = part + (j * 4 + vnt) * 1024 + L.lane * 4;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(ps + gq * 256);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ab[0][4 * gq + e] += v[e];
+                    }
+                }
+                store_tile_h<true, 128>(ab[0], vt, vnt, 0, L);
+            }
+            __syncthreads();
+            // ---- rgb head: 16 lanes per row, 8 features each ----
+            const int row = (tid >> 4) & 31, part16 = tid & 15;     // (threads >= 512 repeat rows; only tid < 512 writes)
+            const float* wr = m.heads + hd_rw(W);
+            const int o = chunk_off<128>(row, part16);
+            const h8 vh = *reinterpret_cast<const h8*>(vt.hi + o);
+            const h8 vl = *reinterpret_cast<const h8*>(vt.lo + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float h = (float)vh[e] + (float)vl[e];
+                r += h * wr[part16 * 8 + e];
+                g += h * wr[128 + part16 * 8 + e];
+                b += h * wr[256 + part16 * 8 + e];
+            }
         }
 #pragma unroll
         for (int o2 = 1; o2 < 16; o2 <<= 1) {
@@ -474,7 +522,10 @@ size_t lds_bytes() {
 
 size_t mip_wpack_h_bytes(int width, int depth, int rgb) { return (size_t)mip_layout_h(width, depth, rgb).total_h8 * 16; }
 
-void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, void* wpack_h, hipStream_t s) {
+size_t mip_fold_floats() { return (size_t)128 * (1024 + 27); }
+
+void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, const float* const* b, void* wpack_h, float* fold_ws,
+                       float* view_bias, hipStream_t s) {
     const MipLayoutH lay = mip_layout_h(width, depth, rgb);
     _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
     const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
@@ -485,12 +536,11 @@ void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, voi
         pack_h(w[i], kin, width, lay.ks_layer[i], 0, sg, base + (size_t)lay.w_layer[i] * 8, s);
     }
     if (rgb) {
-        PackSegs sb = none;
-        sb.len[0] = width;
-        pack_h(w[depth + 1], width, 256, width / 16, 0, sb, base + (size_t)lay.w_bott * 8, s);
+        // w / b order: trunk, density_layer, bottleneck_layer (256 x width), views_linear.0 (128 x 283), rgb_layer
+        launch_fold_bottleneck(w[depth + 2], w[depth + 1], b[depth + 1], b[depth + 2], 128, 256, width, 27, fold_ws, view_bias, s);
         PackSegs sv = none;
-        sv.len[0] = 283;
-        pack_h(w[depth + 2], 283, 128, 18, 0, sv, base + (size_t)lay.w_view * 8, s);
+        sv.len[0] = width + 27;
+        pack_h(fold_ws, width + 27, 128, width / 16 + 2, 0, sv, base + (size_t)lay.w_view * 8, s);
     }
 }
 
