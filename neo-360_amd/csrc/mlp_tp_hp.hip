@@ -633,6 +633,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
         store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
         TP_SYNC();
+        if (NEO_TP_PRIO) __builtin_amdgcn_s_setprio(NEO_TP_PRIO);      // L1..L3: this wave issues almost only MFMAs
         static_for<0, 24>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int layer = g / 8, ks = g % 8;
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        if (NEO_TP_PRIO) __builtin_amdgcn_s_setprio(0);
 #else
         // ---- L0 epilogue, L1, L2 ----
         f32x16 acc[1][2];

@@ -6,6 +6,10 @@
 #include "split_tile.h"
 #include "tp_common.h"
 
+#ifndef NEO_TP_PRIO
+#define NEO_TP_PRIO 0     // > 0: s_setprio around the L1..L3 k-steps of both evaluators (the wave that issues MFMAs wins the SIMD's arbitration)
+#endif
+
 namespace neo {
 namespace hp {
 
