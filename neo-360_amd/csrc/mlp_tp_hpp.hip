@@ -62,6 +62,15 @@
 #define NEO_TPP_MMA_INSIDE 2   // pos_enc k-steps: 1 between the gather items of every pipeline variant, 2 only inside the all-maps pipeline (after the pipeline otherwise), 0 always after the pipeline
 #endif
 #define TPP_SYNC() __syncthreads()
+#ifndef NEO_TP_TRACE
+#define NEO_TP_TRACE 0         // 1: per-phase s_memtime sums of wave 0 of every workgroup -> g_tpp_trace (tools/bench_tp_kernel.py TRACE=1)
+#endif
+#if NEO_TP_TRACE
+__device__ unsigned long long g_tpp_trace[16];
+#define TPP_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tr_[k] += now_ - tlast_; tlast_ = now_; } while (0)
+#else
+#define TPP_MARK(k) do { } while (0)
+#endif
 
 namespace neo {
 
@@ -131,6 +140,9 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
     constexpr int KSP = pe_ksteps(PE_C);         // pos_enc k-steps: 4 (63 -> 64 features) / 6 (84 -> 96)
     constexpr int NPE = PE_C == 3 ? 1 : 2;
 
+#if NEO_TP_TRACE
+    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#endif
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     float* dens_w = smem + PP_OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
     for (int r = 0; r < 16; ++r) { hsum[0][r] = 0.f; hsum[1][r] = 0.f; }
     const int vnt = L.wv & 1, vmt = L.wv >> 1;
 
+    TPP_MARK(0);
 #pragma unroll 1
     for (int v = 0; v < sc.nv; ++v) {
         // per-lane indices re-derived from an opaque lane id inside the loop: keeps the swizzled LDS addresses of the
@@ -241,6 +254,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             if constexpr (NPE == 2) pe_chunk(std::integral_constant<int, 32>(), xpe1, 1, 0);      // features 64..95 (84..95 padding)
         }
         TPP_SYNC();
+        TPP_MARK(1);
 #if NEO_TPP_WORKLIST
         // (the work list below decides per (row group, map) what is gathered)
 #elif NEO_TPP_ZSKIP
@@ -404,6 +418,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 taps[1][0] = tp::load_tap(proj, (uint32_t)o1.x + lane_b); taps[1][1] = tp::load_tap(proj, (uint32_t)o1.y + lane_b);
                 taps[1][2] = tp::load_tap(proj, (uint32_t)o1.z + lane_b); taps[1][3] = tp::load_tap(proj, (uint32_t)o1.w + lane_b);
             }
+            TPP_MARK(2);
             // One step = one list entry e of chunk c (ring slot j = e % 3: n_p is a multiple of 3, so slots are static):
             //   weights of entry e + 1, records of e + 4 / e + 1, tap offsets of e + 3 are read from LDS (used in the NEXT step);
             //   the taps of entry e + 2 are requested; entry e is blended, added to the group's running sum, and the sum stored
@@ -552,6 +567,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
 #endif
         }
         TPP_SYNC();          // the transposition tiles alias the activation tile: every wave has consumed the last chunk
+        TPP_MARK(3);
         // ---- L0 epilogue; L1, L2, L3 as ONE weight stream of 24 k-steps (N-tile = wave) requested LD k-steps ahead
         //      across the layer boundaries: the weights of the next layer do not wait for the barriers ----
         {
@@ -619,6 +635,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             if (NEO_TP_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         TPP_SYNC();           // every wave is done reading this view's tiles
+        TPP_MARK(4);
     }
 
     // ---- view mean of the trunk -> density head (x * (1 / nv): see mlp_tp_hp.hip) ----
@@ -813,9 +830,28 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                                   colour_act(b + lheads[HD_RB + 2]), density_act(raw_sigma));
         }
     }
+#if NEO_TP_TRACE
+    TPP_MARK(5);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_tpp_trace[k], tr_[k]);
+        atomicAdd(&g_tpp_trace[7], 1ull);
+    }
+#endif
 }
 
 }  // namespace
+
+#if NEO_TP_TRACE
+extern "C" void neo_debug_tpp_trace(unsigned long long* host16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_tpp_trace), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tpp_trace), z, sizeof(z));
+    }
+}
+#endif
 
 void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj_all, const long plane_base_texels[3],
                        const TpScene& sc, const TpViews& views, const float* rays_o, const float* rays_d, const float* viewdirs,

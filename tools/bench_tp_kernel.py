@@ -69,18 +69,21 @@ for SLOT in SLOTS:
         ("%.0f" % ts["sclk_mhz_mean"]) if ts.get("sclk_mhz_mean") else "?", ("%.0f" % ts["power_w_mean"]) if ts.get("power_w_mean") else "?",
         ts.get("telemetry_samples", 0)), flush=True)
 if os.environ.get("TRACE"):
-    # variant built with -DNEO_TP_TRACE=1: per-phase s_memtime sums of wave 0 of every workgroup
+    # variant built with -DNEO_TP_TRACE=1: per-phase s_memtime sums of wave 0 of every workgroup (k_tp_mlp_hp; TRACE=hpp: k_tp_mlp_hpp)
     import ctypes
     from neo360_amd import _lib
     lib = _lib.load()
     buf = (ctypes.c_ulonglong * 16)()
-    lib.neo_debug_tp_trace(buf, 1)                 # reset (drops warm-up + timed launches above)
+    hpp = os.environ["TRACE"] == "hpp"
+    read = lib.neo_debug_tpp_trace if hpp else lib.neo_debug_tp_trace
+    read(buf, 1)                 # reset (drops warm-up + timed launches above)
     net.eval_mlp(SLOT, rays, t, far=far)
-    lib.neo_debug_tp_trace(buf, 0)
-    names = ["setup", "descriptors", "G gather+consume", "planes (+X ks0-3)", "X ks4.. + pos_enc", "L0 epi + L1..L3", "tail"]
+    read(buf, 0)
+    names = (["setup", "descriptors + pos_enc", "work list + prologue", "gather + pos_enc k-steps + adds", "L0 epi + L1..L3", "tail"] if hpp else
+             ["setup", "descriptors", "G gather+consume", "planes (+X ks0-3)", "X ks4.. + pos_enc", "L0 epi + L1..L3", "tail"])
     n = max(int(buf[7]), 1)
-    tot = sum(int(buf[k]) for k in range(7))
-    print("%s phase trace slot %d: %d workgroups, %.0f cycles (s_memtime ticks, 100 MHz?) per tile" % (os.environ.get("TAG", ""), SLOT, n, tot / n))
+    tot = sum(int(buf[k]) for k in range(len(names)))
+    print("%s phase trace slot %d: %d workgroups, %.0f cycles (s_memtime ticks, 100 MHz) per tile" % (os.environ.get("TAG", ""), SLOT, n, tot / n))
     for k, nm in enumerate(names):
-        print("   %-22s %10.1f per tile  (%5.1f %%)%s" % (nm, int(buf[k]) / n, 100.0 * int(buf[k]) / max(tot, 1),
-                                                       "   [per view: %.1f]" % (int(buf[k]) / n / NV) if 1 <= k <= 5 else ""))
+        print("   %-32s %10.1f per tile  (%5.1f %%)%s" % (nm, int(buf[k]) / n, 100.0 * int(buf[k]) / max(tot, 1),
+                                                       "   [per view: %.1f]" % (int(buf[k]) / n / NV) if 1 <= k <= len(names) - 2 else ""))
