@@ -188,18 +188,23 @@ __device__ __forceinline__ void lift_rows(const float* __restrict__ basis, const
     }
 }
 
-// integrated_pos_enc (helper.py:77-88), feature f < 504 of row `row`; 0 for the padding features
-__device__ __forceinline__ float ipe_feature(const float* __restrict__ lift, int row, int f) {
-    float val = 0.0f;
-    if (f < 504) {
-        const bool shifted = f >= 252;
-        const int g = shifted ? f - 252 : f;
+// integrated_pos_enc (helper.py:77-88) in PAIR ORDER: packed features 2 g, 2 g + 1 = the reference's features g and 252 + g
+// (g = octave k * 21 + direction j < 252): exp(-var 4^k / 2) * sin(a) and exp(...) * sin(fl32(a + fl32(pi / 2))), a = mean 2^k.
+// The two share the exponential and ONE argument reduction (common.h:sincos_pair reproduces the fp32 rounding of a + pi/2):
+// ~50 VALU instructions per pair instead of ~80 for two separate features.  launch_mip_pack_h packs the encoding's weight
+// columns in the same order.  g >= 252: the zero padding (504 -> 512).
+__device__ __forceinline__ void ipe_pair(const float* __restrict__ lift, int row, int g, float& f0, float& f1) {
+    f0 = 0.0f;
+    f1 = 0.0f;
+    if (g < 252) {
         const int k = g / NB, j = g - k * NB;
         const float mean = lift[row * 44 + j], var = lift[row * 44 + NB + j];
-        const float arg = ldexpf(mean, k);
-        val = expf(-0.5f * ldexpf(var, 2 * k)) * sin_cw(shifted ? arg + HALF_PI_F32 : arg);
+        float sn, cs;
+        sincos_pair(ldexpf(mean, k), sn, cs);
+        const float ex = expf(-0.5f * ldexpf(var, 2 * k));
+        f0 = ex * sn;
+        f1 = ex * cs;
     }
-    return val;
 }
 
 // acc[nt] += W-stage k-steps [ks0, ks0+n) x tile k-steps [tks0, tks0+n); N-tiles nt0..nt0+NTW-1, the one M-tile.
@@ -320,14 +325,17 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
     }
     __syncthreads();
 
-    // integrated_pos_enc (helper.py:77-88): 64 features of stage s; thread = (row, 4 consecutive features)
+    // integrated_pos_enc (helper.py:77-88): 64 packed features (32 pairs) of stage s; thread = (row, FPT consecutive features)
     auto produce = [&](int s, const HT& buf) {
         const int row = tid & 31, q = tid >> 5;              // q: group of FPT consecutive features
+        static_assert(FPT % 2 == 0, "whole (sin, shifted sin) pairs per thread");
         _Float16 vh[FPT], vl[FPT];
 #pragma unroll
-        for (int e = 0; e < FPT; ++e) {
-            const float val = ipe_feature(lift, row, s * 64 + q * FPT + e);
-            split(val, vh[e], vl[e]);
+        for (int e = 0; e < FPT; e += 2) {
+            float f0, f1;
+            ipe_pair(lift, row, (s * 64 + q * FPT + e) >> 1, f0, f1);
+            split(f0, vh[e], vl[e]);
+            split(f1, vh[e + 1], vl[e + 1]);
         }
         const int o = chunk_off<64>(row, (q * FPT) >> 3) + ((q * FPT) & 7);
 #pragma unroll
@@ -501,15 +509,46 @@ __global__ __launch_bounds__(256) void k_mip_ipe_h(const float* __restrict__ bas
     for (int s = 0; s < 8; ++s) {
         h8 vh, vl;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 8; e += 2) {
+            float f0, f1;
+            ipe_pair(lift, row, (s * 64 + q * 8 + e) >> 1, f0, f1);
             _Float16 h, l;
-            split(ipe_feature(lift, row, s * 64 + q * 8 + e), h, l);
+            split(f0, h, l);
             vh[e] = h;
             vl[e] = l;
+            split(f1, h, l);
+            vh[e + 1] = h;
+            vl[e + 1] = l;
         }
         char* p = xt + (size_t)(s * 4 + (q >> 1)) * 2048;
         *reinterpret_cast<h8*>(p) = vh;
         *reinterpret_cast<h8*>(p + 1024) = vl;
+    }
+}
+
+// Trunk-layer fragments with the encoding's 504 source columns [col0, col0 + 504) packed in pair order at packed k in
+// [k_enc, k_enc + 512): packed k_enc + 2 g + h <- column col0 + 252 h + g (g < 252), zeros behind; every other packed k < kin
+// maps to itself (the hidden features of the skip layer).  Same fragment layout as pack_h (split_tile.h).
+__global__ void k_mip_pack_layer_h(const float* __restrict__ src, int ld, int rows, int KS, int k_enc, int col0, int k_plain,
+                                   _Float16* __restrict__ dst) {
+    const int total = (rows / 32) * KS * 512;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9;
+        const int ks = blk % KS, ntl = blk / KS;
+        const int n = ntl * 32 + (lane & 31);
+        const int k = ks * 16 + 8 * (lane >> 5) + e;
+        float w = 0.0f;
+        if (k >= k_enc && k < k_enc + 504) {
+            const int p = k - k_enc;
+            w = src[(long)n * ld + col0 + 252 * (p & 1) + (p >> 1)];
+        } else if (k < k_plain) {
+            w = src[(long)n * ld + k];
+        }
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        const long base = ((long)(ntl * KS + ks) * 2) * 512 + lane * 8 + e;
+        dst[base] = hi;
+        dst[base + 512] = lo;
     }
 }
 
@@ -530,10 +569,18 @@ void launch_mip_pack_h(int width, int depth, int rgb, const float* const* w, con
     _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
     const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int i = 0; i < depth; ++i) {
-        PackSegs sg = none;
         const int kin = i == 0 ? 504 : (i == 5 ? width + 504 : width);
-        sg.len[0] = kin;                      // [h | ipe] are contiguous source columns; zero padded to 16*KS
-        pack_h(w[i], kin, width, lay.ks_layer[i], 0, sg, base + (size_t)lay.w_layer[i] * 8, s);
+        if (i == 0 || i == 5) {
+            // the encoding's columns in pair order (ipe_pair): layer 0 = [enc], layer 5 = [h | enc] (model.py:76-79)
+            const int k_enc = i == 0 ? 0 : width;
+            const int total = (width / 32) * lay.ks_layer[i] * 512;
+            hipLaunchKernelGGL(k_mip_pack_layer_h, dim3((total + 255) / 256), dim3(256), 0, s, w[i], kin, width, lay.ks_layer[i], k_enc,
+                               k_enc, k_enc, base + (size_t)lay.w_layer[i] * 8);
+        } else {
+            PackSegs sg = none;
+            sg.len[0] = kin;
+            pack_h(w[i], kin, width, lay.ks_layer[i], 0, sg, base + (size_t)lay.w_layer[i] * 8, s);
+        }
     }
     if (rgb) {
         // w / b order: trunk, density_layer, bottleneck_layer (256 x width), views_linear.0 (128 x 283), rgb_layer
