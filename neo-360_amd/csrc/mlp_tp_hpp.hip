@@ -373,26 +373,32 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                     if (((am >> (4 * q)) & 0xFu) == 0u) am |= 1u << (4 * q);      // to the zeros the group's rows must receive
                 const int n = __builtin_popcount(am);
                 n_p = ((n + RING - 1) / RING) * RING;
-                int mine = -1;                               // lane i: the i-th set bit of am
-#pragma unroll
-                for (int b = 0; b < 16; ++b)
-                    if (((am >> b) & 1u) && __builtin_popcount(am & ((1u << b) - 1u)) == L.lane) mine = b;
-                if (L.lane < n_p) {
-                    int4 rec;                                // x: byte offset of the group's first descriptor row; y: 16 q;
-                    if (mine >= 0) {                         // z: 0.0f for the first map of a group, 1.0f after (wsum * z + blend); w: last map
-                        const int q = mine >> 2, mp = mine & 3;
-                        const unsigned grp = (am >> (4 * q)) & 0xFu;
-                        rec.x = (mp * TM + 16 * q) * 16;
-                        rec.y = 16 * q;
-                        rec.z = (grp & ((1u << mp) - 1u)) == 0u ? 0 : 0x3f800000;
-                        rec.w = (grp >> (mp + 1)) == 0u ? 1 : 0;
-                    } else {
-                        rec.x = 4 * DESC_BLOCK * 4;          // padding: the all-zero block - adds 0.0, stores nothing
-                        rec.y = 0;
-                        rec.z = 0x3f800000;
-                        rec.w = 0;
+                // lane b < 16 with bit b set writes ITS record at its rank (number of set bits below b); lanes 32 + n .. 32 + n_p - 1
+                // write the padding records behind them (scatter by rank: a dozen instructions; finding the i-th set bit per
+                // lane took ~80)
+                {
+                    const int b = L.lane;
+                    const bool real = b < 16 && ((am >> b) & 1u);
+                    const bool pad = b - 32 >= n && b - 32 < n_p;
+                    if (real || pad) {
+                        int4 rec;                            // x: byte offset of the group's first descriptor row; y: 16 q;
+                        int at = b - 32;                     // z: 0.0f for the first map of a group, 1.0f after (wsum * z + blend); w: last map
+                        if (real) {
+                            const int q = b >> 2, mp = b & 3;
+                            const unsigned grp = (am >> (4 * q)) & 0xFu;
+                            rec.x = (mp * TM + 16 * q) * 16;
+                            rec.y = 16 * q;
+                            rec.z = (grp & ((1u << mp) - 1u)) == 0u ? 0 : 0x3f800000;
+                            rec.w = (grp >> (mp + 1)) == 0u ? 1 : 0;
+                            at = __builtin_popcount(am & ((1u << b) - 1u));
+                        } else {
+                            rec.x = 4 * DESC_BLOCK * 4;      // padding: the all-zero block - adds 0.0, stores nothing
+                            rec.y = 0;
+                            rec.z = 0x3f800000;
+                            rec.w = 0;
+                        }
+                        mylist[at] = rec;
                     }
-                    mylist[L.lane] = rec;
                 }
                 list = mylist;
             }
