@@ -40,7 +40,10 @@ constexpr int MG_THREADS = 512;
 constexpr int MG_STAGE_BYTES = 8 * 2 * 2048;      // 8 interval tiles x 2 k-steps x (hi | lo)
 constexpr int MG_LDS_BYTES = 2 * MG_STAGE_BYTES;
 
-template <bool RELU>
+// A_LDS (experiment, tools/gemm_h_bench.hip): the weight fragments are staged through LDS as well ([8 output tiles | 8 interval
+// tiles] x 2 k-steps = 64 KB per stage, 128 KB double-buffered): half the weight bytes through the vector-memory path (16 KB
+// instead of 32 KB per k-step and workgroup), 50 % more LDS traffic.
+template <bool RELU, bool A_LDS = false>
 __global__ __launch_bounds__(MG_THREADS, 2) void k_mip_gemm_h(MipGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char mg_lds[];
     LaneCtx L;
@@ -57,22 +60,30 @@ __global__ __launch_bounds__(MG_THREADS, 2) void k_mip_gemm_h(MipGemmArgs a) {
     const int it_l = tid >> 8;
     const uint32_t rem = (uint32_t)(tid & 255) * 16u;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 g[4];
+    constexpr int STAGE = A_LDS ? 2 * MG_STAGE_BYTES : MG_STAGE_BYTES;      // A_LDS: [8 output tiles | 8 interval tiles]
+    constexpr int B_AT = A_LDS ? MG_STAGE_BYTES : 0;
+    constexpr int NP = A_LDS ? 8 : 4;
+    u32x4 g[NP];
     auto load_stage = [&](int s) {
         const bool second = s >= S0;
         const char* xs = second ? a.x1 : a.x0;
         const int kss = second ? a.ks1 : a.ks0;
         const int sl = second ? s - S0 : s;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const size_t off = ((size_t)(it0 + 2 * p + it_l) * kss + 2 * sl) * 2048 + rem;
-            g[p] = *reinterpret_cast<const u32x4*>(xs + off);
+        for (int p = 0; p < NP; ++p) {
+            if (A_LDS && p < 4) {
+                const size_t off = ((size_t)(slab_o * 8 + 2 * p + it_l) * KS + 2 * s) * 2048 + rem;
+                g[p] = *reinterpret_cast<const u32x4*>(a.w + off);
+            } else {
+                const size_t off = ((size_t)(it0 + 2 * (p - (A_LDS ? 4 : 0)) + it_l) * kss + 2 * sl) * 2048 + rem;
+                g[p] = *reinterpret_cast<const u32x4*>(xs + off);
+            }
         }
     };
     auto put_stage = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            *reinterpret_cast<u32x4*>(mg_lds + buf * MG_STAGE_BYTES + p * 8192 + tid * 16) = g[p];
+        for (int p = 0; p < NP; ++p)
+            *reinterpret_cast<u32x4*>(mg_lds + buf * STAGE + p * 8192 + tid * 16) = g[p];
     };
     // ---- weight fragments: four slots, k-step k + 2 is requested when k-step k starts.  The vector-memory counter retires
     // loads in order, so a wait for the weights of k + 1 also waits for every older request: the depth of the weight
@@ -97,8 +108,16 @@ __global__ __launch_bounds__(MG_THREADS, 2) void k_mip_gemm_h(MipGemmArgs a) {
     // interval fragments: one tile (hi, lo) per sub-step, read from the stage buffer one sub-step (6 MFMAs) ahead
     h8 bh[2], bl[2];
     const int boff = wi * (4 * 4096) + L.lane * 16;
+    auto load_a_lds = [&](int slot, int buf, int u) {      // A_LDS: this wave's two output tiles of k-step u of the stage
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const char* p = mg_lds + buf * STAGE + (wo * 2 + nt) * 4096 + u * 2048 + L.lane * 16;
+            ah[slot][nt] = *reinterpret_cast<const h8*>(p);
+            al[slot][nt] = *reinterpret_cast<const h8*>(p + 1024);
+        }
+    };
     auto load_b = [&](int slot, int buf, int u, int it) {
-        const char* bb = mg_lds + buf * MG_STAGE_BYTES + boff + u * 2048 + it * 4096;
+        const char* bb = mg_lds + buf * STAGE + B_AT + boff + u * 2048 + it * 4096;
         bh[slot] = *reinterpret_cast<const h8*>(bb);
         bl[slot] = *reinterpret_cast<const h8*>(bb + 1024);
     };
@@ -108,12 +127,15 @@ __global__ __launch_bounds__(MG_THREADS, 2) void k_mip_gemm_h(MipGemmArgs a) {
     //   after (1, 2):     stage s + 1: registers -> LDS | barrier | stage s + 2: global -> registers requested
     //   (1, 3) reads its "next" fragment from the buffer the barrier has just published.
     load_stage(0);
-    load_a(0, 0);
-    load_a(1, 1);
+    if (!A_LDS) {
+        load_a(0, 0);
+        load_a(1, 1);
+    }
     put_stage(0);
     __syncthreads();
     load_stage(S > 1 ? 1 : 0);
     load_b(0, 0, 0, 0);
+    if (A_LDS) load_a_lds(0, 0, 0);
 #pragma unroll 1
     for (int sp = 0; sp < S; sp += 2) {
 #pragma unroll
@@ -125,15 +147,20 @@ __global__ __launch_bounds__(MG_THREADS, 2) void k_mip_gemm_h(MipGemmArgs a) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int sub = u * 4 + it;
-                    if (it == 0) load_a((slot + 2) & 3, 2 * s + u + 2);
+                    if (!A_LDS && it == 0) load_a((slot + 2) & 3, 2 * s + u + 2);
+                    if (A_LDS && sub == 3) load_a_lds(1, q, 1);                                // the stage's second k-step
                     if (sub < 7) load_b((sub + 1) & 1, q, (sub + 1) >> 2, (sub + 1) & 3);      // buffer s & 1 == q (sp is even)
-                    else load_b(0, q ^ 1, 0, 0);                                               // first fragment of stage s + 1
+                    else {
+                        load_b(0, q ^ 1, 0, 0);                                                // first fragment of stage s + 1
+                        if (A_LDS) load_a_lds(0, q ^ 1, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
+                    const int as = A_LDS ? u : slot;
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        acc[nt][it] = NEO_MFMA_H(al[slot][nt], bh[sub & 1], acc[nt][it]);
-                        acc[nt][it] = NEO_MFMA_H(ah[slot][nt], bl[sub & 1], acc[nt][it]);
-                        acc[nt][it] = NEO_MFMA_H(ah[slot][nt], bh[sub & 1], acc[nt][it]);
+                        acc[nt][it] = NEO_MFMA_H(al[as][nt], bh[sub & 1], acc[nt][it]);
+                        acc[nt][it] = NEO_MFMA_H(ah[as][nt], bl[sub & 1], acc[nt][it]);
+                        acc[nt][it] = NEO_MFMA_H(ah[as][nt], bh[sub & 1], acc[nt][it]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (sub == 6) {

@@ -91,7 +91,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dBias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dFlags, 4));
     CK(hipMemset(dFlags, 0, 4));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_gemm_h<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES));
+#ifndef GEMM_A_LDS
+#define GEMM_A_LDS false
+#endif
+    constexpr int LDS_BYTES = GEMM_A_LDS ? 2 * MG_LDS_BYTES : MG_LDS_BYTES;
+    auto kern = k_mip_gemm_h<true, GEMM_A_LDS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -106,7 +111,7 @@ int main(int argc, char** argv) {
         a.y = out;
         a.n_it = n_it;
         a.flags = dFlags;
-        hipLaunchKernelGGL(k_mip_gemm_h<true>, dim3(mip_gemm_grid(n_it)), dim3(MG_THREADS), MG_LDS_BYTES, st, a);
+        hipLaunchKernelGGL(kern, dim3(mip_gemm_grid(n_it)), dim3(MG_THREADS), LDS_BYTES, st, a);
     };
     auto chain = [&]() {
         char* bufs[2] = {dA, dB};
