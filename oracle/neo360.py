@@ -49,7 +49,8 @@ def region_eval(params, prefix, rays, scene, tvals, inside, far=None):
     return _predict(params, prefix, cam, dir_cam, world, local, B, N, nv)
 
 
-def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_depth=True, keep=False, uniforms=None):
+def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_depth=True, keep=False, uniforms=None,
+           fine_samples=None):
     """Return value of NeRF_TP.forward for randomized=False
     (neo360/model.py:266-581, decoder half from :276).
 
@@ -59,6 +60,9 @@ def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_
     bg_lambda, depth); else (rgb, fg_w, bg_w, fg_sdist, bg_sdist, bg_acc).
     uniforms: None = randomized=False; else dict(fg0, bg0 (B,n_coarse+1), fg1, bg1 (B,n_fine)) = the draws the
     reference's randomized=True path takes from torch.rand, in call order (helper.py:49 twice, :196 twice).
+    fine_samples: None, or (fg_t, bg_s) (B, n_coarse+1+n_fine) = level-1 sample positions to USE instead of resampling
+    (derivative checks: the resampled positions carry no gradient - helper.py:224 detaches them - but their value decides
+    which texels a sample blends, so a gradient comparison between two arithmetics wants both sides at the same positions).
     """
     from . import training
     o, d, vd = rays["rays_o"], rays["rays_d"], rays["viewdirs"]
@@ -80,6 +84,12 @@ def render(params, rays, scene, n_coarse=128, n_fine=256, white_bkgd=False, out_
             fg_t, fg_p = sampling.neo_fg_level0(o, d, n_coarse, near, far)
             bg_s, bg_p4, bg_lin = sampling.neo_bg_level0(o, d, n_coarse, far, 3.0)
             fg_name, bg_name = "fg_coarse_mlp.", "bg_coarse_mlp."
+        elif level == 1 and uniforms is None and fine_samples is not None:
+            fg_t, bg_s = fine_samples
+            fg_p = sampling.points_on_rays(fg_t, o, d)
+            bg_p4 = sampling.inverted_sphere_points(o, d, bg_s)
+            bg_lin = sampling.points_on_rays(far * (1.0 - bg_s) + 3.0 * bg_s, o, d)
+            fg_name, bg_name = "fg_fine_mlp.", "bg_fine_mlp."
         elif level == 1 and uniforms is None:
             fg_mid = 0.5 * (fg_t[..., 1:] + fg_t[..., :-1])
             bg_mid = 0.5 * (bg_s[..., 1:] + bg_s[..., :-1])

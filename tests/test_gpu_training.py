@@ -472,9 +472,7 @@ def test_module_training_call_is_differentiable():
     (neo360/model.py:725-732 inside :697-820) - under autograd: same return tuple and forward values as the fused no-grad call,
     and the gradients of the reference's loss (rgb L2 on both levels + eff_distloss on the fine weights, :1246-1260) with
     respect to EVERY parameter of the four MLPs, the three tri-planes and the latent against fp64 autograd of
-    oracle.neo360.render.  Rays whose fine-level samples differ between the fp32 pipeline and the fp64 oracle (the
-    reference's inverse-CDF sampler is discontinuous, see conftest.check_vs_reference_noise) are masked out of the loss on
-    both sides - the comparison is about derivatives, not about which side of a threshold a quantile falls."""
+    oracle.neo360.render evaluated at the same fine-level sample positions (they carry no gradient; see below)."""
     sc = cases.small_scene()
     R = 256
     sd = synth.nerf_tp_state(0)
@@ -509,45 +507,63 @@ def test_module_training_call_is_differentiable():
                     assert float(err.median()) < 1e-6 and float(err.quantile(0.999)) < 1e-3, (nm, lv)
                 else:
                     assert float(err.max()) < 1e-4, (nm, lv, float(err.max()))
-        # ---- oracle, fp64, autograd ----
-        dbl = lambda d: {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in d.items()}
-        cm = {k: v.clone().double().requires_grad_(True) for k, v in sc.items() if isinstance(v, torch.Tensor)}
-        cm["image_wh"] = sc["image_wh"]
-        pp = {k: v.double().requires_grad_(True) for k, v in sd.items()}
-        want = oracle.neo360.render(pp, dbl(batch), cm, n_coarse=NC, n_fine=NF, white_bkgd=False, out_depth=False)
-        # rays on which both pipelines drew the same fine-level samples
-        same = ((diff[1][3].detach().cpu().double() - want[1][3].detach()).abs().amax(-1) < 1e-4) & \
-               ((diff[1][4].detach().cpu().double() - want[1][4].detach()).abs().amax(-1) < 1e-4)
-        assert int(same.sum()) >= int(0.9 * R), int(same.sum())
-        mask_c = same.double()
-        loss_c = loss_of(want, target.double(), mask_c, T.eff_distloss)
-        pnames = sorted(pp)
-        g_c = torch.autograd.grad(loss_c, [pp[k] for k in pnames] + [cm[k] for k in ("plane_xz", "plane_xy", "plane_yz", "latent")])
+        # ---- oracle, fp64, autograd, AT THE LIBRARY'S FINE SAMPLE POSITIONS.  The resampled positions carry no gradient
+        # (helper.py:224), but their VALUE decides which texels a sample blends: the fp64 oracle's own inverse-CDF positions
+        # differ from the fp32 pipeline's by 1e-7 .. 1e-4 (conftest.check_vs_reference_noise), which moves bilinear weights -
+        # and with them single entries of the feature-map gradients - by up to 1e-2.  The positions the library drew are
+        # reproduced here with its own operators (bitwise what tp_render_train used) and handed to the oracle. ----
+        far_g, _ = ops.intersect_sphere(gb["rays_o"], gb["rays_d"])
+        fg_t0, bg_s0 = training.sample_level0(far_g, NC, None, None)
+        fg_t1 = ops.resample(fg_t0, diff[0][1].detach(), NF, False)
+        bg_s1 = ops.resample(bg_s0, diff[0][2].detach(), NF, True)
+        sd_of = lambda t: torch.cat([0.5 * (t[..., 1:] + t[..., :-1]), t[..., -1:]], dim=-1)
+        assert torch.equal(sd_of(bg_s1), diff[1][4].detach())              # really the positions of the differentiable call
+        ones = torch.ones(R)
+        pnames = sorted(sd)
+        maps = ("plane_xz", "plane_xy", "plane_yz", "latent")
+
+        def oracle_grads(dtype):
+            cv = lambda v: v.to(dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v
+            cm = {k: (cv(v).clone().requires_grad_(True) if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+            pp = {k: cv(v).clone().requires_grad_(True) for k, v in sd.items()}
+            want = oracle.neo360.render(pp, {k: cv(v) for k, v in batch.items()}, cm, n_coarse=NC, n_fine=NF, white_bkgd=False,
+                                        out_depth=False, fine_samples=(cv(fg_t1.cpu()), cv(bg_s1.cpu())))
+            loss = loss_of(want, cv(target), cv(ones), T.eff_distloss)
+            return float(loss), torch.autograd.grad(loss, [pp[k] for k in pnames] + [cm[k] for k in maps])
+
+        loss_c, g_c = oracle_grads(torch.float64)
+        _, g_r = oracle_grads(torch.float32)                 # the REFERENCE's arithmetic (fp32) on the same positions
         # ---- library ----
-        loss_g = loss_of(diff, target.to(DEV), same.to(DEV).float(), training.eff_distloss)
+        loss_g = loss_of(diff, target.to(DEV), torch.ones(R, device=DEV), training.eff_distloss)
         params = dict(net.named_parameters())
-        g_g = torch.autograd.grad(loss_g, [params[k] for k in pnames] + [gm[k] for k in ("plane_xz", "plane_xy", "plane_yz", "latent")])
-    assert abs(float(loss_g) - float(loss_c)) < 1e-5 * max(1.0, abs(float(loss_c))), (float(loss_g), float(loss_c))
-    worst, worst_name, worst_l2 = 0.0, "", 0.0
-    report = {}
-    for nm, a, b in zip(pnames + ["plane_xz", "plane_xy", "plane_yz", "latent"], g_g, g_c):
+        g_g = torch.autograd.grad(loss_g, [params[k] for k in pnames] + [gm[k] for k in maps])
+    assert abs(float(loss_g) - loss_c) < 1e-5 * max(1.0, abs(loss_c)), (float(loss_g), loss_c)
+    # The gradients of this loss are ILL-CONDITIONED in the forward pass's rounding: the fp32 oracle - the reference's own
+    # arithmetic - misses its fp64 twin by up to 3.4e-3 (relative L2, the latent) / 1.1e-2 (one entry) at identical sample
+    # positions (ten octaves of positional encoding amplify the last bits of a camera-frame coordinate; ReLU units near
+    # their kink switch).  So the yardstick is that self-noise, tensor by tensor: the library may miss the fp64 gradients by
+    # no more than 1.5 x what the reference's arithmetic misses them by (+ 2e-5).  Derivative correctness without the
+    # forward noise is test_training_step_end_to_end's job (same intermediates on both sides: 1e-6).
+    rel = lambda x, ref: (float(x.abs().max()) / (float(ref.abs().max()) + 1e-15), float(x.norm()) / (float(ref.norm()) + 1e-30))
+    report, worst = {}, (0.0, "")
+    for nm, a, b, r in zip(pnames + list(maps), g_g, g_c, g_r):
         assert a.shape == b.shape, nm
-        diff_t = a.detach().cpu().double() - b
-        err = float(diff_t.abs().max()) / (float(b.abs().max()) + 1e-15)        # worst entry, relative to the tensor's largest
-        l2 = float(diff_t.norm()) / (float(b.norm()) + 1e-30)                     # the whole tensor
-        report[nm] = (err, l2)
-        if err > worst:
-            worst, worst_name = err, nm
-        worst_l2 = max(worst_l2, l2)
+        a = a.detach().cpu().double()
+        lib, ref, both = rel(a - b, b), rel(r.double() - b, b), rel(a - r.double(), b)
+        report[nm] = (lib, ref, both)
+        if lib[1] > worst[0]:
+            worst = (lib[1], nm)
+        assert lib[0] <= 1.5 * ref[0] + 2e-5 and lib[1] <= 1.5 * ref[1] + 2e-5, (nm, lib, ref)
     from conftest import record_parity
-    record_parity("train_module_call_differentiable", max_rel_grad_err_vs_fp64=worst, worst_tensor=worst_name,
-                  max_rel_l2_grad_err=worst_l2, rays_compared=int(same.sum()), rays=R, loss_abs_err=abs(float(loss_g) - float(loss_c)))
-    print("worst entry-wise %.2e (%s), worst relative L2 %.2e" % (worst, worst_name, worst_l2))
-    # A ReLU unit within an ulp of its kink is active on one side and not on the other: one row of one layer contributes
-    # differently.  Entry-wise that shows as up to ~1e-2 of a tensor's largest entry on small tensors (a bias of the coarse
-    # MLPs; test_nerfpp_mlp_backward_vs_autograd excludes such points and holds 2e-5); over a whole tensor it stays below 1e-2.
-    for nm, (err, l2) in report.items():
-        assert err < 2e-2 and l2 < 1e-2, (nm, err, l2)
+    record_parity("train_module_call_differentiable",
+                  max_rel_l2_grad_err_vs_fp64=max(v[0][1] for v in report.values()), worst_tensor=worst[1],
+                  max_rel_l2_of_the_fp32_oracle_vs_fp64=max(v[1][1] for v in report.values()),
+                  max_entry_err_vs_fp64=max(v[0][0] for v in report.values()),
+                  max_entry_err_of_the_fp32_oracle_vs_fp64=max(v[1][0] for v in report.values()),
+                  max_rel_l2_library_vs_fp32_oracle=max(v[2][1] for v in report.values()),
+                  rays=R, loss_abs_err=abs(float(loss_g) - loss_c))
+    print("worst relative L2 vs fp64: library %.2e (%s); fp32 oracle %.2e; library vs fp32 oracle %.2e" % (
+        worst[0], worst[1], max(v[1][1] for v in report.values()), max(v[2][1] for v in report.values())))
     for p in net.parameters():
         p.requires_grad_(False)
 
