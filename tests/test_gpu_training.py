@@ -540,8 +540,8 @@ def test_module_training_call_is_differentiable():
     assert abs(float(loss_g) - loss_c) < 1e-5 * max(1.0, abs(loss_c)), (float(loss_g), loss_c)
     # The gradients of this loss are ILL-CONDITIONED in the forward pass's rounding: the fp32 oracle - the reference's own
     # arithmetic - misses its fp64 twin by up to 3.4e-3 (relative L2, the latent) / 1.1e-2 (one entry) at identical sample
-    # positions (ten octaves of positional encoding amplify the last bits of a camera-frame coordinate; ReLU units near
-    # their kink switch).  So the yardstick is that self-noise, tensor by tensor: the library may miss the fp64 gradients by
+    # positions (a sample within rounding of a texel boundary moves its contribution to the neighbouring texel; ReLU units
+    # near their kink switch; ten octaves of positional encoding amplify the last bits of a camera-frame coordinate).  So the yardstick is that self-noise, tensor by tensor: the library may miss the fp64 gradients by
     # no more than 1.5 x what the reference's arithmetic misses them by (+ 2e-5).  Derivative correctness without the
     # forward noise is test_training_step_end_to_end's job (same intermediates on both sides: 1e-6).
     rel = lambda x, ref: (float(x.abs().max()) / (float(ref.abs().max()) + 1e-15), float(x.norm()) / (float(ref.norm()) + 1e-30))
