@@ -51,6 +51,57 @@ constexpr int NST = 9;                                    // streamed stages: 8 
 // in mlp_tp_hp.hip): G = F . W0_loc^T, 128 channels = 512 B per texel instead of 2 KB; its two 64-channel chunks are
 // blended into an fp32 LDS tile and ADDED to the L0 accumulators, and only the pos_enc stage (4 of the 36 k-steps of
 // the first layer) is still multiplied per point.
+// Chunk ch (8 packed features) of the 63-wide positional encoding in PAIR order (as mlp_tp_hp.hip): packed positions 2 p, 2 p + 1 =
+// sin(a), sin(fl32(a + fl32(pi / 2))) of pair p = octave * 3 + coordinate, a = x 2^octave (reference columns 3 + p and 33 + p:
+// model_pixel.py / helper.py:121-125), both from ONE argument reduction (common.h:sincos_pair); positions 60..62 = x, y, z, 63 = 0.
+// launch_pix_pack_h packs the weight columns in the same order.
+__device__ __forceinline__ void pe_chunk_pairs(const float (&xc)[4], int ch, h8& vh, h8& vl) {
+    float f[8];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (ch == 7 && jj >= 2) {
+            f[2 * jj] = jj == 2 ? xc[0] : xc[2];
+            f[2 * jj + 1] = jj == 2 ? xc[1] : 0.0f;
+            continue;
+        }
+        const int p = ch * 4 + jj;                 // wave-uniform
+        const int oct = p / 3, a = p - 3 * oct;
+        const float x = a == 0 ? xc[0] : a == 1 ? xc[1] : xc[2];
+        sincos_pair(ldexpf(x, oct), f[2 * jj], f[2 * jj + 1]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        h2 h, l;
+        split2(f[e], f[e + 1], h, l);
+        vh[e] = h[0]; vh[e + 1] = h[1];
+        vl[e] = l[0]; vl[e + 1] = l[1];
+    }
+}
+
+// first-layer fragments: packed k = [latent 512 | pos_enc 63 in pair order | 0] <- source columns [pos_enc 63 | latent 512]
+__global__ void k_pix_pack_x_h(const float* __restrict__ src, _Float16* __restrict__ dst) {
+    const int total = 4 * KSX * 512;               // 128 outputs = 4 N-tiles
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx & 7, lane = (idx >> 3) & 63, blk = idx >> 9;
+        const int ks = blk % KSX, ntl = blk / KSX;
+        const int n = ntl * 32 + (lane & 31);
+        const int k = ks * 16 + 8 * (lane >> 5) + e;
+        int col = -1;
+        if (k < 512) col = 63 + k;
+        else {
+            const int q = k - 512;
+            if (q < 60) col = 3 + (q >> 1) + ((q & 1) ? 30 : 0);
+            else if (q < 63) col = q - 60;
+        }
+        const float w = col >= 0 ? src[(long)n * 575 + col] : 0.0f;
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        const long base = ((long)(ntl * KSX + ks) * 2) * 512 + lane * 8 + e;
+        dst[base] = hi;
+        dst[base + 512] = lo;
+    }
+}
+
 template <bool PROJ>
 __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(TpMlpHDev m, const float* __restrict__ proj,
                                                       TpScene sc, TpViews views,
@@ -182,13 +233,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
                 for (int hf = 0; hf < 2; ++hf) {
                     const int ch = hf * 4 + q;
                     h8 vh, vl;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        _Float16 h, l;
-                        split(pe_feature<3>(xc, ch * 8 + e), h, l);
-                        vh[e] = h;
-                        vl[e] = l;
-                    }
+                    pe_chunk_pairs(xc, ch, vh, vl);
                     const int o = chunk_off<64>(row, ch);
                     *reinterpret_cast<h8*>(buf.hi + o) = vh;
                     *reinterpret_cast<h8*>(buf.lo + o) = vl;
@@ -244,13 +289,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
                 range_see(L, xc[0]); range_see(L, xc[1]); range_see(L, xc[2]);     // identity features (the rest are sines)
                 const int ch = hf * 4 + q;
                 h8 vh, vl;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    _Float16 h, l;
-                    split(pe_feature<3>(xc, ch * 8 + e), h, l);
-                    vh[e] = h;
-                    vl[e] = l;
-                }
+                pe_chunk_pairs(xc, ch, vh, vl);
                 const int o = chunk_off<64>(row, ch);
                 *reinterpret_cast<h8*>(buf.hi + o) = vh;
                 *reinterpret_cast<h8*>(buf.lo + o) = vl;
@@ -456,8 +495,8 @@ void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack
     // w order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
     _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
     const PackSegs none = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    PackSegs sx = {{0, 512, 0}, {512, 63, 0}, {63, 0, 0}};      // packed [latent | pos_enc] <- source [pos_enc | latent]
-    pack_h(w[0], 575, 128, KSX, 0, sx, base + (size_t)PX_X * 8, s);
+    // packed [latent | pos_enc in pair order] <- source [pos_enc | latent]
+    hipLaunchKernelGGL(k_pix_pack_x_h, dim3((4 * KSX * 512 + 255) / 256), dim3(256), 0, s, w[0], base + (size_t)PX_X * 8);
     PackSegs p128 = none;
     p128.len[0] = 128;
     pack_h(w[1], 128, 128, 8, 0, p128, base + (size_t)PX_1 * 8, s);
