@@ -46,9 +46,15 @@ int neo_abi_version(void);                       /* bumps on any signature chang
 const char* neo_last_error(void);
 int neo_ctx_create(int device, neo_ctx** out);
 int neo_ctx_destroy(neo_ctx* ctx);
-/* Read-and-clear the device-side assertion word (bit0: a ray missed the unit
- * sphere — the reference's AssertionError at models/neo360/helper.py:271,:426).
+/* Read-and-clear the device-side assertion word.  bit0 (NEO_FLAG_SPHERE_MISS): a ray missed the unit
+ * sphere — the reference's AssertionError at models/neo360/helper.py:271,:426.  bit1 (NEO_FLAG_SPLIT_RANGE): an
+ * operand of a split-fp16 kernel left the fp16 range (results of that call invalid; select precision 0).  bit2
+ * (NEO_FLAG_SPLIT_STATIC, always together with bit1): the offending operand is a static one - packed weights or an
+ * uploaded feature map - so every call on this (weights, scene) pair trips again.
  * Synchronises `stream`.  [flags: host out] */
+#define NEO_FLAG_SPHERE_MISS 1u
+#define NEO_FLAG_SPLIT_RANGE 2u
+#define NEO_FLAG_SPLIT_STATIC 4u
 int neo_ctx_poll_flags(neo_ctx* ctx, uint32_t* flags, void* stream);
 /* The same read WITHOUT a synchronisation (what a caller's chunk loop wants: the reference's own loop makes 300
  * forward calls per frame, neo360/model.py:861-907).  post: enqueue on `stream` a copy of the word into a pinned host
@@ -73,8 +79,7 @@ int neo_ctx_stream_waits(neo_ctx* ctx, uint64_t* cross_stream_waits);
  * operand split into hi+lo fp16 and three products per term (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32
  * accumulate) - fp32-class error at a 5.3x higher matrix-pipe ceiling; operands must stay below the fp16
  * range (|x| < 65504: checked, see NEO_FLAG_SPLIT_RANGE).  0 ("f32"): exact fp32 MFMA
- * (v_mfma_f32_32x32x2_f32), no range limit (not available for the PixelNeRF evaluator).  Both meet the
- * 1e-4 parity contract. */
+ * (v_mfma_f32_32x32x2_f32), no range limit.  Both meet the 1e-4 parity contract. */
 int neo_ctx_set_precision(neo_ctx* ctx, int mode);
 
 /* torch.linspace(start, end, steps) for fp32 on the host (symmetric fill,

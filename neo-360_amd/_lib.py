@@ -110,7 +110,10 @@ class NeoError(RuntimeError):
 
 class NeoRangeError(NeoError):
     """The range guard of the split-fp16 arithmetic tripped (device flag bit 1): the results of that call are invalid.
-    render.render_rays_test catches exactly this and re-renders the frame on the exact fp32 kernels."""
+    render.render_rays_test catches exactly this and re-renders the frame on the exact fp32 kernels.
+    `static_operand` (flag bit 2): the operand that left the range is a packed weight or an uploaded feature map, i.e.
+    every frame on the same (weights, scene) pair trips again."""
+    static_operand = False
 
 
 def load():

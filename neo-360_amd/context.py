@@ -111,7 +111,8 @@ class Context:
 
     KERNEL_NAMES = {0: "unspecified", 1: "k_tp_mlp_hp", 2: "k_tp_mlp_hpp", 3: "k_tp_mlp_h", 4: "k_tp_mlp",
                     5: "k_mip_mlp_h<256> (proposal MLP)", 6: "k_mip_mlp_h<1024> (NeRF MLP, fused)",
-                    7: "k_mip_ipe_h + 8 x k_mip_gemm_h + k_mip_mlp_h<tail> (NeRF MLP, layer by layer)", 8: "k_mip_mlp"}
+                    7: "k_mip_ipe_h + 8 x k_mip_gemm_h + k_mip_mlp_h<tail> (NeRF MLP, layer by layer)", 8: "k_mip_mlp",
+                    9: "k_pix_mlp"}
 
     def read_spans(self):
         """Every timed evaluator launch since set_timing(True), in order: [(ms, kernel name, points, algorithmic flops)]."""

@@ -86,10 +86,12 @@ const float* neo_ctx::get_edges(int n, float near, float far, hipStream_t s) {
 }
 
 int neo_ctx::order_begin(hipStream_t s) {
-    if (order_valid && s != order_stream) {
+    // nested scopes (neo_tp_render -> tp_launch, an upload inside a render call): only the OUTERMOST one waits and records
+    if (order_depth == 0 && order_valid && s != order_stream) {
         if (hipStreamWaitEvent(s, order_ev, 0) != hipSuccess) return neo_host::fail(NEO_ERR_HIP, "hipStreamWaitEvent failed");
         order_waits += 1;
     }
+    order_depth += 1;
     return NEO_OK;
 }
 void neo_ctx::order_end(hipStream_t s) {
@@ -97,7 +99,9 @@ void neo_ctx::order_end(hipStream_t s) {
     if (hipEventRecord(order_ev, s) == hipSuccess) { order_stream = s; order_valid = true; }
 }
 
-neo_order_scope::~neo_order_scope() { c->order_end(s); }
+neo_order_scope::~neo_order_scope() {
+    if (--c->order_depth == 0) c->order_end(s);
+}
 
 void neo_ctx::span_begin(hipStream_t s) {
     if (!timing) return;
@@ -402,6 +406,7 @@ int neo_pos_enc(neo_ctx* ctx, const float* x, int n, int C, int min_deg, int max
 int neo_resample(neo_ctx* ctx, const float* t_prev, const float* weights, int R, int n_prev, int n_new,
                  int descending, float* t_out, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(R >= 0 && n_new >= 1, "bad shape");
     REQUIRE(n_prev >= 4 && n_prev <= 257 && n_prev + n_new <= 1024, "unsupported sample counts");
     if (R == 0) return NEO_OK;
@@ -432,6 +437,7 @@ int neo_composite(neo_ctx* ctx, int mode, const float* rgbsigma, const float* t,
 int neo_vanilla_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, const float* const* biases,
                            void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(slot == 0 || slot == 1, "slot must be 0 (coarse) or 1 (fine)");
     REQUIRE(weights && biases, "null pointer table");
     for (int i = 0; i < 12; ++i) REQUIRE(weights[i] && biases[i], "null layer pointer");
@@ -471,6 +477,7 @@ static int vanilla_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const
 int neo_vanilla_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* dirs, const float* t,
                     int t_row_stride, int R, int N, float* out, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1");
     REQUIRE(R >= 0 && N >= 1, "bad shape");
     REQUIRE(t_row_stride == 0 || t_row_stride == N, "t_row_stride must be 0 or N");

@@ -8,6 +8,7 @@ extern "C" {
 
 int neo_enc_upload(neo_ctx* ctx, const float* const* weights, const float* const* biases, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(weights && biases, "null pointer table");
     for (int i = 0; i < 9; ++i) REQUIRE(weights[i] && biases[i], "null layer pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -34,6 +35,7 @@ int neo_enc_floorplans(neo_ctx* ctx, const float* latent, int NV, int Hf, int Wf
                        const float* src_poses, float focal, float cx, float cy, int G0, int G1, int G2, float* fp_yz,
                        float* fp_xz, float* fp_xy, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(latent && src_poses && fp_yz && fp_xz && fp_xy, "null pointer");
     REQUIRE(NV >= 1 && NV <= neo::TP_MAX_VIEWS, "1..8 source views supported");
     REQUIRE(Hf >= 2 && Wf >= 2, "latent must be at least 2x2");

@@ -56,6 +56,7 @@ extern "C" {
 int neo_mip_upload_mlp(neo_ctx* ctx, int slot, int width, int depth, int rgb, const float* const* weights,
                        const float* const* biases, const float* basis, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(slot >= 0 && slot < 3, "slot must be 0..2");
     REQUIRE((width == 256 && depth == 4 && !rgb) || (width == 1024 && depth == 8 && rgb),
             "supported shapes: PropMLP (256, 4, no rgb) and NeRFMLP (1024, 8, rgb)");
@@ -86,6 +87,7 @@ int neo_mip_resample(neo_ctx* ctx, const float* s_prev, const float* w_prev, int
                      float dilation, float anneal, int n, float near, float far, float* sdist, float* tdist,
                      void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(R >= 0 && n_prev >= 1 && n >= 2, "bad shape");
     if (R == 0) return NEO_OK;
     REQUIRE(s_prev && w_prev && sdist && tdist, "null pointer");

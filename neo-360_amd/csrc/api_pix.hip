@@ -29,8 +29,16 @@ int pix_launch(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo::TpView
                float* out, hipStream_t s) {
     MlpSlot& sl = ctx->pix[slot];
     if (!sl.ready) return fail(NEO_ERR_STATE, "PixelNeRF MLP slot %d has no weights", slot);
-    if (ctx->precision != 1)
-        return fail(NEO_ERR_STATE, "the PixelNeRF evaluator exists in the split-fp16 arithmetic only (neo_ctx_set_precision(ctx, 1))");
+    if (ctx->precision != 1) {
+        // exact fp32 MFMA, the reference's operation order up to the folded view layer (mlp_pix.hip): what a range-guard retry
+        // of the split evaluator lands on
+        neo::TpMlpDev mf{sl.wpack.as<float>(), sl.bias_hp.as<float>(), sl.heads.as<float>()};
+        ctx->span_kernel_next = 9;
+        ctx->span_begin(s);
+        neo::launch_pix_mlp(mf, sc, views, rays_o, rays_d, viewdirs, tvals, t_shared, R, N, chunk, out, s);
+        ctx->span_end(s, static_cast<double>(R) * N, pix_flop_per_point(sc.nv));
+        return NEO_OK;
+    }
     guard_split_weights(sl, sl.wpack_h.p, neo::pix_wpack_h_bytes(), ctx->flags, s);
     if (!ctx->pix_latent_checked) {
         neo::launch_f32_range_check(sc.latent, static_cast<size_t>(sc.nv) * sc.Hf * sc.Wf * 512, 65504.0f, ctx->flags, s);
@@ -43,7 +51,7 @@ int pix_launch(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo::TpView
         if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->pix_scene_epoch) {
             const long texels = static_cast<long>(sc.nv) * sc.Hf * sc.Wf;
             if (sl.proj.reserve(static_cast<size_t>(texels) * 512)) return NEO_ERR_NOMEM;
-            neo::launch_tp_preproject(sc.latent, texels, sl.wpack.as<float>(), 64, sl.proj.as<float>(), s, 128);
+            neo::launch_tp_preproject(sc.latent, texels, sl.wpack.as<float>(), neo::pix_kc_x(), sl.proj.as<float>(), s, 128);
             sl.proj_weights = sl.weights_epoch;
             sl.proj_scene = ctx->pix_scene_epoch;
         }
@@ -63,6 +71,7 @@ extern "C" {
 int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, const float* const* biases,
                        void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(slot == 0 || slot == 1, "slot must be 0 (coarse_mlp) or 1 (fine_mlp)");
     REQUIRE(weights && biases, "null pointer table");
     for (int i = 0; i < 9; ++i) REQUIRE(weights[i] && biases[i], "null layer pointer");
@@ -70,11 +79,15 @@ int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, cons
     if (sl.wpack_h.reserve(neo::pix_wpack_h_bytes())) return NEO_ERR_NOMEM;
     if (sl.bias.reserve(neo::pix_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.heads.reserve(neo::pix_heads_floats() * sizeof(float))) return NEO_ERR_NOMEM;
-    if (sl.wpack.reserve(neo::pix_wproj_bytes())) return NEO_ERR_NOMEM;
+    if (sl.wpack.reserve(neo::pix_wpack_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     if (sl.fold_ws.reserve(neo::pix_fold_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    if (sl.bias_hp.reserve(neo::pix_bias_floats() * sizeof(float))) return NEO_ERR_NOMEM;
     neo::launch_pix_pack_h(weights, biases, sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), sl.fold_ws.as<float>(),
                            static_cast<hipStream_t>(stream));
-    neo::launch_pix_pack_proj(weights[0], sl.wpack.as<float>(), static_cast<hipStream_t>(stream));
+    // fp32 fragments of the exact evaluator (mlp_pix.hip); the first 64 k-chunks of its first stage are the latent columns of
+    // pts_linears.0 that k_tp_preproject multiplies the scene latent with (pre-projection of the split evaluator)
+    neo::launch_pix_pack(weights, biases, sl.fold_ws.as<float>(), sl.bias.as<float>(), sl.bias_hp.as<float>(), sl.wpack.as<float>(),
+                         static_cast<hipStream_t>(stream));
     sl.input_ch = 3;
     sl.weights_epoch += 1;
     sl.ready = true;
@@ -84,6 +97,7 @@ int neo_pix_upload_mlp(neo_ctx* ctx, int slot, const float* const* weights, cons
 int neo_pix_set_scene(neo_ctx* ctx, const float* latent, int NV, int Cl, int Hf, int Wf, float image_w,
                       float image_h, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(latent, "null pointer");
     REQUIRE(NV >= 1 && NV <= neo::TP_MAX_VIEWS, "1..8 source views supported");
     REQUIRE(Cl == 512, "the latent width is fixed by the reference MLP (512)");
@@ -119,6 +133,7 @@ int neo_pix_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d
                 const float* tvals, int R, int N, int chunk, const float* src_poses, int NV, float focal, float cx,
                 float cy, float* out, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(slot == 0 || slot == 1, "slot must be 0 or 1");
     REQUIRE(R >= 0 && N >= 1 && chunk >= 1, "bad shape");
     if (R == 0) return NEO_OK;

@@ -137,6 +137,7 @@ extern "C" {
 int neo_tp_upload_mlp(neo_ctx* ctx, int slot, int input_ch, const float* const* weights,
                       const float* const* biases, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(slot >= 0 && slot < 4, "slot must be 0..3 (fg_coarse, fg_fine, bg_coarse, bg_fine)");
     REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (fg) or 4 (bg)");
     REQUIRE(weights && biases, "null pointer table");
@@ -165,6 +166,7 @@ int neo_tp_set_scene(neo_ctx* ctx, const float* plane_xz, const float* plane_xy,
                      int Cw, int Hp, int Wp, const float* latent, int Cl, int Hf, int Wf, float image_w,
                      float image_h, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(plane_xz && plane_xy && plane_yz && latent, "null pointer");
     REQUIRE(NV >= 1 && NV <= neo::TP_MAX_VIEWS, "1..8 source views supported");
     REQUIRE(Cw == 128 && Cl == 512, "feature widths are fixed by the reference MLP (128 world, 512 local)");
@@ -214,6 +216,7 @@ int neo_tp_mlp(neo_ctx* ctx, int slot, const float* rays_o, const float* rays_d,
                const float* tvals, const float* far, int R, int N, int chunk, const float* src_poses, int NV,
                float focal, float cx, float cy, float* out, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(slot >= 0 && slot < 4, "slot must be 0..3");
     REQUIRE(R >= 0 && N >= 1 && chunk >= 1, "bad shape");
     if (R == 0) return NEO_OK;

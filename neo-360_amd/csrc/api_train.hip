@@ -42,6 +42,7 @@ int neo_rand_uniform(neo_ctx* ctx, uint64_t seed, uint32_t stream_id, int rows, 
 int neo_tp_sample_level0(neo_ctx* ctx, const float* far, int R, int n_coarse, const float* u_fg, const float* u_bg,
                          float* fg_t, float* bg_s, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(R >= 0 && n_coarse >= 3 && n_coarse <= 1023, "bad shape");
     if (R == 0) return NEO_OK;
     REQUIRE(far && fg_t && bg_s, "null pointer");
@@ -57,6 +58,7 @@ int neo_tp_sample_level0(neo_ctx* ctx, const float* far, int R, int n_coarse, co
 int neo_resample_u(neo_ctx* ctx, const float* t_prev, const float* weights, const float* u, int R, int n_prev, int n_new,
                    int descending, float* t_out, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(R >= 0 && n_new >= 1, "bad shape");
     REQUIRE(n_prev >= 4 && n_prev <= 257 && n_prev + n_new <= 1024, "unsupported sample counts");
     if (R == 0) return NEO_OK;
@@ -96,6 +98,7 @@ int neo_distloss(neo_ctx* ctx, const float* w, const float* m, int R, int N, flo
 int neo_tp_gather(neo_ctx* ctx, const float* pts, long P, const float* src_poses, int NV, float focal, float cx, float cy,
                   float* world, float* local, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(P >= 0, "negative point count");
     if (P == 0) return NEO_OK;
     REQUIRE(pts && src_poses && world && local, "null pointer");
@@ -113,6 +116,7 @@ int neo_tp_gather_backward(neo_ctx* ctx, const float* pts, long P, const float* 
                            float cy, const float* g_world, const float* g_local, float* g_plane_xz, float* g_plane_xy,
                            float* g_plane_yz, float* g_latent, void* stream) {
     ENTER(ctx);
+    ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(P >= 0, "negative point count");
     if (P == 0) return NEO_OK;
     REQUIRE(pts && src_poses && g_world && g_local && g_plane_xz && g_plane_xy && g_plane_yz && g_latent, "null pointer");

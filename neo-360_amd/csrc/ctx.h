@@ -111,7 +111,10 @@ inline int check_launch() {
 }  // namespace neo_host
 
 // Orders this call behind the previous call of the same context when the stream differs (neo_ctx::order_begin) and
-// records the ordering event when the enclosing scope ends, on every exit path.
+// records the ordering event when the enclosing scope ends, on every exit path.  EVERY entry point that reads or writes
+// context-owned device memory opens one - the evaluators and renders (workspaces, direction table, projected maps) and,
+// since round 5, the uploads / set_scene / gather calls as well (packed weights, folded biases, channels-last maps: a repack
+// on stream B must not overtake a frame still reading the old fragments on stream A).
 struct neo_order_scope {
     neo_ctx* c;
     hipStream_t s;
@@ -177,6 +180,7 @@ struct neo_ctx {
     hipEvent_t order_ev = nullptr;
     bool order_valid = false;
     uint64_t order_waits = 0;                    // cross-stream waits inserted (tests)
+    int order_depth = 0;                         // live ORDERED scopes of the current call (only the outermost waits / records)
     int order_begin(hipStream_t s);
     void order_end(hipStream_t s);
     bool timing = false;

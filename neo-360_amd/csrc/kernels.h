@@ -214,18 +214,24 @@ void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj_all, 
 
 // (train_mlp.hip's launchers are declared in train_kernels.h)
 
-// mlp_pix_h.hip — PixelNeRF baseline decoder evaluator (split-fp16 arithmetic only)
+// mlp_pix_h.hip — PixelNeRF baseline decoder evaluator, split-fp16 arithmetic (the default)
 size_t pix_wpack_h_bytes();
 size_t pix_bias_floats();
 size_t pix_heads_floats();
 size_t pix_fold_floats();        // scratch of launch_pix_pack_h (the folded view-layer-0 matrix)
 void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack_h, float* bias, float* heads,
                        float* fold_ws, hipStream_t s);
-size_t pix_wproj_bytes();        // fp32 MFMA fragments of pts_linears.0's latent columns (pre-projection, mlp_pix_h.hip)
-void launch_pix_pack_proj(const float* w0, float* wproj, hipStream_t s);
 void launch_pix_mlp_h(const TpMlpHDev& m, const float* proj /* null: gather the latent itself */, const TpScene& sc, const TpViews& views, const float* rays_o,
                       const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N,
                       int chunk, float* out, hipStream_t s);
+
+// mlp_pix.hip — the same decoder in EXACT fp32 MFMA arithmetic, latent gathered as the reference gathers it (round 5)
+size_t pix_wpack_floats();
+int pix_kc_x();                  // k-chunks per N-tile of its first stage (the first 64 = the latent columns k_tp_preproject reads)
+void launch_pix_pack(const float* const* w, const float* const* b, float* fold_v0, const float* bias_src, float* bias_f32,
+                     float* wpack, hipStream_t s);
+void launch_pix_mlp(const TpMlpDev& m, const TpScene& sc, const TpViews& views, const float* rays_o, const float* rays_d,
+                    const float* viewdirs, const float* tvals, int t_shared, int R, int N, int chunk, float* out, hipStream_t s);
 
 // pillar.hip — pillar stage of the scene encoder
 struct PillarGeom {

@@ -522,14 +522,6 @@ void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack
     cp(w[7], 128, heads + HD_DW); cp(b[7], 1, heads + HD_DB); cp(w[8], 384, heads + HD_RW); cp(b[8], 3, heads + HD_RB);
 }
 
-size_t pix_wproj_bytes() { return (size_t)4 * 64 * 64 * 16; }        // 4 N-tiles x 64 k-chunks of 8 x 64 lanes x 4 floats
-
-void launch_pix_pack_proj(const float* w0, float* wproj, hipStream_t s) {
-    // fp32 MFMA fragments (mlp_tp.hip:pack_block order) of pts_linears.0[:, 63:575]: the latent columns of the 575-wide input
-    const PackSegs latent = {{0, 0, 0}, {512, 0, 0}, {63, 0, 0}};
-    pack_block(w0, 575, 128, 64, 0, latent, wproj, s);
-}
-
 void launch_pix_mlp_h(const TpMlpHDev& m, const float* proj, const TpScene& sc, const TpViews& views, const float* rays_o,
                       const float* rays_d, const float* viewdirs, const float* tvals, int t_shared, int R, int N,
                       int chunk, float* out, hipStream_t s) {

@@ -868,11 +868,15 @@ void launch_tp_mlp_hpp(int input_ch, const TpMlpHDev& m, const float* proj_all, 
     const float* proj = proj_all;
     const TpPlaneBase pp{{(int)plane_base_texels[0], (int)plane_base_texels[1], (int)plane_base_texels[2]}};
     const size_t lds = (size_t)PP_LDS_WORDS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device AND per function: a process may hold contexts on several GPUs, so it is cached per device
+    // (not in a process-wide flag); the device is current here (ENTER's DeviceGuard)
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hpp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hpp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const long tiles = tp::xcd_grid((P + TM - 1) / TM);
     if (input_ch == 3)

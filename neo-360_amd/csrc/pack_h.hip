@@ -45,12 +45,14 @@ __global__ void k_pack_block_h_perm(const float* __restrict__ src, int ld, int r
     }
 }
 
-// any fp16 inf / NaN (exponent all ones) among n halves -> flags |= FLAG_SPLIT_RANGE
+// any fp16 inf / NaN (exponent all ones) among n halves -> flags |= FLAG_SPLIT_RANGE | FLAG_SPLIT_STATIC (bit 2: the operand that
+// left the range is a STATIC one - packed weights or an uploaded feature map -, so every frame on this (weights, scene) pair will
+// trip again: render.render_rays_test latches the module to the exact kernels until either changes)
 __global__ void k_half_range_check(const uint16_t* __restrict__ h, size_t n, uint32_t* __restrict__ flags) {
     bool bad = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         bad |= (h[i] & 0x7c00u) == 0x7c00u;
-    if (bad) atomicOr(flags, FLAG_SPLIT_RANGE);
+    if (bad) atomicOr(flags, FLAG_SPLIT_RANGE | FLAG_SPLIT_STATIC);
 }
 
 __global__ void k_f32_range_check(const float* __restrict__ x, size_t n4, size_t n, float limit, uint32_t* __restrict__ flags) {
@@ -61,7 +63,7 @@ __global__ void k_f32_range_check(const float* __restrict__ x, size_t n4, size_t
         bad = bad || !(fabsf(v[0]) < limit) || !(fabsf(v[1]) < limit) || !(fabsf(v[2]) < limit) || !(fabsf(v[3]) < limit);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(fabsf(x[n4 * 4 + threadIdx.x]) < limit);
-    if (bad) atomicOr(flags, FLAG_SPLIT_RANGE);
+    if (bad) atomicOr(flags, FLAG_SPLIT_RANGE | FLAG_SPLIT_STATIC);
 }
 
 // Bottleneck folded into the layer that consumes it (tp_hp_layout.h NEO_TP_FOLDB; the same algebra for the vanilla NeRFMLP,

@@ -47,7 +47,7 @@ __device__ __forceinline__ void split(float x, _Float16& hi, _Float16& lo) {
 // a per-thread running max (v_max3_f32 with |.| modifiers: half an instruction per element), and a thread that saw
 // |x| >= 65504 (or inf / NaN accumulators) raises NEO_FLAG_SPLIT_RANGE once, at the end of the kernel.  Weights
 // are checked when they are packed, feature maps when they are uploaded (api*.hip).
-constexpr uint32_t FLAG_SPHERE_MISS = 1u, FLAG_SPLIT_RANGE = 2u;
+constexpr uint32_t FLAG_SPHERE_MISS = 1u, FLAG_SPLIT_RANGE = 2u, FLAG_SPLIT_STATIC = 4u;
 constexpr float SPLIT_LIMIT = 65504.0f;
 __device__ __forceinline__ void range_see4(const LaneCtx& L, const f32x4 v) {
     L.amax = fmaxf(fmaxf(L.amax, fabsf(v[0])), fabsf(v[1]));

@@ -172,7 +172,7 @@ class _HipModule(nn.Module):
                 if flags:
                     warnings.warn("%s.close(): unread device assertions of earlier calls (flags=%d: %s); results of those "
                                   "calls were invalid - call check_flags() before consuming outputs"
-                                  % (type(self).__name__, flags, " + ".join(
+                                  % (type(self).__name__, flags & 3, " + ".join(
                                       n for b, n in ((1, "ray missed the unit sphere"), (2, "split-fp16 range guard")) if flags & b)),
                                   RuntimeWarning, stacklevel=2)
             ctx.close()
@@ -186,15 +186,45 @@ class _HipModule(nn.Module):
         if flags & 1:
             raise AssertionError("1.0 - p_norm_sq should be greater than 0" + where)
         if flags & 2:
-            raise _lib.NeoRangeError(
+            err = _lib.NeoRangeError(
                 "split-fp16 arithmetic (precision 'f16x3') met an operand outside the fp16 range (|x| >= 65504 or "
-                "non-finite weights / features / activations): results of that call are invalid; use precision 'f32'" + where)
+                "non-finite %s): results of that call are invalid; use precision 'f32'"
+                % ("weights / feature maps" if flags & 4 else "activations / gathered features") + where)
+            err.static_operand = bool(flags & 4)
+            raise err
 
     @staticmethod
     def _check_mode(randomized):
         if randomized:
             raise NotImplementedError(
                 "randomized=True (stratified jitter / training) is outside the accelerated inference path")
+
+    # Which path a training-shaped call takes (NeRF.forward, NeRF_TP.forward(out_depth=False)):
+    #   None (default)  automatic: the differentiable operator chain of training.py when autograd is on and anything that
+    #                   could receive a gradient requires one - a parameter of this module (incl. an attached encoder's) or
+    #                   a scene tensor given to set_scene; otherwise the fused no-grad kernels;
+    #   True / False    always / never the operator chain, whatever autograd says.
+    # The operator chain materialises per-point-view feature rows and an activation tape, re-runs an attached encoder per
+    # call and synchronises once per call: a forward-only caller outside torch.no_grad() with default nn.Module parameters
+    # (requires_grad=True) takes it unless it says `module.differentiable = False` (or wraps the call in no_grad).
+    differentiable = None
+
+    def _scene_tensors_for_grad(self):
+        return ()
+
+    def operands_key(self):
+        """Identity of the STATIC operands of the split arithmetic: every parameter (address + version) and the uploaded
+        scene.  render.render_rays_test latches a module whose weights / feature maps tripped the range guard to the exact
+        kernels for as long as this key stays the same."""
+        return (tuple((p.data_ptr(), p._version) for p in self.parameters()), getattr(self, "_scene_serial", 0))
+
+    def _wants_grad(self):
+        if self.differentiable is not None:
+            return bool(self.differentiable)
+        if not torch.is_grad_enabled():
+            return False
+        return (any(p.requires_grad for p in self.parameters())
+                or any(t is not None and t.requires_grad for t in self._scene_tensors_for_grad()))
 
 
 class NeRF(_HipModule):
@@ -223,10 +253,19 @@ class NeRF(_HipModule):
             _lib.check(ctx.lib.neo_vanilla_upload_mlp(ctx.handle, slot, _ptr_table(ws), _ptr_table(bs), ctx.stream()))
             ctx.uploaded[("vanilla", slot)] = fp
 
-    @torch.no_grad()
-    def forward(self, rays, randomized, white_bkgd, near, far):
-        """Returns [(rgb (B,3), acc (B,), depth (B,))] * 2, as the reference."""
-        self._check_mode(randomized)
+    def forward(self, rays, randomized, white_bkgd, near, far, seed=None):
+        """Returns [(rgb (B,3), acc (B,), depth (B,))] * 2, as the reference.  randomized=True (stratified samples, random
+        quantiles, `noise_std`) or a call that wants gradients (`_wants_grad`: the reference's training_step,
+        vanilla_nerf/model.py:281-283) runs on the differentiable operators of training.py (nerf_render_train: NeRFMLP
+        with a native backward, samplers on the counter-based generator, compositing with a native backward);
+        the deterministic no-grad call is ONE fused library call."""
+        if randomized or self._wants_grad():
+            from . import training
+            return training.nerf_render_train(self, rays, randomized, white_bkgd, near, far, seed)
+        with torch.no_grad():
+            return self._forward_fused(rays, white_bkgd, near, far)
+
+    def _forward_fused(self, rays, white_bkgd, near, far):
         rays_o = f32(rays["rays_o"], "rays_o")
         viewdirs = f32(rays["viewdirs"], "viewdirs")
         rays_d = f32(rays["rays_d"], "rays_d")
@@ -381,6 +420,7 @@ class NeRF_TP(_HipModule):
                                             ctx.stream()))
         torch.cuda.current_stream(latent.device).synchronize()   # inputs may be freed by the caller
         self._scene_ctx = ctx
+        self._scene_serial = getattr(self, "_scene_serial", 0) + 1
         self._scene_wh = (float(image_wh[0]), float(image_wh[1]))
         # identity (weak references, compared with `is`) + versions: a (data_ptr, version, shape) fingerprint alone
         # matches a NEW tensor the caching allocator placed at a freed map's address (a training loop's fresh encoder
@@ -464,7 +504,7 @@ class NeRF_TP(_HipModule):
         level-1 quantiles from the library's counter-based generator (`seed`, default: one fresh seed per call from
         torch's CPU generator, so torch.manual_seed makes runs repeatable)."""
         if self.density_noise != 0.0 and randomized:
-            raise NotImplementedError("density_noise (neo360/model.py:381-384) is not part of the accelerated path")
+            raise _lib.NeoError("density_noise is applied by the operator chain (training.tp_render_train), not by the fused call")
         rays_o, rays_d, viewdirs = f32(rays["rays_o"], "rays_o"), f32(rays["rays_d"], "rays_d"), f32(rays["viewdirs"], "viewdirs")
         dev = rays_o.device
         ctx = self._context(dev)
@@ -519,8 +559,9 @@ class NeRF_TP(_HipModule):
                                 "tensors passed to set_scene(...) alive (the module holds only weak references to them)")
         return maps
 
-    def _wants_grad(self):
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+    def _scene_tensors_for_grad(self):
+        held = getattr(self, "_scene_src", None)
+        return tuple(r() for r in held[0]) if held is not None else ()
 
     def forward(self, rays, randomized, white_bkgd, near, far, out_depth=False, chunk=None, seed=None):
         """out_depth=True (evaluation, neo360/model.py:521-527): per level (comp_rgb, fg_rgb, bg_rgb, fg_acc, bg_lambda,
@@ -528,11 +569,13 @@ class NeRF_TP(_HipModule):
         bg_weights, fg_sdist, bg_sdist, bg_acc), randomized as asked.  `near`/`far` are ignored
         exactly as in the reference (:277-278).  All rays of the call form ONE reference chunk unless `chunk` is given
         (whole-frame rendering, see render.py).
-        The training call is DIFFERENTIABLE when autograd is on and a parameter requires grad (the reference's
-        training_step, model.py:697-820): it then runs on the operators of training.py (lookups, NeRFPPMLP with a native
-        backward, compositing) instead of the fused no-grad kernels; same return tuple, same samples for one seed."""
+        The training call is DIFFERENTIABLE when `_wants_grad()` says so (`self.differentiable`; default: autograd on and a
+        parameter, an attached encoder's parameter or a set_scene tensor requires grad - the reference's training_step,
+        model.py:697-820): it then runs on the operators of training.py (lookups, NeRFPPMLP with a native backward,
+        compositing) instead of the fused no-grad kernels; same return tuple, same samples for one seed at any `chunk`."""
         if not out_depth:
-            if self._wants_grad():
+            # density_noise (model.py:381-384) exists on the operator chain only: a randomized call with it takes that path
+            if self._wants_grad() or (randomized and self.density_noise != 0.0):
                 from . import training
                 return training.tp_render_train(self, rays, randomized, white_bkgd, self._maps_for_grad(rays), chunk, seed)
             with torch.no_grad():
@@ -628,8 +671,6 @@ class PixelNeRF(_HipModule):
 
     def _context(self, device):
         ctx = super()._context(device)
-        if getattr(ctx, "_precision", None) != "f16x3":
-            raise _lib.NeoError("the PixelNeRF evaluator exists in the split-fp16 arithmetic only (precision 'f16x3')")
         if getattr(ctx, "_pix_preproject", None) != bool(self.preproject):
             _lib.check(ctx.lib.neo_pix_set_preproject(ctx.handle, int(bool(self.preproject))))
             ctx._pix_preproject = bool(self.preproject)
@@ -657,6 +698,7 @@ class PixelNeRF(_HipModule):
                                              float(image_wh[1]), ctx.stream()))
         torch.cuda.current_stream(latent.device).synchronize()   # the caller may free its tensor
         self._scene_ctx = ctx
+        self._scene_serial = getattr(self, "_scene_serial", 0) + 1
 
     def _ensure_scene(self, rays):
         enc = getattr(self, "encoder", None)

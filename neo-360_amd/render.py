@@ -46,7 +46,16 @@ def _render_once(model, batch, chunk, white_bkgd, near, far, train_frac):
     raise TypeError("unsupported renderer %r" % type(model))
 
 
-_warned_downgrade = set()
+def _render_exact(model, batch, chunk, white_bkgd, near, far, train_frac):
+    prev = model.precision
+    model.precision = "f32"
+    try:
+        out = _render_once(model, batch, chunk, white_bkgd, near, far, train_frac)
+        model.check_flags()
+    finally:
+        model.precision = prev
+    out["precision_used"] = "f32"
+    return out
 
 
 @torch.no_grad()
@@ -61,31 +70,43 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
     on_range: what happens when the range guard of the split-fp16 arithmetic trips for this frame (an operand beyond the
     fp16 range: a trained checkpoint or an un-normalised encoder; the reference is plain fp32 and never fails,
     neo360/model.py:343-407).  "retry_f32" (default): the frame is rendered again on the exact fp32-MFMA kernels of the
-    same library - bitwise the frame `model.precision = "f32"` returns - and a RuntimeWarning says so once per module;
-    "raise": the NeoRangeError goes to the caller.  Needs check=True (the guard is read when the frame is complete)."""
+    same library - bitwise the frame `model.precision = "f32"` returns - and a RuntimeWarning says so once per module
+    (the flag lives ON the module); "raise": the NeoRangeError goes to the caller.  Needs check=True (the guard is read when
+    the frame is complete).  When the operand that left the range is a STATIC one (packed weights, an uploaded feature map:
+    `NeoRangeError.static_operand`) every later frame would trip again, so the module is LATCHED: until its parameters or
+    its scene change (`model.operands_key()`), frames go straight to the exact kernels - one render per frame, not a failed
+    split attempt plus a retry.  A trip on activations is per frame and is not latched.  `out["precision_used"] = "f32"`
+    marks such frames; `model.last_precision_used` holds the arithmetic of the last frame either way."""
     if on_range not in ("retry_f32", "raise"):
         raise ValueError("on_range must be 'retry_f32' or 'raise', got %r" % (on_range,))
+    latch = getattr(model, "_range_latch", None)
+    if latch is not None and on_range == "retry_f32" and check and (model.precision or model.default_precision) != "f32":
+        if latch == model.operands_key():
+            out = _render_exact(model, batch, chunk, white_bkgd, near, far, train_frac)
+            model.last_precision_used = "f32"
+            for k in ("target", "instance_mask"):
+                if k in batch:
+                    out[k] = batch[k]
+            return out
+        model._range_latch = None          # weights or scene changed: the split arithmetic gets another chance
     out = _render_once(model, batch, chunk, white_bkgd, near, far, train_frac)
+    model.last_precision_used = model.precision or model.default_precision
     if check:
         try:
             model.check_flags()      # the deferred reads of the assertion word: raise before the frame is handed out
-        except _lib.NeoRangeError:
-            if on_range != "retry_f32" or isinstance(model, models.PixelNeRF):     # PixelNeRF has no exact-fp32 evaluator
+        except _lib.NeoRangeError as err:
+            if on_range != "retry_f32":
                 raise
-            if id(model) not in _warned_downgrade:
-                _warned_downgrade.add(id(model))
+            if not getattr(model, "_warned_range_downgrade", False):
+                model._warned_range_downgrade = True
                 warnings.warn("%s: an operand left the fp16 range of the split arithmetic (precision 'f16x3'); this frame "
                               "(and any later one that trips the guard) is re-rendered on the exact fp32 kernels "
-                              "(~6x slower). Set model.precision = 'f32' to skip the failed attempt."
+                              "(~3-6x slower). Set model.precision = 'f32' to skip the failed attempt."
                               % type(model).__name__, RuntimeWarning, stacklevel=2)
-            prev = model.precision
-            model.precision = "f32"
-            try:
-                out = _render_once(model, batch, chunk, white_bkgd, near, far, train_frac)
-                model.check_flags()
-            finally:
-                model.precision = prev
-            out["precision_used"] = "f32"
+            if getattr(err, "static_operand", False):
+                model._range_latch = model.operands_key()
+            out = _render_exact(model, batch, chunk, white_bkgd, near, far, train_frac)
+            model.last_precision_used = "f32"
     for k in ("target", "instance_mask"):
         if k in batch:
             out[k] = batch[k]
@@ -94,14 +115,19 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
 
 @torch.no_grad()
 def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False, near=0.2, far=3.0, group=None,
-                         gather=True, train_frac=1.0, n_rays=None, out=None, reuse=False, check=True, always_gather=False):
+                         gather=True, train_frac=1.0, n_rays=None, out=None, reuse=False, check=True, always_gather=False,
+                         info=None):
     """This rank renders its contiguous range of whole chunks; `gather=True` reassembles
     the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather.
     `batch` holds the whole frame's rays, or - with n_rays = R given - only this rank's shard
     (rays [shard_bounds(R, world, rank)), e.g. from ops.get_ray_directions_and_rays(ray_range=...)).
     The gathered frame is a fresh tensor unless `out=` / `reuse=True` are given (parallel.gather_tiles).
     always_gather: run the collective at world == 1 too (a one-rank process group: the RCCL call path of the N-GPU job
-    on a one-GPU box; bench.py under `torchrun --nproc-per-node 1`)."""
+    on a one-GPU box; bench.py under `torchrun --nproc-per-node 1`).
+    info: an optional dict that receives `precision_used` = the arithmetic THIS rank's shard was rendered in ("f16x3" /
+    "f32": a range-guard retry, see render_rays_test) and, when the frame is gathered over more than one rank,
+    `precision_by_rank` (one extra 4-byte all-gather, only when `info` is given): a frame whose ranks mixed arithmetics
+    says so instead of hiding it in the gathered tile."""
     if n_rays is None:
         R = batch["rays_o"].shape[0]
         lo, hi = shard_bounds(R, world, rank, unit=chunk)
@@ -113,8 +139,17 @@ def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False
         mine = batch
     part = render_rays_test(model, mine, chunk, white_bkgd, near, far, train_frac, check=check)
     tile = torch.cat([part["rgb"], part["depth"][:, None], part["acc"][:, None]], dim=1)
+    used = part.get("precision_used") or getattr(model, "last_precision_used", None) or model.precision or model.default_precision
+    if info is not None:
+        info["precision_used"] = used
     if not gather or (world == 1 and not always_gather):
         return tile
+    if info is not None and world > 1:
+        import torch.distributed as dist
+        mine_p = torch.tensor([1 if used == "f32" else 0], dtype=torch.int32, device=tile.device)
+        every = torch.empty(world, dtype=torch.int32, device=tile.device)
+        dist.all_gather_into_tensor(every, mine_p, group=group)
+        info["precision_by_rank"] = ["f32" if int(x) else "f16x3" for x in every.tolist()]
     return gather_tiles(tile, R, world, unit=chunk, group=group, out=out, reuse=reuse)
 
 

@@ -334,6 +334,24 @@ def _outside_points(o, d, inv_r):
     return torch.cat((turned, inv_r.unsqueeze(-1)), dim=-1)
 
 
+def _draws(module, B, randomized, seed, c, n0, n1, noise):
+    """Every uniform a randomized call consumes, for ALL B rows of the call, from the library's counter-based generator:
+    stream ids 0 / 1 level-0 jitter inside / outside the sphere, 2 / 3 level-1 quantiles, 4..7 the density noise
+    (neo360/model.py:381-384: torch.rand_like(raw_sigma) * density_noise) of (level, region).  Row r of every table belongs
+    to ray r of the call whatever the chunking, which is what the fused neo_tp_render_train draws (rows 0..R-1 from one seed)."""
+    if not randomized:
+        return None, 0
+    seed = int(seed) if seed is not None else int(torch.randint(1, 2 ** 62, (1,)).item())
+    seed = seed or 1
+    d = dict(u_fg=rand_uniform(seed, 0, B, n0 + 1, ctx=c), u_bg=rand_uniform(seed, 1, B, n0 + 1, ctx=c),
+             q_fg=rand_uniform(seed, 2, B, n1, ctx=c), q_bg=rand_uniform(seed, 3, B, n1, ctx=c))
+    if noise:
+        for level, n in ((0, n0 + 1), (1, n0 + 1 + n1)):
+            d["n_fg%d" % level] = rand_uniform(seed, 4 + 2 * level, B, n, ctx=c)
+            d["n_bg%d" % level] = rand_uniform(seed, 5 + 2 * level, B, n, ctx=c)
+    return d, seed
+
+
 def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed=None):
     """NeRF_TP.forward(out_depth=False) WITH autograd: per level (comp_rgb, fg_weights, bg_weights, fg_sdist, bg_sdist,
     bg_acc) exactly as the fused call returns them (neo360/model.py:531-579), built from the differentiable operators of
@@ -343,20 +361,32 @@ def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed
     (helper.py:224) - so the reference's training_step (model.py:697-820: rgb loss on both levels + eff_distloss on the
     weights) runs unchanged on `loss.backward()`.  maps = (plane_xz, plane_xy, plane_yz, latent) NCHW tensors (the
     encoder's outputs, or the tensors given to set_scene).  randomized draws come from the library's counter-based
-    generator with the stream ids of the fused call (0 / 1 level-0 jitter fg / bg, 2 / 3 level-1 quantiles), so both
-    paths see the same samples for one seed.  All rays form ONE reference chunk unless `chunk` is given."""
+    generator with the stream ids of the fused call (0 / 1 level-0 jitter fg / bg, 2 / 3 level-1 quantiles), ONE table per
+    stream for all rays of the call, sliced per chunk: both paths see the same samples for one seed at any `chunk`
+    (round 5; the first version re-seeded every chunk).  `module.density_noise` (model.py:381-384, uniform noise on the raw
+    density when randomized) is drawn from streams 4..7.  All rays form ONE reference chunk unless `chunk` is given."""
+    rays_o = f32(rays["rays_o"], "rays_o")
+    B = rays_o.shape[0]
+    c = module._context(rays_o.device)
+    n0, n1 = module.num_coarse_samples, module.num_fine_samples
+    with torch.no_grad():
+        draws, _ = _draws(module, B, randomized, seed, c, n0, n1, module.density_noise != 0.0)
+    step = int(chunk) if chunk is not None and int(chunk) < B else B
+    parts = []
+    for i in range(0, B, max(step, 1)):
+        sub = {k: (v[i:i + step] if k in ("rays_o", "rays_d", "viewdirs") else v) for k, v in rays.items()}
+        rows = {k: v[i:i + step] for k, v in draws.items()} if draws is not None else None
+        parts.append(_tp_render_train_chunk(module, sub, randomized, white_bkgd, maps, rows))
+    if len(parts) == 1:
+        return parts[0]
+    return [tuple(torch.cat([p[lv][j] for p in parts], dim=0) for j in range(6)) for lv in range(2)]
+
+
+def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws):
+    """One reference chunk of tp_render_train; `draws` = this chunk's rows of the call's uniform tables (None: deterministic)."""
     from . import ops
     rays_o, rays_d, viewdirs = f32(rays["rays_o"], "rays_o"), f32(rays["rays_d"], "rays_d"), f32(rays["viewdirs"], "viewdirs")
     B = rays_o.shape[0]
-    if chunk is not None and int(chunk) < B:
-        parts = []
-        for i in range(0, B, int(chunk)):
-            sub = {k: (v[i:i + int(chunk)] if k in ("rays_o", "rays_d", "viewdirs") else v) for k, v in rays.items()}
-            parts.append(tp_render_train(module, sub, randomized, white_bkgd, maps, None,
-                                         None if seed is None else int(seed) + i))
-        return [tuple(torch.cat([p[lv][j] for p in parts], dim=0) for j in range(6)) for lv in range(2)]
-    if module.density_noise != 0.0 and randomized:
-        raise NotImplementedError("density_noise (neo360/model.py:381-384) is not part of the accelerated path")
     dev = rays_o.device
     c = module._context(dev)
     poses = f32(rays["src_poses"], "src_poses")
@@ -364,12 +394,7 @@ def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed
     n0, n1 = module.num_coarse_samples, module.num_fine_samples
     with torch.no_grad():
         far, _ = ops.intersect_sphere(rays_o, rays_d, ctx=c)                                   # model.py:278
-        if randomized:
-            seed = int(seed) if seed is not None else int(torch.randint(1, 2 ** 62, (1,)).item())
-            seed = seed or 1
-            u_fg, u_bg = rand_uniform(seed, 0, B, n0 + 1, ctx=c), rand_uniform(seed, 1, B, n0 + 1, ctx=c)
-        else:
-            u_fg = u_bg = None
+        u_fg, u_bg = (draws["u_fg"], draws["u_bg"]) if draws is not None else (None, None)
         fg_t, bg_s = sample_level0(far, n0, u_fg, u_bg, ctx=c)
         rot = poses[:, :3, :3].transpose(1, 2)
         dir_cam = torch.matmul(rot[:, None], viewdirs[None, :, :, None])[..., 0]              # (NV,B,3): model.py:339-341
@@ -391,6 +416,8 @@ def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed
         for name, mlp, look, x_enc in (("fg", mlps[level], fg_p, fg_x), ("bg", mlps[2 + level], bg_lin, bg_x)):
             world, local = gather_features(module, look.reshape(-1, 3), maps[0], maps[1], maps[2], maps[3], rays)
             raw_rgb, raw_sigma = nerfpp_mlp(mlp, x_enc, cond, world, local, NV, ctx=c)
+            if draws is not None and module.density_noise != 0.0:                                # model.py:381-384
+                raw_sigma = raw_sigma + draws["n_%s%d" % (name, level)].reshape(raw_sigma.shape) * module.density_noise
             rgb = (torch.sigmoid(raw_rgb) * (1.0 + 2.0 * 0.001) - 0.001).reshape(B, N, 3)     # model.py:383-385
             sigma = torch.nn.functional.softplus(raw_sigma + (-1.0)).reshape(B, N, 1)          # model.py:380-381
             res[name] = (rgb, sigma)
@@ -403,12 +430,70 @@ def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed
         out.append((rgb, fg_w, bg_w, fg_sd, bg_sd, bg_acc))
         if level == 0:
             with torch.no_grad():
-                if randomized:
-                    fg_t = resample_u(fg_t, fg_w, rand_uniform(seed, 2, B, n1, ctx=c), False, ctx=c)
-                    bg_s = resample_u(bg_s, bg_w, rand_uniform(seed, 3, B, n1, ctx=c), True, ctx=c)
+                if draws is not None:
+                    fg_t = resample_u(fg_t, fg_w, draws["q_fg"], False, ctx=c)
+                    bg_s = resample_u(bg_s, bg_w, draws["q_bg"], True, ctx=c)
                 else:
                     fg_t = ops.resample(fg_t, fg_w.detach(), n1, False, ctx=c)
                     bg_s = ops.resample(bg_s, bg_w.detach(), n1, True, ctx=c)
     flags = c.poll_flags()
     module._raise_flags(flags)
     return out
+
+
+# ---- the vanilla renderer's training call (vanilla_nerf/model.py:281-283 calls self.model(batch, randomized=True, ...)) ---------
+
+def nerf_render_train(module, rays, randomized, white_bkgd, near, far, seed=None, return_samples=False):
+    """models.NeRF.forward WITH autograd / stratified sampling (vanilla_nerf/model.py:154-216 under training_step :255-300):
+    per level (comp_rgb (B,3), acc (B,), depth (B,)).  Chained from the operators of this file: level-0 samples along
+    `viewdirs` between the scalar near / far (helper.py:415-442; randomized = one uniform per sample inside its stratum), 63-d
+    encodings (neo_pos_enc), the vanilla NeRFMLP with its native backward (nerf_mlp: gradients reach all 24 parameter tensors of
+    each MLP), `noise_std` (model.py:194-195: uniform noise on the raw density when randomized), the reference's activations,
+    compositing with `rays_d` norms (composite mode 0), inverse-CDF resampling on detached weights (helper.py:610-616).
+    Uniforms: the library's counter-based generator, stream 0 = level-0 jitter, 2 = level-1 quantiles, 4 / 6 = density noise of
+    level 0 / 1 (torch.manual_seed makes the default seed repeatable).  return_samples: also return [t0 (B,n0+1), t1 (B,n0+1+n1)],
+    the sample positions of the two levels (tests evaluate the oracle at them)."""
+    from . import ops
+    rays_o, rays_d, viewdirs = f32(rays["rays_o"], "rays_o"), f32(rays["rays_d"], "rays_d"), f32(rays["viewdirs"], "viewdirs")
+    B = rays_o.shape[0]
+    dev = rays_o.device
+    c = module._context(dev)
+    n0, n1 = module.num_coarse_samples, module.num_fine_samples
+    noise = float(module.noise_std) if randomized else 0.0
+    used = []
+    with torch.no_grad():
+        if randomized:
+            seed = int(seed) if seed is not None else int(torch.randint(1, 2 ** 62, (1,)).item())
+            seed = seed or 1
+        # helper.py:424-429: linspace(0,1,n+1) -> near (1 - t) + far t, fp32 (the CPU linspace the library's tables use)
+        lin = torch.linspace(0.0, 1.0, n0 + 1).to(dev)
+        edges = float(near) * (1.0 - lin) + float(far) * lin
+        if randomized:                                                                          # helper.py:431-436
+            mids = 0.5 * (edges[1:] + edges[:-1])
+            upper, lower = torch.cat([mids, edges[-1:]]), torch.cat([edges[:1], mids])
+            t = lower + (upper - lower) * rand_uniform(seed, 0, B, n0 + 1, ctx=c)
+        else:
+            t = edges[None, :].expand(B, n0 + 1).contiguous()
+        d_enc = ops.pos_enc(viewdirs, 0, module.deg_view, ctx=c)                                # (B,27), model.py:190
+    out = []
+    for level, mlp in enumerate((module.coarse_mlp, module.fine_mlp)):
+        N = t.shape[1]
+        used.append(t)
+        with torch.no_grad():
+            pts = rays_o[:, None, :] + t[..., None] * viewdirs[:, None, :]                      # cast_rays along viewdirs (:161, :177)
+            x_enc = ops.pos_enc(pts, module.min_deg_point, module.max_deg_point, ctx=c)         # (B,N,63)
+        raw_rgb, raw_sigma = nerf_mlp(mlp, x_enc, d_enc, ctx=c)
+        if noise > 0.0:                                                                         # model.py:194-195
+            raw_sigma = raw_sigma + rand_uniform(seed, 4 + 2 * level, B, N, ctx=c).reshape(raw_sigma.shape) * noise
+        rgb = torch.sigmoid(raw_rgb) * (1.0 + 2.0 * 0.001) - 0.001                              # model.py:200-202
+        sigma = torch.nn.functional.softplus(raw_sigma + (-1.0))                                # model.py:204-205
+        comp_rgb, acc, w, _, depth = composite(0, rgb.reshape(B, N, 3), sigma.reshape(B, N, 1), t, rays_d, None, white_bkgd, ctx=c)
+        out.append((comp_rgb, acc, depth))
+        if level == 0:
+            with torch.no_grad():                                                               # helper.py:610-616 (detached)
+                if randomized:
+                    t = resample_u(t, w, rand_uniform(seed, 2, B, n1, ctx=c), False, ctx=c)
+                else:
+                    t = ops.resample(t, w.detach(), n1, False, ctx=c)
+    module._raise_flags(c.poll_flags())
+    return (out, used) if return_samples else out

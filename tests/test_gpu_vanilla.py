@@ -76,9 +76,12 @@ def test_single_ray_and_empty():
     assert res[1][0].shape == (0, 3)
 
 
-def test_randomized_is_refused():
-    with pytest.raises(NotImplementedError):
-        _net()(_to(cases.strided_rays(4)), True, False, 0.2, 3.0)
+def test_randomized_call_runs():
+    """randomized=True is the training call (vanilla_nerf/model.py:281-283): since round 5 it runs on the operators of
+    training.py (tests/test_gpu_host_r5.py checks values and gradients); same return structure as the fused call."""
+    res = _net()(_to(cases.strided_rays(4)), True, False, 0.2, 3.0, seed=3)
+    assert len(res) == 2 and res[1][0].shape == (4, 3) and res[1][1].shape == (4,) and res[1][2].shape == (4,)
+    assert bool(torch.isfinite(res[1][0]).all())
 
 
 def test_weights_reupload_on_change(golden):
