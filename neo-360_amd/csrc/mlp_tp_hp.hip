@@ -56,6 +56,12 @@
 #ifndef NEO_TP_DPF
 #define NEO_TP_DPF 1          // 1: a gather item's tap offsets / weights are read from LDS ONE ITEM AHEAD of their use (the ISA of the plain form waits out a full LDS round trip twice per item: ds_read offsets -> s_waitcnt -> 4 loads, ds_read weights -> s_waitcnt -> blend)
 #endif
+#ifndef NEO_TP_PLANE_FMA
+#define NEO_TP_PLANE_FMA 1    // 1 (round 5): the blends of a row group's three tri-planes are chained through the running sum (fma onto the sum) instead of blend + add
+#endif
+#ifndef NEO_TP_BIAS2
+#define NEO_TP_BIAS2 1        // 1 (round 5): the second M-tile's accumulators are initialised by a second LDS read of the biases instead of 16 register copies
+#endif
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
 // tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
@@ -210,9 +216,18 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
         f32x16 accx[2][2];
         bias_tile(accx[0][0], lbias + B_0, L.wv, L);
-        accx[0][1] = accx[0][0];
         bias_tile(accx[1][0], lbias + B_3, L.wv, L);
+#if NEO_TP_BIAS2 && NEO_TP_LDS_BIAS
+        {
+            int z = 0;                               // an opaque zero: without it the compiler merges the two reads and copies registers
+            asm volatile("" : "+v"(z));
+            bias_tile(accx[0][1], lbias + B_0 + z, L.wv, L);
+            bias_tile(accx[1][1], lbias + B_3 + z, L.wv, L);
+        }
+#else
+        accx[0][1] = accx[0][0];
         accx[1][1] = accx[1][0];
+#endif
         {
             const int col4 = tid & 15, rg = tid >> 4;
             const uint32_t lane_b = 16u * col4;
@@ -296,11 +311,16 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     constexpr int w = i - 16, s2 = w / 12, q = (w % 12) / 3, j = w % 3;
                     const int row = rg + 16 * q;
 #if NEO_TP_DPF
-                    const f32x4 val = blend4(taps[i % RING], d_w[i & 1]);
+                    const f32x4 wts = d_w[i & 1];
 #else
-                    const f32x4 val = blend4(taps[i % RING], *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4));
+                    const f32x4 wts = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4);
 #endif
+#if NEO_TP_PLANE_FMA
+                    if constexpr (j == 0) wsum = blend4(taps[i % RING], wts); else wsum = tp::blend4_acc(taps[i % RING], wts, wsum);
+#else
+                    const f32x4 val = blend4(taps[i % RING], wts);
                     if constexpr (j == 0) wsum = val; else wsum = wsum + val;
+#endif
                     if constexpr (j == 2) write_x(xbuf(s2), row, wsum);
                 }
             };
@@ -331,7 +351,13 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 const int chs = hf * 4 + q;                    // chunk inside this 64-feature stage (wave-uniform)
                 const int ch = pstage * 8 + chs;               // chunk of the whole encoding
                 float f[8];
+                h8 vh, vl;
+#if NEO_PE_PAIR2
+                pe2_chunk<PE_C>(xv, ch, vh, vl, L);             // doubling order (tp_hp_layout.h): two octaves of one coordinate per half-chunk
+                if (false) {
+#else
                 if (ch * 4 < 10 * PE_C) {                      // pairs (C = 3: chunk 7 holds pairs 28, 29 and the identity features)
+#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         if (PE_C == 3 && jj >= 2 && ch == 7) {  // pairs 30, 31 do not exist: positions 60..63 = x, y, z, 0
@@ -353,7 +379,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                         }
                         sincos_pair(ldexpf(x, oct), f[2 * jj], f[2 * jj + 1]);
                     }
-                } else {                                        // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
+                } else if (!NEO_PE_PAIR2) {                     // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = 0.0f;
                     if (ch * 4 == 10 * PE_C) {
@@ -361,7 +387,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                         f[0] = xv[0]; f[1] = xv[1]; f[2] = xv[2]; f[3] = xv[3];
                     }
                 }
-                h8 vh, vl;
+#if !NEO_PE_PAIR2
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     h2 h, l;
@@ -369,6 +395,9 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     vh[e] = h[0]; vh[e + 1] = h[1];
                     vl[e] = l[0]; vl[e + 1] = l[1];
                 }
+#else
+                (void)f;
+#endif
                 const int o = chunk_off<64>(row, chs);
                 *reinterpret_cast<h8*>(buf.hi + o) = vh;
                 *reinterpret_cast<h8*>(buf.lo + o) = vl;
@@ -484,7 +513,11 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             static_for<4, 8>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
                 mma_k(xbuf(1), kc);
-                if constexpr (ks & 1) finish_pe(xbuf(0), 0, (ks - 4) >> 1);
+                if constexpr (ks & 1) {
+                    if (NEO_PE_PAIR2) __builtin_amdgcn_sched_barrier(0);      // keeps the encoding's temporaries out of the k-steps' live ranges
+                    finish_pe(xbuf(0), 0, (ks - 4) >> 1);
+                    if (NEO_PE_PAIR2) __builtin_amdgcn_sched_barrier(0);
+                }
             });
             TP_SYNC();
             // ---- the pos_enc stage(s) ----
@@ -640,7 +673,15 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             if constexpr (ks == 0) {
                 if constexpr (layer < 2) {
                     bias_tile(acc[0][0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
+#if NEO_TP_BIAS2 && NEO_TP_LDS_BIAS
+                    {
+                        int z = 0;
+                        asm volatile("" : "+v"(z));
+                        bias_tile(acc[0][1], lbias + (layer == 0 ? B_1 : B_2) + z, L.wv, L);
+                    }
+#else
                     acc[0][1] = acc[0][0];
+#endif
                 } else {
                     acc[0][0] = accx[1][0];
                     acc[0][1] = accx[1][1];
@@ -1088,8 +1129,13 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, const float* const* 
     PackPerm px;
     for (int k = 0; k < 256; ++k) px.col[k] = -1;
     for (int k = 0; k < 128; ++k) px.col[k] = (short)(pe + 512 + k);
+#if NEO_PE_PAIR2
+    // doubling order (tp_hp_layout.h:pe2_source_column): half-chunks of two consecutive octaves of one coordinate
+    for (int j = 0; j < pe_ksteps(C) * 16; ++j) px.col[128 + j] = (short)pe2_source_column(C, j);
+#else
     for (int j = 0; j < 20 * C; ++j) px.col[128 + j] = (short)(C + ((j & 1) ? 10 * C : 0) + (j >> 1));
     for (int a = 0; a < C; ++a) px.col[128 + 20 * C + a] = (short)a;
+#endif
     pack_h_perm(w[0], x0w, 128, ksx, 0, px, base + (long)hoff_x() * 8, s);
     PackPerm px3 = px;
     for (int k = 0; k < 256; ++k)

@@ -196,7 +196,13 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 const int chs = hf * 4 + q;                    // chunk inside this stage (wave-uniform)
                 const int ch = pstage * 8 + chs;               // chunk of the whole encoding
                 float f[8];
+                h8 vh, vl;
+#if NEO_PE_PAIR2
+                pe2_chunk<PE_C>(xv, ch, vh, vl, L);             // doubling order (tp_hp_layout.h): two octaves of one coordinate per half-chunk
+                if (false) {
+#else
                 if (ch * 4 < 10 * PE_C) {                      // pairs (C = 3: chunk 7 holds pairs 28, 29 and the identity features)
+#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         if (PE_C == 3 && jj >= 2 && ch == 7) {  // pairs 30, 31 do not exist: positions 60..63 = x, y, z, 0
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         }
                         sincos_pair(ldexpf(x, oct), f[2 * jj], f[2 * jj + 1]);
                     }
-                } else {                                        // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
+                } else if (!NEO_PE_PAIR2) {                     // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = 0.0f;
                     if (ch * 4 == 10 * PE_C) {
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         f[0] = xv[0]; f[1] = xv[1]; f[2] = xv[2]; f[3] = xv[3];
                     }
                 }
-                h8 vh, vl;
+#if !NEO_PE_PAIR2
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     h2 h, l;
@@ -237,6 +243,9 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                     vh[e] = h[0]; vh[e + 1] = h[1];
                     vl[e] = l[0]; vl[e + 1] = l[1];
                 }
+#else
+                (void)f;
+#endif
                 const int o = chunk_off<LDH>(row, chs);
                 if (NEO_TPP_PE_WCACHE && PE_C == 4 && v > 0 && ch * 4 < 10 * PE_C) {      // an octave chunk of a later view: x, y, z pairs only
                     typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
@@ -279,10 +288,22 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
 
         // ---- [L0 | L3 skip half] pre-activations: bias + four pre-projected maps (adds) + pos_enc GEMM ----
         f32x16 accx[2][2];
+#ifndef NEO_TP_BIAS2
+#define NEO_TP_BIAS2 1        // the second M-tile's accumulators from a second LDS read of the biases instead of 16 register copies (mlp_tp_hp.hip)
+#endif
         bias_tile(accx[0][0], lbias + B_0, L.wv, L);
-        accx[0][1] = accx[0][0];
         bias_tile(accx[1][0], lbias + B_3, L.wv, L);
+#if NEO_TP_BIAS2
+        {
+            int z = 0;                               // an opaque zero: without it the compiler merges the two reads and copies registers
+            asm volatile("" : "+v"(z));
+            bias_tile(accx[0][1], lbias + B_0 + z, L.wv, L);
+            bias_tile(accx[1][1], lbias + B_3 + z, L.wv, L);
+        }
+#else
+        accx[0][1] = accx[0][0];
         accx[1][1] = accx[1][0];
+#endif
         {
             const int col4 = tid & 15, rg = tid >> 4;
             const uint32_t lane_b = 16u * col4;
@@ -602,7 +623,15 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 if constexpr (ks == 0) {
                     if constexpr (layer < 2) {
                         bias_tile(acc[0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
+#if NEO_TP_BIAS2
+                        {
+                            int z = 0;
+                            asm volatile("" : "+v"(z));
+                            bias_tile(acc[1], lbias + (layer == 0 ? B_1 : B_2) + z, L.wv, L);
+                        }
+#else
                         acc[1] = acc[0];
+#endif
                     } else {
                         acc[0] = accx[1][0];
                         acc[1] = accx[1][1];

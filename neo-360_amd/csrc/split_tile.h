@@ -63,9 +63,24 @@ __device__ __forceinline__ void range_commit(const LaneCtx& L, uint32_t* __restr
 // (one instruction instead of cvt_f32_f16 + sub); lo pair packed by a second v_cvt_pk_f16_f32.  Same values bit for
 // bit as split(): hi = fp16(x), lo = fp16(x - hi) (the subtraction is exact).  The compiler's own lowering of the
 // scalar form costs 5 instructions per value (separate conversions, a re-widening and a pack).
+#ifndef NEO_SPLIT_MIXLO
+#define NEO_SPLIT_MIXLO 1     // 1 (round 5): the lo pair by v_fma_mixlo_f16 + v_fma_mixhi_f16 - 3 instructions per pair of values instead of 4
+#endif
 __device__ __forceinline__ void split2(float x0, float x1, h2& hi, h2& lo) {
     const f32x2 v = {x0, x1};
     hi = __builtin_convertvector(v, h2);
+#if NEO_SPLIT_MIXLO
+    // lo = fp16(x - hi) straight into the two halves of one register: the mixed-precision fma reads the fp16 hi out of the
+    // packed pair (op_sel picks the half), subtracts it from the fp32 x EXACTLY (x - fp16(x) is representable) and rounds once
+    // to fp16 - bit for bit what v_fma_mix_f32 + v_cvt_pk_f16_f32 produced (tools/split2_check.hip).  This is the explicit,
+    // operand-by-operand use of the instruction; what tests/test_build_cpu.py keeps out of the library is the COMPILER folding
+    // float(fp16(a * b)) into it with a different rounding of hi.
+    unsigned packed;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(packed) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(packed) : "v"(hi), "v"(x1));
+    lo = __builtin_bit_cast(h2, packed);
+    return;
+#endif
     float r0, r1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));

@@ -100,6 +100,21 @@ __device__ __forceinline__ f32x4 blend4(const f32x4 (&tap)[4], const f32x4 w) {
     return v;
 }
 
+// the same blend ADDED to a running sum (tri-planes: the three maps of a row group are summed; chaining the fused multiply-adds
+// through the sum saves the separate add per value - one rounding per tap instead of per tap and per map)
+__device__ __forceinline__ f32x4 blend4_acc(const f32x4 (&tap)[4], const f32x4 w, const f32x4 acc) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = __builtin_fmaf(tap[0][e], w[0], acc[e]);
+        a = __builtin_fmaf(tap[1][e], w[1], a);
+        a = __builtin_fmaf(tap[2][e], w[2], a);
+        a = __builtin_fmaf(tap[3][e], w[3], a);
+        v[e] = a;
+    }
+    return v;
+}
+
 // 16 B of gathered features at byte offset `off` (32-bit) from a uniform base: the address stays
 // SGPR base + one VGPR offset instead of 64-bit per-lane pointer arithmetic
 __device__ __forceinline__ f32x4 load_tap(const float* __restrict__ base, uint32_t off) {

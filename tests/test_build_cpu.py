@@ -69,7 +69,12 @@ def test_library_isa_has_no_inconsistent_split_conversions(tmp_path):
     op_sel modifier (the forms that glitch beside v_mfma_f32_32x32x16_f16: profiles/r02_pk_f32_repro.log)."""
     isa = _disassemble_library(tmp_path)
     assert "v_mfma_f32_32x32x16_f16" in isa                                     # the disassembly is the real thing
-    assert "v_fma_mixlo_f16" not in isa and "v_fma_mixhi_f16" not in isa
+    # Round 5: split_tile.h:split2 USES the instruction pair explicitly, operand by operand - lo = fp16(x - float(hi)) with hi
+    # read out of the packed pair: `v_fma_mix{lo,hi}_f16 vD, vHI, -1.0, vX op_sel_hi:[1,0,0]`.  That form is the only one allowed;
+    # the compiler's own folding of a product (two fp32 register sources, no -1.0) must still never appear.
+    mixed = [l.strip() for l in isa.splitlines() if "v_fma_mixlo_f16" in l or "v_fma_mixhi_f16" in l]
+    rogue = [l for l in mixed if ", -1.0, " not in l or "op_sel_hi:[1,0,0]" not in l]
+    assert not rogue, rogue[:5]
     # walk kernel by kernel: a kernel with split-fp16 MFMAs must not contain op_sel'd packed fp32 arithmetic
     kernel, has_mfma, bad = None, {}, {}
     for line in isa.splitlines():

@@ -19,6 +19,18 @@ __device__ __forceinline__ void split2(float x0, float x1, h2& hi, h2& lo) {
     const f32x2 r = {r0, r1};
     lo = __builtin_convertvector(r, h2);
 }
+// round 5: the lo pair by v_fma_mixlo_f16 + v_fma_mixhi_f16 (3 instructions per pair of values; build with -DMIXLO=1)
+__device__ __forceinline__ void split2_mixlo(float x0, float x1, h2& hi, h2& lo) {
+    const f32x2 v = {x0, x1};
+    hi = __builtin_convertvector(v, h2);
+    unsigned packed;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(packed) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(packed) : "v"(hi), "v"(x1));
+    lo = __builtin_bit_cast(h2, packed);
+}
+#ifdef MIXLO
+#define split2 split2_mixlo
+#endif
 __global__ void k(const float* x, unsigned short* a, unsigned short* b, int n) {
     int i = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i + 1 >= n) return;
