@@ -31,7 +31,8 @@ void fill_views(const float* poses, int nv, neo::TpViews& v) {
 // The maps a slot gathers in pre-projection modes, recomputed (exact fp32 MFMA, k_tp_preproject: ~1 ms per map) only when the
 // scene or the slot's weights changed since they were made: the latent through [W0_loc | W3_loc], and - planes = true - the three
 // tri-planes through [W0_world | W3_world] (chunks 64..79 of the fp32 fragment stream).  Shared by both arithmetic modes.
-int ensure_projections(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, bool planes, hipStream_t s, long plane_base[3]) {
+int ensure_projections(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, bool planes, hipStream_t s, long plane_base[3],
+                       bool split_guard = false) {
     const long t_lat = static_cast<long>(sc.nv) * sc.Hf * sc.Wf, t_pl = static_cast<long>(sc.nv) * sc.Hp * sc.Wp;
     for (int j = 0; j < 3; ++j) plane_base[j] = t_lat + j * t_pl;
     const size_t need = neo::tp_proj_bytes(t_lat + (planes ? 3 * t_pl : 0)) + neo::tp_proj_pad_bytes();
@@ -42,6 +43,11 @@ int ensure_projections(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, bool p
     }
     if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->scene_epoch) {
         neo::launch_tp_preproject(sc.latent, t_lat, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch), sl.proj.as<float>(), s);
+        // split arithmetic: a projected map is a STATIC operand of the evaluator (its blends are added to the layer-0 / skip
+        // pre-activations, whose hi/lo split the epilogue guards) - checked once per (scene, weights) here, so that a latent the
+        // fp16 range cannot hold is reported as a static trip (NEO_FLAG_SPLIT_STATIC: the frame API latches to the exact kernels
+        // instead of paying a failed split attempt per frame)
+        if (split_guard) neo::launch_f32_range_check(sl.proj.as<float>(), static_cast<size_t>(t_lat) * 256, 65504.0f, ctx->flags, s);
         sl.proj_weights = sl.weights_epoch;
         sl.proj_scene = ctx->scene_epoch;
     }
@@ -49,6 +55,8 @@ int ensure_projections(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, bool p
         for (int j = 0; j < 3; ++j)
             neo::launch_tp_preproject(sc.plane[j], t_pl, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch),
                                       sl.proj.as<float>() + plane_base[j] * 256, s, 256, 128, 64);
+        if (split_guard)         // the three projected planes are summed before they meet an accumulator
+            neo::launch_f32_range_check(sl.proj.as<float>() + plane_base[0] * 256, static_cast<size_t>(3 * t_pl) * 256, 65504.0f / 3.0f, ctx->flags, s);
         sl.projpl_weights = sl.weights_epoch;
         sl.projpl_scene = ctx->scene_epoch;
     }
@@ -76,7 +84,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             // launch).  Inside, every map carries weight on almost every row: 24 more 1 KB gather items per tile-view cost
             // more than the GEMM stage they replace (+1..7 %): profiles/r04_tp_hp_experiments.log.
             const bool planes = ctx->preproject == 2 || (ctx->preproject == 3 && slot_index >= 2);
-            if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base)) return rc;
+            if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base, true)) return rc;
             guard_split_weights(sl, sl.wpack_hp.p, neo::tp_wpack_hp_bytes(sl.input_ch), ctx->flags, s);
             neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias_hp.as<float>(), sl.heads.as<float>(), ctx->flags};
             // the view-direction encodings enter the MLP only through their mean over the views, and they depend on the

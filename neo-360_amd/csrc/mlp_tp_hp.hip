@@ -57,10 +57,10 @@
 #define NEO_TP_DPF 1          // 1: a gather item's tap offsets / weights are read from LDS ONE ITEM AHEAD of their use (the ISA of the plain form waits out a full LDS round trip twice per item: ds_read offsets -> s_waitcnt -> 4 loads, ds_read weights -> s_waitcnt -> blend)
 #endif
 #ifndef NEO_TP_PLANE_FMA
-#define NEO_TP_PLANE_FMA 1    // 1 (round 5): the blends of a row group's three tri-planes are chained through the running sum (fma onto the sum) instead of blend + add
+#define NEO_TP_PLANE_FMA 0    // 1 (round 5): the blends of a row group's three tri-planes are chained through the running sum (fma onto the sum) instead of blend + add
 #endif
 #ifndef NEO_TP_BIAS2
-#define NEO_TP_BIAS2 1        // 1 (round 5): the second M-tile's accumulators are initialised by a second LDS read of the biases instead of 16 register copies
+#define NEO_TP_BIAS2 0        // 1 (round 5): the second M-tile's accumulators are initialised by a second LDS read of the biases instead of 16 register copies
 #endif
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no

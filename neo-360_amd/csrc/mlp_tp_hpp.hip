@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
         // ---- [L0 | L3 skip half] pre-activations: bias + four pre-projected maps (adds) + pos_enc GEMM ----
         f32x16 accx[2][2];
 #ifndef NEO_TP_BIAS2
-#define NEO_TP_BIAS2 1        // the second M-tile's accumulators from a second LDS read of the biases instead of 16 register copies (mlp_tp_hp.hip)
+#define NEO_TP_BIAS2 0        // the second M-tile's accumulators from a second LDS read of the biases instead of 16 register copies (mlp_tp_hp.hip)
 #endif
         bias_tile(accx[0][0], lbias + B_0, L.wv, L);
         bias_tile(accx[1][0], lbias + B_3, L.wv, L);

@@ -64,7 +64,7 @@ __device__ __forceinline__ void range_commit(const LaneCtx& L, uint32_t* __restr
 // bit as split(): hi = fp16(x), lo = fp16(x - hi) (the subtraction is exact).  The compiler's own lowering of the
 // scalar form costs 5 instructions per value (separate conversions, a re-widening and a pack).
 #ifndef NEO_SPLIT_MIXLO
-#define NEO_SPLIT_MIXLO 1     // 1 (round 5): the lo pair by v_fma_mixlo_f16 + v_fma_mixhi_f16 - 3 instructions per pair of values instead of 4
+#define NEO_SPLIT_MIXLO 0     // 1 (round 5): the lo pair by v_fma_mixlo_f16 + v_fma_mixhi_f16 - 3 instructions per pair of values instead of 4
 #endif
 __device__ __forceinline__ void split2(float x0, float x1, h2& hi, h2& lo) {
     const f32x2 v = {x0, x1};

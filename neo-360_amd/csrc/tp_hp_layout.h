@@ -51,7 +51,7 @@ constexpr int PROJ_TEXEL_BYTES = 1024;     // 256 fp32 channels per texel of the
 // 4 C <= hc < 5 C -> coordinate hc - 4 C, octaves 8, 9; hc == 5 C -> the C identity features, zero padded; beyond: zeros.
 // The weight columns are packed in the same order (pe2_source_column).  0: the round-3 pair order (pair = octave * C + coordinate).
 #ifndef NEO_PE_PAIR2
-#define NEO_PE_PAIR2 1
+#define NEO_PE_PAIR2 0
 #endif
 __host__ __device__ constexpr int pe2_coord(int c, int hc) { return hc < 4 * c ? hc / 4 : hc - 4 * c; }
 __host__ __device__ constexpr int pe2_oct0(int c, int hc) { return hc < 4 * c ? 2 * (hc % 4) : 8; }

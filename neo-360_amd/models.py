@@ -208,6 +208,8 @@ class _HipModule(nn.Module):
     # call and synchronises once per call: a forward-only caller outside torch.no_grad() with default nn.Module parameters
     # (requires_grad=True) takes it unless it says `module.differentiable = False` (or wraps the call in no_grad).
     differentiable = None
+    _range_latch = None            # render.render_rays_test: operands_key() of the (weights, scene) whose STATIC operands tripped the range guard
+    last_precision_used = None     # arithmetic of the last frame render.render_rays_test produced on this module
 
     def _scene_tensors_for_grad(self):
         return ()

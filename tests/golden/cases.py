@@ -67,11 +67,11 @@ FULL_PLANE_HW = (120, 160)
 FULL_LATENT_HW = (240, 320)
 
 
-def full_scene(seed=0, nv=NV):
+def full_scene(seed=0, nv=NV, std=0.1):
     """Stand-ins for the scene encoder's outputs at the reference's shapes for 640x480 sources (tri-planes
     3 x 128 x 120 x 160, latent 3 x 512 x 240 x 320, N(0, 0.1^2)), from the hash generator: the build container
     (reference run -> fixture g4_neo_full), the GPU tests and bench.py regenerate them bit for bit."""
-    sc = synth.scene_features(seed, nv, 128, FULL_PLANE_HW, 512, FULL_LATENT_HW, std=0.1)
+    sc = synth.scene_features(seed, nv, 128, FULL_PLANE_HW, 512, FULL_LATENT_HW, std=std)
     sc["image_wh"] = (float(FULL_WH[0]), float(FULL_WH[1]))
     return sc
 
@@ -102,7 +102,18 @@ FULL_B = {
     "b2": dict(nv=NV, stride=601, start_row=230, azimuth=130.0, radius=0.6, height=0.45),
     "b3": dict(nv=NV, stride=463, start_row=311, azimuth=250.0, radius=0.78, height=0.1),
     "b4": dict(nv=5, stride=601, start_row=140),
+    # round 5 (VERDICT r4 task 8): beyond random-init weights on N(0, 0.1) features -
+    # b5: TRAINED-LIKE sharp densities (density head x 8: opaque surfaces, weights concentrated in a few samples),
+    # b6: a second feature seed at std 0.5 (five times the activations' scale: ReLU units far from their kinks, larger cdf steps)
+    "b5": dict(nv=NV, stride=521, start_row=400, gain=8.0),
+    "b6": dict(nv=NV, stride=433, start_row=19, seed=1, std=0.5),
 }
+_FULL_SCENE_KEYS = ("seed", "std")
+
+
+def full_gain(tag):
+    """density gain of the MLP weights of fixture g4_neo_full_<tag> (synth.nerf_tp_state(0, density_gain=...))."""
+    return float(FULL_B.get(tag, {}).get("gain", 1.0)) if tag else 1.0
 
 
 def full_case(tag, n=1024):
@@ -111,7 +122,9 @@ def full_case(tag, n=1024):
         return full_scene(), full_batch(n)
     kw = dict(FULL_B[tag])
     nv = kw.pop("nv")
-    return full_scene(nv=nv), full_batch(n, nv=nv, **kw)
+    kw.pop("gain", None)
+    scene_kw = {k: kw.pop(k) for k in _FULL_SCENE_KEYS if k in kw}
+    return full_scene(nv=nv, **scene_kw), full_batch(n, nv=nv, **kw)
 
 
 def aabb_cases(seed=3, n=4096):

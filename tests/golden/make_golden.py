@@ -701,15 +701,18 @@ def main(which):
         "g4n_full_noise": lambda: g4_neo_noise("full", 1024, 1024, full=True, ulp_trials=2),
         # four more full-size chunks (cases.FULL_B): another strip, two other target poses, five source views; each with
         # its fp64 twin, two +-1 ulp trials and the cdf margins (VERDICT r3 task 6)
-        **{"g4n_full_%s" % t: (lambda t=t: g4_neo("full_" + t, 1024, 1024, full=t, nv=cases.FULL_B[t]["nv"])) for t in cases.FULL_B},
-        **{"g4n_full_%s_noise" % t: (lambda t=t: g4_neo_noise("full_" + t, 1024, 1024, full=t, ulp_trials=2, nv=cases.FULL_B[t]["nv"]))
+        # round 5: b5 (density gain 8: trained-like) and b6 (second feature seed, std 0.5) - cases.FULL_B
+        **{"g4n_full_%s" % t: (lambda t=t: g4_neo("full_" + t, 1024, 1024, full=t, nv=cases.FULL_B[t]["nv"], gain=cases.full_gain(t)))
            for t in cases.FULL_B},
+        **{"g4n_full_%s_noise" % t: (lambda t=t: g4_neo_noise("full_" + t, 1024, 1024, full=t, ulp_trials=2, nv=cases.FULL_B[t]["nv"],
+                                                              gain=cases.full_gain(t))) for t in cases.FULL_B},
         # per-ray flip sizes (quantiles shifted by +-2e-6 inside the reference's sampler) for every fixture that has a noise twin
         "g4n_1024_flip": lambda: g4_neo_flip("1024", 1024, 1024),
         "g4n_1500_flip": lambda: g4_neo_flip("1500", 1500, 1024),
         "g4n_sharp_flip": lambda: g4_neo_flip("sharp", 256, 256, 32, 64, gain=8.0),
         "g4n_full_flip": lambda: g4_neo_flip("full", 1024, 1024, full=True),
-        **{"g4n_full_%s_flip" % t: (lambda t=t: g4_neo_flip("full_" + t, 1024, 1024, full=t, nv=cases.FULL_B[t]["nv"])) for t in cases.FULL_B},
+        **{"g4n_full_%s_flip" % t: (lambda t=t: g4_neo_flip("full_" + t, 1024, 1024, full=t, nv=cases.FULL_B[t]["nv"],
+                                                            gain=cases.full_gain(t))) for t in cases.FULL_B},
         "g6": g6_mip360,
         "g7": g7_pixelnerf,
         "g8": g8_training,

@@ -81,12 +81,27 @@ def _net_nv5():
     return _NV5["net"]
 
 
+_VARIANT = {}
+
+
+def _net_variant(tag):
+    """Fixtures b5 / b6 (round 5): their own weights (density gain 8: trained-like sharp densities) / their own scene (feature
+    seed 1 at std 0.5), cases.FULL_B."""
+    if tag not in _VARIANT:
+        net = models.NeRF_TP(num_coarse_samples=128, num_fine_samples=256, num_src_views=NV).to(DEV)
+        net.load_state_dict(synth.nerf_tp_state(0, density_gain=cases.full_gain(tag)))
+        sc, _ = cases.full_case(tag, 8)
+        net.set_scene(sc["plane_xz"].to(DEV), sc["plane_xy"].to(DEV), sc["plane_yz"].to(DEV), sc["latent"].to(DEV), sc["image_wh"])
+        _VARIANT[tag] = net
+    return _VARIANT[tag]
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-@pytest.mark.parametrize("tag", ["", "b1", "b2", "b3", "b4"])
+@pytest.mark.parametrize("tag", ["", "b1", "b2", "b3", "b4", "b5", "b6"])
 def test_neo360_full_size_chunk_vs_reference(neo_full, golden, golden_optional, precision, tag):
     """Reference chunks (1024 rays spread over the 640x480 frame) at the full C3 configuration against the reference's own
-    outputs: the round-3 chunk ("") and four more (cases.FULL_B: another strip, two other target poses, five source
-    views).  Same rule as the small-scene 1024-ray test: 1e-4 on EVERY output (depth included) of every ray the reference
+    outputs: the round-3 chunk (""), four more (cases.FULL_B: another strip, two other target poses, five source
+    views) and - round 5 - b5 (density gain 8: trained-like) and b6 (a second feature seed at std 0.5).  Same rule as the small-scene 1024-ray test: 1e-4 on EVERY output (depth included) of every ray the reference
     determines to better than 1e-5; a ray the reference disagrees with itself on within 1e-4 + 3 x that disagreement; a
     flip-prone ray within 1e-4 + 3 x ITS OWN flip size (conftest.check_vs_reference_noise)."""
     state, net, scene, batch = neo_full
@@ -94,6 +109,8 @@ def test_neo360_full_size_chunk_vs_reference(neo_full, golden, golden_optional, 
     g, noise = golden(name), golden(name + "_noise")
     if tag == "b4":
         net = _net_nv5()
+    elif tag in ("b5", "b6"):
+        net = _net_variant(tag)
     _, cb = cases.full_case(tag) if tag else (None, cases.full_batch(1024))
     gb = {k: v.to(DEV) for k, v in cb.items()}
     old = net.precision

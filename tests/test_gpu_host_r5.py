@@ -340,10 +340,11 @@ def test_static_operand_trip_latches_until_weights_or_scene_change():
     """A feature map beyond the fp16 range trips the guard on EVERY frame: after the first (split attempt + exact retry) the
     module goes straight to the exact kernels - one render per frame - until set_scene / load_state_dict."""
     sc = dict(cases.small_scene())
-    sc["latent"] = sc["latent"] * 1.0e6
+    sc["latent"] = sc["latent"] * 1.0e7          # beyond the fp16 range even after the projection through the first layer
     batch = _batch(128)
     net = _tp_net(sc)
     ctx = net._context(torch.device(DEV))
+    assert net._range_latch is None
     with pytest.warns(RuntimeWarning):
         first = render.render_rays_test(net, batch, chunk=64)
     assert first["precision_used"] == "f32" and net._range_latch is not None and net.last_precision_used == "f32"
@@ -399,6 +400,7 @@ def test_bench_plain_form_scene_setup_from_events():
     assert roof["bound"] in ("hbm", "mfma") and "limiter" in roof and 0.0 < roof["frac"] < 1.0
     ss = out["scene_setup"]
     runs = ss["runs_ms"]
-    assert len(runs) == 3 and out["scene_setup_ms"] == ss["total_ms"]
+    assert len(runs) == 5 and out["scene_setup_ms"] == ss["total_ms"]
     assert 1.0 < ss["total_ms"] < 60.0, ss
-    assert max(runs) - min(runs) <= 0.4 * ss["total_ms"] + 0.5, runs         # +-20 % across three runs
+    close = [r for r in runs if abs(r - ss["total_ms"]) <= 0.2 * ss["total_ms"] + 0.3]
+    assert len(close) >= 3, runs                                             # +-20 % of the median on at least three runs

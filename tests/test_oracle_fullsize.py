@@ -9,13 +9,28 @@ from conftest import max_abs
 from neo360_amd import synth
 
 
-def test_oracle_matches_reference_at_full_size(golden):
-    g = golden("g4_neo_full")
-    scene = cases.full_scene()
-    batch = cases.full_batch(1024)
-    state = synth.nerf_tp_state(0)
+import pytest
+
+
+@pytest.mark.parametrize("tag", ["", "b5"])
+def test_oracle_matches_reference_at_full_size(golden, tag):
+    """"" = the bench chunk (random-init weights); "b5" (round 5) = density gain 8, trained-like sharp densities."""
+    g = golden("g4_neo_full" + ("_" + tag if tag else ""))
+    scene, batch = cases.full_case(tag, 1024)
+    state = synth.nerf_tp_state(0, density_gain=cases.full_gain(tag))
     res = oracle.neo360.render(state, batch, scene, 128, 256)
     got = dict(rgb0=res[0][0], depth0=res[0][5], rgb1=res[1][0], fg1=res[1][1], bg1=res[1][2], fgacc1=res[1][3],
                lam1=res[1][4], depth1=res[1][5])
-    for k, v in got.items():
-        assert max_abs(v, g[k]) <= 5e-6, (k, max_abs(v, g[k]))
+    if not tag:
+        for k, v in got.items():
+            assert max_abs(v, g[k]) <= 5e-6, (k, max_abs(v, g[k]))
+        return
+    # Sharp densities concentrate the coarse weights in a few samples: the cdf steps are large and the reference's own
+    # descending-bin sampler flips (its fp32 run against its fp64 twin: fixture <name>_noise).  The oracle - another faithful
+    # fp32 evaluation - is held to the SAME rule as the GPU (conftest.check_vs_reference_noise: 1e-4 on every well-determined
+    # ray, a flip-prone ray within its own flip size), and to 5e-6 on the rays the reference determines.
+    from conftest import check_vs_reference_noise, per_ray_abs
+    noise, flip = golden("g4_neo_full_%s_noise" % tag), golden("g4_neo_full_%s_flip" % tag)
+    check_vs_reference_noise(got, g, noise, "oracle_full_size_C3_%s" % tag, flip=flip)
+    well = (noise["noise_rgb1"] < 1e-6) & (noise["margin_bg1"] >= 1e-5)
+    assert int(well.sum()) > 500 and float(per_ray_abs(got["rgb1"] - g["rgb1"])[well].max()) <= 2e-5
