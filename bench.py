@@ -480,6 +480,94 @@ class Runner:
         return roof
 
 
+def run_train(args, dev):
+    """`--workload neo360_train`: the reference's NeO-360 training step on this path (neo360/model.py:697-820: the module's
+    randomized forward on a batch of rays, rgb L2 on both levels + 0.01 x eff_distloss on the fine inside / outside weights,
+    backward, optimizer step on the four MLPs) at the reference's training batch - 500 rays (opt.py batch_size), 3 source views,
+    128 + 256 samples, the bench scene at full map size with the four feature maps as leaves that receive gradients (the stand-in
+    for the encoder's outputs).  value = rays/s through whole steps; `steps_per_s` beside it; the CPU leg is the oracle under
+    torch autograd on a bounded sample of the same batch."""
+    import statistics as st
+    from neo360_amd import models, synth, training
+    torch.set_grad_enabled(True)
+    nv, B = 3, args.train_rays
+    net = models.NeRF_TP(num_coarse_samples=128, num_fine_samples=256, num_src_views=nv).to(dev)
+    state = synth.nerf_tp_state(0)
+    net.load_state_dict(state)
+    sc = synth.scene_features(0, nv, 128, (120, 160), 512, (240, 320), std=0.1)
+    maps = [sc[k].to(dev).requires_grad_(True) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")]
+    net.set_scene(*maps, (float(W), float(H)))
+    from neo360_amd import ops
+    ro, vd, rd, _ = ops.get_ray_directions_and_rays(H, W, 0.8 * W, synth.look_at_origin(40.0))
+    sel = (torch.arange(B, device=dev) * 601 + 230 * W) % (H * W)
+    poses, focal, centre = synth.source_views(nv, W, H)
+    batch = dict(rays_o=ro[sel].contiguous(), rays_d=rd[sel].contiguous(), viewdirs=vd[sel].contiguous(), src_poses=poses.to(dev),
+                 src_focal=focal.to(dev), src_c=centre.to(dev), src_imgs=torch.zeros(nv, 3, H, W, device=dev))
+    target = synth.uniform(5, "train_target", (B, 3), 0.0, 1.0).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    interval = 1.0 / (128 + 1 + 256)
+
+    def step(i):
+        opt.zero_grad(set_to_none=True)
+        for m in maps:
+            m.grad = None
+        lv = net(batch, True, False, 0.0, 0.0, out_depth=False, seed=1000 + i)
+        loss = sum(((l[0] - target) ** 2).mean() for l in lv)
+        loss = loss + 0.01 * (training.eff_distloss(lv[1][1], lv[1][3], interval) + training.eff_distloss(lv[1][2], lv[1][4], interval))
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup + 1):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(100 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # phases of one step (events): forward, loss + backward, optimizer
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    opt.zero_grad(set_to_none=True)
+    ev[0].record()
+    lv = net(batch, True, False, 0.0, 0.0, out_depth=False, seed=7)
+    ev[1].record()
+    l2 = sum(((l[0] - target) ** 2).mean() for l in lv) + 0.01 * (training.eff_distloss(lv[1][1], lv[1][3], interval) + training.eff_distloss(lv[1][2], lv[1][4], interval))
+    l2.backward()
+    ev[2].record()
+    opt.step()
+    ev[3].record()
+    torch.cuda.synchronize()
+    out = {"metric": "NeO-360 training step: rays/s through forward + loss + backward + optimizer step", "value": B / dt, "unit": "rays/s",
+           "steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+           "dtype": "f32 (exact fp32 MFMA GEMMs of the training operators)", "data": "synthetic",
+           "config": {"workload": "neo360 training step, %d rays, 3 source views, 128 + 256 samples inside + outside the sphere, randomized "
+                                  "sampling, full-size feature maps (3x128x120x160 planes, 3x512x240x320 latent) receiving gradients, Adam on the four MLPs" % B,
+                      "rays_per_step": B},
+           "phases_ms": {"forward": ev[0].elapsed_time(ev[1]), "loss_and_backward": ev[1].elapsed_time(ev[2]), "optimizer": ev[2].elapsed_time(ev[3])},
+           "loss": float(loss.detach())}
+    if args.cpu_rays != 0:
+        import oracle
+        from oracle import training as T
+        n = min(B, args.cpu_rays if args.cpu_rays > 0 else 48)
+        torch.set_num_threads(min(CPU_THREADS["neo360"], os.cpu_count() or 1))
+        cb = {k: (v[:n].cpu() if k in ("rays_o", "rays_d", "viewdirs") else v.cpu()) for k, v in batch.items()}
+        pp = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+        cm = {k: sc[k].clone().requires_grad_(True) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")}
+        cm["image_wh"] = (float(W), float(H))
+        t0 = time.perf_counter()
+        want = oracle.neo360.render(pp, cb, cm, n_coarse=128, n_fine=256, white_bkgd=False, out_depth=False)
+        lc = sum(((l[0] - target[:n].cpu()) ** 2).mean() for l in want)
+        lc = lc + 0.01 * (T.eff_distloss(want[1][1], want[1][3], interval) + T.eff_distloss(want[1][2], want[1][4], interval))
+        lc.backward()
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / tc, "unit": "rays/s", "cores": physical_cores(), "threads": torch.get_num_threads(), "kind": "port",
+                               "sample": "first %d rays of the same batch: oracle forward (deterministic samples) + the same loss + torch "
+                                         "autograd backward on the CPU, one repetition, %.1f s" % (n, tc)}
+        out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
 class FakeRunner:
     """CPU stand-in for Runner (tests/test_bench_cpu.py: `--fake`, gloo): the same sharding (whole 1024-ray chunks), the same
     barrier / max-over-ranks timing and the same tile all-gather as the GPU path, with a 'renderer' that writes each ray's index
@@ -552,7 +640,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=tuple(BUILDERS), default="neo360")
+    ap.add_argument("--workload", choices=tuple(BUILDERS) + ("neo360_train",), default="neo360")
+    ap.add_argument("--train-rays", type=int, default=500, dest="train_rays", help="rays per step of --workload neo360_train (the reference's training batch)")
     ap.add_argument("--precision", choices=("auto", "f32", "f16x3"), default="auto",
                     help="MLP arithmetic: exact fp32 MFMA, or fp16 MFMA with hi/lo-split operands (fp32-equivalent, "
                          "the default of every renderer)")
@@ -594,6 +683,10 @@ def main():
         return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "neo360_train":
+        if world != 1:
+            sys.exit("bench.py: --workload neo360_train is a single-GPU line")
+        return run_train(args, dev)
     torch.set_grad_enabled(False)
     dist = None
     # one process per GPU over RCCL; a launch under torch.distributed.run with ONE rank (RANK set, world 1) initialises the

@@ -748,6 +748,28 @@ int launch_mip_mlp_h_layered(const MipMlpHDev& m, const MipLayeredWs& ws, const 
         const long pb = P - p0 < ws.cap ? P - p0 : ws.cap;
         const int n_it = (int)((pb + 2047) / 2048) * 64;            // the GEMM's grid wants whole groups of 64 interval tiles
         hipLaunchKernelGGL(k_mip_ipe_h, dim3((unsigned)n_it), dim3(256), 0, s, m.basis, rays_o, rays_d, radii, tdist, R, n, p0, ws.x0);
+#ifndef NEO_MIP_CHAIN
+#define NEO_MIP_CHAIN 1           // 1 (round 5): the eight trunk layers as ONE launch with slab-local barriers (mip_gemm_h.h:k_mip_chain_h)
+#endif
+        if (NEO_MIP_CHAIN && ws.arrive) {
+            MipChainArgs c{};
+            for (int l = 0; l < DEPTH; ++l) {
+                c.w[l] = wbase + (size_t)woff_of(W, l) * 16;
+                c.ks0[l] = l == 0 ? 32 : W / 16;
+                c.ks1[l] = l == 5 ? 32 : 0;                         // skip concat [h | encoding] (model.py:76-79)
+            }
+            c.bias = m.bias;
+            c.x0 = ws.x0;
+            c.y[0] = bufs[0];
+            c.y[1] = bufs[1];
+            c.n_it = n_it;
+            c.layers = DEPTH;
+            c.flags = m.flags;
+            c.arrive = ws.arrive;
+            (void)hipMemsetAsync(ws.arrive, 0, mip_layered_sync_bytes(ws.cap), s);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_chain_h<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES);
+            hipLaunchKernelGGL(k_mip_chain_h<true>, dim3(mip_gemm_grid(n_it)), dim3(MG_THREADS), MG_LDS_BYTES, s, c);
+        } else
         for (int l = 0; l < DEPTH; ++l) {
             MipGemmArgs a{};
             a.w = wbase + (size_t)woff_of(W, l) * 16;

@@ -79,3 +79,40 @@ def gather_tiles(tile, n_rays, world, unit=1024, group=None, out=None, reuse=Fal
         frame[lo: lo + counts[r]].copy_(recv[r * biggest: r * biggest + counts[r]])
         lo += counts[r]
     return frame
+
+
+def alter_gather_cat(outputs, key, image_sizes, group=None):
+    """The reference's evaluation gather for a LIST of images per rank (LitModel.alter_gather_cat, models/interface.py:30-50;
+    call sites neo360/model.py:1073-1086, vanilla_nerf/model.py:380-393): every rank holds the outputs of ITS test images
+    (`outputs[i][key]`: (h w, 3) colours or (h w,) / (h w, 1) scalars); they are concatenated, all-gathered into (world, n, C),
+    reordered with the reference's `permute(1, 0, 2).flatten(0, 1)` - row j of rank 0, row j of rank 1, ... - and cut into
+    images of `image_sizes` (h, w).  ONE all_gather_into_tensor (RCCL on devices, gloo on CPU tensors) instead of Lightning's
+    `self.all_gather`; all ranks must hold the same number of rows, as Lightning's all_gather requires.  The row interleaving
+    is the reference's behaviour at world > 1 and is reproduced as is (so is its failure on 1-D per-pixel scalars at world > 1:
+    pass them as (n, 1), as the reference's call sites do).  Without an initialised process group (single process) the gather
+    is the identity, as Lightning's is."""
+    import torch.distributed as dist
+    each = torch.cat([o[key] for o in outputs]).detach()
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world > 1:
+        flat = each.contiguous()
+        every = torch.empty((world,) + tuple(flat.shape), device=flat.device, dtype=flat.dtype)
+        dist.all_gather_into_tensor(every.view(world * flat.shape[0], *flat.shape[1:]) if flat.dim() > 0 else every, flat, group=group)
+        all_ = every
+    else:
+        all_ = each                              # Lightning's all_gather outside a distributed run returns its input
+    if all_.dim() == 3:
+        all_ = all_.permute((1, 0, 2)).flatten(0, 1)
+    if all_.dim() >= 1 and all_.shape[-1] == 1:
+        all_ = all_.squeeze(-1)
+    ret, curr = [], 0
+    for (h, w) in image_sizes:
+        part = all_[curr: curr + h * w]
+        if all_.dim() == 2 and all_.shape[-1] == 3:
+            if part.shape[0] == 0:
+                continue
+            ret.append(part.reshape(h, w, 3))
+        else:
+            ret.append(part.reshape(h, w))
+        curr += h * w
+    return ret

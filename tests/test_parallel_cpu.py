@@ -151,3 +151,50 @@ def test_always_gather_runs_the_collective_at_world_one():
         ret = mgr.dict()
         mp.spawn(_world1_worker, args=(port, ret), nprocs=1, join=True)
         assert ret.get(0) is True
+
+
+def _agc_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = [(4, 6), (3, 5)]
+        n = sum(h * w for h, w in sizes)
+        assert n % world == 0
+        rows = n // world                                  # every rank holds the same number of rows (Lightning's all_gather)
+        outs_rgb = [{"rgb": torch.arange(rows * 3, dtype=torch.float32).reshape(rows, 3) + 1000.0 * rank}]
+        outs_d = [{"depth": torch.arange(rows, dtype=torch.float32).reshape(rows, 1) + 1000.0 * rank}]
+        got_rgb = parallel.alter_gather_cat(outs_rgb, "rgb", sizes)
+        got_d = parallel.alter_gather_cat(outs_d, "depth", sizes)
+        # the reference's arithmetic restated on the stacked per-rank tensors (interface.py:31-36: all_gather -> (world, n, C) ->
+        # permute(1, 0, 2).flatten(0, 1) -> squeeze a trailing 1)
+        every_rgb = torch.stack([torch.arange(rows * 3, dtype=torch.float32).reshape(rows, 3) + 1000.0 * r for r in range(world)])
+        every_d = torch.stack([torch.arange(rows, dtype=torch.float32).reshape(rows, 1) + 1000.0 * r for r in range(world)])
+        want_rgb = every_rgb.permute(1, 0, 2).flatten(0, 1)
+        want_d = every_d.permute(1, 0, 2).flatten(0, 1).squeeze(-1)
+        ok, curr = True, 0
+        for i, (h, w) in enumerate(sizes):
+            ok = ok and bool(torch.equal(got_rgb[i], want_rgb[curr:curr + h * w].reshape(h, w, 3)))
+            ok = ok and bool(torch.equal(got_d[i], want_d[curr:curr + h * w].reshape(h, w)))
+            curr += h * w
+        ret[rank] = ok and len(got_rgb) == 2 and got_rgb[0].shape == (4, 6, 3) and got_d[1].shape == (3, 5)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_alter_gather_cat_world_3_matches_the_reference_reordering():
+    """models/interface.py:30-50 for a list of images per rank: one all_gather_into_tensor + the reference's row interleave."""
+    world, port = 3, _free_port()                          # 24 + 15 = 39 rows = 3 x 13
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_agc_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert all(ret.get(r) is True for r in range(world)), dict(ret)
+
+
+def test_alter_gather_cat_single_process_is_the_identity_gather():
+    sizes = [(2, 3), (1, 4)]
+    outs = [{"rgb": torch.arange(18, dtype=torch.float32).reshape(6, 3)}, {"rgb": torch.arange(12, dtype=torch.float32).reshape(4, 3) + 50.0}]
+    got = parallel.alter_gather_cat(outs, "rgb", sizes)
+    assert torch.equal(got[0], outs[0]["rgb"].reshape(2, 3, 3)) and torch.equal(got[1], outs[1]["rgb"].reshape(1, 4, 3))
+    d = parallel.alter_gather_cat([{"depth": torch.arange(10, dtype=torch.float32)}], "depth", sizes)
+    assert torch.equal(d[0], torch.arange(6, dtype=torch.float32).reshape(2, 3)) and d[1].shape == (1, 4)

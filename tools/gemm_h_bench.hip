@@ -148,6 +148,32 @@ int main(int argc, char** argv) {
         printf("check (400 samples each): layer0 %.2e  layer1 %.2e  skip layer %.2e  (relative, vs float64 on the same operands)\n", e0, e1, e5);
     }
 
+    // ---- the same trunk as ONE launch (k_mip_chain_h, slab-local barriers): bitwise the 8-launch result ----
+    unsigned* dArrive;
+    const size_t arrive_bytes = (size_t)(n_it / 8) * 8 * sizeof(unsigned);
+    CK(hipMalloc(&dArrive, arrive_bytes));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_chain_h<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES));
+    auto chain1 = [&]() {
+        MipChainArgs c{};
+        for (int l = 0; l < 8; ++l) { c.w[l] = dW[l]; c.ks0[l] = l == 0 ? 32 : 64; c.ks1[l] = l == 5 ? 32 : 0; }
+        c.bias = dBias; c.x0 = dX; c.y[0] = dA; c.y[1] = dB; c.n_it = n_it; c.layers = 8; c.flags = dFlags; c.arrive = dArrive;
+        CK(hipMemsetAsync(dArrive, 0, arrive_bytes, st));
+        hipLaunchKernelGGL(k_mip_chain_h<true>, dim3(mip_gemm_grid(n_it)), dim3(MG_THREADS), MG_LDS_BYTES, st, c);
+    };
+    {
+        std::vector<char> ref(act_bytes), got(act_bytes);
+        chain();
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ref.data(), dB, act_bytes, hipMemcpyDeviceToHost));       // layer 7 writes bufs[1]
+        CK(hipMemset(dB, 0xff, act_bytes));
+        chain1();
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(got.data(), dB, act_bytes, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < act_bytes; ++i) bad += ref[i] != got[i];
+        printf("one-launch chain vs eight launches: %zu differing bytes of %zu\n", bad, act_bytes);
+    }
+
     hipEvent_t ev[10];
     for (auto& e : ev) CK(hipEventCreate(&e));
     chain();
@@ -179,6 +205,17 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
         const double tf = 2.0 * macs * Mb * batches / (ms * 1e-3) / 1e12;
         printf("chain: %d intervals x %d batches  %.3f ms per batch  %.1f algorithmic TFLOP/s (%.1f %% of 833; executed %.0f)  scale %g\n",
+               Mb, batches, ms / batches, tf, tf / 833.0 * 100.0, tf * 3, scale);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(ev[0], st));
+        for (int b = 0; b < batches; ++b) chain1();
+        CK(hipEventRecord(ev[1], st));
+        CK(hipStreamSynchronize(st));
+        float ms;
+        CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        const double tf = 2.0 * macs * Mb * batches / (ms * 1e-3) / 1e12;
+        printf("ONE LAUNCH (k_mip_chain_h): %d intervals x %d batches  %.3f ms per batch  %.1f algorithmic TFLOP/s (%.1f %% of 833; executed %.0f)  scale %g\n",
                Mb, batches, ms / batches, tf, tf / 833.0 * 100.0, tf * 3, scale);
     }
     uint32_t fl;
