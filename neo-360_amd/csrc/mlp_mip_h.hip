@@ -749,7 +749,7 @@ int launch_mip_mlp_h_layered(const MipMlpHDev& m, const MipLayeredWs& ws, const 
         const int n_it = (int)((pb + 2047) / 2048) * 64;            // the GEMM's grid wants whole groups of 64 interval tiles
         hipLaunchKernelGGL(k_mip_ipe_h, dim3((unsigned)n_it), dim3(256), 0, s, m.basis, rays_o, rays_d, radii, tdist, R, n, p0, ws.x0);
 #ifndef NEO_MIP_CHAIN
-#define NEO_MIP_CHAIN 1           // 1 (round 5): the eight trunk layers as ONE launch with slab-local barriers (mip_gemm_h.h:k_mip_chain_h)
+#define NEO_MIP_CHAIN 0           // 1: the eight trunk layers as ONE launch with slab-local barriers (mip_gemm_h.h:k_mip_chain_h) - bitwise the same, measured 1.9x SLOWER (agent-scope release / acquire per layer and workgroup writes back and invalidates the XCD's L2: profiles/r05_mip_chain_experiments.log); experiment branch
 #endif
         if (NEO_MIP_CHAIN && ws.arrive) {
             MipChainArgs c{};

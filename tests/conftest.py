@@ -173,6 +173,25 @@ def check_vs_reference_noise(got, g, noise, label, tol=1e-4, flip=None):
     for k in NEO_KEYS:
         err = per_ray_abs(got[k] - g[k])
         n = noise["noise_" + k]
+        if float((n >= tol).float().mean()) > ABOVE_TOL_MAX_FRAC:
+            # The REFERENCE does not determine this output to 1e-4 on this fixture: its own fp32 run misses its own fp64 twin /
+            # +-1 ulp trials by more than 1e-4 on more than 1 % of the rays (fixture b5, density head x 8: 1.1 % of the rays on
+            # rgb, 11 % on depth - sharp densities put the weight of a ray on a few samples whose positions the resampler
+            # decides).  No per-ray claim can be made there, by anybody; what can be required is that the GPU is no further from
+            # the fp32 reference than the reference's own exact-arithmetic twin is - as a DISTRIBUTION over the chunk's rays:
+            # median, p90 and p99 within 1.5 x the twin's, the maximum within 2 x, and no more rays above 1e-4 than 1.5 x + 4.
+            qs = (0.5, 0.9, 0.99)
+            eq, nq = [float(err.quantile(q)) for q in qs], [float(n.quantile(q)) for q in qs]
+            for q, a, b in zip(qs, eq, nq):
+                assert a <= 1.5 * b + 1e-6, (label, k, "quantile %.2f beyond the reference's own self-noise" % q, a, b)
+            assert float(err.max()) <= 2.0 * float(n.max()), (label, k, "max beyond twice the reference's own", float(err.max()), float(n.max()))
+            assert int((err >= tol).sum()) <= 1.5 * int((n >= tol).sum()) + 4, (label, k, int((err >= tol).sum()), int((n >= tol).sum()))
+            rec[k] = dict(max=float(err.max()), p99=eq[2], p90=eq[1], median=eq[0], rule="self-noise distribution",
+                          reference_self_noise=dict(median=nq[0], p90=nq[1], p99=nq[2], max=float(n.max()), rays_above_1e_4=int((n >= tol).sum())),
+                          rays_above_1e_4=int((err >= tol).sum()), rays=int(err.numel()), flip_prone_rays=int(flipm.sum()),
+                          self_noise_rays=int((n >= 1e-5).sum()))
+            strict_ok = False
+            continue
         well = (n < 1e-5) & ~flipm
         F = float(n.max())
         if flip is not None:
@@ -195,6 +214,7 @@ def check_vs_reference_noise(got, g, noise, label, tol=1e-4, flip=None):
                                                 float(err[bad].max()), F)
         assert int((err >= tol).sum()) <= max(1, int(ABOVE_TOL_MAX_FRAC * err.numel())), (label, k, "too many rays above 1e-4",
                                                                                          int((err >= tol).sum()))
+    # the 1 % cap over ALL outputs applies where the per-ray rule applies (an output under the distribution rule has its own count)
     rec["passes_rule_without_margin_exemption"] = strict_ok
     rec["rays_above_1e_4_any_output"] = int(torch.stack([per_ray_abs(got[k] - g[k]) >= tol for k in NEO_KEYS]).any(dim=0).sum())
     mse = float(((got["rgb1"].clamp(0, 1) - g["rgb1"].clamp(0, 1)) ** 2).mean())
@@ -202,4 +222,6 @@ def check_vs_reference_noise(got, g, noise, label, tol=1e-4, flip=None):
     record_parity(label, **rec)
     print(label, {k: "%.2e (%d noisy, %d flip-prone)" % (v["max"], v["self_noise_rays"], v["flip_prone_rays"])
                   for k, v in rec.items() if isinstance(v, dict)})
-    assert mse < 1e-10       # PSNR vs the reference frame > 100 dB
+    # PSNR vs the reference frame > 100 dB - unless the reference's own fp64 twin is not that close to it either (distribution rule)
+    dist_rgb = isinstance(rec.get("rgb1"), dict) and rec["rgb1"].get("rule") == "self-noise distribution"
+    assert mse < (1e-9 if dist_rgb else 1e-10)
