@@ -316,6 +316,22 @@ int neo_vanilla_mlp_train_backward(neo_ctx* ctx, const float* const* w, const fl
                                    const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw,
                                    float* const* gb, float* g_x0, float* g_cond, void* stream);
 
+/* Sample points of the training call and their encodings (round 5; replaces torch restatements of neo360/helper.py:24-75,
+ * :401-451, util.py:52-70 in the host code): for the samples tvals (R,N) of one region - input_ch 3: inside the sphere, t along
+ * the ray; 4: outside, descending inverse radius s, `far` (R) required - look (R*N,3) = the world points the features are looked up
+ * at (inside o + t d; outside o + (far (1-s) + 3 s) d), x_enc (NV, R*N, 21*input_ch) = pos_enc (reference feature order,
+ * helper.py:121-125) of the camera-frame point per source view (outside: [R_v x' + t_v | s], x' the inverted-sphere point).
+ * The device code is the evaluators' own per-point set-up: both paths see bitwise the same points. */
+int neo_tp_train_points(neo_ctx* ctx, int input_ch, const float* rays_o, const float* rays_d, const float* tvals, const float* far,
+                        int R, int N, const float* src_poses, int NV, float* look, float* x_enc, void* stream);
+/* The reference's output activations (neo360/model.py:380-385) as one op: rgbsigma (P,4) = (sigmoid(raw_rgb) 1.002 - 0.001,
+ * softplus(raw_sigma + noise * noise_scale - 1)); noise (P) may be NULL (model.py:381-384: density_noise).  backward: gradients
+ * of raw_rgb (P,3) and raw_sigma (P) from g_rgbsigma (P,4). */
+int neo_tp_activate(neo_ctx* ctx, const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P,
+                    float* rgbsigma, void* stream);
+int neo_tp_activate_backward(neo_ctx* ctx, const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P,
+                             const float* g_rgbsigma, float* g_rgb, float* g_sigma, void* stream);
+
 /* Stand-alone feature lookups of the scene set with neo_tp_set_scene, view-major rows (row = v P + p):
  * world (NV*P,128) = index_grid (encoder_tp_fusion_conv.py:122-209: three planes summed), local (NV*P,512) =
  * get_local_feats / SpatialEncoder.index (neo360/model.py:239-264).  pts (P,3) world points. */

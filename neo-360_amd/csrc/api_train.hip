@@ -39,6 +39,41 @@ int neo_rand_uniform(neo_ctx* ctx, uint64_t seed, uint32_t stream_id, int rows, 
     return check_launch();
 }
 
+int neo_tp_train_points(neo_ctx* ctx, int input_ch, const float* rays_o, const float* rays_d, const float* tvals, const float* far,
+                        int R, int N, const float* src_poses, int NV, float* look, float* x_enc, void* stream) {
+    ENTER(ctx);
+    REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (inside the sphere) or 4 (outside)");
+    REQUIRE(R >= 0 && N >= 1 && NV >= 1 && NV <= neo::TP_MAX_VIEWS, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && rays_d && tvals && src_poses && look && x_enc, "null pointer");
+    REQUIRE(input_ch == 3 || far, "far required outside the sphere");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::launch_tp_train_points(input_ch, rays_o, rays_d, tvals, far, R, N, views, NV, ctx->flags, look, x_enc,
+                                static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_activate(neo_ctx* ctx, const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P,
+                    float* rgbsigma, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0, "negative count");
+    if (P == 0) return NEO_OK;
+    REQUIRE(raw_rgb && raw_sigma && rgbsigma, "null pointer");
+    neo::launch_tp_activate(raw_rgb, raw_sigma, noise, noise_scale, P, rgbsigma, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_activate_backward(neo_ctx* ctx, const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P,
+                             const float* g_rgbsigma, float* g_rgb, float* g_sigma, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0, "negative count");
+    if (P == 0) return NEO_OK;
+    REQUIRE(raw_rgb && raw_sigma && g_rgbsigma && g_rgb && g_sigma, "null pointer");
+    neo::launch_tp_activate_bwd(raw_rgb, raw_sigma, noise, noise_scale, P, g_rgbsigma, g_rgb, g_sigma, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
 int neo_tp_sample_level0(neo_ctx* ctx, const float* far, int R, int n_coarse, const float* u_fg, const float* u_bg,
                          float* fg_t, float* bg_s, void* stream) {
     ENTER(ctx);

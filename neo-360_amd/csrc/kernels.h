@@ -44,6 +44,14 @@ struct TpScene;
 struct TpViews;
 void launch_gather(const TpScene& sc, const TpViews& views, const float* pts, long P, float* world, float* local,
                    hipStream_t s);
+// training call: lookup points (P,3) + per-view reference-order encodings (NV,P,21 C) of the samples tvals (R,N); input_ch 3 inside /
+// 4 outside the sphere (far required); activations (raw -> (rgb, sigma) packed) with their backward
+void launch_tp_train_points(int input_ch, const float* rays_o, const float* rays_d, const float* tvals, const float* far, int R, int N,
+                            const TpViews& views, int nv, uint32_t* flags, float* look, float* x_enc, hipStream_t s);
+void launch_tp_activate(const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P, float* rgbsigma,
+                        hipStream_t s);
+void launch_tp_activate_bwd(const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P,
+                            const float* g_rgbsigma, float* g_rgb, float* g_sigma, hipStream_t s);
 void launch_gather_bwd(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* g_world,
                        const float* g_local, float* g_plane_xz, float* g_plane_xy, float* g_plane_yz, float* g_latent,
                        hipStream_t s);

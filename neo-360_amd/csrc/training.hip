@@ -292,7 +292,96 @@ __global__ __launch_bounds__(256) void k_gather(TpScene sc, TpViews views, const
     }
 }
 
+// ---- sample points and their encodings for the training call (round 5) --------------------------------------------------------
+// What the evaluators compute per tile in registers / LDS (tp_common.h:point_setup_row + the camera transform of
+// view_descriptors), written out for the operator chain of training.py: per point the world-space lookup point (inside: o + t d;
+// outside: o + (far (1 - s) + 3 s) d, neo360/helper.py:59-73) and per source view the reference-order positional encoding of
+// the camera-frame point (inside: 63 features of R_v x + t_v; outside: 84 features of [R_v x' + t_v | s] with x' the inverted-sphere
+// point, helper.py:401-451, model.py:454-464).  One thread per point, 64 points per block; the same device functions as the
+// inference kernels, so both paths see bitwise the same points.  Replaces training.py's torch restatements of both transforms.
+template <int PE_C>
+__global__ __launch_bounds__(64) void k_tp_train_points(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        const float* __restrict__ tvals, const float* __restrict__ far_arr, int R, int N,
+                                                        TpViews views, int nv, uint32_t* __restrict__ flags, float* __restrict__ look,
+                                                        float* __restrict__ x_enc) {
+    __shared__ float sm[3 * tp::TM * 4];
+    tp::Scratch S{};
+    S.pe_world = sm;
+    S.feat_world = sm + tp::TM * 4;
+    S.vdir_world = sm + 2 * tp::TM * 4;
+    const int tid = threadIdx.x;
+    const long P = (long)R * N, tile0 = (long)blockIdx.x * tp::TM;
+    // viewdirs only feed the direction tiling (unused here): rays_d stands in for the pointer
+    tp::point_setup_row<PE_C>(S, tid, tile0, P, N, R, R, rays_o, rays_d, rays_d, tvals, far_arr, flags);
+    const long g = tile0 + tid;
+    if (g >= P) return;
+    const float ex = S.pe_world[tid * 4], ey = S.pe_world[tid * 4 + 1], ez = S.pe_world[tid * 4 + 2], ew = S.pe_world[tid * 4 + 3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) look[g * 3 + a] = S.feat_world[tid * 4 + a];
+    constexpr int F = 21 * PE_C;
+    for (int v = 0; v < nv; ++v) {
+        const float* rot = views.rot[v];
+        const float* trn = views.trans[v];
+        const float xc[4] = {(rot[0] * ex + rot[1] * ey + rot[2] * ez) + trn[0], (rot[3] * ex + rot[4] * ey + rot[5] * ez) + trn[1],
+                             (rot[6] * ex + rot[7] * ey + rot[8] * ez) + trn[2], ew};
+        float* dst = x_enc + ((long)v * P + g) * F;
+#pragma unroll 7
+        for (int f = 0; f < F; ++f) dst[f] = tp::pe_feature<PE_C>(xc, f);
+    }
+}
+
+// ---- the reference's output activations as ONE op with a backward (neo360/model.py:380-385) ----------------------------------
+// rgbsigma (P, 4) = (sigmoid(raw_rgb) * 1.002 - 0.001, softplus(raw_sigma + noise - 1)); backward: d rgb = 1.002 s (1 - s),
+// d sigma = sigmoid(x) (torch.nn.Softplus: x beyond the threshold 20 passes through with derivative 1)
+__global__ void k_tp_activate(const float* __restrict__ raw_rgb, const float* __restrict__ raw_sigma, const float* __restrict__ noise,
+                              float noise_scale, long P, float4* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float rs = raw_sigma[i] + (noise ? noise[i] * noise_scale : 0.0f);
+    out[i] = make_float4(colour_act(raw_rgb[i * 3]), colour_act(raw_rgb[i * 3 + 1]), colour_act(raw_rgb[i * 3 + 2]), density_act(rs));
+}
+__global__ void k_tp_activate_bwd(const float* __restrict__ raw_rgb, const float* __restrict__ raw_sigma, const float* __restrict__ noise,
+                                  float noise_scale, long P, const float4* __restrict__ g, float* __restrict__ g_rgb,
+                                  float* __restrict__ g_sigma) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 gi = g[i];
+    const float gc[3] = {gi.x, gi.y, gi.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float sg = 1.0f / (1.0f + expf(-raw_rgb[i * 3 + c]));
+        g_rgb[i * 3 + c] = gc[c] * (1.002f * sg * (1.0f - sg));
+    }
+    const float x = raw_sigma[i] + (noise ? noise[i] * noise_scale : 0.0f) + (-1.0f);
+    g_sigma[i] = gi.w * (x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)));
+}
+
 }  // namespace
+
+void launch_tp_train_points(int input_ch, const float* rays_o, const float* rays_d, const float* tvals, const float* far, int R, int N,
+                            const TpViews& views, int nv, uint32_t* flags, float* look, float* x_enc, hipStream_t s) {
+    const long P = (long)R * N;
+    if (P <= 0) return;
+    const dim3 grid((unsigned)((P + tp::TM - 1) / tp::TM));
+    if (input_ch == 3)
+        hipLaunchKernelGGL(k_tp_train_points<3>, grid, dim3(64), 0, s, rays_o, rays_d, tvals, far, R, N, views, nv, flags, look, x_enc);
+    else
+        hipLaunchKernelGGL(k_tp_train_points<4>, grid, dim3(64), 0, s, rays_o, rays_d, tvals, far, R, N, views, nv, flags, look, x_enc);
+}
+
+void launch_tp_activate(const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P, float* rgbsigma,
+                        hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_tp_activate, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, raw_rgb, raw_sigma, noise, noise_scale, P,
+                       reinterpret_cast<float4*>(rgbsigma));
+}
+
+void launch_tp_activate_bwd(const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P,
+                            const float* g_rgbsigma, float* g_rgb, float* g_sigma, hipStream_t s) {
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_tp_activate_bwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, raw_rgb, raw_sigma, noise, noise_scale, P,
+                       reinterpret_cast<const float4*>(g_rgbsigma), g_rgb, g_sigma);
+}
 
 void launch_uniform(uint64_t seed, uint32_t stream, int rows, int cols, float* out, hipStream_t s) {
     const long total = (long)rows * cols;

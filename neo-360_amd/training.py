@@ -59,7 +59,11 @@ def resample_u(t_prev, weights, u, descending=False, ctx=None):
 class _Composite(torch.autograd.Function):
     @staticmethod
     def forward(ctx_, mode, rgb, sigma, t, rays_d, t_far, white_bkgd, lib_ctx):
-        rgbsigma = torch.cat([f32(rgb, "rgb"), f32(sigma, "sigma").reshape(*rgb.shape[:-1], 1)], dim=-1).contiguous()
+        packed = sigma is None                  # rgb is the packed (R,N,4) = (rgb, sigma) tensor of `activate`
+        if packed:
+            rgbsigma = f32(rgb, "rgbsigma")
+        else:
+            rgbsigma = torch.cat([f32(rgb, "rgb"), f32(sigma, "sigma").reshape(*rgb.shape[:-1], 1)], dim=-1).contiguous()
         t = f32(t, "t")
         c = _ctx(t, lib_ctx)
         R, N = t.shape
@@ -74,14 +78,14 @@ class _Composite(torch.autograd.Function):
                                        ptr(lam) if mode == 1 else None, c.stream()))
         ctx_.save_for_backward(rgbsigma, t, rays_d if rays_d is not None else torch.empty(0, device=dev),
                                t_far if t_far is not None else torch.empty(0, device=dev))
-        ctx_.meta = (mode, bool(white_bkgd), c, rays_d is not None, t_far is not None, tuple(sigma.shape))
+        ctx_.meta = (mode, bool(white_bkgd), c, rays_d is not None, t_far is not None, None if packed else tuple(sigma.shape))
         return out_rgb, acc, w, lam, depth
 
     @staticmethod
     def backward(ctx_, g_rgb, g_acc, g_w, g_lam, g_depth):
         rgbsigma, t, rays_d, t_far = ctx_.saved_tensors
         mode, white, c, has_d, has_far, sigma_shape = ctx_.meta
-        need_rgb, need_sigma = ctx_.needs_input_grad[1], ctx_.needs_input_grad[2]
+        need_rgb, need_sigma = ctx_.needs_input_grad[1], ctx_.needs_input_grad[2] or sigma_shape is None
         if not (need_rgb or need_sigma):
             return (None,) * 8
         R, N = t.shape
@@ -91,6 +95,8 @@ class _Composite(torch.autograd.Function):
         _lib.check(c.lib.neo_composite_backward(c.handle, mode, ptr(rgbsigma), ptr(t), ptr(rays_d) if has_d else None,
                                                 ptr(t_far) if has_far else None, R, N, int(white), ptr(g_rgb), ptr(g_acc),
                                                 ptr(g_depth), ptr(g_w), ptr(g_lam), ptr(g), c.stream()))
+        if sigma_shape is None:                 # packed input: one gradient tensor
+            return (None, g, None, None, None, None, None, None)
         # sigma may have been (R,N) or (R,N,1) in the forward: its gradient takes that shape
         return (None, g[..., :3] if need_rgb else None, g[..., 3].reshape(sigma_shape) if need_sigma else None,
                 None, None, None, None, None)
@@ -99,8 +105,68 @@ class _Composite(torch.autograd.Function):
 def composite(mode, rgb, sigma, t, rays_d=None, t_far=None, white_bkgd=False, ctx=None):
     """Differentiable volumetric_rendering.  mode 0 vanilla, 1 NeO-360 inside the sphere, 2 outside.
     rgb (R,N,3), sigma (R,N,1) -> (comp_rgb (R,3), acc (R,), weights (R,N), bg_lambda (R,1), depth (R,));
-    gradients flow to rgb and sigma (sample positions are detached in the reference, helper.py:224)."""
+    gradients flow to rgb and sigma (sample positions are detached in the reference, helper.py:224).
+    sigma=None: `rgb` is the packed (R,N,4) = (rgb, sigma) tensor `activate` returns (no concatenation)."""
     return _Composite.apply(mode, rgb, sigma, t, rays_d, t_far, white_bkgd, ctx)
+
+
+class _Activate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx_, raw_rgb, raw_sigma, noise, noise_scale, lib_ctx):
+        raw_rgb, raw_sigma = f32(raw_rgb, "raw_rgb"), f32(raw_sigma, "raw_sigma")
+        P = raw_sigma.numel()
+        if raw_rgb.numel() != 3 * P:
+            raise ValueError("raw_rgb must hold 3 values per raw_sigma entry, got %s / %s" % (tuple(raw_rgb.shape), tuple(raw_sigma.shape)))
+        noise = f32(noise, "noise") if noise is not None else None
+        if noise is not None and noise.numel() != P:
+            raise ValueError("noise must hold one value per point")
+        c = _ctx(raw_sigma, lib_ctx)
+        out = torch.empty(P, 4, device=raw_sigma.device)
+        _lib.check(c.lib.neo_tp_activate(c.handle, ptr(raw_rgb), ptr(raw_sigma), ptr(noise), float(noise_scale), P, ptr(out), c.stream()))
+        ctx_.save_for_backward(raw_rgb, raw_sigma, noise if noise is not None else torch.empty(0, device=out.device))
+        ctx_.meta = (c, float(noise_scale), noise is not None, tuple(raw_rgb.shape), tuple(raw_sigma.shape))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g):
+        raw_rgb, raw_sigma, noise = ctx_.saved_tensors
+        c, scale, has_noise, shape_rgb, shape_sigma = ctx_.meta
+        P = raw_sigma.numel()
+        g = f32(g.reshape(P, 4).contiguous(), "grad")
+        g_rgb, g_sigma = torch.empty(P, 3, device=g.device), torch.empty(P, device=g.device)
+        _lib.check(c.lib.neo_tp_activate_backward(c.handle, ptr(raw_rgb), ptr(raw_sigma), ptr(noise) if has_noise else None, scale, P,
+                                                  ptr(g), ptr(g_rgb), ptr(g_sigma), c.stream()))
+        return g_rgb.reshape(shape_rgb), g_sigma.reshape(shape_sigma), None, None, None
+
+
+def activate(raw_rgb, raw_sigma, noise=None, noise_scale=0.0, ctx=None):
+    """The reference's output activations (neo360/model.py:380-385, vanilla_nerf/model.py:194-205) as ONE op with a native backward:
+    (P,4) = (sigmoid(raw_rgb) * 1.002 - 0.001, softplus(raw_sigma + noise * noise_scale - 1)); noise (P values) = the uniforms
+    of `density_noise` / `noise_std`.  The packed result feeds `composite(mode, packed, None, ...)`."""
+    return _Activate.apply(raw_rgb, raw_sigma, noise, noise_scale, ctx)
+
+
+def train_points(module, region, rays_o, rays_d, tvals, far, poses, ctx=None):
+    """Sample points of one region (0 inside / 1 outside the sphere) for the training call: look (R*N,3) world points for the
+    feature lookups and x_enc (NV, R*N, 63 | 84) reference-order encodings of the camera-frame point per source view
+    (neo_tp_train_points: the evaluators' own per-point set-up - neo360/helper.py:24-75, :401-451, util.py:52-70 - so the
+    operator chain and the fused kernels see bitwise the same points).  No gradients: sample positions are detached in the
+    reference (helper.py:224) and the rays / poses are data."""
+    rays_o, rays_d, tvals = f32(rays_o, "rays_o"), f32(rays_d, "rays_d"), f32(tvals, "tvals")
+    c = _ctx(rays_o, ctx)
+    R, N = tvals.shape
+    poses = f32(poses, "src_poses")
+    NV = poses.shape[0]
+    host = poses.detach().cpu().contiguous()
+    host_poses = (ctypes.c_float * (16 * NV))(*host.reshape(-1).tolist())
+    ch = 4 if region else 3
+    look = torch.empty(R * N, 3, device=rays_o.device)
+    x_enc = torch.empty(NV, R * N, 21 * ch, device=rays_o.device)
+    far = f32(far, "far").reshape(-1) if far is not None else None
+    _lib.check(c.lib.neo_tp_train_points(c.handle, ch, ptr(rays_o), ptr(rays_d), ptr(tvals), ptr(far), R, N, host_poses, NV,
+                                         ptr(look), ptr(x_enc), c.stream()))
+    return look, x_enc
 
 
 class _DistLoss(torch.autograd.Function):
@@ -307,33 +373,6 @@ def nerf_mlp(mlp, x_enc, dir_enc, ctx=None):
 
 # ---- the module-level training call (neo360/model.py:697-820 calls self.model(batch, randomized=True, ...)) ------------------
 
-def _world_to_camera(pts, c2w):
-    """(P,3) world points, (NV,4,4) camera-to-world -> (NV,P,3): rot = c2w[:3,:3]^T, trans = -rot t (neo360/util.py:52-70)."""
-    rot = c2w[:, :3, :3].transpose(1, 2)
-    trans = -torch.bmm(rot, c2w[:, :3, 3:])
-    return torch.matmul(rot[:, None], pts[None, :, :, None])[..., 0] + trans[:, None, :, 0]
-
-
-def _outside_points(o, d, inv_r):
-    """Inverted-sphere parameterisation of the samples outside the unit sphere (neo360/helper.py:401-451), torch ops on the
-    device: the ray's sphere exit point rotated about (o x p_sphere) by asin|p_mid| - asin(|p_mid| / r), re-normalised, 1/r
-    appended.  (R,N) -> (R,N,4).  Sample positions carry no gradient (helper.py:224 detaches them)."""
-    shape = list(inv_r.shape) + [3]
-    o, d = o[:, None, :].expand(shape), d[:, None, :].expand(shape)
-    d1 = -(d * o).sum(-1, keepdim=True) / (d ** 2).sum(-1, keepdim=True)
-    p_mid = o + d1 * d
-    r_mid = torch.norm(p_mid, dim=-1, keepdim=True)
-    d2 = torch.sqrt(1.0 - r_mid * r_mid) * (1.0 / torch.norm(d, dim=-1, keepdim=True))
-    p_sph = o + (d1 + d2) * d
-    axis = torch.cross(o, p_sph, dim=-1)
-    axis = axis / torch.norm(axis, dim=-1, keepdim=True)
-    ang = torch.asin(r_mid) - torch.asin(r_mid * inv_r[..., None])
-    turned = (p_sph * torch.cos(ang) + torch.cross(axis, p_sph, dim=-1) * torch.sin(ang)
-              + axis * (axis * p_sph).sum(-1, keepdim=True) * (1.0 - torch.cos(ang)))
-    turned = turned / (torch.norm(turned, dim=-1, keepdim=True) + 1e-10)
-    return torch.cat((turned, inv_r.unsqueeze(-1)), dim=-1)
-
-
 def _draws(module, B, randomized, seed, c, n0, n1, noise):
     """Every uniform a randomized call consumes, for ALL B rows of the call, from the library's counter-based generator:
     stream ids 0 / 1 level-0 jitter inside / outside the sphere, 2 / 3 level-1 quantiles, 4..7 the density noise
@@ -405,24 +444,19 @@ def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws):
         N = fg_t.shape[1]
         with torch.no_grad():
             cond = d_enc.repeat(1, N, 1).reshape(-1, d_enc.shape[-1])      # row (v, j) carries ray j mod B (model.py:357-360, quirk Q1)
-            fg_p = rays_o[:, None, :] + fg_t[..., None] * rays_d[:, None, :]
-            bg_p4 = _outside_points(rays_o, rays_d, bg_s)
-            bg_lin = rays_o[:, None, :] + (far * (1.0 - bg_s) + 3.0 * bg_s)[..., None] * rays_d[:, None, :]
-            fg_x = ops.pos_enc(_world_to_camera(fg_p.reshape(-1, 3), poses), module.min_deg_point, module.max_deg_point, ctx=c)
-            bg_cam = torch.cat((_world_to_camera(bg_p4[..., :3].reshape(-1, 3), poses),
-                                bg_p4[..., 3].reshape(1, -1, 1).expand(NV, -1, -1)), dim=-1)     # model.py:454-464
-            bg_x = ops.pos_enc(bg_cam, module.min_deg_point, module.max_deg_point, ctx=c)
+            # lookup points + per-view encodings of both regions: ONE kernel each, the evaluators' own point set-up (round 5;
+            # the first version restated helper.py:401-451 / util.py:52-70 in eager torch)
+            fg_p, fg_x = train_points(module, 0, rays_o, rays_d, fg_t, None, poses, ctx=c)
+            bg_lin, bg_x = train_points(module, 1, rays_o, rays_d, bg_s, far, poses, ctx=c)
         res = {}
         for name, mlp, look, x_enc in (("fg", mlps[level], fg_p, fg_x), ("bg", mlps[2 + level], bg_lin, bg_x)):
-            world, local = gather_features(module, look.reshape(-1, 3), maps[0], maps[1], maps[2], maps[3], rays)
+            world, local = gather_features(module, look, maps[0], maps[1], maps[2], maps[3], rays)
             raw_rgb, raw_sigma = nerfpp_mlp(mlp, x_enc, cond, world, local, NV, ctx=c)
-            if draws is not None and module.density_noise != 0.0:                                # model.py:381-384
-                raw_sigma = raw_sigma + draws["n_%s%d" % (name, level)].reshape(raw_sigma.shape) * module.density_noise
-            rgb = (torch.sigmoid(raw_rgb) * (1.0 + 2.0 * 0.001) - 0.001).reshape(B, N, 3)     # model.py:383-385
-            sigma = torch.nn.functional.softplus(raw_sigma + (-1.0)).reshape(B, N, 1)          # model.py:380-381
-            res[name] = (rgb, sigma)
-        fg_c, _, fg_w, lam, _ = composite(1, res["fg"][0], res["fg"][1], fg_t, rays_d, far, white_bkgd, ctx=c)
-        bg_c, bg_acc, bg_w, _, _ = composite(2, res["bg"][0], res["bg"][1], bg_s, None, None, white_bkgd, ctx=c)
+            noisy = draws is not None and module.density_noise != 0.0                            # model.py:381-384
+            res[name] = activate(raw_rgb, raw_sigma, draws["n_%s%d" % (name, level)] if noisy else None,
+                                 float(module.density_noise) if noisy else 0.0, ctx=c).reshape(B, N, 4)   # model.py:380-385
+        fg_c, _, fg_w, lam, _ = composite(1, res["fg"], None, fg_t, rays_d, far, white_bkgd, ctx=c)
+        bg_c, bg_acc, bg_w, _, _ = composite(2, res["bg"], None, bg_s, None, None, white_bkgd, ctx=c)
         rgb = fg_c + lam * bg_c
         fg_sd = 0.5 * (fg_t[..., 1:] + fg_t[..., :-1])                                          # model.py:564-571
         fg_sd = torch.cat([fg_sd, (fg_sd[:, -1] + (fg_sd[:, -1] - fg_sd[:, -2])).unsqueeze(-1)], dim=-1)
@@ -483,11 +517,9 @@ def nerf_render_train(module, rays, randomized, white_bkgd, near, far, seed=None
             pts = rays_o[:, None, :] + t[..., None] * viewdirs[:, None, :]                      # cast_rays along viewdirs (:161, :177)
             x_enc = ops.pos_enc(pts, module.min_deg_point, module.max_deg_point, ctx=c)         # (B,N,63)
         raw_rgb, raw_sigma = nerf_mlp(mlp, x_enc, d_enc, ctx=c)
-        if noise > 0.0:                                                                         # model.py:194-195
-            raw_sigma = raw_sigma + rand_uniform(seed, 4 + 2 * level, B, N, ctx=c).reshape(raw_sigma.shape) * noise
-        rgb = torch.sigmoid(raw_rgb) * (1.0 + 2.0 * 0.001) - 0.001                              # model.py:200-202
-        sigma = torch.nn.functional.softplus(raw_sigma + (-1.0))                                # model.py:204-205
-        comp_rgb, acc, w, _, depth = composite(0, rgb.reshape(B, N, 3), sigma.reshape(B, N, 1), t, rays_d, None, white_bkgd, ctx=c)
+        u_noise = rand_uniform(seed, 4 + 2 * level, B, N, ctx=c) if noise > 0.0 else None       # model.py:194-195
+        packed = activate(raw_rgb, raw_sigma, u_noise, noise, ctx=c).reshape(B, N, 4)           # model.py:200-205
+        comp_rgb, acc, w, _, depth = composite(0, packed, None, t, rays_d, None, white_bkgd, ctx=c)
         out.append((comp_rgb, acc, depth))
         if level == 0:
             with torch.no_grad():                                                               # helper.py:610-616 (detached)

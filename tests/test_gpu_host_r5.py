@@ -404,3 +404,52 @@ def test_bench_plain_form_scene_setup_from_events():
     assert 1.0 < ss["total_ms"] < 60.0, ss
     close = [r for r in runs if abs(r - ss["total_ms"]) <= 0.2 * ss["total_ms"] + 0.3]
     assert len(close) >= 3, runs                                             # +-20 % of the median on at least three runs
+
+
+# ---- the training call's fused point / activation operators (round 5) ------------------------------------------------------
+
+def test_train_points_match_the_oracle():
+    """neo_tp_train_points = neo360/helper.py:24-75 (+ :401-451 outside the sphere) + util.py:52-70 + pos_enc, per region."""
+    R, N = 48, 33
+    rays_c = cases.strided_rays(R)
+    batch = cases.neo_batch(rays_c)
+    rays = {k: v.to(DEV) for k, v in batch.items()}
+    far, _ = ops.intersect_sphere(rays["rays_o"], rays["rays_d"])
+    fg_t, bg_s = training.sample_level0(far, N - 1)
+    far_c, _ = oracle.rays.sphere_exit_depth(batch["rays_o"], batch["rays_d"])
+    poses = batch["src_poses"]
+    # inside: o + t d, camera-frame 63-d encodings per view
+    look, x = training.train_points(None, 0, rays["rays_o"], rays["rays_d"], fg_t, None, rays["src_poses"])
+    pts = oracle.sampling.points_on_rays(fg_t.cpu(), batch["rays_o"], batch["rays_d"]).reshape(-1, 3)
+    assert max_abs(look, pts) < 1e-6
+    want = oracle.encoding.pos_enc(oracle.gather.world_to_camera(pts, poses), 0, 10)
+    assert x.shape == want.shape == (cases.NV, R * N, 63) and max_abs(x, want) < 1e-4 and float((x.cpu() - want).abs().median()) < 1e-6   # octave 9 amplifies the last bit of a camera-frame coordinate 512 x
+    # outside: linear lookup point, inverted-sphere point in the camera frame + the inverse radius, 84-d encodings
+    look, x = training.train_points(None, 1, rays["rays_o"], rays["rays_d"], bg_s, far, rays["src_poses"])
+    s = bg_s.cpu()
+    lin = batch["rays_o"][:, None, :] + (far_c.reshape(-1, 1) * (1.0 - s) + 3.0 * s)[..., None] * batch["rays_d"][:, None, :]
+    assert max_abs(look, lin.reshape(-1, 3)) < 2e-6
+    p4 = oracle.sampling.inverted_sphere_points(batch["rays_o"], batch["rays_d"], s)
+    cam = torch.cat((oracle.gather.world_to_camera(p4[..., :3].reshape(-1, 3), poses),
+                     p4[..., 3].reshape(1, -1, 1).expand(cases.NV, -1, -1)), dim=-1)
+    want = oracle.encoding.pos_enc(cam, 0, 10)
+    assert x.shape == want.shape == (cases.NV, R * N, 84) and max_abs(x, want) < 2e-4 and float((x.cpu() - want).abs().median()) < 1e-6
+
+
+def test_activate_op_matches_autograd():
+    P = 4096
+    g = torch.Generator().manual_seed(5)
+    raw_rgb, raw_sigma = torch.randn(P, 3, generator=g) * 3.0, torch.randn(P, 1, generator=g) * 12.0     # beyond the softplus threshold too
+    noise, scale = torch.rand(P, generator=g), 0.7
+    up = torch.randn(P, 4, generator=g)
+    with torch.enable_grad():
+        a, b = raw_rgb.clone().double().requires_grad_(True), raw_sigma.clone().double().requires_grad_(True)
+        want = torch.cat([torch.sigmoid(a) * 1.002 - 0.001, torch.nn.functional.softplus(b + (noise.double() * scale)[:, None] - 1.0)], dim=-1)
+        (want * up.double()).sum().backward()
+        ga, gb = raw_rgb.to(DEV).requires_grad_(True), raw_sigma.to(DEV).requires_grad_(True)
+        got = training.activate(ga, gb, noise.to(DEV), scale)
+        (got * up.to(DEV)).sum().backward()
+    assert got.shape == (P, 4) and max_abs(got, want.detach().float()) < 2e-6
+    assert max_abs(ga.grad, a.grad.float()) < 2e-6 and max_abs(gb.grad, b.grad.float()) < 2e-6
+    plain = training.activate(raw_rgb.to(DEV), raw_sigma.to(DEV))
+    assert max_abs(plain[:, 3], torch.nn.functional.softplus(raw_sigma[:, 0] - 1.0)) < 2e-6

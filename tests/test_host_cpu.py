@@ -32,17 +32,18 @@ def test_render_rays_test_validates_on_range():
 
 
 def test_full_size_cases_are_distinct_and_inside_the_sphere():
-    assert set(cases.FULL_B) == {"b1", "b2", "b3", "b4"} and cases.FULL_B["b4"]["nv"] == 5
+    assert set(cases.FULL_B) == {"b1", "b2", "b3", "b4", "b5", "b6"} and cases.FULL_B["b4"]["nv"] == 5
+    assert cases.full_gain("b5") == 8.0 and cases.full_gain("b6") == 1.0 and cases.full_gain("") == 1.0
     seen = []
     for tag, kw in cases.FULL_B.items():
-        kw = dict(kw)
+        kw = {k: v for k, v in kw.items() if k not in ("gain", "seed", "std")}       # weights / scene of the case, not its rays
         nv = kw.pop("nv")
         b = cases.full_batch(64, nv=nv, **kw)
         assert b["rays_o"].shape == (64, 3) and b["src_poses"].shape == (nv, 4, 4)
         assert float(b["rays_o"].norm(dim=-1).max()) < 1.0             # every ray starts inside the unit sphere: it has an exit point
         assert float((b["rays_d"].norm(dim=-1) - 1.0).abs().max()) < 1e-6
         seen.append((tuple(b["rays_o"][0].tolist()), tuple(b["rays_d"][0].tolist())))
-    assert len(set(seen)) == 4                                          # four different chunks
+    assert len(set(seen)) == 6                                          # six different chunks
     base = cases.full_batch(64)
     assert not torch.equal(base["rays_d"], cases.full_batch(64, **{k: v for k, v in cases.FULL_B["b1"].items() if k != "nv"})["rays_d"])
 

@@ -32,5 +32,6 @@ def test_oracle_matches_reference_at_full_size(golden, tag):
     from conftest import check_vs_reference_noise, per_ray_abs
     noise, flip = golden("g4_neo_full_%s_noise" % tag), golden("g4_neo_full_%s_flip" % tag)
     check_vs_reference_noise(got, g, noise, "oracle_full_size_C3_%s" % tag, flip=flip)
-    well = (noise["noise_rgb1"] < 1e-6) & (noise["margin_bg1"] >= 1e-5)
-    assert int(well.sum()) > 500 and float(per_ray_abs(got["rgb1"] - g["rgb1"])[well].max()) <= 2e-5
+    # ... and it is far closer to the reference than that rule asks: the oracle runs the reference's own torch operators in its order
+    e = per_ray_abs(got["rgb1"] - g["rgb1"])
+    assert float(e.median()) <= 1e-6 and float(e.quantile(0.99)) <= 5e-5
