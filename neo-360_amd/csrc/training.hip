@@ -292,6 +292,93 @@ __global__ __launch_bounds__(256) void k_gather(TpScene sc, TpViews views, const
     }
 }
 
+// ---- lookup backward with RUN MERGING (round 5) -----------------------------------------------------------------------------------
+// The scatter-add above issues one fp32 atomic per (row, tap, channel): 5.5e9 atomics per training step of 500 rays - 41 % of the
+// step (profiles/r05_train_step_kernel_stats.csv).  Consecutive rows are consecutive samples of one ray, and at the fine level
+// 3-6 of them fall into the SAME texel cell (profiles/r03_tile_footprint.json: 32-38 distinct plane texels among the 256 taps of 64
+// samples).  Here a 16-lane group walks 16 consecutive rows; per map and tap slot it keeps the texel it is accumulating for and
+// the running w * g sum in registers, and issues the atomics only when the texel changes (and at the end of the run): the same
+// sums, a few times fewer atomics.  The 16 rows' tap descriptors are computed once (lane c computes row c) and shared through LDS.
+constexpr int GRUN = 16;
+__global__ __launch_bounds__(256) void k_gather_bwd_runs(TpScene sc, TpViews views, const float* __restrict__ pts, long P,
+                                                        const float* __restrict__ g_world, const float* __restrict__ g_local,
+                                                        float* __restrict__ g_plane0, float* __restrict__ g_plane1,
+                                                        float* __restrict__ g_plane2, float* __restrict__ g_latent) {
+    __shared__ int s_off[16][GRUN][4][4];        // [group][row of the run][map: 0 latent, 1..3 planes][tap] texel index incl. the view's base, -1 = no weight
+    __shared__ float s_w[16][GRUN][4][4];
+    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const long rows = P * sc.nv;
+    const long row0 = ((long)blockIdx.x * 16 + grp) * GRUN;
+    {
+        const long row = row0 + c;
+        if (row < rows) {
+            const int v = (int)(row / P);
+            const long p = row - (long)v * P;
+            const float p3[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
+            const RowTaps t = row_taps(sc, views.rot[v], views.trans[v], p3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_off[grp][c][0][k] = t.loc.w[k] != 0.0f ? v * sc.Hf * sc.Wf + t.loc.off[k] : -1;
+                s_w[grp][c][0][k] = t.loc.w[k];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    s_off[grp][c][1 + j][k] = t.pl[j].w[k] != 0.0f ? v * sc.Hp * sc.Wp + t.pl[j].off[k] : -1;
+                    s_w[grp][c][1 + j][k] = t.pl[j].w[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s_off[grp][c][m][k] = -1; s_w[grp][c][m][k] = 0.0f; }
+        }
+    }
+    __syncthreads();
+    if (row0 >= rows) return;
+    float* gmap[4] = {g_latent, g_plane0, g_plane1, g_plane2};
+#pragma unroll 1
+    for (int m = 0; m < 4; ++m) {
+        const int ch = m == 0 ? 512 : 128;
+        const float* gsrc = m == 0 ? g_local : g_world;
+        const int pieces = ch / 64;                       // 16-byte pieces per lane: 8 (latent) or 2 (a plane)
+#pragma unroll 1
+        for (int q = 0; q < pieces; ++q) {
+            const int piece = c + 16 * q;
+            int cur[4] = {-1, -1, -1, -1};
+            f32x4 acc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto flush = [&](int k) {
+                if (cur[k] >= 0) {
+                    float* dst = gmap[m] + (long)cur[k] * ch + piece * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[k][e]);
+                }
+            };
+#pragma unroll 1
+            for (int r = 0; r < GRUN; ++r) {
+                if (row0 + r >= rows) break;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + (row0 + r) * ch + piece * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int o = s_off[grp][r][m][k];
+                    if (o < 0) continue;
+                    const float w = s_w[grp][r][m][k];
+                    if (o != cur[k]) {
+                        flush(k);
+                        cur[k] = o;
+                        acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[k][e] = __builtin_fmaf(w, g[e], acc[k][e]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) flush(k);
+        }
+    }
+}
+
 // ---- sample points and their encodings for the training call (round 5) --------------------------------------------------------
 // What the evaluators compute per tile in registers / LDS (tp_common.h:point_setup_row + the camera transform of
 // view_descriptors), written out for the operator chain of training.py: per point the world-space lookup point (inside: o + t d;
@@ -428,8 +515,15 @@ void launch_gather_bwd(const TpScene& sc, const TpViews& views, const float* pts
                        hipStream_t s) {
     const long rows = P * sc.nv;
     if (rows <= 0) return;
-    hipLaunchKernelGGL((k_gather<true>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, sc, views, pts, P,
-                       const_cast<float*>(g_world), const_cast<float*>(g_local), g_plane_xz, g_plane_xy, g_plane_yz, g_latent);
+#ifndef NEO_GATHER_BWD_RUNS
+#define NEO_GATHER_BWD_RUNS 1          // 1 (round 5): atomics merged over runs of consecutive rows in one texel cell (k_gather_bwd_runs); 0: one atomic per (row, tap, channel)
+#endif
+    if (NEO_GATHER_BWD_RUNS)
+        hipLaunchKernelGGL(k_gather_bwd_runs, dim3((unsigned)((rows + 16 * GRUN - 1) / (16 * GRUN))), dim3(256), 0, s, sc, views, pts, P,
+                           g_world, g_local, g_plane_xz, g_plane_xy, g_plane_yz, g_latent);
+    else
+        hipLaunchKernelGGL((k_gather<true>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, sc, views, pts, P,
+                           const_cast<float*>(g_world), const_cast<float*>(g_local), g_plane_xz, g_plane_xy, g_plane_yz, g_latent);
 }
 
 }  // namespace neo
