@@ -116,8 +116,10 @@ _SCENE_CACHE = {}
 
 # what limits each split evaluator (PMC summaries + power envelope; `bound` stays the priced roofline)
 LIMITER = {
-    "neo360": "vector-ALU issue (gather blends, encodings, layer epilogues: ~7-8 VALU per MFMA against ~6 that issue for free) "
-              "+ socket power limit (the clock settles near 2.1-2.2 GHz at ~1.33 kW of 1.4 kW); matrix pipe ~41 % busy, HBM < 5 %",
+    "neo360": "socket power limit (1.33-1.35 kW of 1.4 kW, clock 2.0-2.2 GHz): time = joules / power, and the ~222 J of an inside-sphere "
+              "launch are set by its matrix instructions (3 fp16 products per multiply), their operand delivery and the gathers - removing "
+              "6 % of the VALU instructions moved neither time nor joules (profiles/r05_tp_hp_experiments.log); matrix pipe ~40 % busy, "
+              "VALU ~41 % of SIMD issue cycles (7.9 per MFMA), HBM < 5 %",
     "pixelnerf": "vector-ALU issue (9 VALU per MFMA) + socket power limit; matrix pipe ~40 % busy",
     "vanilla": "socket power limit (1.9 GHz at ~1.3 kW; the same instruction stream on zero operands runs at 2.4 GHz) on top of "
                "operand delivery (matrix pipe ~62 % busy)",
