@@ -281,7 +281,7 @@ class Runner:
         if workload == "neo360" and setup_timing:
             self.scene_setup = self._time_scene_setup()
 
-    def _time_scene_setup(self, reps=5):
+    def _time_scene_setup(self, reps=7):
         """Once-per-scene work that the per-frame numbers do not contain: channels-last re-layout of the feature maps
         (set_scene), weight upload + fragment packing, and the pre-projection of the latent through each of the four
         MLPs' first-layer weights (k_tp_preproject; the 131,072 MACs per point-view the evaluator no longer executes) and -

@@ -400,10 +400,11 @@ def test_bench_plain_form_scene_setup_from_events():
     assert roof["bound"] in ("hbm", "mfma") and "limiter" in roof and 0.0 < roof["frac"] < 1.0
     ss = out["scene_setup"]
     runs = ss["runs_ms"]
-    assert len(runs) == 5 and out["scene_setup_ms"] == ss["total_ms"]
+    assert len(runs) == 7 and out["scene_setup_ms"] == ss["total_ms"]
     assert 1.0 < ss["total_ms"] < 60.0, ss
     close = [r for r in runs if abs(r - ss["total_ms"]) <= 0.2 * ss["total_ms"] + 0.3]
-    assert len(close) >= 3, runs                                             # +-20 % of the median on at least three runs
+    assert len(close) >= 3, runs                 # +-20 % of the median on at least three of the seven runs (the window holds ~150
+                                                 # enqueues and 72 small host-to-device copies: an occasional host hiccup is an outlier run)
 
 
 # ---- the training call's fused point / activation operators (round 5) ------------------------------------------------------
