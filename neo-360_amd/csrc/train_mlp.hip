@@ -359,6 +359,22 @@ inline GemmEpi epi(const float* bias = nullptr, int relu = 0, int accumulate = 0
 
 inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
 
+// split-K of a weight-gradient GEMM (C (M x N) += A^T B over K = rows): enough K slices that the grid holds >= ~1024 workgroups
+// whatever the layer's shape - a 128 x 128 layer is 2 output tiles, and 71 slices of 8192 rows (round 3's rule) left 142 workgroups
+// on 256 CUs; each slice keeps >= 1024 rows so the atomically accumulated partial tiles stay few
+#ifndef NEO_TRAIN_SPLITK
+#define NEO_TRAIN_SPLITK 1
+#endif
+inline int split_k(int M, int N, long K) {
+    if (!NEO_TRAIN_SPLITK) return (int)((K + 8191) / 8192);
+    const long tiles = (long)((N + GTN - 1) / GTN) * ((M + GTM - 1) / GTM);
+    long nz = (1024 + tiles - 1) / tiles;
+    const long cap = K / 1024 > 0 ? K / 1024 : 1;
+    if (nz > cap) nz = cap;
+    const long floor_ = (K + 8191) / 8192;
+    return (int)(nz > floor_ ? nz : floor_);
+}
+
 }  // namespace
 
 // ---- tape layout (floats): h0, h1, h2, h3, bott (R x 128 each), y0 (R x 64), hm (P x 128), ym (P x 64), y1 (P x 64) ----
@@ -414,53 +430,52 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     (void)y0;
     float* ga = scratch; float* gb2 = ga + R * 128; float* gy0 = gb2 + R * 128;                 // R-sized
     float* g_hm = gy0 + R * 64; float* g_y1 = g_hm + P * 128; float* g_ym = g_y1 + P * 64;       // P-sized
-    const int SP = (int)((P + 8191) / 8192), SR = (int)((R + 8191) / 8192);                     // split-K of the weight gradients
     const float* in[3] = {x_enc, local, world};
     float* g_in[3] = {g_x_enc, g_local, g_world};
     const int kin[3] = {pe, 512, 128}, off[3] = {0, pe, pe + 512};
     // rgb head
-    gemm<true, true>(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, epi(nullptr, 0, 2), SP, s);
+    gemm<true, true>(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, epi(nullptr, 0, 2), split_k(3, 64, (int)P), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_rgb, P, 3, gb[8]);
     gemm<false, true>((int)P, 64, 3, g_rgb, 3, w[8], 64, g_y1, 64, epi(nullptr, 0, 0, y1, 64), 1, s);            // x relu'(y1)
     // view layer 1
-    gemm<true, true>(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, epi(nullptr, 0, 2), SP, s);
+    gemm<true, true>(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, epi(nullptr, 0, 2), split_k(64, 64, (int)P), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_y1, P, 64, gb[5]);
     gemm<false, true>((int)P, 64, 64, g_y1, 64, w[5], 64, g_ym, 64, epi(nullptr, 0, 0, ym, 64), 1, s);           // x relu'(mean)
     // mean over views -> per-view rows; view layer 0 on [bott | cond]
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0);
-    gemm<true, true>(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, epi(nullptr, 0, 2), SR, s);
-    gemm<true, true>(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, epi(nullptr, 0, 2), split_k(64, 128, (int)R), s);
+    gemm<true, true>(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, epi(nullptr, 0, 2), split_k(64, 27, (int)R), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, gy0, R, 64, gb[4]);
     gemm<false, true>((int)R, 128, 64, gy0, 64, w[4], 155, ga, 128, epi(), 1, s);                                // g_bott (R x 128)
     // bottleneck
-    gemm<true, true>(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[6]);
     gemm<false, true>((int)R, 128, 128, ga, 128, w[6], 128, gb2, 128, epi(), 1, s);                              // g_h3 from the bottleneck
     // density head on the view mean of h3
-    gemm<true, true>(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, epi(nullptr, 0, 2), SP, s);
+    gemm<true, true>(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, epi(nullptr, 0, 2), split_k(1, 128, (int)P), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_sigma, P, 1, gb[7]);
     gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 1, gb2);          // g_h3 += g_hm / NV
     hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, h3, R * 128);                   // g_z3
     // layer 3 on [h2 | x0]
-    gemm<true, true>(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
     for (int i = 0; i < 3; ++i) {
-        gemm<true, true>(128, kin[i], (int)R, gb2, 128, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, epi(nullptr, 0, 2), SR, s);
+        gemm<true, true>(128, kin[i], (int)R, gb2, 128, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, epi(nullptr, 0, 2), split_k(128, kin[i], (int)R), s);
         if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, gb2, 128, w[3] + 128 + off[i], 128 + K0, g_in[i], kin[i], epi(), 1, s);
     }
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[3]);
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[3], 128 + K0, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);    // g_z2 = (g_z3 W3a) relu'(h2)
     // layer 2
-    gemm<true, true>(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[2]);
     gemm<false, true>((int)R, 128, 128, ga, 128, w[2], 128, gb2, 128, epi(nullptr, 0, 0, h1, 128), 1, s);         // g_z1
     // layer 1
-    gemm<true, true>(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[1]);
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, ga, 128, epi(nullptr, 0, 0, h0, 128), 1, s);         // g_z0
     // layer 0
     for (int i = 0; i < 3; ++i) {
-        gemm<true, true>(128, kin[i], (int)R, ga, 128, in[i], kin[i], gw[0] + off[i], K0, epi(nullptr, 0, 2), SR, s);
+        gemm<true, true>(128, kin[i], (int)R, ga, 128, in[i], kin[i], gw[0] + off[i], K0, epi(nullptr, 0, 2), split_k(128, kin[i], (int)R), s);
         if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, ga, 128, w[0] + off[i], K0, g_in[i], kin[i], epi(nullptr, 0, 1), 1, s);
     }
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[0]);
@@ -506,21 +521,21 @@ void launch_vanilla_train_backward(const float* const* w, const float* x0, const
     const float* bott = tape + (size_t)8 * R * 256;
     const float* v = bott + (size_t)R * 256;
     float* ga = scratch; float* gb2 = ga + (size_t)R * 256; float* gv = gb2 + (size_t)R * 256;
-    const int M = (int)R, SR = (int)((R + 8191) / 8192);
+    const int M = (int)R;
     // rgb head, view layer on [bott | cond]
-    gemm<true, true>(3, 128, M, g_rgb, 3, v, 128, gw[11], 128, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(3, 128, M, g_rgb, 3, v, 128, gw[11], 128, epi(nullptr, 0, 2), split_k(3, 128, M), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, g_rgb, R, 3, gb[11]);
     gemm<false, true>(M, 128, 3, g_rgb, 3, w[11], 128, gv, 128, epi(nullptr, 0, 0, v, 128), 1, s);
-    gemm<true, true>(128, 256, M, gv, 128, bott, 256, gw[8], 283, epi(nullptr, 0, 2), SR, s);
-    gemm<true, true>(128, 27, M, gv, 128, cond, 27, gw[8] + 256, 283, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(128, 256, M, gv, 128, bott, 256, gw[8], 283, epi(nullptr, 0, 2), split_k(128, 256, M), s);
+    gemm<true, true>(128, 27, M, gv, 128, cond, 27, gw[8] + 256, 283, epi(nullptr, 0, 2), split_k(128, 27, M), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gv, R, 128, gb[8]);
     if (g_cond) gemm<false, true>(M, 27, 128, gv, 128, w[8] + 256, 283, g_cond, 27, epi(), 1, s);
     gemm<false, true>(M, 256, 128, gv, 128, w[8], 283, ga, 256, epi(), 1, s);                                     // g_bott
     // bottleneck + density head -> g_h7
-    gemm<true, true>(256, 256, M, ga, 256, h[7], 256, gw[9], 256, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(256, 256, M, ga, 256, h[7], 256, gw[9], 256, epi(nullptr, 0, 2), split_k(256, 256, M), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, ga, R, 256, gb[9]);
     gemm<false, true>(M, 256, 256, ga, 256, w[9], 256, gb2, 256, epi(), 1, s);
-    gemm<true, true>(1, 256, M, g_sigma, 1, h[7], 256, gw[10], 256, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(1, 256, M, g_sigma, 1, h[7], 256, gw[10], 256, epi(nullptr, 0, 2), split_k(1, 256, M), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, g_sigma, R, 1, gb[10]);
     gemm<false, true>(M, 256, 1, g_sigma, 1, w[10], 256, gb2, 256, epi(nullptr, 0, 1), 1, s);
     hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 256)), dim3(256), 0, s, gb2, h[7], R * 256);                  // g_z7
@@ -529,19 +544,19 @@ void launch_vanilla_train_backward(const float* const* w, const float* x0, const
     for (int i = 7; i >= 1; --i) {
         // cur = g_z_i (R x 256)
         if (i == 5) {
-            gemm<true, true>(256, 256, M, cur, 256, h[4], 256, gw[5], 319, epi(nullptr, 0, 2), SR, s);
-            gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[5] + 256, 319, epi(nullptr, 0, 2), SR, s);
+            gemm<true, true>(256, 256, M, cur, 256, h[4], 256, gw[5], 319, epi(nullptr, 0, 2), split_k(256, 256, M), s);
+            gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[5] + 256, 319, epi(nullptr, 0, 2), split_k(256, 63, M), s);
             if (g_x0) gemm<false, true>(M, 63, 256, cur, 256, w[5] + 256, 319, g_x0, 63, epi(), 1, s);
             hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[5]);
             gemm<false, true>(M, 256, 256, cur, 256, w[5], 319, nxt, 256, epi(nullptr, 0, 0, h[4], 256), 1, s);
         } else {
-            gemm<true, true>(256, 256, M, cur, 256, h[i - 1], 256, gw[i], 256, epi(nullptr, 0, 2), SR, s);
+            gemm<true, true>(256, 256, M, cur, 256, h[i - 1], 256, gw[i], 256, epi(nullptr, 0, 2), split_k(256, 256, M), s);
             hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[i]);
             gemm<false, true>(M, 256, 256, cur, 256, w[i], 256, nxt, 256, epi(nullptr, 0, 0, h[i - 1], 256), 1, s);
         }
         float* t = cur; cur = nxt; nxt = t;
     }
-    gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[0], 63, epi(nullptr, 0, 2), SR, s);
+    gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[0], 63, epi(nullptr, 0, 2), split_k(256, 63, M), s);
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[0]);
     if (g_x0) gemm<false, true>(M, 63, 256, cur, 256, w[0], 63, g_x0, 63, epi(nullptr, 0, 1), 1, s);
 }
