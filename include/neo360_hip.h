@@ -332,9 +332,30 @@ int neo_tp_activate(neo_ctx* ctx, const float* raw_rgb, const float* raw_sigma, 
 int neo_tp_activate_backward(neo_ctx* ctx, const float* raw_rgb, const float* raw_sigma, const float* noise, float noise_scale, long P,
                              const float* g_rgbsigma, float* g_rgb, float* g_sigma, void* stream);
 
+/* Projected-space training (round 5): the training analogue of the evaluators' pre-projection.  NeRFPPMLP reads the 512-channel
+ * latent only through W0_loc and the skip half W3_loc (neo360/model.py:123-137), and bilinear interpolation is linear, so the caller
+ * forms G = latent . [W0_loc | W3_loc]^T per TEXEL (a plain (texels, 512) x (512, 256) GEMM under autograd), gathers 256 instead of
+ * 512 channels and hands them to the MLP as `pre` (NV*P, 256) = the local features' contribution to the pre-activations of layer 0
+ * and of the skip half of layer 3.  neo_tp_gather_map / _backward: the lookup (and its scatter-add backward) in a CALLER-OWNED
+ * channels-last map (NV Hf Wf, C), C % 64 == 0, at get_local_feats' taps of the scene geometry set with neo_tp_set_scene.
+ * neo_tp_mlp_train_forward_pre / _backward_pre: as neo_tp_mlp_train_forward / _backward with `pre` in place of the local feature
+ * rows; the backward returns g_pre (NV*P, 256) = [dL/dz0 | dL/dz3] and leaves the local columns of gw[0] / gw[3] untouched (their
+ * gradient is formed in texel space by the caller's GEMM). */
+int neo_tp_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+                      float cx, float cy, float* out, void* stream);
+int neo_tp_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+                               float cy, const float* g_out, float* g_map, void* stream);
+int neo_tp_mlp_train_forward_pre(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x_enc,
+                                 const float* pre, const float* world_feat, const float* cond, int NV, long P, float* tape,
+                                 float* raw_rgb, float* raw_sigma, void* stream);
+int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const* w, const float* x_enc, const float* world_feat,
+                                  const float* cond, int NV, long P, const float* tape, const float* g_rgb, const float* g_sigma,
+                                  float* const* gw, float* const* gb, float* g_x_enc, float* g_pre, float* g_world, void* stream);
+
 /* Stand-alone feature lookups of the scene set with neo_tp_set_scene, view-major rows (row = v P + p):
  * world (NV*P,128) = index_grid (encoder_tp_fusion_conv.py:122-209: three planes summed), local (NV*P,512) =
- * get_local_feats / SpatialEncoder.index (neo360/model.py:239-264).  pts (P,3) world points. */
+ * get_local_feats / SpatialEncoder.index (neo360/model.py:239-264).  pts (P,3) world points.  local (and, in the backward, g_local
+ * together with g_latent) may be NULL: the tri-planes only. */
 int neo_tp_gather(neo_ctx* ctx, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
                   float cy, float* world, float* local, void* stream);
 /* Its backward: g_world / g_local scattered (atomic adds) into CHANNELS-LAST gradient maps the caller zeroed:

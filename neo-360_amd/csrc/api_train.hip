@@ -136,7 +136,7 @@ int neo_tp_gather(neo_ctx* ctx, const float* pts, long P, const float* src_poses
     ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(P >= 0, "negative point count");
     if (P == 0) return NEO_OK;
-    REQUIRE(pts && src_poses && world && local, "null pointer");
+    REQUIRE(pts && src_poses && world, "null pointer");            // local may be NULL: tri-planes only
     if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
     REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
     neo::TpViews views{};
@@ -154,7 +154,8 @@ int neo_tp_gather_backward(neo_ctx* ctx, const float* pts, long P, const float* 
     ORDERED(ctx, static_cast<hipStream_t>(stream));      // touches context-owned memory: ordered across streams
     REQUIRE(P >= 0, "negative point count");
     if (P == 0) return NEO_OK;
-    REQUIRE(pts && src_poses && g_world && g_local && g_plane_xz && g_plane_xy && g_plane_yz && g_latent, "null pointer");
+    REQUIRE(pts && src_poses && g_world && g_plane_xz && g_plane_xy && g_plane_yz, "null pointer");
+    REQUIRE((g_local == nullptr) == (g_latent == nullptr), "g_local and g_latent go together (both NULL: tri-planes only)");
     if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene features not set (neo_tp_set_scene)");
     REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
     neo::TpViews views{};
@@ -163,6 +164,38 @@ int neo_tp_gather_backward(neo_ctx* ctx, const float* pts, long P, const float* 
     sc.focal = focal; sc.cx = cx; sc.cy = cy;
     neo::launch_gather_bwd(sc, views, pts, P, g_world, g_local, g_plane_xz, g_plane_xy, g_plane_yz, g_latent,
                            static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+                      float cx, float cy, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
+    if (P == 0) return NEO_OK;
+    REQUIRE(map && pts && src_poses && out, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_map_gather(sc, views, pts, P, map, C, out, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_tp_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+                               float cy, const float* g_out, float* g_map, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
+    if (P == 0) return NEO_OK;
+    REQUIRE(pts && src_poses && g_out && g_map, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_map_gather_bwd(sc, views, pts, P, g_out, C, g_map, static_cast<hipStream_t>(stream));
     return check_launch();
 }
 
@@ -292,6 +325,38 @@ int neo_tp_mlp_train_backward(neo_ctx* ctx, int input_ch, const float* const* w,
     return check_launch();
 }
 
+
+int neo_tp_mlp_train_forward_pre(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x_enc,
+                                 const float* pre, const float* world_feat, const float* cond, int NV, long P, float* tape,
+                                 float* raw_rgb, float* raw_sigma, void* stream) {
+    ENTER(ctx);
+    REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (inside the sphere) or 4 (outside)");
+    REQUIRE(NV >= 1 && P >= 0, "bad shape");
+    if (P == 0) return NEO_OK;
+    REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
+    REQUIRE(w && b && x_enc && pre && world_feat && cond && tape && raw_rgb && raw_sigma, "null pointer");
+    for (int i = 0; i < 9; ++i) REQUIRE(w[i] && b[i], "null weight / bias pointer");
+    neo::launch_tp_train_forward(input_ch * 21, w, b, x_enc, nullptr, world_feat, cond, NV, P, tape, raw_rgb, raw_sigma,
+                                 static_cast<hipStream_t>(stream), pre);
+    return check_launch();
+}
+
+int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const* w, const float* x_enc, const float* world_feat,
+                                  const float* cond, int NV, long P, const float* tape, const float* g_rgb, const float* g_sigma,
+                                  float* const* gw, float* const* gb, float* g_x_enc, float* g_pre, float* g_world, void* stream) {
+    ENTER(ctx);
+    REQUIRE(NV >= 1 && P >= 0, "bad shape");
+    if (P == 0) return NEO_OK;
+    REQUIRE(input_ch == 3 || input_ch == 4, "input_ch must be 3 (inside the sphere) or 4 (outside)");
+    REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
+    REQUIRE(w && x_enc && world_feat && cond && tape && g_rgb && g_sigma && gw && gb && g_pre, "null pointer");
+    for (int i = 0; i < 9; ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
+    if (ctx->train_scratch.reserve(neo::tp_train_scratch_floats(NV, P) * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_tp_train_backward(input_ch * 21, w, x_enc, nullptr, world_feat, cond, NV, P, tape, ctx->train_scratch.as<float>(),
+                                  g_rgb, g_sigma, gw, gb, g_x_enc, nullptr, g_world, static_cast<hipStream_t>(stream), g_pre);
+    return check_launch();
+}
 
 long neo_vanilla_mlp_train_tape_floats(long R) { return R >= 0 ? (long)neo::vanilla_train_tape_floats(R) : 0; }
 

@@ -14,11 +14,11 @@ size_t tp_train_tape_floats(int NV, long P);
 size_t tp_train_scratch_floats(int NV, long P);
 void launch_tp_train_forward(int pe, const float* const* w, const float* const* b, const float* x_enc, const float* local,
                              const float* world, const float* cond, int NV, long P, float* tape, float* raw_rgb,
-                             float* raw_sigma, hipStream_t s);
+                             float* raw_sigma, hipStream_t s, const float* pre = nullptr);
 void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc, const float* local, const float* world,
                               const float* cond, int NV, long P, const float* tape, float* scratch, const float* g_rgb,
                               const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc, float* g_local,
-                              float* g_world, hipStream_t s);
+                              float* g_world, hipStream_t s, float* g_pre = nullptr);
 
 // vanilla NeRFMLP (vanilla_nerf/model.py:100-125): rows R = rays x samples; x0 (R, 63), cond (R, 27).  w / b order as
 // neo_vanilla_upload_mlp.

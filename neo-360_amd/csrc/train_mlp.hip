@@ -319,6 +319,18 @@ __global__ void k_relu_mask(float* __restrict__ g, const float* __restrict__ mas
     if (i < n && !(mask[i] > 0.0f)) g[i] = 0.0f;
 }
 
+// dst[r][0..cols) = src[r][0..cols) between row-major matrices of different pitch (cols % 4 == 0): the projected-space training path
+// initialises a layer's pre-activations with its half of the gathered (rows, 256) projected features and hands the two first-layer
+// gradients back as the halves of one (rows, 256) tensor
+__global__ void k_copy_cols(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, long rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = cols / 4;
+    if (i >= rows * c4) return;
+    const long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    *reinterpret_cast<f4u*>(dst + r * ldd + c) = *reinterpret_cast<const f4u*>(src + r * lds_ + c);
+}
+
 // out[c] += sum_m g[m][c]: one column per thread, 256 rows per block, atomics across blocks (out zeroed by the caller)
 __global__ void k_colsum(const float* __restrict__ g, long M, int C, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,20 +403,37 @@ size_t tp_train_scratch_floats(int NV, long P) {
 // w / b order as neo_tp_upload_mlp: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
 // the input rows [x_enc (pe) | local (512) | world (128)] are never concatenated: the two layers that read them take the three
 // tensors as segments of one reduction (gemm_cat)
+// pre (round 5, the training analogue of the evaluators' pre-projection): (R, 256) = the gathered PROJECTED latent, i.e. the local
+// features' contribution [W0_loc f | W3_loc f] to the pre-activations of layer 0 and of the skip half of layer 3, formed in texel space
+// by the caller (bilerp is linear: W bilerp(F) = bilerp(W F)).  With pre != null `local` is not read: the two layers start from their
+// half of `pre` and reduce over [x_enc | world] only - the 512-wide segments of both GEMMs (and of their dX / dW) are gone.
 void launch_tp_train_forward(int pe, const float* const* w, const float* const* b, const float* x_enc, const float* local,
                              const float* world, const float* cond, int NV, long P, float* tape, float* raw_rgb,
-                             float* raw_sigma, hipStream_t s) {
+                             float* raw_sigma, hipStream_t s, const float* pre) {
     const long R = (long)NV * P;
     const int K0 = pe + 640;
     float* h0 = tape; float* h1 = h0 + R * 128; float* h2 = h1 + R * 128; float* h3 = h2 + R * 128;
     float* bott = h3 + R * 128; float* y0 = bott + R * 128; float* hm = y0 + R * 64; float* ym = hm + P * 128; float* y1 = ym + P * 64;
-    const Seg in0[3] = {{x_enc, pe}, {local, 512}, {world, 128}};
-    gemm_cat((int)R, 128, in0, 3, w[0], K0, h0, 128, epi(b[0], 1), s);
+    if (pre) {
+        hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, pre, 256L, h0, 128L, R, 128);
+        gemm<false, false>((int)R, 128, pe, x_enc, pe, w[0], K0, h0, 128, epi(b[0], 0, 1), 1, s);                    // h0 = pre0 + x_enc W0_pe + b0
+        gemm<false, false>((int)R, 128, 128, world, 128, w[0] + pe + 512, K0, h0, 128, epi(nullptr, 1, 1), 1, s);     // relu(h0 + world W0_w)
+    } else {
+        const Seg in0[3] = {{x_enc, pe}, {local, 512}, {world, 128}};
+        gemm_cat((int)R, 128, in0, 3, w[0], K0, h0, 128, epi(b[0], 1), s);
+    }
     gemm<false, false>((int)R, 128, 128, h0, 128, w[1], 128, h1, 128, epi(b[1], 1), 1, s);
     gemm<false, false>((int)R, 128, 128, h1, 128, w[2], 128, h2, 128, epi(b[2], 1), 1, s);
+    if (pre) {
+        hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, pre + 128, 256L, h3, 128L, R, 128);
+        const Seg in3p[2] = {{h2, 128}, {x_enc, pe}};                                                                   // columns [0, 128 + pe) of W3
+        gemm_cat((int)R, 128, in3p, 2, w[3], 128 + K0, h3, 128, epi(b[3], 0, 1), s);
+        gemm<false, false>((int)R, 128, 128, world, 128, w[3] + 128 + pe + 512, 128 + K0, h3, 128, epi(nullptr, 1, 1), 1, s);
+    } else {
     // layer 3 on [h2 | x_enc | local | world] (the skip concat after layer index 2): one reduction over four segments
     const Seg in3[4] = {{h2, 128}, {x_enc, pe}, {local, 512}, {world, 128}};
     gemm_cat((int)R, 128, in3, 4, w[3], 128 + K0, h3, 128, epi(b[3], 1), s);
+    }
     gemm<false, false>((int)R, 128, 128, h3, 128, w[6], 128, bott, 128, epi(b[6], 0), 1, s);                     // bottleneck, per view
     hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
     gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
@@ -421,7 +450,9 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
 void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc, const float* local, const float* world,
                               const float* cond, int NV, long P, const float* tape, float* scratch, const float* g_rgb,
                               const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc, float* g_local,
-                              float* g_world, hipStream_t s) {
+                              float* g_world, hipStream_t s, float* g_pre) {
+    // g_pre != null: the forward ran on `pre` (projected-space path): the local segment has no dW / dX here; instead the two
+    // first-layer gradients are returned as g_pre (R, 256) = [g_z0 | g_z3] for the lookup's backward into the projected map
     const long R = (long)NV * P;
     const int K0 = pe + 640;
     const float* h0 = tape; const float* h1 = h0 + R * 128; const float* h2 = h1 + R * 128; const float* h3 = h2 + R * 128;
@@ -459,7 +490,9 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, h3, R * 128);                   // g_z3
     // layer 3 on [h2 | x0]
     gemm<true, true>(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
+    if (g_pre) hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, gb2, 128L, g_pre + 128, 256L, R, 128);
     for (int i = 0; i < 3; ++i) {
+        if (g_pre && i == 1) continue;
         gemm<true, true>(128, kin[i], (int)R, gb2, 128, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, epi(nullptr, 0, 2), split_k(128, kin[i], (int)R), s);
         if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, gb2, 128, w[3] + 128 + off[i], 128 + K0, g_in[i], kin[i], epi(), 1, s);
     }
@@ -474,7 +507,9 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[1]);
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, ga, 128, epi(nullptr, 0, 0, h0, 128), 1, s);         // g_z0
     // layer 0
+    if (g_pre) hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, ga, 128L, g_pre, 256L, R, 128);
     for (int i = 0; i < 3; ++i) {
+        if (g_pre && i == 1) continue;
         gemm<true, true>(128, kin[i], (int)R, ga, 128, in[i], kin[i], gw[0] + off[i], K0, epi(nullptr, 0, 2), split_k(128, kin[i], (int)R), s);
         if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, ga, 128, w[0] + off[i], K0, g_in[i], kin[i], epi(nullptr, 0, 1), 1, s);
     }

@@ -267,7 +267,9 @@ __global__ __launch_bounds__(256) void k_gather(TpScene sc, TpViews views, const
                 }
         }
     }
-    // pixel-aligned latent: 512 channels = 128 pieces -> 8 per lane
+    // pixel-aligned latent: 512 channels = 128 pieces -> 8 per lane (local == nullptr: planes only - the projected-space training
+    // path gathers the latent through neo_tp_gather_map instead)
+    if (local == nullptr) return;
 #pragma unroll 2
     for (int k8 = 0; k8 < 8; ++k8) {
         const int piece = c + 16 * k8;
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256) void k_gather_bwd_runs(TpScene sc, TpViews vie
     if (row0 >= rows) return;
     float* gmap[4] = {g_latent, g_plane0, g_plane1, g_plane2};
 #pragma unroll 1
-    for (int m = 0; m < 4; ++m) {
+    for (int m = g_local ? 0 : 1; m < 4; ++m) {
         const int ch = m == 0 ? 512 : 128;
         const float* gsrc = m == 0 ? g_local : g_world;
         const int pieces = ch / 64;                       // 16-byte pieces per lane: 8 (latent) or 2 (a plane)
@@ -376,6 +378,91 @@ __global__ __launch_bounds__(256) void k_gather_bwd_runs(TpScene sc, TpViews vie
 #pragma unroll
             for (int k = 0; k < 4; ++k) flush(k);
         }
+    }
+}
+
+// ---- lookup in a CALLER-OWNED channels-last map at the latent's taps (round 5: projected-space training) ---------------------------
+// map (NV Hf Wf, C) fp32, C a multiple of 64 (256 for the latent projected through [W0_loc | W3_loc]); rows view-major as above, the
+// taps those of get_local_feats (row_taps: view 0's intrinsics, the uploaded scene's latent geometry).  Forward: one 16-lane group
+// per row; backward: the run-merged scatter of k_gather_bwd_runs for the one map.
+__global__ __launch_bounds__(256) void k_map_gather(TpScene sc, TpViews views, const float* __restrict__ pts, long P,
+                                                    const float* __restrict__ map, int C, float* __restrict__ out) {
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = threadIdx.x & 15;
+    if (row >= P * sc.nv) return;
+    const int v = (int)(row / P);
+    const long p = row - (long)v * P;
+    const float p3[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
+    const RowTaps t = row_taps(sc, views.rot[v], views.trans[v], p3);
+    const f32x4 wv4 = {t.loc.w[0], t.loc.w[1], t.loc.w[2], t.loc.w[3]};
+    for (int piece = c; piece < C / 4; piece += 16) {
+        f32x4 tap[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            tap[k] = *reinterpret_cast<const f32x4*>(map + ((long)v * sc.Hf * sc.Wf + t.loc.off[k]) * C + piece * 4);
+        *reinterpret_cast<f32x4*>(out + row * C + piece * 4) = tp::blend4(tap, wv4);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_map_gather_bwd_runs(TpScene sc, TpViews views, const float* __restrict__ pts, long P,
+                                                            const float* __restrict__ g_out, int C, float* __restrict__ g_map) {
+    __shared__ int s_off[16][GRUN][4];
+    __shared__ float s_w[16][GRUN][4];
+    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const long rows = P * sc.nv;
+    const long row0 = ((long)blockIdx.x * 16 + grp) * GRUN;
+    {
+        const long row = row0 + c;
+        if (row < rows) {
+            const int v = (int)(row / P);
+            const long p = row - (long)v * P;
+            const float p3[3] = {pts[p * 3], pts[p * 3 + 1], pts[p * 3 + 2]};
+            const RowTaps t = row_taps(sc, views.rot[v], views.trans[v], p3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_off[grp][c][k] = t.loc.w[k] != 0.0f ? v * sc.Hf * sc.Wf + t.loc.off[k] : -1;
+                s_w[grp][c][k] = t.loc.w[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s_off[grp][c][k] = -1; s_w[grp][c][k] = 0.0f; }
+        }
+    }
+    __syncthreads();
+    if (row0 >= rows) return;
+#pragma unroll 1
+    for (int piece = c; piece < C / 4; piece += 16) {
+        int cur[4] = {-1, -1, -1, -1};
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto flush = [&](int k) {
+            if (cur[k] >= 0) {
+                float* dst = g_map + (long)cur[k] * C + piece * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[k][e]);
+            }
+        };
+#pragma unroll 1
+        for (int r = 0; r < GRUN; ++r) {
+            if (row0 + r >= rows) break;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(g_out + (row0 + r) * C + piece * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = s_off[grp][r][k];
+                if (o < 0) continue;
+                const float w = s_w[grp][r][k];
+                if (o != cur[k]) {
+                    flush(k);
+                    cur[k] = o;
+                    acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[k][e] = __builtin_fmaf(w, g[e], acc[k][e]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) flush(k);
     }
 }
 
@@ -444,6 +531,21 @@ __global__ void k_tp_activate_bwd(const float* __restrict__ raw_rgb, const float
 }
 
 }  // namespace
+
+void launch_map_gather(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* map, int C, float* out,
+                       hipStream_t s) {
+    const long rows = P * sc.nv;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_map_gather, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, sc, views, pts, P, map, C, out);
+}
+
+void launch_map_gather_bwd(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* g_out, int C, float* g_map,
+                           hipStream_t s) {
+    const long rows = P * sc.nv;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_map_gather_bwd_runs, dim3((unsigned)((rows + 16 * GRUN - 1) / (16 * GRUN))), dim3(256), 0, s, sc, views, pts, P,
+                       g_out, C, g_map);
+}
 
 void launch_tp_train_points(int input_ch, const float* rays_o, const float* rays_d, const float* tvals, const float* far, int R, int N,
                             const TpViews& views, int nv, uint32_t* flags, float* look, float* x_enc, hipStream_t s) {

@@ -10,6 +10,7 @@ The fused MLP evaluators are inference kernels: these ops cover the parts of the
 the reference's training tuple (forward values) through `neo_tp_render_train`.
 """
 import ctypes
+import os
 
 import torch
 
@@ -196,7 +197,7 @@ def eff_distloss(w, m, interval, ctx=None):
 
 class _Gather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx_, module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
+    def forward(ctx_, module, pts, plane_xz, plane_xy, plane_yz, latent, rays, planes_only=False):
         # the module's context holds channels-last copies of the scene: they must be copies of THESE tensors at THIS
         # version (an optimizer step or a fresh encoder output would otherwise leave the forward values stale while
         # gradients still flow to the arguments) - re-upload when the fingerprint differs
@@ -209,26 +210,29 @@ class _Gather(torch.autograd.Function):
         host_poses, NV, focal, cx, cy = module._camera_args(rays)
         P = pts.shape[0]
         world = torch.empty(NV * P, 128, device=pts.device)
-        local = torch.empty(NV * P, 512, device=pts.device)
+        local = None if planes_only else torch.empty(NV * P, 512, device=pts.device)
         _lib.check(c.lib.neo_tp_gather(c.handle, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(world), ptr(local), c.stream()))
         ctx_.save_for_backward(pts)
-        ctx_.meta = (c, host_poses, NV, focal, cx, cy, plane_xz.shape, latent.shape)
+        ctx_.meta = (c, host_poses, NV, focal, cx, cy, plane_xz.shape, latent.shape, bool(planes_only))
+        if planes_only:
+            return world, torch.empty(0, device=pts.device)
         return world, local
 
     @staticmethod
     def backward(ctx_, g_world, g_local):
         (pts,) = ctx_.saved_tensors
-        c, host_poses, NV, focal, cx, cy, pshape, lshape = ctx_.meta
+        c, host_poses, NV, focal, cx, cy, pshape, lshape, planes_only = ctx_.meta
         dev = pts.device
         _, Cw, Hp, Wp = pshape
         _, Cl, Hf, Wf = lshape
         gp = [torch.zeros(NV, Hp, Wp, Cw, device=dev) for _ in range(3)]
-        gl = torch.zeros(NV, Hf, Wf, Cl, device=dev)
-        gw, gloc = f32(g_world.contiguous(), "g_world"), f32(g_local.contiguous(), "g_local")
+        gl = None if planes_only else torch.zeros(NV, Hf, Wf, Cl, device=dev)
+        gw = f32(g_world.contiguous(), "g_world")
+        gloc = None if planes_only else f32(g_local.contiguous(), "g_local")
         _lib.check(c.lib.neo_tp_gather_backward(c.handle, ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy, ptr(gw),
                                                 ptr(gloc), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(gl), c.stream()))
         nchw = lambda x: x.permute(0, 3, 1, 2)
-        return None, None, nchw(gp[0]), nchw(gp[1]), nchw(gp[2]), nchw(gl), None
+        return None, None, nchw(gp[0]), nchw(gp[1]), nchw(gp[2]), (nchw(gl) if gl is not None else None), None, None
 
 
 def gather_features(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
@@ -239,6 +243,119 @@ def gather_features(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
     `rays["src_imgs"]`), so forward values and gradients always refer to the same data.  Gradients flow to the four
     feature maps (NCHW, like the inputs)."""
     return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays)
+
+
+def gather_planes(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
+    """The tri-plane half of gather_features alone: world (NV*P,128).  The latent is not looked up (the projected-space
+    training path gathers it through `gather_map`); it is still passed so that the device-side scene - geometry included -
+    follows these tensors."""
+    return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays, True)[0]
+
+
+class _MapGather(torch.autograd.Function):
+    """Bilinear lookup in a caller-owned channels-last map (NV Hf Wf, C) at get_local_feats' taps, with the run-merged
+    scatter-add as its backward (neo_tp_gather_map / _backward)."""
+
+    @staticmethod
+    def forward(ctx_, module, gmap, pts, rays):
+        pts = f32(pts, "pts").reshape(-1, 3)
+        gmap = f32(gmap, "map")
+        if gmap.dim() != 2 or gmap.shape[1] % 64 != 0:
+            raise ValueError("map must be (texels, C) with C a multiple of 64, got %s" % (tuple(gmap.shape),))
+        c = module._context(pts.device)
+        host_poses, NV, focal, cx, cy = module._camera_args(rays)
+        P, C = pts.shape[0], gmap.shape[1]
+        out = torch.empty(NV * P, C, device=pts.device)
+        _lib.check(c.lib.neo_tp_gather_map(c.handle, ptr(gmap), C, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
+        ctx_.save_for_backward(pts)
+        ctx_.meta = (c, host_poses, NV, focal, cx, cy, tuple(gmap.shape))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g_out):
+        (pts,) = ctx_.saved_tensors
+        c, host_poses, NV, focal, cx, cy, mshape = ctx_.meta
+        g_map = torch.zeros(mshape, device=pts.device)
+        g = f32(g_out.contiguous(), "g_out")
+        _lib.check(c.lib.neo_tp_gather_map_backward(c.handle, mshape[1], ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy,
+                                                    ptr(g), ptr(g_map), c.stream()))
+        return None, g_map, None, None
+
+
+def gather_map(module, gmap, pts, rays):
+    """Lookup of world points pts (P,3) in a channels-last map gmap (NV*Hf*Wf, C) with the latent's geometry, every source view:
+    (NV*P, C) view-major rows; gradients flow to `gmap`.  The module's scene must be set (its geometry is what is used)."""
+    return _MapGather.apply(module, gmap, pts, rays)
+
+
+class _TrainMLPPre(torch.autograd.Function):
+    """NeRFPPMLP on the PROJECTED latent: `pre` (NV*P, 256) = [W0_loc f | W3_loc f] replaces the (NV*P, 512) local feature rows
+    (neo_tp_mlp_train_forward_pre / _backward_pre).  The gradient of the local weight columns is NOT produced here: it flows
+    through `pre` into the texel-space GEMM that made the projected map."""
+
+    @staticmethod
+    def forward(ctx_, lib_ctx, input_ch, nv, x_enc, cond_rows, world_feat, pre, *params):
+        ws, bs = params[:9], params[9:]
+        pe, npts = input_ch * 21, x_enc.shape[1]
+        if x_enc.dim() != 3 or tuple(x_enc.shape) != (nv, npts, pe):
+            raise ValueError("x_enc must be (NV, P, %d), got %s" % (pe, tuple(x_enc.shape)))
+        for name, t, width in (("cond_rows", cond_rows, 27), ("world_feat", world_feat, 128), ("pre", pre, 256)):
+            if tuple(t.shape) != (nv * npts, width):
+                raise ValueError("%s must be (NV*P, %d) = (%d, %d), got %s" % (name, width, nv * npts, width, tuple(t.shape)))
+        xe = f32(x_enc, "x_enc").reshape(-1, pe)
+        pf, wf, cond = f32(pre, "pre"), f32(world_feat, "world_feat"), f32(cond_rows, "cond_rows")
+        c = _ctx(xe, lib_ctx)
+        wd = [f32(w.detach(), "weight") for w in ws]
+        bd = [f32(b.detach(), "bias") for b in bs]
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        raw_rgb = torch.empty(npts, 3, device=xe.device)
+        raw_sigma = torch.empty(npts, 1, device=xe.device)
+        tape = torch.empty(c.lib.neo_tp_mlp_train_tape_floats(nv, npts), device=xe.device)
+        _lib.check(c.lib.neo_tp_mlp_train_forward_pre(c.handle, input_ch, tab(wd), tab(bd), ptr(xe), ptr(pf), ptr(wf), ptr(cond), nv,
+                                                      npts, ptr(tape), ptr(raw_rgb), ptr(raw_sigma), c.stream()))
+        ctx_.save_for_backward(xe, wf, cond, tape, *wd)
+        ctx_.meta = (c, input_ch, nv, npts, x_enc.shape, [tuple(w.shape) for w in ws], [tuple(b.shape) for b in bs])
+        return raw_rgb, raw_sigma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g_rgb, g_sigma):
+        xe, wf, cond, tape, *wd = ctx_.saved_tensors
+        c, input_ch, nv, npts, xshape, wshapes, bshapes = ctx_.meta
+        if ctx_.needs_input_grad[4]:
+            raise NotImplementedError("nerfpp_mlp: no gradient for cond_rows (the reference's view directions are data)")
+        dev = xe.device
+        g_rgb = f32(g_rgb.contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(npts, 3, device=dev)
+        g_sigma = f32(g_sigma.contiguous(), "g_sigma") if g_sigma is not None else torch.zeros(npts, 1, device=dev)
+        gw = [torch.zeros(s, device=dev) for s in wshapes]
+        gb = [torch.zeros(s, device=dev) for s in bshapes]
+        gx = torch.empty_like(xe) if ctx_.needs_input_grad[3] else None
+        gworld = torch.empty_like(wf) if ctx_.needs_input_grad[5] else None
+        gpre = torch.empty(nv * npts, 256, device=dev)
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(c.lib.neo_tp_mlp_train_backward_pre(c.handle, input_ch, tab(wd), ptr(xe), ptr(wf), ptr(cond), nv, npts, ptr(tape),
+                                                       ptr(g_rgb), ptr(g_sigma), tab(gw), tab(gb), ptr(gx), ptr(gpre), ptr(gworld),
+                                                       c.stream()))
+        return (None, None, None, gx.reshape(xshape) if gx is not None else None, None, gworld, gpre, *gw, *gb)
+
+
+def project_latent(mlp, latent_cl):
+    """G = F [W0_loc | W3_loc]^T per texel: latent_cl (texels, 512) channels-last -> (texels, 256), a plain library GEMM under
+    autograd (its backward IS the gradient of the two local weight blocks and of the latent).  W0_loc = pts_linears.0's columns of
+    the 512 latent features, W3_loc = the same columns of the skip half of pts_linears.3 (neo360/model.py:123-137)."""
+    pe = mlp.input_ch * 21
+    w0, w3 = mlp.pts_linears[0].weight, mlp.pts_linears[3].weight
+    wcat = torch.cat([w0[:, pe:pe + 512], w3[:, 128 + pe:128 + pe + 512]], dim=0)          # (256, 512)
+    return latent_cl @ wcat.t()
+
+
+def nerfpp_mlp_projected(mlp, x_enc, cond_rows, world_feat, pre, nv, ctx=None):
+    """nerfpp_mlp with the gathered projected latent `pre` (NV*P, 256) in place of the (NV*P, 512) local features: the
+    512-wide segments of layer 0 and of the skip layer - forward, dX and dW - are not executed per row."""
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    return _TrainMLPPre.apply(ctx, mlp.input_ch, nv, x_enc, cond_rows, world_feat, pre, *params)
 
 
 class _TrainMLP(torch.autograd.Function):
@@ -411,18 +528,25 @@ def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed
     with torch.no_grad():
         draws, _ = _draws(module, B, randomized, seed, c, n0, n1, module.density_noise != 0.0)
     step = int(chunk) if chunk is not None and int(chunk) < B else B
+    # projected-space path (round 5, default): the latent goes through [W0_loc | W3_loc] of each MLP ONCE per call, in texel space;
+    # the per-row work gathers 256 instead of 512 channels and skips the 512-wide GEMM segments (forward, dX, dW)
+    projected = getattr(module, "train_projected", None)
+    if projected is None:
+        projected = os.environ.get("NEO360_TRAIN_PROJECTED", "1") != "0"
+    proj = {"latent_cl": maps[3].permute(0, 2, 3, 1).reshape(-1, maps[3].shape[1])} if projected else None
     parts = []
     for i in range(0, B, max(step, 1)):
         sub = {k: (v[i:i + step] if k in ("rays_o", "rays_d", "viewdirs") else v) for k, v in rays.items()}
         rows = {k: v[i:i + step] for k, v in draws.items()} if draws is not None else None
-        parts.append(_tp_render_train_chunk(module, sub, randomized, white_bkgd, maps, rows))
+        parts.append(_tp_render_train_chunk(module, sub, randomized, white_bkgd, maps, rows, proj))
     if len(parts) == 1:
         return parts[0]
     return [tuple(torch.cat([p[lv][j] for p in parts], dim=0) for j in range(6)) for lv in range(2)]
 
 
-def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws):
-    """One reference chunk of tp_render_train; `draws` = this chunk's rows of the call's uniform tables (None: deterministic)."""
+def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws, proj=None):
+    """One reference chunk of tp_render_train; `draws` = this chunk's rows of the call's uniform tables (None: deterministic);
+    `proj` = the call's cache of projected maps (None: the local features are gathered and multiplied per row)."""
     from . import ops
     rays_o, rays_d, viewdirs = f32(rays["rays_o"], "rays_o"), f32(rays["rays_d"], "rays_d"), f32(rays["viewdirs"], "viewdirs")
     B = rays_o.shape[0]
@@ -450,8 +574,15 @@ def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws):
             bg_lin, bg_x = train_points(module, 1, rays_o, rays_d, bg_s, far, poses, ctx=c)
         res = {}
         for name, mlp, look, x_enc in (("fg", mlps[level], fg_p, fg_x), ("bg", mlps[2 + level], bg_lin, bg_x)):
-            world, local = gather_features(module, look, maps[0], maps[1], maps[2], maps[3], rays)
-            raw_rgb, raw_sigma = nerfpp_mlp(mlp, x_enc, cond, world, local, NV, ctx=c)
+            if proj is not None:
+                if (name, level) not in proj:
+                    proj[(name, level)] = project_latent(mlp, proj["latent_cl"])                  # (texels, 256), once per call
+                world = gather_planes(module, look, maps[0], maps[1], maps[2], maps[3], rays)
+                pre = gather_map(module, proj[(name, level)], look, rays)
+                raw_rgb, raw_sigma = nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, NV, ctx=c)
+            else:
+                world, local = gather_features(module, look, maps[0], maps[1], maps[2], maps[3], rays)
+                raw_rgb, raw_sigma = nerfpp_mlp(mlp, x_enc, cond, world, local, NV, ctx=c)
             noisy = draws is not None and module.density_noise != 0.0                            # model.py:381-384
             res[name] = activate(raw_rgb, raw_sigma, draws["n_%s%d" % (name, level)] if noisy else None,
                                  float(module.density_noise) if noisy else 0.0, ctx=c).reshape(B, N, 4)   # model.py:380-385

@@ -454,3 +454,45 @@ def test_activate_op_matches_autograd():
     assert max_abs(ga.grad, a.grad.float()) < 2e-6 and max_abs(gb.grad, b.grad.float()) < 2e-6
     plain = training.activate(raw_rgb.to(DEV), raw_sigma.to(DEV))
     assert max_abs(plain[:, 3], torch.nn.functional.softplus(raw_sigma[:, 0] - 1.0)) < 2e-6
+
+
+def test_projected_space_training_equals_the_per_row_path():
+    """Round 5: the training analogue of the pre-projection - the latent goes through [W0_loc | W3_loc] once per call in texel
+    space (a library GEMM under autograd), 256 channels are gathered and handed to the MLP as `pre`.  A reassociation: same
+    forward values, same gradients for EVERY parameter (the local weight columns included: their gradient now comes out of the
+    texel-space GEMM's backward), the three tri-planes and the latent, as the per-row path (which the fp64-autograd test of
+    tests/test_gpu_training.py pins to the oracle)."""
+    sc = cases.small_scene()
+    R = 96
+    gb = _batch(R)
+    target = synth.uniform(17, "proj_target", (R, 3), 0.0, 1.0).to(DEV)
+    results = {}
+    for projected in (False, True):
+        net = models.NeRF_TP(num_coarse_samples=16, num_fine_samples=24, num_src_views=cases.NV).to(DEV)
+        net.load_state_dict(synth.nerf_tp_state(0))
+        net.train_projected = projected
+        maps = [sc[k].to(DEV).clone().requires_grad_(True) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")]
+        with torch.enable_grad():
+            net.set_scene(*maps, sc["image_wh"])
+            for p in net.parameters():
+                p.requires_grad_(True)
+            out = net(gb, True, False, 0.0, 0.0, out_depth=False, seed=99)
+            loss = sum(((lv[0] - target) ** 2).mean() for lv in out) + 0.01 * training.eff_distloss(out[1][1], out[1][3], 1.0 / 41)
+            names = sorted(n for n, _ in net.named_parameters())
+            params = dict(net.named_parameters())
+            grads = torch.autograd.grad(loss, [params[n] for n in names] + maps)
+        results[projected] = (float(loss), [o.detach() for lv in out for o in lv], names, [g.detach() for g in grads])
+    (l0, o0, names, g0), (l1, o1, _, g1) = results[False], results[True]
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
+    for a, b in zip(o0, o1):
+        assert float((a - b).abs().median()) < 1e-6 and max_abs(a, b) < 1e-3         # fine-level rows may flip a resampled position
+    worst = 0.0
+    for nm, a, b in zip(names + ["plane_xz", "plane_xy", "plane_yz", "latent"], g0, g1):
+        rel = float((a - b).norm()) / (float(a.norm()) + 1e-20)
+        worst = max(worst, rel)
+        assert rel < 2e-3, (nm, rel)
+        assert float(b.abs().max()) > 0.0, nm                                            # nothing lost: every tensor receives a gradient
+    # the local columns of the first layer really are trained through the texel-space path
+    i0 = names.index("fg_fine_mlp.pts_linears.0.weight")
+    assert float(g1[i0][:, 63:63 + 512].abs().max()) > 0.0
+    record_parity("train_projected_vs_per_row", worst_rel_l2_grad_diff=worst, loss_diff=abs(l0 - l1), rays=R)
