@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        accx[nt][mt] = NEO_MFMA_H(wl[ks % XS][nt], bh[mt], accx[nt][mt]);
-                        accx[nt][mt] = NEO_MFMA_H(wh[ks % XS][nt], bl[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H_LH(wl[ks % XS][nt], bh[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H_HL(wh[ks % XS][nt], bl[mt], accx[nt][mt]);
                         accx[nt][mt] = NEO_MFMA_H(wh[ks % XS][nt], bh[mt], accx[nt][mt]);
                     }
                 load_wk(std::integral_constant<int, ks + XD>());
@@ -601,8 +601,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     hsum[emt][2 * ks] += fmaxf(src[2 * ks], 0.0f);
                     hsum[emt][2 * ks + 1] += fmaxf(src[2 * ks + 1], 0.0f);
                 }
-                Bc = NEO_MFMA_H(lwl[g % LS], bh[ks & 1], Bc);
-                Bc = NEO_MFMA_H(lwh[g % LS], bl[ks & 1], Bc);
+                Bc = NEO_MFMA_H_LH(lwl[g % LS], bh[ks & 1], Bc);
+                Bc = NEO_MFMA_H_HL(lwh[g % LS], bl[ks & 1], Bc);
                 load_lw(std::integral_constant<int, g + LD>());
                 if constexpr (EPI == 1 && (ks & 1)) {
                     constexpr int gq = ks >> 1;
@@ -697,8 +697,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             }
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                acc[0][mt] = NEO_MFMA_H(lwl[g % LS], bh[mt], acc[0][mt]);
-                acc[0][mt] = NEO_MFMA_H(lwh[g % LS], bl[mt], acc[0][mt]);
+                acc[0][mt] = NEO_MFMA_H_LH(lwl[g % LS], bh[mt], acc[0][mt]);
+                acc[0][mt] = NEO_MFMA_H_HL(lwh[g % LS], bl[mt], acc[0][mt]);
                 acc[0][mt] = NEO_MFMA_H(lwh[g % LS], bh[mt], acc[0][mt]);
             }
             if constexpr (ks == 7) {
@@ -823,8 +823,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 bh = *reinterpret_cast<const h8*>(act.hi + o);
                 bl = *reinterpret_cast<const h8*>(act.lo + o);
             }
-            y = NEO_MFMA_H(twl[g % TS], bh, y);
-            y = NEO_MFMA_H(twh[g % TS], bl, y);
+            y = NEO_MFMA_H_LH(twl[g % TS], bh, y);
+            y = NEO_MFMA_H_HL(twh[g % TS], bl, y);
             y = NEO_MFMA_H(twh[g % TS], bh, y);
             if constexpr (g == 9) {
                 TP_SYNC();          // every wave has read the view-mean trunk (density head, view layer 0)
@@ -874,8 +874,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     const int o = chunk_off<128>(mt * 32 + L.l31, (g << 1) + L.half);
                     const h8 bh = *reinterpret_cast<const h8*>(act.hi + o);
                     const h8 bl = *reinterpret_cast<const h8*>(act.lo + o);
-                    acc2[mt] = NEO_MFMA_H(twl[g % TS], bh, acc2[mt]);
-                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bl, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H_LH(twl[g % TS], bh, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H_HL(twh[g % TS], bl, acc2[mt]);
                     acc2[mt] = NEO_MFMA_H(twh[g % TS], bh, acc2[mt]);
                 }
                 if constexpr (g == 7) {
@@ -898,8 +898,8 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     bh = *reinterpret_cast<const h8*>(act.hi + o);
                     bl = *reinterpret_cast<const h8*>(act.lo + o);
                 }
-                y = NEO_MFMA_H(twl[g % TS], bh, y);
-                y = NEO_MFMA_H(twh[g % TS], bl, y);
+                y = NEO_MFMA_H_LH(twl[g % TS], bh, y);
+                y = NEO_MFMA_H_HL(twh[g % TS], bl, y);
                 y = NEO_MFMA_H(twh[g % TS], bh, y);
                 if constexpr (g == 17) {
                     TP_SYNC();

@@ -350,8 +350,8 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        accx[nt][mt] = NEO_MFMA_H(wl[kp % XS][nt], bh[mt], accx[nt][mt]);
-                        accx[nt][mt] = NEO_MFMA_H(wh[kp % XS][nt], bl[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H_LH(wl[kp % XS][nt], bh[mt], accx[nt][mt]);
+                        accx[nt][mt] = NEO_MFMA_H_HL(wh[kp % XS][nt], bl[mt], accx[nt][mt]);
                         accx[nt][mt] = NEO_MFMA_H(wh[kp % XS][nt], bh[mt], accx[nt][mt]);
                     }
                 load_wk(std::integral_constant<int, kp + XD>());
@@ -647,8 +647,8 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    acc[mt] = NEO_MFMA_H(lwl[g % LS], bh[mt], acc[mt]);
-                    acc[mt] = NEO_MFMA_H(lwh[g % LS], bl[mt], acc[mt]);
+                    acc[mt] = NEO_MFMA_H_LH(lwl[g % LS], bh[mt], acc[mt]);
+                    acc[mt] = NEO_MFMA_H_HL(lwh[g % LS], bl[mt], acc[mt]);
                     acc[mt] = NEO_MFMA_H(lwh[g % LS], bh[mt], acc[mt]);
                 }
                 if constexpr (ks == 7) {
@@ -744,8 +744,8 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 bh = *reinterpret_cast<const h8*>(act.hi + o);
                 bl = *reinterpret_cast<const h8*>(act.lo + o);
             }
-            y = NEO_MFMA_H(twl[g % TS], bh, y);
-            y = NEO_MFMA_H(twh[g % TS], bl, y);
+            y = NEO_MFMA_H_LH(twl[g % TS], bh, y);
+            y = NEO_MFMA_H_HL(twh[g % TS], bl, y);
             y = NEO_MFMA_H(twh[g % TS], bh, y);
             if constexpr (g == 9) {
                 TPP_SYNC();          // every wave has read the view-mean trunk (density head, view layer 0)
@@ -795,8 +795,8 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                     const int o = chunk_off<128>(mt * 32 + L.l31, (g << 1) + L.half);
                     const h8 bh = *reinterpret_cast<const h8*>(act.hi + o);
                     const h8 bl = *reinterpret_cast<const h8*>(act.lo + o);
-                    acc2[mt] = NEO_MFMA_H(twl[g % TS], bh, acc2[mt]);
-                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bl, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H_LH(twl[g % TS], bh, acc2[mt]);
+                    acc2[mt] = NEO_MFMA_H_HL(twh[g % TS], bl, acc2[mt]);
                     acc2[mt] = NEO_MFMA_H(twh[g % TS], bh, acc2[mt]);
                 }
                 if constexpr (g == 7) {
@@ -819,8 +819,8 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                     bh = *reinterpret_cast<const h8*>(act.hi + o);
                     bl = *reinterpret_cast<const h8*>(act.lo + o);
                 }
-                y = NEO_MFMA_H(twl[g % TS], bh, y);
-                y = NEO_MFMA_H(twh[g % TS], bl, y);
+                y = NEO_MFMA_H_LH(twl[g % TS], bh, y);
+                y = NEO_MFMA_H_HL(twh[g % TS], bl, y);
                 y = NEO_MFMA_H(twh[g % TS], bh, y);
                 if constexpr (g == 17) {
                     TPP_SYNC();

@@ -15,6 +15,13 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define NEO_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// the two cross terms of a split product (a_lo·b_hi, a_hi·b_lo).  NEO_SPLIT_TERMS < 3 drops them: WRONG results, a timing /
+// energy experiment only (what a launch costs per matrix instruction); the build never sets it.
+#ifndef NEO_SPLIT_TERMS
+#define NEO_SPLIT_TERMS 3
+#endif
+#define NEO_MFMA_H_LH(a, b, c) (NEO_SPLIT_TERMS >= 3 ? NEO_MFMA_H(a, b, c) : (c))
+#define NEO_MFMA_H_HL(a, b, c) (NEO_SPLIT_TERMS >= 2 ? NEO_MFMA_H(a, b, c) : (c))
 
 struct HT {   // a swizzled fp16 hi/lo tile
     _Float16* hi;
