@@ -292,6 +292,180 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
     }
 }
 
+// Weight gradient of one layer segment, with the bias gradient fused: W[M][N] += Z^T X, db[M] += colsum(Z) over the K = rows
+// slice of this workgroup (Z = dZ stored [K][M], X stored [K][N]: both with the reduction index slowest).  128 x NT tiles -
+// a 128 x 128 layer is ONE tile, so every row of Z and of X is read once (k_sgemm<true, true> read Z once per 64 columns of X
+// and k_colsum once more) - 4 waves of 64 (m) x NT / 2 (n), K stepped by 32 through two [k][rows] LDS tiles, the next step's
+// operands in registers while this one is multiplied (2 workgroups per CU: a step is >= 4096 MFMA cycles per wave, the loads
+// of one step have that long to arrive).  At 32 flop per byte the launch is balanced between the fp32 matrix peak and HBM.
+// Partial tiles of the K slices are accumulated atomically (W, db zeroed by the caller).
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float* __restrict__ Z, long ldz,
+                                               const float* __restrict__ X, long ldx, float* __restrict__ part,
+                                               float* __restrict__ part_db, int k_per_split) {
+    constexpr int PA = 128 + 4, PB = NT + 4;     // pitches: 4 * pitch = 16 mod 32 (the two lane halves of a fragment read hit different bank halves)
+    constexpr int NF = NT / 64;                  // n fragments per wave
+    constexpr int JB = NT / 32;                  // 16-B pieces of the X tile per thread and K step (Z: 4)
+    constexpr int QB = NT / 4;
+    __shared__ __attribute__((aligned(16))) float As[2][GK * PA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK * PB];
+    LaneCtx L;
+    L.init();
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * NT;
+    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    const int wm = L.wv & 1, wn = L.wv >> 1;
+    f32x16 acc[2][NF];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NF; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    // this thread's pieces: Z piece j = row k (tid >> 5) + 8 j, columns m0 + 4 (tid & 31) ..; X piece j = row k tid / QB + (256 / QB) j
+    const int ka = tid >> 5, ra = (tid & 31) * 4, kb = tid / QB, rb = (tid % QB) * 4;
+    unsigned mka = 0, mkb = 0;                   // valid elements of a piece (edge tiles: M = 1, 3, 64; N = 27, 63)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (m0 + ra + e < M) mka |= 1u << e;
+        if (n0 + rb + e < N) mkb |= 1u << e;
+    }
+    const float* pa = Z + (long)(kbeg + ka) * ldz + m0 + ra;
+    const float* pb = X + (long)(kbeg + kb) * ldx + n0 + rb;
+    f32x4 qa[4], qb[JB];
+    auto guarded = [&](const float* p, unsigned mask, bool kv) -> f32x4 {
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (kv) {
+            if (mask == 15u) v = *reinterpret_cast<const f4u*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (mask >> e & 1u) v[e] = p[e];
+            }
+        }
+        return v;
+    };
+    // operands of the K step starting at k0 -> registers (FAST: interior tile and a full step, no guards)
+    auto fetch = [&](auto fastc, int k0) {
+        constexpr bool FAST = decltype(fastc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* p = pa + (long)(8 * j) * ldz;
+            if constexpr (FAST) qa[j] = *reinterpret_cast<const f4u*>(p);
+            else qa[j] = guarded(p, mka, k0 + ka + 8 * j < kend);
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const float* p = pb + (long)((256 / QB) * j) * ldx;
+            if constexpr (FAST) qb[j] = *reinterpret_cast<const f4u*>(p);
+            else qb[j] = guarded(p, mkb, k0 + kb + (256 / QB) * j < kend);
+        }
+        pa += (long)GK * ldz;
+        pb += (long)GK * ldx;
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(As[buf] + (ka + 8 * j) * PA + ra) = qa[j];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) *reinterpret_cast<f32x4*>(Bs[buf] + (kb + (256 / QB) * j) * PB + rb) = qb[j];
+    };
+    const bool bias_wg = part_db != nullptr && blockIdx.x == 0 && tid < 128;
+    float cs = 0.0f;
+    auto compute = [&](int buf) {
+        if (bias_wg) {
+#pragma unroll
+            for (int k = 0; k < GK; ++k) cs += As[buf][k * PA + tid];
+        }
+#pragma unroll
+        for (int c = 0; c < GK / 8; ++c) {
+            f32x4 a[NF], b[2];                    // 4 consecutive k (8 c + 4 half + e) of rows n / m
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * c + 4 * L.half + e;
+#pragma unroll
+                for (int nt = 0; nt < NF; ++nt) a[nt][e] = Bs[buf][k * PB + wn * (NT / 2) + 32 * nt + L.l31];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) b[mt][e] = As[buf][k * PA + wm * 64 + 32 * mt + L.l31];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NF; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = NEO_MFMA(b[mt][e], a[nt][e], acc[mt][nt]);   // D rows = m, D cols = n
+        }
+    };
+    // nst K steps from k0: one barrier per step
+    auto run = [&](auto fastc, int k0, int nst) {
+        if (nst <= 0) return;
+        fetch(fastc, k0);
+        stage(0);
+        __syncthreads();
+        for (int i = 0; i < nst; ++i) {
+            const bool more = i + 1 < nst;
+            if (more) fetch(fastc, k0 + (i + 1) * GK);
+            compute(i & 1);
+            if (more) stage((i + 1) & 1);
+            __syncthreads();
+        }
+    };
+    const bool interior = m0 + 128 <= M && n0 + NT <= N;
+    const int nfull = interior ? (kend - kbeg) / GK : 0;
+    run(std::true_type(), kbeg, nfull);
+    const int kdone = kbeg + nfull * GK;
+    run(std::false_type(), kdone, (kend - kdone + GK - 1) / GK);
+    // ---- epilogue: this slice's partial tile -> part[slice][tile][m][n]; k_dw_reduce sums the slices.  Adding the slices
+    //      atomically into W is what the weight gradients used to cost: ~500 workgroups finish together and add into the same
+    //      64 KB (profiles/r05_train_dw.log, dW of a 1.18 M-row training op: k_sgemm<true, true> + k_colsum 13.0 ms, this kernel
+    //      with atomics 10.4 ms (lane = m) / 6.1 ms (lane = n), with partial tiles 5.5 ms = 110 TFLOP/s).
+    //      lane = n (l31), registers 4 g + e = m = 8 g + 4 half + e: a store instruction covers 32 consecutive floats of two rows ----
+    const long tile = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* pt = part + tile * (128 * NT);
+#pragma unroll
+    for (int nt = 0; nt < NF; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    pt[(wm * 64 + 32 * mt + 8 * g + 4 * L.half + e) * NT + wn * (NT / 2) + 32 * nt + L.l31] = acc[mt][nt][4 * g + e];
+    if (bias_wg) part_db[((long)blockIdx.z * gridDim.y + blockIdx.y) * 128 + tid] = cs;
+}
+
+// W[m][n] += sum over slices of part[slice][tile][m][n], db[m] += sum of part_db: one float4 of one tile row per thread and
+// DW_ZG slices per workgroup row (their loads all in flight), then one atomic per element and slice group (<= 32 per element)
+constexpr int DW_ZG = 16;
+template <int NT>
+__global__ void k_dw_reduce(int M, int N, int nz, const float* __restrict__ part, const float* __restrict__ part_db, int tiles_x,
+                            int tiles_y, float* __restrict__ W, long ldw, float* __restrict__ db) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int z0 = blockIdx.y * DW_ZG, z1 = min(nz, z0 + DW_ZG);
+    constexpr int Q = 128 * NT / 4;                // float4 pieces of a tile
+    const long tiles = (long)tiles_x * tiles_y;
+    if (i < tiles * Q) {
+        const int t = (int)(i / Q), q = (int)(i - (long)t * Q);
+        const int ml = q / (NT / 4), nl = (q % (NT / 4)) * 4;
+        const int gm = (t / tiles_x) * 128 + ml, gn = (t % tiles_x) * NT + nl;
+        if (gm < M && gn < N) {
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+            for (int z = z0; z < z1; ++z) {
+                const f32x4 p = *reinterpret_cast<const f32x4*>(part + ((long)z * tiles + t) * (128 * NT) + ml * NT + nl);
+                v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (gn + e < N) atomicAdd(W + (long)gm * ldw + gn + e, v[e]);
+        }
+    }
+    if (db != nullptr && i < (long)tiles_y * 128 && i < M) {
+        float sacc = 0.0f;
+        for (int z = z0; z < z1; ++z) sacc += part_db[((long)z * tiles_y + i / 128) * 128 + (i & 127)];
+        atomicAdd(db + i, sacc);
+    }
+}
+
 // out[p][c] = (1 / NV) sum_v in[v P + p][c]   (neo360/util.py:599-610 combine_interleaved 'average'), optional ReLU
 __global__ void k_view_mean(const float* __restrict__ in, int NV, long P, int C, int relu, float* __restrict__ out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,6 +561,43 @@ inline int split_k(int M, int N, long K) {
     return (int)(nz > floor_ ? nz : floor_);
 }
 
+// W (M x N, row pitch ldw) += Z^T X over K rows, db (M) += column sums of Z (null: a later segment of the same layer);
+// enough K slices for one resident wave of workgroups (2 per CU), each at least 1024 rows
+#ifndef NEO_TRAIN_DW
+#define NEO_TRAIN_DW 1          // 0: k_sgemm<true, true> + k_colsum (rounds 3-4; A/B)
+#endif
+// part: DW_PART_FLOATS of scratch (the slices' partial tiles and bias sums)
+constexpr long DW_PART_TILES = 520;        // slices x tiles of one call: <= 512 + tiles - 1, tiles <= 8 (256 x 256: 4)
+constexpr long DW_PART_FLOATS = DW_PART_TILES * (128 * 128 + 128);
+void dw_gemm(int M, int N, int K, const float* Z, long ldz, const float* X, long ldx, float* W, long ldw, float* db, float* part,
+             hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0) return;
+    if (!NEO_TRAIN_DW) {
+        gemm<true, true>(M, N, K, Z, ldz, X, ldx, W, ldw, epi(nullptr, 0, 2), split_k(M, N, K), s);
+        if (db) hipLaunchKernelGGL(k_colsum, dim3((M + 127) / 128, blocks(K)), dim3(M < 128 ? 64 : 128), 0, s, Z, (long)K, M, db);
+        return;
+    }
+    const int NT = N > 64 ? 128 : 64;
+    const int tx = (N + NT - 1) / NT, ty = (M + 127) / 128, tiles = tx * ty;
+    long nz = (512 + tiles - 1) / tiles;
+    const long cap = K / 1024 > 0 ? K / 1024 : 1;
+    if (nz > cap) nz = cap;
+    if (nz * tiles > DW_PART_TILES) nz = DW_PART_TILES / tiles;
+    int kps = (int)((K + nz - 1) / nz);
+    kps = ((kps + GK - 1) / GK) * GK;
+    const int slices = (K + kps - 1) / kps;
+    float* part_db = part + DW_PART_TILES * (128 * 128);
+    const dim3 grid(tx, ty, slices);
+    const dim3 rgrid((unsigned)(((long)tiles * 128 * NT / 4 + 255) / 256), (slices + DW_ZG - 1) / DW_ZG);
+    if (NT == 128) {
+        hipLaunchKernelGGL((k_dw<128>), grid, dim3(256), 0, s, M, N, K, Z, ldz, X, ldx, part, db ? part_db : nullptr, kps);
+        hipLaunchKernelGGL((k_dw_reduce<128>), rgrid, dim3(256), 0, s, M, N, slices, part, part_db, tx, ty, W, ldw, db);
+    } else {
+        hipLaunchKernelGGL((k_dw<64>), grid, dim3(256), 0, s, M, N, K, Z, ldz, X, ldx, part, db ? part_db : nullptr, kps);
+        hipLaunchKernelGGL((k_dw_reduce<64>), rgrid, dim3(256), 0, s, M, N, slices, part, part_db, tx, ty, W, ldw, db);
+    }
+}
+
 }  // namespace
 
 // ---- tape layout (floats): h0, h1, h2, h3, bott (R x 128 each), y0 (R x 64), hm (P x 128), ym (P x 64), y1 (P x 64) ----
@@ -397,7 +608,7 @@ size_t tp_train_tape_floats(int NV, long P) {
 // scratch of the backward: two R x 128 gradient buffers, one R x 64, three P-sized
 size_t tp_train_scratch_floats(int NV, long P) {
     const long R = (long)NV * P;
-    return (size_t)(R * (2 * 128 + 64) + P * (128 + 64 + 64));
+    return (size_t)(R * (2 * 128 + 64) + P * (128 + 64 + 64) + DW_PART_FLOATS);
 }
 
 // w / b order as neo_tp_upload_mlp: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
@@ -461,59 +672,51 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     (void)y0;
     float* ga = scratch; float* gb2 = ga + R * 128; float* gy0 = gb2 + R * 128;                 // R-sized
     float* g_hm = gy0 + R * 64; float* g_y1 = g_hm + P * 128; float* g_ym = g_y1 + P * 64;       // P-sized
+    float* part = g_ym + P * 64;                                                                 // DW_PART_FLOATS (dw_gemm)
     const float* in[3] = {x_enc, local, world};
     float* g_in[3] = {g_x_enc, g_local, g_world};
     const int kin[3] = {pe, 512, 128}, off[3] = {0, pe, pe + 512};
     // rgb head
-    gemm<true, true>(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, epi(nullptr, 0, 2), split_k(3, 64, (int)P), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_rgb, P, 3, gb[8]);
+    dw_gemm(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, gb[8], part, s);
     gemm<false, true>((int)P, 64, 3, g_rgb, 3, w[8], 64, g_y1, 64, epi(nullptr, 0, 0, y1, 64), 1, s);            // x relu'(y1)
     // view layer 1
-    gemm<true, true>(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, epi(nullptr, 0, 2), split_k(64, 64, (int)P), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_y1, P, 64, gb[5]);
+    dw_gemm(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, gb[5], part, s);
     gemm<false, true>((int)P, 64, 64, g_y1, 64, w[5], 64, g_ym, 64, epi(nullptr, 0, 0, ym, 64), 1, s);           // x relu'(mean)
     // mean over views -> per-view rows; view layer 0 on [bott | cond]
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0);
-    gemm<true, true>(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, epi(nullptr, 0, 2), split_k(64, 128, (int)R), s);
-    gemm<true, true>(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, epi(nullptr, 0, 2), split_k(64, 27, (int)R), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, gy0, R, 64, gb[4]);
+    dw_gemm(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, gb[4], part, s);
+    dw_gemm(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, nullptr, part, s);
     gemm<false, true>((int)R, 128, 64, gy0, 64, w[4], 155, ga, 128, epi(), 1, s);                                // g_bott (R x 128)
     // bottleneck
-    gemm<true, true>(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[6]);
+    dw_gemm(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, gb[6], part, s);
     gemm<false, true>((int)R, 128, 128, ga, 128, w[6], 128, gb2, 128, epi(), 1, s);                              // g_h3 from the bottleneck
     // density head on the view mean of h3
-    gemm<true, true>(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, epi(nullptr, 0, 2), split_k(1, 128, (int)P), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(P)), dim3(64), 0, s, g_sigma, P, 1, gb[7]);
+    dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);
     gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 1, gb2);          // g_h3 += g_hm / NV
     hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, h3, R * 128);                   // g_z3
     // layer 3 on [h2 | x0]
-    gemm<true, true>(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
+    dw_gemm(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, gb[3], part, s);
     if (g_pre) hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, gb2, 128L, g_pre + 128, 256L, R, 128);
     for (int i = 0; i < 3; ++i) {
         if (g_pre && i == 1) continue;
-        gemm<true, true>(128, kin[i], (int)R, gb2, 128, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, epi(nullptr, 0, 2), split_k(128, kin[i], (int)R), s);
+        dw_gemm(128, kin[i], (int)R, gb2, 128, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, nullptr, part, s);
         if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, gb2, 128, w[3] + 128 + off[i], 128 + K0, g_in[i], kin[i], epi(), 1, s);
     }
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[3]);
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[3], 128 + K0, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);    // g_z2 = (g_z3 W3a) relu'(h2)
     // layer 2
-    gemm<true, true>(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[2]);
+    dw_gemm(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, gb[2], part, s);
     gemm<false, true>((int)R, 128, 128, ga, 128, w[2], 128, gb2, 128, epi(nullptr, 0, 0, h1, 128), 1, s);         // g_z1
     // layer 1
-    gemm<true, true>(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, epi(nullptr, 0, 2), split_k(128, 128, (int)R), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gb2, R, 128, gb[1]);
+    dw_gemm(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, gb[1], part, s);
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, ga, 128, epi(nullptr, 0, 0, h0, 128), 1, s);         // g_z0
     // layer 0
     if (g_pre) hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, ga, 128L, g_pre, 256L, R, 128);
     for (int i = 0; i < 3; ++i) {
         if (g_pre && i == 1) continue;
-        gemm<true, true>(128, kin[i], (int)R, ga, 128, in[i], kin[i], gw[0] + off[i], K0, epi(nullptr, 0, 2), split_k(128, kin[i], (int)R), s);
+        dw_gemm(128, kin[i], (int)R, ga, 128, in[i], kin[i], gw[0] + off[i], K0, i == 0 ? gb[0] : nullptr, part, s);
         if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, ga, 128, w[0] + off[i], K0, g_in[i], kin[i], epi(nullptr, 0, 1), 1, s);
     }
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, ga, R, 128, gb[0]);
 }
 
 // ---- vanilla NeRFMLP (vanilla_nerf/model.py:100-125) ---------------------------------------------------------------------
@@ -522,7 +725,7 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
 // bottleneck (256 -> 256), density (256 -> 1), rgb (128 -> 3).
 // tape (floats): h0..h7 (R x 256 each), bott (R x 256), v (R x 128)
 size_t vanilla_train_tape_floats(long R) { return (size_t)(R * (9 * 256 + 128)); }
-size_t vanilla_train_scratch_floats(long R) { return (size_t)(R * (2 * 256 + 128)); }
+size_t vanilla_train_scratch_floats(long R) { return (size_t)(R * (2 * 256 + 128) + DW_PART_FLOATS); }
 
 void launch_vanilla_train_forward(const float* const* w, const float* const* b, const float* x0, const float* cond, long R,
                                   float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s) {
@@ -556,22 +759,19 @@ void launch_vanilla_train_backward(const float* const* w, const float* x0, const
     const float* bott = tape + (size_t)8 * R * 256;
     const float* v = bott + (size_t)R * 256;
     float* ga = scratch; float* gb2 = ga + (size_t)R * 256; float* gv = gb2 + (size_t)R * 256;
+    float* part = gv + (size_t)R * 128;                                              // DW_PART_FLOATS (dw_gemm)
     const int M = (int)R;
     // rgb head, view layer on [bott | cond]
-    gemm<true, true>(3, 128, M, g_rgb, 3, v, 128, gw[11], 128, epi(nullptr, 0, 2), split_k(3, 128, M), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, g_rgb, R, 3, gb[11]);
+    dw_gemm(3, 128, M, g_rgb, 3, v, 128, gw[11], 128, gb[11], part, s);
     gemm<false, true>(M, 128, 3, g_rgb, 3, w[11], 128, gv, 128, epi(nullptr, 0, 0, v, 128), 1, s);
-    gemm<true, true>(128, 256, M, gv, 128, bott, 256, gw[8], 283, epi(nullptr, 0, 2), split_k(128, 256, M), s);
-    gemm<true, true>(128, 27, M, gv, 128, cond, 27, gw[8] + 256, 283, epi(nullptr, 0, 2), split_k(128, 27, M), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(128), 0, s, gv, R, 128, gb[8]);
+    dw_gemm(128, 256, M, gv, 128, bott, 256, gw[8], 283, gb[8], part, s);
+    dw_gemm(128, 27, M, gv, 128, cond, 27, gw[8] + 256, 283, nullptr, part, s);
     if (g_cond) gemm<false, true>(M, 27, 128, gv, 128, w[8] + 256, 283, g_cond, 27, epi(), 1, s);
     gemm<false, true>(M, 256, 128, gv, 128, w[8], 283, ga, 256, epi(), 1, s);                                     // g_bott
     // bottleneck + density head -> g_h7
-    gemm<true, true>(256, 256, M, ga, 256, h[7], 256, gw[9], 256, epi(nullptr, 0, 2), split_k(256, 256, M), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, ga, R, 256, gb[9]);
+    dw_gemm(256, 256, M, ga, 256, h[7], 256, gw[9], 256, gb[9], part, s);
     gemm<false, true>(M, 256, 256, ga, 256, w[9], 256, gb2, 256, epi(), 1, s);
-    gemm<true, true>(1, 256, M, g_sigma, 1, h[7], 256, gw[10], 256, epi(nullptr, 0, 2), split_k(1, 256, M), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(64), 0, s, g_sigma, R, 1, gb[10]);
+    dw_gemm(1, 256, M, g_sigma, 1, h[7], 256, gw[10], 256, gb[10], part, s);
     gemm<false, true>(M, 256, 1, g_sigma, 1, w[10], 256, gb2, 256, epi(nullptr, 0, 1), 1, s);
     hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 256)), dim3(256), 0, s, gb2, h[7], R * 256);                  // g_z7
     float* cur = gb2;
@@ -579,20 +779,17 @@ void launch_vanilla_train_backward(const float* const* w, const float* x0, const
     for (int i = 7; i >= 1; --i) {
         // cur = g_z_i (R x 256)
         if (i == 5) {
-            gemm<true, true>(256, 256, M, cur, 256, h[4], 256, gw[5], 319, epi(nullptr, 0, 2), split_k(256, 256, M), s);
-            gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[5] + 256, 319, epi(nullptr, 0, 2), split_k(256, 63, M), s);
+            dw_gemm(256, 256, M, cur, 256, h[4], 256, gw[5], 319, gb[5], part, s);
+            dw_gemm(256, 63, M, cur, 256, x0, 63, gw[5] + 256, 319, nullptr, part, s);
             if (g_x0) gemm<false, true>(M, 63, 256, cur, 256, w[5] + 256, 319, g_x0, 63, epi(), 1, s);
-            hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[5]);
             gemm<false, true>(M, 256, 256, cur, 256, w[5], 319, nxt, 256, epi(nullptr, 0, 0, h[4], 256), 1, s);
         } else {
-            gemm<true, true>(256, 256, M, cur, 256, h[i - 1], 256, gw[i], 256, epi(nullptr, 0, 2), split_k(256, 256, M), s);
-            hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[i]);
+            dw_gemm(256, 256, M, cur, 256, h[i - 1], 256, gw[i], 256, gb[i], part, s);
             gemm<false, true>(M, 256, 256, cur, 256, w[i], 256, nxt, 256, epi(nullptr, 0, 0, h[i - 1], 256), 1, s);
         }
         float* t = cur; cur = nxt; nxt = t;
     }
-    gemm<true, true>(256, 63, M, cur, 256, x0, 63, gw[0], 63, epi(nullptr, 0, 2), split_k(256, 63, M), s);
-    hipLaunchKernelGGL(k_colsum, dim3(1, blocks(R)), dim3(256), 0, s, cur, R, 256, gb[0]);
+    dw_gemm(256, 63, M, cur, 256, x0, 63, gw[0], 63, gb[0], part, s);
     if (g_x0) gemm<false, true>(M, 63, 256, cur, 256, w[0], 63, g_x0, 63, epi(nullptr, 0, 1), 1, s);
 }
 
