@@ -302,6 +302,32 @@ __global__ __launch_bounds__(256) void k_gather(TpScene sc, TpViews views, const
 // the running w * g sum in registers, and issues the atomics only when the texel changes (and at the end of the run): the same
 // sums, a few times fewer atomics.  The 16 rows' tap descriptors are computed once (lane c computes row c) and shared through LDS.
 constexpr int GRUN = 16;
+// channel order of a 16-lane group's 64-channel piece: 1 = lane c holds channels c, c + 16, c + 32, c + 48 (one atomic instruction of
+// the group = one 64-byte sector of the texel; with 0 = 4 consecutive channels per lane, every one of the 4 instructions touched
+// all 4 sectors)
+#ifndef NEO_SCATTER_LANE_MAJOR
+#define NEO_SCATTER_LANE_MAJOR 1
+#endif
+#ifndef NEO_SCATTER_SCOPE_WG
+#define NEO_SCATTER_SCOPE_WG 0      // 1: workgroup-scope atomics - a TIMING PROBE only (sums from different XCDs may be lost)
+#endif
+__device__ __forceinline__ int scatter_channel(int piece64, int c, int e) {
+    return NEO_SCATTER_LANE_MAJOR ? piece64 * 64 + 16 * e + c : piece64 * 64 + 4 * c + e;
+}
+__device__ __forceinline__ void scatter_add(float* dst, float v) {
+#if NEO_SCATTER_SCOPE_WG
+    __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    atomicAdd(dst, v);
+#endif
+}
+__device__ __forceinline__ f32x4 scatter_grad(const float* row, int piece64, int c) {
+    if (!NEO_SCATTER_LANE_MAJOR) return *reinterpret_cast<const f32x4*>(row + piece64 * 64 + 4 * c);
+    f32x4 g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = row[piece64 * 64 + 16 * e + c];
+    return g;
+}
 __global__ __launch_bounds__(256) void k_gather_bwd_runs(TpScene sc, TpViews views, const float* __restrict__ pts, long P,
                                                         const float* __restrict__ g_world, const float* __restrict__ g_local,
                                                         float* __restrict__ g_plane0, float* __restrict__ g_plane1,
@@ -345,22 +371,21 @@ __global__ __launch_bounds__(256) void k_gather_bwd_runs(TpScene sc, TpViews vie
         const int pieces = ch / 64;                       // 16-byte pieces per lane: 8 (latent) or 2 (a plane)
 #pragma unroll 1
         for (int q = 0; q < pieces; ++q) {
-            const int piece = c + 16 * q;
             int cur[4] = {-1, -1, -1, -1};
             f32x4 acc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             auto flush = [&](int k) {
                 if (cur[k] >= 0) {
-                    float* dst = gmap[m] + (long)cur[k] * ch + piece * 4;
+                    float* dst = gmap[m] + (long)cur[k] * ch;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[k][e]);
+                    for (int e = 0; e < 4; ++e) scatter_add(dst + scatter_channel(q, c, e), acc[k][e]);
                 }
             };
 #pragma unroll 1
             for (int r = 0; r < GRUN; ++r) {
                 if (row0 + r >= rows) break;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + (row0 + r) * ch + piece * 4);
+                const f32x4 g = scatter_grad(gsrc + (row0 + r) * ch, q, c);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int o = s_off[grp][r][m][k];
@@ -431,22 +456,22 @@ __global__ __launch_bounds__(256) void k_map_gather_bwd_runs(TpScene sc, TpViews
     __syncthreads();
     if (row0 >= rows) return;
 #pragma unroll 1
-    for (int piece = c; piece < C / 4; piece += 16) {
+    for (int q = 0; q < C / 64; ++q) {
         int cur[4] = {-1, -1, -1, -1};
         f32x4 acc[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto flush = [&](int k) {
             if (cur[k] >= 0) {
-                float* dst = g_map + (long)cur[k] * C + piece * 4;
+                float* dst = g_map + (long)cur[k] * C;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[k][e]);
+                for (int e = 0; e < 4; ++e) scatter_add(dst + scatter_channel(q, c, e), acc[k][e]);
             }
         };
 #pragma unroll 1
         for (int r = 0; r < GRUN; ++r) {
             if (row0 + r >= rows) break;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(g_out + (row0 + r) * C + piece * 4);
+            const f32x4 g = scatter_grad(g_out + (row0 + r) * C, q, c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int o = s_off[grp][r][k];
