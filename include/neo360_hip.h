@@ -352,6 +352,13 @@ int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const
                                   const float* cond, int NV, long P, const float* tape, const float* g_rgb, const float* g_sigma,
                                   float* const* gw, float* const* gb, float* g_x_enc, float* g_pre, float* g_world, void* stream);
 
+/* Weight (and bias) gradient of a linear layer y = x W^T + b over K rows - what autograd forms for every nn.Linear of the
+ * reference's MLPs (torch's addmm backward), here for the texel-space projection of training.project_latent:
+ * dW (M, N; row pitch ldw) += dY^T X, db (M) += column sums of dY (db may be NULL).  dY (K, M) row pitch ldy, X (K, N) row pitch
+ * ldx, fp32, exact fp32 MFMA; M <= 1024, N <= 4096 (a (texels, 256)^T (texels, 512) product runs at ~110 TFLOP/s). */
+int neo_linear_weight_grad(neo_ctx* ctx, int M, int N, long K, const float* dY, long ldy, const float* X, long ldx, float* dW,
+                           long ldw, float* db, void* stream);
+
 /* Stand-alone feature lookups of the scene set with neo_tp_set_scene, view-major rows (row = v P + p):
  * world (NV*P,128) = index_grid (encoder_tp_fusion_conv.py:122-209: three planes summed), local (NV*P,512) =
  * get_local_feats / SpatialEncoder.index (neo360/model.py:239-264).  pts (P,3) world points.  local (and, in the backward, g_local

@@ -77,6 +77,7 @@ SIGNATURES = {
                                           _vp, _vp]),
     "neo_tp_mlp_train_backward_pre": (_i, [_vp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp,
                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
+    "neo_linear_weight_grad": (_i, [_vp, _i, _i, ctypes.c_long, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp]),
     "neo_tp_gather": (_i, [_vp, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
     "neo_tp_gather_backward": (_i, [_vp, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "neo_tp_mlp_train_tape_floats": (ctypes.c_long, [_i, ctypes.c_long]),

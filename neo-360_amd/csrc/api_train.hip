@@ -358,6 +358,19 @@ int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const
     return check_launch();
 }
 
+int neo_linear_weight_grad(neo_ctx* ctx, int M, int N, long K, const float* dY, long ldy, const float* X, long ldx, float* dW,
+                           long ldw, float* db, void* stream) {
+    ENTER(ctx);
+    REQUIRE(M >= 1 && M <= 1024 && N >= 1 && N <= 4096 && K >= 0 && K <= 2000000000L, "bad shape (M <= 1024, N <= 4096)");
+    REQUIRE(ldy >= M && ldx >= N && ldw >= N, "row pitch smaller than the row");
+    if (K == 0) return NEO_OK;
+    REQUIRE(dY && X && dW, "null pointer");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
+    if (ctx->train_scratch.reserve(neo::weight_grad_scratch_floats() * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_weight_grad(M, N, (int)K, dY, ldy, X, ldx, dW, ldw, db, ctx->train_scratch.as<float>(), static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
 long neo_vanilla_mlp_train_tape_floats(long R) { return R >= 0 ? (long)neo::vanilla_train_tape_floats(R) : 0; }
 
 int neo_vanilla_mlp_train_forward(neo_ctx* ctx, const float* const* w, const float* const* b, const float* x0, const float* cond,

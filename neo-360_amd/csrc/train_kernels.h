@@ -23,6 +23,10 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
 // vanilla NeRFMLP (vanilla_nerf/model.py:100-125): rows R = rays x samples; x0 (R, 63), cond (R, 27).  w / b order as
 // neo_vanilla_upload_mlp.
 size_t vanilla_train_tape_floats(long R);
+// dW (M x N) += dY^T X over K rows, db (M, may be null) += column sums of dY; scratch: weight_grad_scratch_floats()
+size_t weight_grad_scratch_floats();
+void launch_weight_grad(int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, float* db,
+                        float* scratch, hipStream_t s);
 size_t vanilla_train_scratch_floats(long R);
 void launch_vanilla_train_forward(const float* const* w, const float* const* b, const float* x0, const float* cond, long R,
                                   float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s);

@@ -600,6 +600,12 @@ void dw_gemm(int M, int N, int K, const float* Z, long ldz, const float* X, long
 
 }  // namespace
 
+size_t weight_grad_scratch_floats() { return (size_t)DW_PART_FLOATS; }
+void launch_weight_grad(int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, float* db,
+                        float* scratch, hipStream_t s) {
+    dw_gemm(M, N, K, dY, ldy, X, ldx, dW, ldw, db, scratch, s);
+}
+
 // ---- tape layout (floats): h0, h1, h2, h3, bott (R x 128 each), y0 (R x 64), hm (P x 128), ym (P x 64), y1 (P x 64) ----
 size_t tp_train_tape_floats(int NV, long P) {
     const long R = (long)NV * P;

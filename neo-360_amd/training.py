@@ -340,14 +340,50 @@ class _TrainMLPPre(torch.autograd.Function):
         return (None, None, None, gx.reshape(xshape) if gx is not None else None, None, gworld, gpre, *gw, *gb)
 
 
-def project_latent(mlp, latent_cl):
-    """G = F [W0_loc | W3_loc]^T per texel: latent_cl (texels, 512) channels-last -> (texels, 256), a plain library GEMM under
-    autograd (its backward IS the gradient of the two local weight blocks and of the latent).  W0_loc = pts_linears.0's columns of
-    the 512 latent features, W3_loc = the same columns of the skip half of pts_linears.3 (neo360/model.py:123-137)."""
+class _LinearNoBias(torch.autograd.Function):
+    """y = x W^T (library GEMM); backward: dx = dy W (library GEMM), dW = dy^T x by the library's weight-gradient kernel
+    (neo_linear_weight_grad: the output is a handful of tiles over ~230 k rows, where the library GEMM ran at a third of its rate)."""
+
+    @staticmethod
+    def forward(ctx_, lib_ctx, x, w):
+        ctx_.lib_ctx = lib_ctx
+        ctx_.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx_, gy):
+        x, w = ctx_.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ w if ctx_.needs_input_grad[1] else None
+        gw = None
+        if ctx_.needs_input_grad[2]:
+            gw = weight_grad(gy, x, ctx=ctx_.lib_ctx)
+        return None, gx, gw
+
+
+def weight_grad(gy, x, bias=False, ctx=None):
+    """dW (M, N) = gy^T x over the rows of gy (K, M) and x (K, N) (and db = column sums of gy with bias=True): the weight gradient of
+    a linear layer, neo_linear_weight_grad."""
+    gy, x = f32(gy, "gy"), f32(x, "x")
+    if gy.dim() != 2 or x.dim() != 2 or gy.shape[0] != x.shape[0]:
+        raise ValueError("gy (K, M) and x (K, N) must share their rows, got %s and %s" % (tuple(gy.shape), tuple(x.shape)))
+    c = _ctx(gy, ctx)
+    K, M, N = gy.shape[0], gy.shape[1], x.shape[1]
+    gw = torch.zeros(M, N, device=gy.device, dtype=torch.float32)
+    gb = torch.zeros(M, device=gy.device, dtype=torch.float32) if bias else None
+    _lib.check(c.lib.neo_linear_weight_grad(c.handle, M, N, K, ptr(gy), M, ptr(x), N, ptr(gw), N, ptr(gb) if bias else None, c.stream()))
+    return (gw, gb) if bias else gw
+
+
+def project_latent(mlp, latent_cl, ctx=None):
+    """G = F [W0_loc | W3_loc]^T per texel: latent_cl (texels, 512) channels-last -> (texels, 256), library GEMMs under autograd
+    (the backward IS the gradient of the two local weight blocks - formed by neo_linear_weight_grad - and of the latent).
+    W0_loc = pts_linears.0's columns of the 512 latent features, W3_loc = the same columns of the skip half of pts_linears.3
+    (neo360/model.py:123-137)."""
     pe = mlp.input_ch * 21
     w0, w3 = mlp.pts_linears[0].weight, mlp.pts_linears[3].weight
     wcat = torch.cat([w0[:, pe:pe + 512], w3[:, 128 + pe:128 + pe + 512]], dim=0)          # (256, 512)
-    return latent_cl @ wcat.t()
+    return _LinearNoBias.apply(ctx, latent_cl, wcat)
 
 
 def nerfpp_mlp_projected(mlp, x_enc, cond_rows, world_feat, pre, nv, ctx=None):
@@ -576,7 +612,7 @@ def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws, pr
         for name, mlp, look, x_enc in (("fg", mlps[level], fg_p, fg_x), ("bg", mlps[2 + level], bg_lin, bg_x)):
             if proj is not None:
                 if (name, level) not in proj:
-                    proj[(name, level)] = project_latent(mlp, proj["latent_cl"])                  # (texels, 256), once per call
+                    proj[(name, level)] = project_latent(mlp, proj["latent_cl"], ctx=c)                  # (texels, 256), once per call
                 world = gather_planes(module, look, maps[0], maps[1], maps[2], maps[3], rays)
                 pre = gather_map(module, proj[(name, level)], look, rays)
                 raw_rgb, raw_sigma = nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, NV, ctx=c)
