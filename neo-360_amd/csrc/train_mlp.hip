@@ -7,7 +7,7 @@
 // orders of magnitude, which the fp16 hi/lo split of the inference kernels would have to rescale tile by tile; the
 // training step is not the path the headline metric measures, so it takes the simple exact arithmetic.
 //
-//   k_sgemm<AT, BT>   C[M][N] (+)= op(A)[M][K] . op(B)[N][K]^T, 64 x 64 tiles, 4 waves of 32 x 32, K stepped by 32 through
+//   k_sgemm<AT, BT, TN>  C[M][N] (+)= op(A)[M][K] . op(B)[N][K]^T, 128 x TN tiles (TN = 64 / 128), 4 waves of 64 x TN / 2, K stepped by 32 through
 //                     two K-major LDS tiles; operands in any of the layouts the chain needs:
 //                       AT = false: A stored [M][K] (K fastest)      AT = true: A stored [K][M]   (reduction index slowest)
 //                       BT = false: B stored [N][K]                  BT = true: B stored [K][N]
@@ -32,13 +32,13 @@ namespace {
 #define NEO_SGEMM_ABLATE 0     // timing experiments only (wrong results; tools/build_variant.py): 1 no MFMAs, 2 no operand loads in the pipelined loop
 #endif
 constexpr int GTM = 128;      // C tile: rows of op(A)
-constexpr int GTN = 64;       //         rows of op(B)
+constexpr int GTN = 64;       //         rows of op(B): 64, or 128 when N > 64 (template parameter TN; a 128-wide layer is one tile:
+                              //         its A rows are read once - at 64 the launch asked the fabric for 8 B per clock and CU)
 constexpr int GK = 32;        // K step
 constexpr int GP = GK + 4;    // pitch (floats) of a K-major LDS tile [rows][k]: 16-B fragment reads of 16 consecutive rows hit 16 distinct bank groups
 constexpr int PRA = GTM + 4;  // pitch of a row-major LDS tile [k][rows] (operands stored with the row index fastest): 4 * pitch = 16 mod 32,
-constexpr int PRB = GTN + 4;  //   so the two lane halves of a fragment read (k and k + 4) fall into different bank halves
+                              //   so the two lane halves of a fragment read (k and k + 4) fall into different bank halves
 constexpr int AS_FLOATS = GTM * GP > GK * PRA ? GTM * GP : GK * PRA;
-constexpr int BS_FLOATS = GTN * GP > GK * PRB ? GTN * GP : GK * PRB;
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-B global access at 4-B alignment (rows of 703 floats)
 
@@ -64,26 +64,33 @@ struct GemmSegs {
 // C[M][N] (+)= op(A) . op(B)^T on 128 x 64 tiles: 4 waves of 64 (m) x 32 (n) = two accumulators sharing the n fragment.
 // Operands travel global -> registers (16-B loads along the stored-fast index, guarded element-wise at the edges) -> LDS
 // (double-buffered: the next K-step is staged into the other buffer while this one is multiplied, one barrier per step).
-template <bool AT, bool BT>
+template <bool AT, bool BT, int TN>
 __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const float* __restrict__ A_in, long lda_in,
                                                   const float* __restrict__ B_in, long ldb, float* __restrict__ C, long ldc,
                                                   GemmEpi ep, int k_per_split, GemmSegs sg) {
+    constexpr int PRB = TN + 4;             // pitch of a row-major B tile [k][rows]
+    constexpr int NF = TN / 64, JB = TN / 32;   // n fragments per wave; 16-B pieces of the B tile per thread and K step
+    constexpr int BS_FLOATS = TN * GP > GK * PRB ? TN * GP : GK * PRB;
     __shared__ __attribute__((aligned(16))) float As[2][AS_FLOATS];
     __shared__ __attribute__((aligned(16))) float Bs[2][BS_FLOATS];
     LaneCtx L;
     L.init();
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * GTM, n0 = blockIdx.x * GTN;
+    const int m0 = blockIdx.y * GTM, n0 = blockIdx.x * TN;
     // the operand range being accumulated (one per segment)
     const float* A = A_in;
     const float* B = B_in;
     long lda = lda_in;
     int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
-    const int wm = L.wv & 1, wn = L.wv >> 1;            // this wave: rows m0 + 64 wm .. + 63, columns n0 + 32 wn .. + 31
-    f32x16 acc[2];
+    const int wm = L.wv & 1, wn = L.wv >> 1;            // this wave: rows m0 + 64 wm .. + 63, columns n0 + (TN / 2) wn .. + TN / 2 - 1
+    f32x16 acc[2][NF];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
-    f32x4 ra[4], rb[2];
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NF; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][nt][r] = 0.0f;
+    f32x4 ra[4], rb[JB];
     // one 16-B piece of an operand tile: T = stored with the row index fastest ([K][rows]), else K fastest ([rows][K])
     auto piece = [&](const float* __restrict__ P, long ld, bool T, int rows0, int rows_end, int k0, int idx4, int rows_tile) -> f32x4 {
         int r, k, dr, dk;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
 #pragma unroll
         for (int j = 0; j < 4; ++j) ra[j] = piece(A, lda, AT, m0, M, k0, tid + 256 * j, GTM);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) rb[j] = piece(B, ldb, BT, n0, N, k0, tid + 256 * j, GTN);
+        for (int j = 0; j < JB; ++j) rb[j] = piece(B, ldb, BT, n0, N, k0, tid + 256 * j, TN);
     };
     auto put = [&](float* tile, bool T, int idx4, int rows_tile, int pitch_t, const f32x4 v) {
         if (T) { const int q = rows_tile / 4; *reinterpret_cast<f32x4*>(tile + (idx4 / q) * pitch_t + (idx4 % q) * 4) = v; }
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
 #pragma unroll
         for (int j = 0; j < 4; ++j) put(As[buf], AT, tid + 256 * j, GTM, PRA, ra[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) put(Bs[buf], BT, tid + 256 * j, GTN, PRB, rb[j]);
+        for (int j = 0; j < JB; ++j) put(Bs[buf], BT, tid + 256 * j, TN, PRB, rb[j]);
     };
     // fragment of 4 consecutive k (k = 8 c + 4 half + e) of one tile row
     auto frag = [&](const float* tile, bool T, int pitch_t, int row, int c) -> f32x4 {
@@ -125,15 +132,19 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
     auto compute = [&](int buf) {
 #pragma unroll
         for (int c = 0; c < GK / 8; ++c) {
-            const f32x4 a = frag(Bs[buf], BT, PRB, wn * 32 + L.l31, c);                    // D rows = n
+            f32x4 a[NF];
+#pragma unroll
+            for (int nt = 0; nt < NF; ++nt) a[nt] = frag(Bs[buf], BT, PRB, wn * (TN / 2) + 32 * nt + L.l31, c);   // D rows = n
             const f32x4 b0 = frag(As[buf], AT, PRA, wm * 64 + L.l31, c);                   // D cols = m
             const f32x4 b1 = frag(As[buf], AT, PRA, wm * 64 + 32 + L.l31, c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (NEO_SGEMM_ABLATE & 1) { acc[0][e] += a[e] * b0[e]; acc[1][e] += a[e] * b1[e]; continue; }
-                acc[0] = NEO_MFMA(a[e], b0[e], acc[0]);
-                acc[1] = NEO_MFMA(a[e], b1[e], acc[1]);
-            }
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NF; ++nt) {
+                    if (NEO_SGEMM_ABLATE & 1) { acc[0][nt][e] += a[nt][e] * b0[e]; acc[1][nt][e] += a[nt][e] * b1[e]; continue; }
+                    acc[0][nt] = NEO_MFMA(a[nt][e], b0[e], acc[0][nt]);
+                    acc[1][nt] = NEO_MFMA(a[nt][e], b1[e], acc[1][nt]);
+                }
         }
     };
     const int nseg = sg.n > 0 ? sg.n : 1;
@@ -151,9 +162,9 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
     // ---- interior tiles: every full K step through a branch-free pipeline, operands requested TWO steps ahead (two register
     //      sets; a step's loads have two multiply phases to arrive from HBM), pointers advanced instead of recomputed ----
     const int nfull = (kend - kbeg) / GK;
-    if (m0 + GTM <= M && n0 + GTN <= N && nfull >= 1) {
+    if (m0 + GTM <= M && n0 + TN <= N && nfull >= 1) {
         const float* pa[4];
-        const float* pb[2];
+        const float* pb[JB];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx4 = tid + 256 * j;
@@ -161,26 +172,26 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
                        : A + (long)(m0 + (idx4 >> 3)) * lda + kbeg + (idx4 & 7) * 4;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JB; ++j) {
             const int idx4 = tid + 256 * j;
-            pb[j] = BT ? B + (long)(kbeg + idx4 / (GTN / 4)) * ldb + n0 + (idx4 % (GTN / 4)) * 4
+            pb[j] = BT ? B + (long)(kbeg + idx4 / (TN / 4)) * ldb + n0 + (idx4 % (TN / 4)) * 4
                        : B + (long)(n0 + (idx4 >> 3)) * ldb + kbeg + (idx4 & 7) * 4;
         }
         const long sa_step = AT ? (long)GK * lda : GK, sb_step = BT ? (long)GK * ldb : GK;
-        f32x4 qa[2][4], qb[2][2];
+        f32x4 qa[2][4], qb[2][JB];
         auto fetch_q = [&](auto sc) {
             constexpr int S = decltype(sc)::value;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { if (!(NEO_SGEMM_ABLATE & 2)) qa[S][j] = *reinterpret_cast<const f4u*>(pa[j]); pa[j] += sa_step; }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { if (!(NEO_SGEMM_ABLATE & 2)) qb[S][j] = *reinterpret_cast<const f4u*>(pb[j]); pb[j] += sb_step; }
+            for (int j = 0; j < JB; ++j) { if (!(NEO_SGEMM_ABLATE & 2)) qb[S][j] = *reinterpret_cast<const f4u*>(pb[j]); pb[j] += sb_step; }
         };
         auto stage_q = [&](auto sc, int buf) {
             constexpr int S = decltype(sc)::value;
 #pragma unroll
             for (int j = 0; j < 4; ++j) put(As[buf], AT, tid + 256 * j, GTM, PRA, qa[S][j]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) put(Bs[buf], BT, tid + 256 * j, GTN, PRB, qb[S][j]);
+            for (int j = 0; j < JB; ++j) put(Bs[buf], BT, tid + 256 * j, TN, PRB, qb[S][j]);
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
@@ -250,8 +261,10 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
         const int gm = m0 + wm * 64 + 32 * t + L.l31;
         if (gm >= M) continue;
 #pragma unroll
+        for (int nt = 0; nt < NF; ++nt)
+#pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int gn = n0 + wn * 32 + 8 * g + 4 * L.half;
+            const int gn = n0 + wn * (TN / 2) + 32 * nt + 8 * g + 4 * L.half;
             if (gn >= N) continue;
             float* dst = C + (long)gm * ldc + gn;
             const bool full = gn + 3 < N;
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = acc[t][4 * g + e] * ep.scale + bs[e];
+                float x = acc[t][nt][4 * g + e] * ep.scale + bs[e];
                 if (ep.accumulate == 1) x = old[e] + x;
                 if (ep.relu) x = fmaxf(x, 0.0f);
                 if (!(mk[e] > 0.0f)) x = 0.0f;
@@ -515,6 +528,11 @@ __global__ void k_colsum(const float* __restrict__ g, long M, int C, float* __re
     atomicAdd(out + c, s);
 }
 
+#ifndef NEO_SGEMM_WIDE
+#define NEO_SGEMM_WIDE 0        // 1: 128 x 128 tiles for N > 64 - measured: no gain (37.2 vs 37.6 ms per training step, profiles/r05_train_dw.log): the chain is not bound by the A rows
+#endif
+inline bool wide_tile(int N) { return NEO_SGEMM_WIDE && N > 64; }
+
 template <bool AT, bool BT>
 void gemm(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const GemmEpi& ep,
           int splits, hipStream_t s) {
@@ -522,8 +540,13 @@ void gemm(int M, int N, int K, const float* A, long lda, const float* B, long ld
     int kps = (K + splits - 1) / splits;
     kps = ((kps + GK - 1) / GK) * GK;
     const int nz = (K + kps - 1) / kps;
-    hipLaunchKernelGGL((k_sgemm<AT, BT>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
-                       ldb, C, ldc, ep, kps, GemmSegs{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0});
+    const GemmSegs none{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0};
+    if (wide_tile(N))
+        hipLaunchKernelGGL((k_sgemm<AT, BT, 128>), dim3((N + 127) / 128, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
+                           ldb, C, ldc, ep, kps, none);
+    else
+        hipLaunchKernelGGL((k_sgemm<AT, BT, GTN>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
+                           ldb, C, ldc, ep, kps, none);
 }
 
 // C[M][N] = [A0 | A1 | ..][M][K0 + K1 + ..] . B[N][K0 + K1 + ..]^T  (B = a weight matrix (out, in), K fastest; dense segments)
@@ -534,8 +557,12 @@ void gemm_cat(int M, int N, const Seg* segs, int nseg, const float* B, long ldb,
     GemmSegs sg{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, {0, 0, 0, 0}, nseg};
     int K = 0;
     for (int i = 0; i < nseg; ++i) { sg.a[i] = segs[i].a; sg.lda[i] = segs[i].k; sg.k[i] = segs[i].k; K += segs[i].k; }
-    hipLaunchKernelGGL((k_sgemm<false, false>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, 1), dim3(256), 0, s, M, N, K,
-                       segs[0].a, (long)segs[0].k, B, ldb, C, ldc, ep, K, sg);
+    if (wide_tile(N))
+        hipLaunchKernelGGL((k_sgemm<false, false, 128>), dim3((N + 127) / 128, (M + GTM - 1) / GTM, 1), dim3(256), 0, s, M, N, K,
+                           segs[0].a, (long)segs[0].k, B, ldb, C, ldc, ep, K, sg);
+    else
+        hipLaunchKernelGGL((k_sgemm<false, false, GTN>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, 1), dim3(256), 0, s, M, N, K,
+                           segs[0].a, (long)segs[0].k, B, ldb, C, ldc, ep, K, sg);
 }
 
 inline GemmEpi epi(const float* bias = nullptr, int relu = 0, int accumulate = 0, const float* mask = nullptr, int ldm = 0,
