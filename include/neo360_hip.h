@@ -352,6 +352,21 @@ int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const
                                   const float* cond, int NV, long P, const float* tape, const float* g_rgb, const float* g_sigma,
                                   float* const* gw, float* const* gb, float* g_x_enc, float* g_pre, float* g_world, void* stream);
 
+/* One linear layer of a training chain the caller composes (models whose MLP has no fused training kernel: PixelNeRF's decoder,
+ * vanilla_nerf/model_pixel.py:96-131): y (rows, out_f) = x (rows, in_f) W^T + bias [then ReLU] (accumulate != 0: added onto y
+ * first), and the input gradient gx (rows, in_f) (+)= gy (rows, out_f) W.  W (out_f, in_f) with row pitch ldw (a column block of
+ * a wider matrix is addressed by its pitch), fp32, exact fp32 MFMA.  With neo_linear_weight_grad these are torch's addmm and its
+ * two backward products. */
+int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float* x, long ldx, const float* w, long ldw,
+                       const float* bias, int relu, int accumulate, float* y, long ldy, void* stream);
+int neo_linear_input_grad(neo_ctx* ctx, long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw,
+                          int accumulate, float* gx, long ldx, void* stream);
+/* neo_tp_gather_map / _backward at the PixelNeRF decoder's taps (scene geometry of neo_pix_set_scene). */
+int neo_pix_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+                       float cx, float cy, float* out, void* stream);
+int neo_pix_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+                                float cy, const float* g_out, float* g_map, void* stream);
+
 /* Weight (and bias) gradient of a linear layer y = x W^T + b over K rows - what autograd forms for every nn.Linear of the
  * reference's MLPs (torch's addmm backward), here for the texel-space projection of training.project_latent:
  * dW (M, N; row pitch ldw) += dY^T X, db (M) += column sums of dY (db may be NULL).  dY (K, M) row pitch ldy, X (K, N) row pitch

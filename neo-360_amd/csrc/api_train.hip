@@ -199,6 +199,39 @@ int neo_tp_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, co
     return check_launch();
 }
 
+// the same lookup at the PixelNeRF decoder's taps (geometry of neo_pix_set_scene: (f, f) projection, model_pixel.py:198-206)
+int neo_pix_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+                      float cx, float cy, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
+    if (P == 0) return NEO_OK;
+    REQUIRE(map && pts && src_poses && out, "null pointer");
+    if (!ctx->pix_scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_pix_set_scene)");
+    REQUIRE(NV == ctx->pix_scene.nv, "NV differs from the uploaded scene");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->pix_scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_map_gather(sc, views, pts, P, map, C, out, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_pix_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+                               float cy, const float* g_out, float* g_map, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
+    if (P == 0) return NEO_OK;
+    REQUIRE(pts && src_poses && g_out && g_map, "null pointer");
+    if (!ctx->pix_scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_pix_set_scene)");
+    REQUIRE(NV == ctx->pix_scene.nv, "NV differs from the uploaded scene");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->pix_scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_map_gather_bwd(sc, views, pts, P, g_out, C, g_map, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
 int neo_tp_render_train(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* viewdirs, int R, int chunk,
                         const float* src_poses, int NV, float focal, float cx, float cy, int n_coarse, int n_fine,
                         int white_bkgd, uint64_t seed, const neo_tp_train_out* level0, const neo_tp_train_out* level1,
@@ -355,6 +388,28 @@ int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const
     if (ctx->train_scratch.reserve(neo::tp_train_scratch_floats(NV, P) * sizeof(float))) return NEO_ERR_NOMEM;
     neo::launch_tp_train_backward(input_ch * 21, w, x_enc, nullptr, world_feat, cond, NV, P, tape, ctx->train_scratch.as<float>(),
                                   g_rgb, g_sigma, gw, gb, g_x_enc, nullptr, g_world, static_cast<hipStream_t>(stream), g_pre);
+    return check_launch();
+}
+
+int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float* x, long ldx, const float* w, long ldw,
+                       const float* bias, int relu, int accumulate, float* y, long ldy, void* stream) {
+    ENTER(ctx);
+    REQUIRE(rows >= 0 && rows <= 2000000000L && out_f >= 1 && out_f <= 4096 && in_f >= 1 && in_f <= 4096, "bad shape (features <= 4096)");
+    REQUIRE(ldx >= in_f && ldw >= in_f && ldy >= out_f, "row pitch smaller than the row");
+    if (rows == 0) return NEO_OK;
+    REQUIRE(x && w && y, "null pointer");
+    neo::launch_linear_forward(rows, out_f, in_f, x, ldx, w, ldw, bias, relu != 0, accumulate != 0, y, ldy, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_linear_input_grad(neo_ctx* ctx, long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw,
+                          int accumulate, float* gx, long ldx, void* stream) {
+    ENTER(ctx);
+    REQUIRE(rows >= 0 && rows <= 2000000000L && out_f >= 1 && out_f <= 4096 && in_f >= 1 && in_f <= 4096, "bad shape (features <= 4096)");
+    REQUIRE(ldy >= out_f && ldw >= in_f && ldx >= in_f, "row pitch smaller than the row");
+    if (rows == 0) return NEO_OK;
+    REQUIRE(gy && w && gx, "null pointer");
+    neo::launch_linear_input_grad(rows, in_f, out_f, gy, ldy, w, ldw, accumulate != 0, gx, ldx, static_cast<hipStream_t>(stream));
     return check_launch();
 }
 

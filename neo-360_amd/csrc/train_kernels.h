@@ -23,6 +23,11 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
 // vanilla NeRFMLP (vanilla_nerf/model.py:100-125): rows R = rays x samples; x0 (R, 63), cond (R, 27).  w / b order as
 // neo_vanilla_upload_mlp.
 size_t vanilla_train_tape_floats(long R);
+// one linear layer (exact fp32 MFMA GEMM, k_sgemm): y (+)= x W^T + b [ReLU];  gx (+)= gy W
+void launch_linear_forward(long rows, int out_f, int in_f, const float* x, long ldx, const float* w, long ldw, const float* bias,
+                           int relu, int accumulate, float* y, long ldy, hipStream_t s);
+void launch_linear_input_grad(long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw, int accumulate,
+                              float* gx, long ldx, hipStream_t s);
 // dW (M x N) += dY^T X over K rows, db (M, may be null) += column sums of dY; scratch: weight_grad_scratch_floats()
 size_t weight_grad_scratch_floats();
 void launch_weight_grad(int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, float* db,

@@ -627,6 +627,16 @@ void dw_gemm(int M, int N, int K, const float* Z, long ldz, const float* X, long
 
 }  // namespace
 
+// y (rows x out_f) (+)= x (rows x in_f) W^T + b, optional ReLU: one linear layer of a training chain composed by the caller
+void launch_linear_forward(long rows, int out_f, int in_f, const float* x, long ldx, const float* w, long ldw, const float* bias,
+                           int relu, int accumulate, float* y, long ldy, hipStream_t s) {
+    gemm<false, false>((int)rows, out_f, in_f, x, ldx, w, ldw, y, ldy, epi(bias, relu, accumulate ? 1 : 0), 1, s);
+}
+// gx (rows x in_f) (+)= gy (rows x out_f) W
+void launch_linear_input_grad(long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw, int accumulate,
+                              float* gx, long ldx, hipStream_t s) {
+    gemm<false, true>((int)rows, in_f, out_f, gy, ldy, w, ldw, gx, ldx, epi(nullptr, 0, accumulate ? 1 : 0), 1, s);
+}
 size_t weight_grad_scratch_floats() { return (size_t)DW_PART_FLOATS; }
 void launch_weight_grad(int M, int N, int K, const float* dY, long ldy, const float* X, long ldx, float* dW, long ldw, float* db,
                         float* scratch, hipStream_t s) {

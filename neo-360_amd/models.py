@@ -692,7 +692,9 @@ class PixelNeRF(_HipModule):
     @torch.no_grad()
     def set_scene(self, latent, image_wh):
         """latent (NV,512,Hf,Wf) as the reference's SpatialEncoder leaves it in `.latent`; image_wh = (W,H) of
-        the source images (model_pixel.py:176-177).  Re-laid out channels-last on the device, once."""
+        the source images (model_pixel.py:176-177).  Re-laid out channels-last on the device, once.  The module keeps a weak
+        reference to the tensor: a differentiable forward sends the latent's gradient there."""
+        self._latent_src = weakref.ref(latent)
         latent = f32(latent, "latent")
         ctx = self._context(latent.device)
         NV, Cl, Hf, Wf = latent.shape
@@ -735,9 +737,44 @@ class PixelNeRF(_HipModule):
         self._raise_flags(ctx.poll_flags())     # stage-level access: always immediate
         return out
 
-    @torch.no_grad()
-    def forward(self, rays, randomized, white_bkgd, near, far, chunk=None):
-        self._check_mode(randomized)
+    def _scene_tensors_for_grad(self):
+        ref = getattr(self, "_latent_src", None)
+        return (ref(),) if ref is not None else ()
+
+    def _latent_for_grad(self, rays):
+        """The latent a differentiable call gathers from: an attached encoder is run WITH autograd on this batch, as the
+        reference's forward does (model_pixel.py:176); otherwise the tensor given to set_scene, if the caller still holds it."""
+        enc = getattr(self, "encoder", None)
+        if enc is not None:
+            src = rays["src_imgs"]
+            enc(src)
+            latent = enc.latent
+            with torch.no_grad():
+                self.set_scene(latent.detach(), (src.shape[-1], src.shape[-2]))
+            self._scene_key = None
+            return latent
+        if self._scene_ctx is None:
+            raise _lib.NeoError("no scene latent: call set_scene(...) or attach an encoder module")
+        ref = getattr(self, "_latent_src", None)
+        latent = ref() if ref is not None else None
+        if latent is None:
+            raise _lib.NeoError("a differentiable / randomized forward needs the latent tensor: attach an encoder module, or keep "
+                                "the tensor passed to set_scene(...) alive (the module holds only a weak reference to it)")
+        return latent
+
+    def forward(self, rays, randomized, white_bkgd, near, far, chunk=None, seed=None):
+        """randomized=True (stratified sampling, `noise_std`) or a call that wants gradients (`_wants_grad()`: the reference's
+        training_step) runs on the operator chain of training.pix_render_train - every matrix product on the library's GEMMs,
+        gradients to all 18 parameter tensors of each MLP and to the latent; otherwise the fused no-grad kernels."""
+        if randomized or self._wants_grad():
+            from . import training
+            if chunk is not None and chunk < rays["rays_o"].shape[0]:
+                raise NotImplementedError("the training call renders its rays as ONE reference chunk")
+            return training.pix_render_train(self, rays, randomized, white_bkgd, near, far, self._latent_for_grad(rays), seed)
+        with torch.no_grad():
+            return self._forward_fused(rays, white_bkgd, near, far, chunk)
+
+    def _forward_fused(self, rays, white_bkgd, near, far, chunk=None):
         rays_o = f32(rays["rays_o"], "rays_o")
         rays_d = f32(rays["rays_d"], "rays_d")
         viewdirs = f32(rays["viewdirs"], "viewdirs")

@@ -257,7 +257,7 @@ class _MapGather(torch.autograd.Function):
     scatter-add as its backward (neo_tp_gather_map / _backward)."""
 
     @staticmethod
-    def forward(ctx_, module, gmap, pts, rays):
+    def forward(ctx_, module, gmap, pts, rays, kind="tp"):
         pts = f32(pts, "pts").reshape(-1, 3)
         gmap = f32(gmap, "map")
         if gmap.dim() != 2 or gmap.shape[1] % 64 != 0:
@@ -266,27 +266,29 @@ class _MapGather(torch.autograd.Function):
         host_poses, NV, focal, cx, cy = module._camera_args(rays)
         P, C = pts.shape[0], gmap.shape[1]
         out = torch.empty(NV * P, C, device=pts.device)
-        _lib.check(c.lib.neo_tp_gather_map(c.handle, ptr(gmap), C, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
+        fn = c.lib.neo_pix_gather_map if kind == "pix" else c.lib.neo_tp_gather_map
+        _lib.check(fn(c.handle, ptr(gmap), C, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
         ctx_.save_for_backward(pts)
-        ctx_.meta = (c, host_poses, NV, focal, cx, cy, tuple(gmap.shape))
+        ctx_.meta = (c, host_poses, NV, focal, cx, cy, tuple(gmap.shape), kind)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx_, g_out):
         (pts,) = ctx_.saved_tensors
-        c, host_poses, NV, focal, cx, cy, mshape = ctx_.meta
+        c, host_poses, NV, focal, cx, cy, mshape, kind = ctx_.meta
         g_map = torch.zeros(mshape, device=pts.device)
         g = f32(g_out.contiguous(), "g_out")
-        _lib.check(c.lib.neo_tp_gather_map_backward(c.handle, mshape[1], ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy,
-                                                    ptr(g), ptr(g_map), c.stream()))
-        return None, g_map, None, None
+        fn = c.lib.neo_pix_gather_map_backward if kind == "pix" else c.lib.neo_tp_gather_map_backward
+        _lib.check(fn(c.handle, mshape[1], ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy, ptr(g), ptr(g_map), c.stream()))
+        return None, g_map, None, None, None
 
 
-def gather_map(module, gmap, pts, rays):
+def gather_map(module, gmap, pts, rays, kind="tp"):
     """Lookup of world points pts (P,3) in a channels-last map gmap (NV*Hf*Wf, C) with the latent's geometry, every source view:
-    (NV*P, C) view-major rows; gradients flow to `gmap`.  The module's scene must be set (its geometry is what is used)."""
-    return _MapGather.apply(module, gmap, pts, rays)
+    (NV*P, C) view-major rows.  kind "tp": NeRF_TP's get_local_feats taps (scene of neo_tp_set_scene); "pix": the PixelNeRF decoder's
+    (neo_pix_set_scene).  Differentiable w.r.t. the map."""
+    return _MapGather.apply(module, gmap, pts, rays, kind)
 
 
 class _TrainMLPPre(torch.autograd.Function):
@@ -338,6 +340,54 @@ class _TrainMLPPre(torch.autograd.Function):
                                                        ptr(g_rgb), ptr(g_sigma), tab(gw), tab(gb), ptr(gx), ptr(gpre), ptr(gworld),
                                                        c.stream()))
         return (None, None, None, gx.reshape(xshape) if gx is not None else None, None, gworld, gpre, *gw, *gb)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b [ReLU] on the library's exact-fp32 GEMM (neo_linear_forward); backward = neo_linear_input_grad and
+    neo_linear_weight_grad.  W may be a column block of a wider matrix (its row pitch is passed on)."""
+
+    @staticmethod
+    def forward(ctx_, lib_ctx, x, w, b, relu):
+        x = f32(x, "x")
+        if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+            raise ValueError("x (rows, in) and W (out, in) do not match: %s, %s" % (tuple(x.shape), tuple(w.shape)))
+        c = _ctx(x, lib_ctx)
+        wd = w.detach()
+        if wd.dtype != torch.float32 or wd.stride(1) != 1:
+            wd = wd.float().contiguous()
+        rows, out_f, in_f = x.shape[0], w.shape[0], w.shape[1]
+        y = torch.empty(rows, out_f, device=x.device)
+        bd = f32(b.detach(), "bias") if b is not None else None
+        _lib.check(c.lib.neo_linear_forward(c.handle, rows, out_f, in_f, ptr(x), in_f, ptr(wd), wd.stride(0), ptr(bd) if bd is not None else None,
+                                            int(bool(relu)), 0, ptr(y), out_f, c.stream()))
+        ctx_.save_for_backward(x, wd, y if relu else None)
+        ctx_.meta = (c, bool(relu), b is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, gy):
+        x, wd, y = ctx_.saved_tensors
+        c, relu, has_b = ctx_.meta
+        g = gy.contiguous()
+        if relu:
+            g = g * (y > 0)
+        rows, out_f, in_f = x.shape[0], wd.shape[0], wd.shape[1]
+        gx = gw = gb = None
+        if ctx_.needs_input_grad[1]:
+            gx = torch.empty(rows, in_f, device=x.device)
+            _lib.check(c.lib.neo_linear_input_grad(c.handle, rows, in_f, out_f, ptr(g), out_f, ptr(wd), wd.stride(0), 0, ptr(gx), in_f, c.stream()))
+        if ctx_.needs_input_grad[2] or (has_b and ctx_.needs_input_grad[3]):
+            gw, gb = weight_grad(g, x, bias=True, ctx=c)
+            if not has_b:
+                gb = None
+        return None, gx, gw, gb, None
+
+
+def linear(x, w, b=None, relu=False, ctx=None):
+    """torch.nn.functional.linear (+ ReLU) with the library's GEMMs forward and backward: x (rows, in), W (out, in) - possibly a
+    column block `W[:, a:b]` of a wider weight -, b (out) or None."""
+    return _Linear.apply(ctx, x, w, b, relu)
 
 
 class _LinearNoBias(torch.autograd.Function):
@@ -696,3 +746,95 @@ def nerf_render_train(module, rays, randomized, white_bkgd, near, far, seed=None
                     t = ops.resample(t, w.detach(), n1, False, ctx=c)
     module._raise_flags(c.poll_flags())
     return (out, used) if return_samples else out
+
+
+# ---- PixelNeRF decoder: the training call (vanilla_nerf/model_pixel.py:174-258 under the LitPixelNeRF training_step) ------------
+def pixel_mlp_projected(mlp, x_enc, cond_rows, pre, nv, ctx=None):
+    """PixelNeRF's late-fusion MLP (model_pixel.py:96-131) under autograd, every product on the library's exact-fp32 GEMMs
+    (`linear`): x_enc (NV,P,63), cond_rows (NV*P,27), pre (NV*P,128) = the gathered latent projected through the local columns
+    of pts_linears.0 (W0 [:, 63:575]; the 512-wide product is formed per texel by project_pixel_latent) -> raw_rgb (P,3),
+    raw_sigma (P,1).  The view means, the concatenation [bottleneck | cond] (two products into one sum) and the ReLU of
+    the first layer are torch elementwise ops between the GEMMs."""
+    P = x_enc.shape[1]
+    xe = x_enc.reshape(-1, x_enc.shape[-1])
+    L = mlp.pts_linears
+    h = torch.relu(linear(xe, L[0].weight[:, :63], L[0].bias, ctx=ctx) + pre)
+    for i in (1, 2, 3):
+        h = linear(h, L[i].weight, L[i].bias, relu=True, ctx=ctx)
+    bott = linear(h, mlp.bottleneck_layer.weight, mlp.bottleneck_layer.bias, ctx=ctx)                 # per view, before the mean (:113-114)
+    hm = h.reshape(nv, P, -1).mean(0)                                                                  # combine_interleaved "average"
+    raw_sigma = linear(hm, mlp.density_layer.weight, mlp.density_layer.bias, ctx=ctx)
+    v0 = mlp.views_linear[0]
+    y = linear(bott, v0.weight[:, :128], v0.bias, ctx=ctx) + linear(cond_rows, v0.weight[:, 128:], None, ctx=ctx)
+    y = torch.relu(y.reshape(nv, P, -1).mean(0))
+    y = linear(y, mlp.views_linear[1].weight, mlp.views_linear[1].bias, relu=True, ctx=ctx)
+    return linear(y, mlp.rgb_layer.weight, mlp.rgb_layer.bias, ctx=ctx), raw_sigma
+
+
+def project_pixel_latent(mlp, latent_cl, ctx=None):
+    """G = F W0_loc^T per texel (texels, 512) -> (texels, 128): the latent's only path into PixelNeRF's MLP (no skip fires at
+    depth 4), as project_latent does for NeRFPPMLP."""
+    return _LinearNoBias.apply(ctx, latent_cl, mlp.pts_linears[0].weight[:, 63:575])
+
+
+def pix_render_train(module, rays, randomized, white_bkgd, near, far, latent, seed=None, return_samples=False):
+    """models.PixelNeRF.forward WITH autograd / stratified sampling (model_pixel.py:174-258): per level (comp_rgb (B,3), acc (B,),
+    depth (B,)).  Level-0 samples along `rays_d` between the scalar near / far (helper.py:415-442), lookup points and camera-frame
+    encodings by neo_tp_train_points, the latent projected per texel and gathered at the decoder's taps (gather_map kind "pix":
+    gradients reach `latent` (NV,512,Hf,Wf) - an attached encoder's output - and the local weight columns), the MLP on the
+    library's GEMMs (pixel_mlp_projected), `noise_std` (:235-236: uniform noise on the raw density when randomized), sigmoid /
+    ReLU (:238-239), vanilla compositing (composite mode 0), inverse-CDF resampling on detached weights.  Uniform streams as
+    nerf_render_train: 0 level-0 jitter, 2 level-1 quantiles, 4 / 6 density noise.  The direction encodings are tiled with the
+    reference's (1, N, 1) pattern on a (NV, B, 27) tensor (:219-222: row (v, j) carries ray j mod B)."""
+    from . import ops
+    rays_o, rays_d, viewdirs = f32(rays["rays_o"], "rays_o"), f32(rays["rays_d"], "rays_d"), f32(rays["viewdirs"], "viewdirs")
+    B = rays_o.shape[0]
+    dev = rays_o.device
+    c = module._context(dev)
+    n0, n1 = module.num_coarse_samples, module.num_fine_samples
+    noise = float(module.noise_std) if randomized else 0.0
+    poses = f32(rays["src_poses"], "src_poses")
+    NV = poses.shape[0]
+    used = []
+    with torch.no_grad():
+        if randomized:
+            seed = int(seed) if seed is not None else int(torch.randint(1, 2 ** 62, (1,)).item())
+            seed = seed or 1
+        lin = torch.linspace(0.0, 1.0, n0 + 1).to(dev)
+        edges = float(near) * (1.0 - lin) + float(far) * lin
+        if randomized:
+            mids = 0.5 * (edges[1:] + edges[:-1])
+            upper, lower = torch.cat([mids, edges[-1:]]), torch.cat([edges[:1], mids])
+            t = lower + (upper - lower) * rand_uniform(seed, 0, B, n0 + 1, ctx=c)
+        else:
+            t = edges[None, :].expand(B, n0 + 1).contiguous()
+        rot = poses[:, :3, :3].transpose(1, 2)                                                  # util.py:45-49: R^T d per view
+        dir_cam = torch.matmul(rot[:, None], viewdirs[None, :, :, None])[..., 0].contiguous()   # (NV,B,3), as tp_render_train
+        d_enc = ops.pos_enc(dir_cam, 0, 4, ctx=c)                                               # (NV,B,27)
+    latent_cl = latent.permute(0, 2, 3, 1).reshape(-1, latent.shape[1])                          # (NV Hf Wf, 512) channels-last, under autograd
+    if latent_cl.dtype != torch.float32:
+        latent_cl = latent_cl.float()
+    out = []
+    for level, mlp in enumerate((module.coarse_mlp, module.fine_mlp)):
+        N = t.shape[1]
+        used.append(t)
+        with torch.no_grad():
+            cond = d_enc.repeat(1, N, 1).reshape(-1, d_enc.shape[-1])                           # tile (1,N,1) of (NV,1,B,27) (:219-222)
+            look, x_enc = train_points(module, 0, rays_o, rays_d, t, None, poses, ctx=c)
+        pre = gather_map(module, project_pixel_latent(mlp, latent_cl, ctx=c), look, rays, kind="pix")
+        raw_rgb, raw_sigma = pixel_mlp_projected(mlp, x_enc, cond, pre, NV, ctx=c)
+        raw_sigma = raw_sigma.reshape(B, N)
+        if noise > 0.0:
+            raw_sigma = raw_sigma + rand_uniform(seed, 4 + 2 * level, B, N, ctx=c) * noise
+        rgb, sigma = torch.sigmoid(raw_rgb.reshape(B, N, 3)), torch.relu(raw_sigma)
+        comp_rgb, acc, w, _, depth = composite(0, rgb, sigma, t, rays_d, None, white_bkgd, ctx=c)
+        out.append((comp_rgb, acc, depth))
+        if level == 0:
+            with torch.no_grad():
+                if randomized:
+                    t = resample_u(t, w, rand_uniform(seed, 2, B, n1, ctx=c), False, ctx=c)
+                else:
+                    t = ops.resample(t, w.detach(), n1, False, ctx=c)
+    module._raise_flags(c.poll_flags())
+    return (out, used) if return_samples else out
+

@@ -7,7 +7,7 @@ import torch
 from . import compositing, encoding, gather, mlp, sampling
 
 
-def region_eval(params, prefix, rays, scene, tvals):
+def region_eval(params, prefix, rays, scene, tvals, sigma_noise=None):
     """Per-point outputs at GIVEN sample positions t (B,N): rgb (B,N,3) = sigmoid(raw), sigma (B,N,1) = relu(raw).
     model_pixel.py:198-237: points o + t*rays_d; latent lookup with view 0's focal (f, f) / centre for
     all views; pos_enc of the CAMERA-frame point; view directions in the camera frame, tiled with
@@ -23,21 +23,28 @@ def region_eval(params, prefix, rays, scene, tvals):
     d_enc = encoding.pos_enc(gather.world_to_camera_dirs(vd, poses), 0, 4)
     d_rows = torch.tile(d_enc[:, None, :], (1, N, 1)).reshape(-1, d_enc.shape[-1])
     raw_rgb, raw_sigma = mlp.pixelnerf_mlp(params, prefix, x_enc, d_rows, local, nv)
+    if sigma_noise is not None:
+        raw_sigma = raw_sigma.reshape(B, N, -1) + sigma_noise.reshape(B, N, 1)
     return torch.sigmoid(raw_rgb.reshape(B, N, -1)), torch.relu(raw_sigma.reshape(B, N, -1))
 
 
-def render(params, rays, scene, near, far, n_coarse=64, n_fine=64, white_bkgd=False, keep=False):
-    """[(rgb (B,3), acc (B,), depth (B,))] x 2 = PixelNeRF.forward for randomized=False."""
+def render(params, rays, scene, near, far, n_coarse=64, n_fine=64, white_bkgd=False, keep=False, samples=None, sigma_noise=None):
+    """[(rgb (B,3), acc (B,), depth (B,))] x 2 = PixelNeRF.forward for randomized=False.
+    samples = (t0 (B,n_coarse+1), t1 (B,n_coarse+1+n_fine)): evaluate at GIVEN sample positions instead of the deterministic
+    ones (the randomized call's draws, taken from the implementation under test; they carry no gradient, helper.py:610-616).
+    sigma_noise = per level (B,N) values added to the raw density (model_pixel.py:235-236: rand_like * noise_std)."""
     o, d = rays["rays_o"], rays["rays_d"]
     out, extra = [], []
     t = w = None
     for level, prefix in enumerate(("coarse_mlp.", "fine_mlp.")):
-        if level == 0:
+        if samples is not None:
+            t = samples[level]
+        elif level == 0:
             t, _ = sampling.vanilla_level0(o, d, n_coarse, near, far)
         else:
             mids = 0.5 * (t[..., 1:] + t[..., :-1])
             t, _ = sampling.vanilla_level1(mids, w[..., 1:-1], o, d, t, n_fine)
-        rgb, sigma = region_eval(params, prefix, rays, scene, t)
+        rgb, sigma = region_eval(params, prefix, rays, scene, t, None if sigma_noise is None else sigma_noise[level])
         comp, acc, w, depth = compositing.vanilla_composite(rgb, sigma, t, d, white_bkgd)
         out.append((comp, acc, depth))
         extra.append(dict(t=t, sigma=sigma, rgb=rgb, weights=w))
