@@ -475,6 +475,22 @@ int neo_mip_set_layered(neo_ctx* ctx, int mode);
 int neo_mip_composite(neo_ctx* ctx, const float* rgbdens, const float* tdist, const float* rays_d,
                       int R, int n, float bg, float* weights, float* rgb, void* stream);
 
+/* Training-side operators of the Mip-NeRF 360 renderer (mipnerf360/model.py:236-365 under training_step :436-470), for a caller
+ * that composes the MLPs from neo_linear_* (training.mip_render_train):
+ * neo_mip_resample_u = neo_mip_resample with the caller's quantile table u (n) and, when jitter != NULL, one offset per ray added
+ * to it - helper.py:358-365 with single_jitter: u = linspace(0, 1 - u_max, n) + rand(R, 1) * max_jitter.
+ * neo_mip_encode: the 504-d integrated positional encoding of the R x n intervals of tdist (R, n + 1) as fp32 rows (R n, 504),
+ * reference feature order (helper.py:33-88, 278-334); pos_basis_t (3, 21) device pointer (the MLP's buffer).
+ * neo_mip_composite_backward: backward of neo_mip_composite - g_weights (R, n) and g_rgb (R, 3) (either may be NULL) ->
+ * g_rgbdens (R, n, 4) = gradients of (rgb, density); sample positions carry no gradient (stop_level_grad). */
+int neo_mip_resample_u(neo_ctx* ctx, const float* s_prev, const float* w_prev, int R, int n_prev, int dilate, float dilation,
+                       float anneal, int n, const float* u, const float* jitter, float near, float far, float* sdist, float* tdist,
+                       void* stream);
+int neo_mip_encode(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* radii, const float* tdist,
+                   const float* pos_basis_t, int R, int n, float* out, void* stream);
+int neo_mip_composite_backward(neo_ctx* ctx, const float* rgbdens, const float* tdist, const float* rays_d, int R, int n, float bg,
+                               const float* g_weights, const float* g_rgb, float* g_rgbdens, void* stream);
+
 /* MipNeRF360.forward(batch, train_frac, randomized=False, is_train=False, near, far)
  * (model.py:236-365), 3 levels (n_prop, n_prop, n_nerf samples).  Per level l (any pointer may be
  * NULL): rgb_l (R,3), sdist_l (R,n_l+1), weights_l (R,n_l), rgbdens_l (R,n_l,4) = per-interval

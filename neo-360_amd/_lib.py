@@ -106,6 +106,9 @@ SIGNATURES = {
     "neo_mip_resample": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _f, _vp, _vp, _vp]),
     "neo_mip_mlp": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "neo_mip_composite": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "neo_mip_resample_u": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "neo_mip_encode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "neo_mip_composite_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "neo_mip_render": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i, _i, ctypes.POINTER(MipLevelOut), _vp]),
     "neo_ctx_set_timing": (_i, [_vp, _i]),
     "neo_ctx_read_timing": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i),

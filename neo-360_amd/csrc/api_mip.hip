@@ -1,6 +1,7 @@
 // Mip-NeRF 360 entry points of the C ABI (models/mipnerf360/model.py:236-365).
 #include "ctx.h"
 #include "mip_layered.h"
+#include "train_kernels.h"
 
 using namespace neo_host;
 
@@ -99,6 +100,41 @@ int neo_mip_resample(neo_ctx* ctx, const float* s_prev, const float* w_prev, int
     const float s_far = static_cast<float>(1.0 / static_cast<double>(far));
     if (neo::launch_mip_resample(s_prev, w_prev, n_prev, dilate, dilation, anneal, u, R, n, s_near, s_far, sdist, tdist, s))
         return fail(NEO_ERR_INVALID, "unsupported sample counts (3*n_prev+1 and n must be <= 256)");
+    return check_launch();
+}
+
+int neo_mip_resample_u(neo_ctx* ctx, const float* s_prev, const float* w_prev, int R, int n_prev, int dilate, float dilation,
+                       float anneal, int n, const float* u, const float* jitter, float near, float far, float* sdist, float* tdist,
+                       void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && n_prev >= 1 && n >= 2, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(s_prev && w_prev && u && sdist && tdist, "null pointer");
+    const float s_near = static_cast<float>(1.0 / static_cast<double>(near));
+    const float s_far = static_cast<float>(1.0 / static_cast<double>(far));
+    if (neo::launch_mip_resample(s_prev, w_prev, n_prev, dilate, dilation, anneal, u, R, n, s_near, s_far, sdist, tdist,
+                                 static_cast<hipStream_t>(stream), jitter))
+        return fail(NEO_ERR_INVALID, "unsupported sample counts (3*n_prev+1 and n must be <= 256)");
+    return check_launch();
+}
+
+int neo_mip_encode(neo_ctx* ctx, const float* rays_o, const float* rays_d, const float* radii, const float* tdist,
+                   const float* pos_basis_t, int R, int n, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && n >= 1, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rays_o && rays_d && radii && tdist && pos_basis_t && out, "null pointer");
+    neo::launch_mip_encode(rays_o, rays_d, radii, tdist, pos_basis_t, R, n, out, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_mip_composite_backward(neo_ctx* ctx, const float* rgbdens, const float* tdist, const float* rays_d, int R, int n, float bg,
+                               const float* g_weights, const float* g_rgb, float* g_rgbdens, void* stream) {
+    ENTER(ctx);
+    REQUIRE(R >= 0 && n >= 1, "bad shape");
+    if (R == 0) return NEO_OK;
+    REQUIRE(rgbdens && tdist && rays_d && g_rgbdens, "null pointer");
+    neo::launch_mip_composite_bwd(rgbdens, tdist, rays_d, R, n, bg, g_weights, g_rgb, g_rgbdens, static_cast<hipStream_t>(stream));
     return check_launch();
 }
 

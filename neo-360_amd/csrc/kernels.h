@@ -171,7 +171,7 @@ int launch_mip_mlp(int width, int depth, int rgb, const MipMlpDev& m, const floa
 // n centre quantiles (u, device table) -> interval endpoints sdist (R,n+1) and metric distances tdist
 int launch_mip_resample(const float* s_prev, const float* w_prev, int n_prev, int dilate, float dilation,
                         float anneal, const float* u, int R, int n, float s_near, float s_far, float* sdist,
-                        float* tdist, hipStream_t s);
+                        float* tdist, hipStream_t s, const float* jitter = nullptr);
 // weights = alpha * exp(-cumsum) with an opaque last interval; rgb = sum w c + max(0,1-acc) * bg
 void launch_mip_composite(const float* rgbdens, const float* tdist, const float* rays_d, int R, int n, float bg,
                           float* weights, float* rgb, hipStream_t s);

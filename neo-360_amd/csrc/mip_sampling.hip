@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void k_mip_resample(const float* __restrict__ 
                                                       const float* __restrict__ w_prev, int n_prev, int dilate,
                                                       float dilation, float anneal, const float* __restrict__ u_arr,
                                                       int R, int n, float s_near, float s_far,
-                                                      float* __restrict__ sdist, float* __restrict__ tdist) {
+                                                      float* __restrict__ sdist, float* __restrict__ tdist,
+                                                      const float* __restrict__ jitter) {
     __shared__ float sh_t[RPB][MAXP];     // histogram edges (sorted)
     __shared__ float sh_w[RPB][MAXP];     // histogram weights -> softmax weights
     __shared__ float sh_c[RPB][MAXP];     // cdf
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(256) void k_mip_resample(const float* __restrict__ 
     __syncthreads();
     // ---- interval centres: sorted_interp(u, cdf, edges) (helper.py:219-234) ----
     for (int m = lane; m < n; m += 64) {
-        const float u = u_arr[m];
+        // randomized (helper.py:358-365, single_jitter): the caller's table linspace(0, 1 - u_max, n) + this ray's one draw
+        const float u = jitter ? u_arr[m] + jitter[ray] : u_arr[m];
         int lo = 0, hi = npts;   // first index with cdf > u
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -213,11 +215,11 @@ __global__ __launch_bounds__(256) void k_mip_composite(const float4* __restrict_
 
 int launch_mip_resample(const float* s_prev, const float* w_prev, int n_prev, int dilate, float dilation,
                         float anneal, const float* u, int R, int n, float s_near, float s_far, float* sdist,
-                        float* tdist, hipStream_t s) {
+                        float* tdist, hipStream_t s, const float* jitter) {
     if (n_prev < 1 || n < 2 || n > MAXP) return -1;
     if (dilate ? (3 * n_prev + 1 > MAXP || n_prev < 2) : (n_prev + 1 > MAXP)) return -1;
     hipLaunchKernelGGL(k_mip_resample, dim3((R + RPB - 1) / RPB), dim3(256), 0, s, s_prev, w_prev, n_prev, dilate,
-                       dilation, anneal, u, R, n, s_near, s_far, sdist, tdist);
+                       dilation, anneal, u, R, n, s_near, s_far, sdist, tdist, jitter);
     return 0;
 }
 

@@ -23,6 +23,12 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
 // vanilla NeRFMLP (vanilla_nerf/model.py:100-125): rows R = rays x samples; x0 (R, 63), cond (R, 27).  w / b order as
 // neo_vanilla_upload_mlp.
 size_t vanilla_train_tape_floats(long R);
+// Mip-NeRF 360 training operators (mip_train.hip): IPE rows (R n, 504) of the intervals of tdist (R, n + 1); backward of the
+// exp(-cumsum) compositing: g_out (R, n, 4) = gradients of (rgb, density) from g_w (R, n, may be null) and g_c (R, 3, may be null)
+void launch_mip_encode(const float* rays_o, const float* rays_d, const float* radii, const float* tdist, const float* basis, int R,
+                       int n, float* out, hipStream_t s);
+void launch_mip_composite_bwd(const float* rgbdens, const float* tdist, const float* rays_d, int R, int n, float bg, const float* g_w,
+                              const float* g_c, float* g_out, hipStream_t s);
 // one linear layer (exact fp32 MFMA GEMM, k_sgemm): y (+)= x W^T + b [ReLU];  gx (+)= gy W
 void launch_linear_forward(long rows, int out_f, int in_f, const float* x, long ldx, const float* w, long ldw, const float* bias,
                            int relu, int accumulate, float* y, long ldy, hipStream_t s);

@@ -878,9 +878,19 @@ class MipNeRF360(_HipModule):
                                                   ptr(basis), ctx.stream()))
             ctx.uploaded[("mip", slot)] = fp
 
-    @torch.no_grad()
-    def forward(self, batch, train_frac, randomized, is_train, near, far):
-        self._check_mode(randomized)
+    def forward(self, batch, train_frac, randomized, is_train, near, far, seed=None):
+        """randomized=True (one sampling jitter per ray and level) or a call that wants gradients (`_wants_grad()`: the
+        reference's training_step, model.py:436-470) runs on the operator chain of training.mip_render_train - resampling,
+        encodings and compositing native, every matrix product on the library's GEMMs, gradients to all parameters through the
+        colours and the interval weights; otherwise the fused no-grad kernels.  `is_train` only selects how the reference
+        evaluates the contraction's Jacobian (helper.py:45-66); both of its forms are the closed form used here."""
+        if randomized or self._wants_grad():
+            from . import training
+            return training.mip_render_train(self, batch, train_frac, randomized, near, far, seed)
+        with torch.no_grad():
+            return self._forward_fused(batch, train_frac, near, far)
+
+    def _forward_fused(self, batch, train_frac, near, far):
         rays_o, rays_d = f32(batch["rays_o"], "rays_o"), f32(batch["rays_d"], "rays_d")
         viewdirs, radii = f32(batch["viewdirs"], "viewdirs"), f32(batch["radii"], "radii")
         dev = rays_o.device

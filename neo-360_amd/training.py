@@ -838,3 +838,142 @@ def pix_render_train(module, rays, randomized, white_bkgd, near, far, latent, se
     module._raise_flags(c.poll_flags())
     return (out, used) if return_samples else out
 
+
+# ---- Mip-NeRF 360: the training call (mipnerf360/model.py:236-365 under LitMipNeRF360.training_step :436-470) --------------------
+_EPS32 = float(torch.finfo(torch.float32).eps)
+
+
+def mip_resample_u(s_prev, w_prev, n, near, far, dilate, dilation, anneal, u, jitter=None, ctx=None):
+    """One proposal-resampling step with the caller's quantile table u (n) and, when given, one jitter per ray (R,)
+    (neo_mip_resample_u; helper.py:343-396).  Returns sdist, tdist (R, n+1); no gradients (stop_level_grad)."""
+    s_prev, w_prev, u = f32(s_prev, "s_prev"), f32(w_prev, "w_prev"), f32(u, "u")
+    c = _ctx(s_prev, ctx)
+    R, n_prev = w_prev.shape
+    sdist = torch.empty(R, n + 1, device=s_prev.device)
+    tdist = torch.empty(R, n + 1, device=s_prev.device)
+    jit = f32(jitter, "jitter").reshape(-1) if jitter is not None else None
+    _lib.check(c.lib.neo_mip_resample_u(c.handle, ptr(s_prev), ptr(w_prev), R, n_prev, int(bool(dilate)), float(dilation),
+                                        float(anneal), n, ptr(u), ptr(jit), float(near), float(far), ptr(sdist), ptr(tdist), c.stream()))
+    return sdist, tdist
+
+
+def mip_encode(rays_o, rays_d, radii, tdist, pos_basis_t, ctx=None):
+    """(R n, 504) integrated positional encodings of the intervals of tdist (R, n+1) (neo_mip_encode; helper.py:33-88, 278-334)."""
+    rays_o, rays_d, radii, tdist = f32(rays_o, "rays_o"), f32(rays_d, "rays_d"), f32(radii, "radii"), f32(tdist, "tdist")
+    basis = f32(pos_basis_t, "pos_basis_t")
+    c = _ctx(tdist, ctx)
+    R, n1 = tdist.shape
+    out = torch.empty(R * (n1 - 1), 504, device=tdist.device)
+    _lib.check(c.lib.neo_mip_encode(c.handle, ptr(rays_o), ptr(rays_d), ptr(radii), ptr(tdist), ptr(basis), R, n1 - 1, ptr(out), c.stream()))
+    return out
+
+
+class _MipComposite(torch.autograd.Function):
+    """compute_alpha_weights(opaque_background=True) + volumetric_rendering (helper.py:246-275) with a native backward
+    (neo_mip_composite / neo_mip_composite_backward): (rgb (R,n,3), density (R,n)) -> weights (R,n), colour (R,3)."""
+
+    @staticmethod
+    def forward(ctx_, rgb, density, tdist, rays_d, bg, lib_ctx):
+        rgbdens = torch.cat([f32(rgb, "rgb"), f32(density, "density")[..., None]], dim=-1).contiguous()
+        tdist, rays_d = f32(tdist, "tdist"), f32(rays_d, "rays_d")
+        c = _ctx(tdist, lib_ctx)
+        R, n1 = tdist.shape
+        w = torch.empty(R, n1 - 1, device=tdist.device)
+        out = torch.empty(R, 3, device=tdist.device)
+        _lib.check(c.lib.neo_mip_composite(c.handle, ptr(rgbdens), ptr(tdist), ptr(rays_d), R, n1 - 1, float(bg), ptr(w), ptr(out), c.stream()))
+        ctx_.save_for_backward(rgbdens, tdist, rays_d)
+        ctx_.meta = (c, float(bg))
+        return w, out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g_w, g_c):
+        rgbdens, tdist, rays_d = ctx_.saved_tensors
+        c, bg = ctx_.meta
+        R, n1 = tdist.shape
+        g = torch.empty(R, n1 - 1, 4, device=tdist.device)
+        gw = f32(g_w.contiguous(), "g_w") if g_w is not None else None
+        gc = f32(g_c.contiguous(), "g_c") if g_c is not None else None
+        _lib.check(c.lib.neo_mip_composite_backward(c.handle, ptr(rgbdens), ptr(tdist), ptr(rays_d), R, n1 - 1, bg, ptr(gw), ptr(gc),
+                                                    ptr(g), c.stream()))
+        return g[..., :3], g[..., 3], None, None, None, None
+
+
+def mip_composite(rgb, density, tdist, rays_d, bg=1.0, ctx=None):
+    return _MipComposite.apply(rgb, density, tdist, rays_d, bg, ctx)
+
+
+def mip_mlp(mlp, x0, d_enc, n, ctx=None):
+    """MipNeRF360MLP.forward (model.py:107-176) on encoded rows x0 (R n, 504) under autograd, every product on the library's
+    exact-fp32 GEMMs (`linear`): trunk of `netdepth` ReLU layers, the encoding concatenated again after layer 4 (two products into
+    one sum instead of the concatenation), density = softplus(raw - 1); with the rgb branch: bottleneck, view layer on
+    [bottleneck | dir_enc] (the direction term once per RAY, broadcast over its n intervals), rgb = sigmoid(.) (1 + 2 pad) - pad.
+    d_enc (R, 27).  Returns density (R, n), rgb (R, n, 3) (zeros without the branch)."""
+    W = mlp.netwidth
+    h = x0
+    for i, layer in enumerate(mlp.pts_linear):
+        if i > 0 and (i - 1) % 4 == 0 and (i - 1) > 0:          # the layer after a skip concat: input [h | x0]
+            h = torch.relu(linear(h, layer.weight[:, :W], layer.bias, ctx=ctx) + linear(x0, layer.weight[:, W:], None, ctx=ctx))
+        else:
+            h = linear(h, layer.weight, layer.bias, relu=True, ctx=ctx)
+    # a skip after the LAST layer (depth 5, 9, ..) would widen the heads' input: not a shape the reference's defaults produce
+    raw = linear(h, mlp.density_layer.weight, mlp.density_layer.bias, ctx=ctx)
+    R = x0.shape[0] // n
+    density = torch.nn.functional.softplus(raw.reshape(R, n) + (-1.0))
+    if mlp.disable_rgb:
+        return density, torch.zeros(R, n, 3, device=x0.device)
+    bott = linear(h, mlp.bottleneck_layer.weight, mlp.bottleneck_layer.bias, ctx=ctx)
+    v0 = mlp.views_linear[0]
+    y = linear(bott, v0.weight[:, :256], v0.bias, ctx=ctx).reshape(R, n, -1) + linear(d_enc, v0.weight[:, 256:], None, ctx=ctx)[:, None, :]
+    y = torch.relu(y).reshape(R * n, -1)
+    rgb = torch.sigmoid(linear(y, mlp.rgb_layer.weight, mlp.rgb_layer.bias, ctx=ctx)).reshape(R, n, 3)
+    return density, rgb * (1 + 2 * 0.001) - 0.001
+
+
+def mip_render_train(module, batch, train_frac, randomized, near, far, seed=None):
+    """models.MipNeRF360.forward WITH autograd / randomized sampling: (renderings, ray_history) as the reference returns them.
+    Per level: proposal resampling on the previous level's detached histogram (neo_mip_resample_u: max-dilation, annealed
+    softmax cdf, interval sampling; randomized = one jitter per ray, helper.py:358-365, drawn from the library's counter-based
+    generator, stream = level), IPE rows (neo_mip_encode), the level's MLP on the linear-layer operators (mip_mlp: gradients
+    to every parameter), compositing with a native backward (mip_composite: gradients arrive through the colour AND through
+    `weights`, which the interlevel / distortion losses of training_step read).  sdist is detached (stop_level_grad)."""
+    from . import ops
+    rays_o, rays_d = f32(batch["rays_o"], "rays_o"), f32(batch["rays_d"], "rays_d")
+    viewdirs, radii = f32(batch["viewdirs"], "viewdirs"), f32(batch["radii"], "radii")
+    dev = rays_o.device
+    c = module._context(dev)
+    B = rays_o.shape[0]
+    counts = (module.num_prop_samples,) * (module.num_levels - 1) + (module.num_nerf_samples,)
+    slope = 10.0
+    anneal = (slope * float(train_frac)) / ((slope - 1.0) * float(train_frac) + 1.0)
+    with torch.no_grad():
+        if randomized:
+            seed = int(seed) if seed is not None else int(torch.randint(1, 2 ** 62, (1,)).item())
+            seed = seed or 1
+        sdist = torch.cat([torch.zeros(B, 1, device=dev), torch.ones(B, 1, device=dev)], dim=-1)
+        weights = torch.ones(B, 1, device=dev)
+        d_enc = ops.pos_enc(viewdirs, 0, 4, ctx=c)                                                # (B,27), append_identity
+    prod = 1
+    renderings, history = [], []
+    for lvl, n in enumerate(counts):
+        mlp = module.mlps[lvl]
+        dilation = 0.0025 + 0.5 * (1.0 - 0.0) / prod                                             # model.py:266-271
+        prod *= n
+        with torch.no_grad():
+            if randomized:                                                                       # helper.py:358-365
+                u_max = _EPS32 + (1 - _EPS32) / n
+                max_jitter = (1 - u_max) / (n - 1) - _EPS32
+                u = torch.linspace(0, 1 - u_max, n).to(dev)
+                jitter = rand_uniform(seed, lvl, B, 1, ctx=c) * max_jitter
+            else:                                                                                # helper.py:352-354
+                pad = 1 / (2 * n)
+                u, jitter = torch.linspace(pad, 1 - pad - _EPS32, n).to(dev), None
+            sdist, tdist = mip_resample_u(sdist, weights.detach(), n, near, far, lvl > 0, dilation, anneal, u, jitter, ctx=c)
+            x0 = mip_encode(rays_o, rays_d, radii, tdist, mlp.pos_basis_t, ctx=c)
+        density, rgb = mip_mlp(mlp, x0, d_enc, n, ctx=c)
+        weights, colour = mip_composite(rgb, density, tdist, rays_d, 1.0, ctx=c)
+        renderings.append({"rgb": colour})
+        history.append(dict(density=density, rgb=rgb, sdist=sdist, weights=weights))
+    module._raise_flags(c.poll_flags())
+    return renderings, history
+

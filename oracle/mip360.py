@@ -107,11 +107,14 @@ def dir_enc(x, deg=4):
 
 # ---- MLP (model.py:30-176) ----------------------------------------------------------------------
 
-def mlp(params, prefix, basis, means, covs, viewdirs, depth, rgb_branch, skip=4):
-    """MipNeRF360MLP.forward: density (B,n), rgb (B,n,3) (zeros when the rgb branch is disabled)."""
-    z, c = contract(means, covs)
-    lm, lv = lift_and_diagonalize(z, c, basis)
-    x0 = integrated_pos_enc(lm, lv, 0, 12)
+def mlp(params, prefix, basis, means, covs, viewdirs, depth, rgb_branch, skip=4, x0=None):
+    """MipNeRF360MLP.forward: density (B,n), rgb (B,n,3) (zeros when the rgb branch is disabled).
+    x0 (B,n,504): evaluate the MLP on GIVEN encodings (the encodings carry no gradient; a gradient test that wants to separate the
+    fp32 conditioning of sin(2^k x) from the MLP's arithmetic feeds both sides the same rows)."""
+    if x0 is None:
+        z, c = contract(means, covs)
+        lm, lv = lift_and_diagonalize(z, c, basis)
+        x0 = integrated_pos_enc(lm, lv, 0, 12)
     h = x0
     for i in range(depth):
         h = torch.relu(F.linear(h, params["%spts_linear.%d.weight" % (prefix, i)], params["%spts_linear.%d.bias" % (prefix, i)]))
@@ -160,16 +163,21 @@ def _sorted_interp(x, xp, fp):
     return fp0 + off * (fp1 - fp0)
 
 
-def sample_intervals(t, w_logits, n, domain):
-    """Deterministic interval endpoints (helper.py:237-243, :337-394): softmax -> cdf ->
-    n centre quantiles linspace(pad, 1-pad-eps, n) -> midpoints, mirrored ends clipped to the domain."""
+def sample_intervals(t, w_logits, n, domain, jitter=None):
+    """Interval endpoints (helper.py:237-243, :337-394): softmax -> cdf -> n centre quantiles -> midpoints, mirrored ends clipped
+    to the domain.  Deterministic quantiles linspace(pad, 1-pad-eps, n); with jitter (B,1) = rand * max_jitter the randomized
+    single_jitter form (:358-365): linspace(0, 1 - u_max, n) + jitter."""
     w = F.softmax(w_logits, dim=-1)
     cw = torch.cumsum(w[..., :-1], dim=-1).clip(max=1.0)
     lead = cw.shape[:-1] + (1,)
     cw0 = torch.cat([torch.zeros(lead).type_as(cw), cw, torch.ones(lead).type_as(cw)], dim=-1)
-    pad = 1 / (2 * n)
-    u = torch.linspace(pad, 1 - pad - EPS, n)
-    u = torch.broadcast_to(u, t.shape[:-1] + (n,)).type_as(t)
+    if jitter is None:
+        pad = 1 / (2 * n)
+        u = torch.linspace(pad, 1 - pad - EPS, n)
+        u = torch.broadcast_to(u, t.shape[:-1] + (n,)).type_as(t)
+    else:
+        u_max = EPS + (1 - EPS) / n
+        u = (torch.linspace(0, 1 - u_max, n) + jitter).type_as(t)
     centers = _sorted_interp(u, cw0, t)
     mid = (centers[..., 1:] + centers[..., :-1]) / 2
     first = torch.clip(2 * centers[..., :1] - mid[..., :1], min=domain[0])
@@ -190,8 +198,12 @@ def alpha_weights(density, tdist, dirs):
 # ---- the model (model.py:199-365) -------------------------------------------------------------------
 
 def render(params, batch, train_frac, near, far, num_prop_samples=64, num_nerf_samples=32, num_levels=3,
-           dilation_multiplier=0.5, dilation_bias=0.0025, anneal_slope=10, bg_rgb=1.0, basis=None):
-    """MipNeRF360.forward(batch, train_frac, False, False, near, far) -> (renderings, ray_history)."""
+           dilation_multiplier=0.5, dilation_bias=0.0025, anneal_slope=10, bg_rgb=1.0, basis=None, jitters=None, sdist_given=None,
+           x0_given=None):
+    """MipNeRF360.forward(batch, train_frac, False, False, near, far) -> (renderings, ray_history).
+    jitters: per level (B,1) = rand * max_jitter, the randomized call's single jitter (helper.py:358-365).
+    sdist_given: per level (B,n+1) interval endpoints to evaluate at instead of resampling (the sample positions of the
+    implementation under test; they carry no gradient, model.py:308-309).  x0_given: per level (B,n,504) encodings (see mlp)."""
     basis = icosahedron_basis() if basis is None else basis
     o, d, vd, radii = batch["rays_o"], batch["rays_d"], batch["viewdirs"], batch["radii"]
     B = o.shape[0]
@@ -211,11 +223,16 @@ def render(params, batch, train_frac, near, far, num_prop_samples=64, num_nerf_s
         anneal = (anneal_slope * train_frac) / ((anneal_slope - 1) * train_frac + 1) if anneal_slope > 0 else 1.0
         logits = torch.where(sdist[..., 1:] > sdist[..., :-1], anneal * torch.log(weights + 0.0),
                              torch.full_like(weights, -torch.inf))
-        sdist = sample_intervals(sdist, logits, n, (0.0, 1.0))
+        if sdist_given is not None:
+            sdist = sdist_given[lvl]
+        else:
+            sdist = sample_intervals(sdist, logits, n, (0.0, 1.0), None if jitters is None else jitters[lvl])
+        sdist = sdist.detach()                                     # stop_level_grad (model.py:308-309)
         tdist = 1 / (sdist * s_far + (1 - sdist) * s_near)
         means, covs = conical_frustum_gaussians(tdist, o, d, radii)
         prefix = "mlps.%d." % lvl
-        density, rgb = mlp(params, prefix, basis, means, covs, vd, 4 if is_prop else 8, not is_prop)
+        density, rgb = mlp(params, prefix, basis, means, covs, vd, 4 if is_prop else 8, not is_prop,
+                           x0=None if x0_given is None else x0_given[lvl])
         weights = alpha_weights(density, tdist, d)
         acc = weights.sum(dim=-1)
         out = (weights[..., None] * rgb).sum(dim=-2) + torch.clip(1 - acc[..., None], min=0) * bg_rgb
