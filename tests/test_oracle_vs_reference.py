@@ -95,3 +95,45 @@ def test_mip360_forward_live():
     got, ghist = mip360.render(state, rays, 1.0, 0.2, 3.0, num_prop_samples=32, num_nerf_samples=16)
     assert max_abs(got[-1]["rgb"], rend[-1]["rgb"].detach()) < 5e-6
     assert max_abs(ghist[-1]["sdist"], hist[-1]["sdist"].detach()) < 5e-6
+
+
+def test_mip360_randomized_forward_and_gradients_live():
+    """The reference's randomized training forward (one jitter per ray and level, helper.py:358-365) and its autograd gradients
+    against the oracle fed the SAME draws: torch.rand is consumed by the reference in level order, (B, 1) per level, so the oracle's
+    `jitters` are reproduced from the same seed.  Pins the oracle hooks the GPU training tests rely on (`jitters`, `sdist_given`)."""
+    M = ref.load("models.mipnerf360.model")
+    n_prop, n_nerf, B = 16, 8, 12
+    net = M.MipNeRF360(num_prop_samples=n_prop, num_nerf_samples=n_nerf)
+    state = synth.mip360_state(0, weight_gain=0.25)
+    net.load_state_dict(state, strict=True)
+    rays = cases.mip_rays(B)
+    eps = float(torch.finfo(torch.float32).eps)
+    torch.manual_seed(5)
+    with torch.enable_grad():
+        rend, hist = net(rays, 0.5, True, True, 0.2, 3.0)
+        loss_ref = (rend[-1]["rgb"] ** 2).mean() + sum((h["weights"] ** 2).sum(-1).mean() for h in hist)
+        names = [k for k, p in net.named_parameters()]
+        g_ref = torch.autograd.grad(loss_ref, [p for _, p in net.named_parameters()], allow_unused=True)
+    torch.manual_seed(5)
+    jit = []
+    for n in (n_prop, n_prop, n_nerf):
+        u_max = eps + (1 - eps) / n
+        jit.append(torch.rand(B, 1) * ((1 - u_max) / (n - 1) - eps))
+    from oracle import mip360
+    with torch.enable_grad():
+        pp = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in state.items()}
+        got, ghist = mip360.render(pp, rays, 0.5, 0.2, 3.0, num_prop_samples=n_prop, num_nerf_samples=n_nerf, jitters=jit)
+        loss = (got[-1]["rgb"] ** 2).mean() + sum((h["weights"] ** 2).sum(-1).mean() for h in ghist)
+        g = torch.autograd.grad(loss, [pp[k] for k in names], allow_unused=True)
+    for lvl in range(3):
+        assert max_abs(ghist[lvl]["sdist"], hist[lvl]["sdist"].detach()) < 5e-6, lvl
+        assert max_abs(ghist[lvl]["weights"].detach(), hist[lvl]["weights"].detach()) < 2e-5, lvl
+    assert max_abs(got[-1]["rgb"].detach(), rend[-1]["rgb"].detach()) < 5e-6
+    for k, a, b in zip(names, g, g_ref):
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert float((a - b).norm()) <= 2e-3 * float(b.norm()) + 1e-9, k       # fp32 autograd of two op orders (ReLU-kink flips: see profiles/r05_mip_train_gradients.log)
+    # evaluating at GIVEN interval endpoints reproduces the same forward
+    again, _ = mip360.render(state, rays, 0.5, 0.2, 3.0, num_prop_samples=n_prop, num_nerf_samples=n_nerf,
+                             sdist_given=[h["sdist"].detach() for h in hist])
+    assert max_abs(again[-1]["rgb"], rend[-1]["rgb"].detach()) < 5e-6
