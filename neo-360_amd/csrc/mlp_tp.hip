@@ -140,8 +140,12 @@ __device__ __forceinline__ void gemm1(f32x16& acc, const f32x4* __restrict__ wp,
     }
 }
 
+#ifndef NEO_TP_F32_WGS
+#define NEO_TP_F32_WGS 2     // workgroups per CU the register budget is set for.  3 (<= 168 VGPRs, 43-48 spilled) measured: 180 k against
+                             // 188 k rays/s (profiles/r05_exact_f32_experiments.log) - the kernel is phase-bound (MFMA busy 55 % at 2.38 GHz, 1.04 kW)
+#endif
 template <int PE_C, int PROJ>
-__global__ __launch_bounds__(256, 2) void k_tp_mlp(TpMlpDev m, const float* __restrict__ proj, TpPlaneProj pp, TpScene sc, TpViews views,
+__global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, const float* __restrict__ proj, TpPlaneProj pp, TpScene sc, TpViews views,
                                                     const float* __restrict__ rays_o,
                                                     const float* __restrict__ rays_d,
                                                     const float* __restrict__ viewdirs,
