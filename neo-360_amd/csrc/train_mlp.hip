@@ -578,20 +578,24 @@ __global__ void k_view_mean(const float* __restrict__ in, int NV, long P, int C,
 }
 
 // its backward: out[v P + p][c] (+)= g[p][c] / NV
-__global__ void k_view_bcast(const float* __restrict__ g, int NV, long P, int C, int accumulate, float* __restrict__ out) {
+__global__ void k_view_bcast(const float* __restrict__ g, int NV, long P, int C, int accumulate, float* __restrict__ out, long ldo) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P * C) return;
+    const long p = i / C;
+    const int c = (int)(i - p * C);
     const float v = g[i] / (float)NV;
     for (int w = 0; w < NV; ++w) {
-        float* d = out + (long)w * P * C + i;
+        float* d = out + ((long)w * P + p) * ldo + c;
         *d = accumulate ? *d + v : v;
     }
 }
 
-// g[i] = mask[i] > 0 ? g[i] : 0   (ReLU backward in place)
-__global__ void k_relu_mask(float* __restrict__ g, const float* __restrict__ mask, long n) {
+// g[r][c] = mask[r][c] > 0 ? g[r][c] : 0   (ReLU backward in place; g with row pitch ldg, mask dense rows x C)
+__global__ void k_relu_mask(float* __restrict__ g, long ldg, const float* __restrict__ mask, int C, long rows) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && !(mask[i] > 0.0f)) g[i] = 0.0f;
+    if (i >= rows * C) return;
+    const long r = i / C;
+    if (!(mask[i] > 0.0f)) g[r * ldg + (i - r * C)] = 0.0f;
 }
 
 // dst[r][0..cols) = src[r][0..cols) between row-major matrices of different pitch (cols % 4 == 0): the projected-space training path
@@ -827,39 +831,42 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     dw_gemm(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, gb[5], part, s);
     gemm<false, true>((int)P, 64, 64, g_y1, 64, w[5], 64, g_ym, 64, epi(nullptr, 0, 0, ym, 64), 1, s);           // x relu'(mean)
     // mean over views -> per-view rows; view layer 0 on [bott | cond]
-    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0);
+    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0, 64L);
     dw_gemm(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, gb[4], part, s);
     dw_gemm(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, nullptr, part, s);
     gemm<false, true>((int)R, 128, 64, gy0, 64, w[4], 155, ga, 128, epi(), 1, s);                                // g_bott (R x 128)
     // bottleneck
     dw_gemm(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, gb[6], part, s);
-    gemm<false, true>((int)R, 128, 128, ga, 128, w[6], 128, gb2, 128, epi(), 1, s);                              // g_h3 from the bottleneck
+    // projected-space path: the two first-layer gradients are produced IN PLACE in the halves of g_pre (R, 256) - g_z3 in
+    // columns 128.., g_z0 in columns 0..127, row pitch 256 - instead of being copied there (2 x R x 128 floats read + written)
+    float* z3 = g_pre ? g_pre + 128 : gb2;
+    float* z0 = g_pre ? g_pre : ga;
+    const long lz = g_pre ? 256 : 128;
+    gemm<false, true>((int)R, 128, 128, ga, 128, w[6], 128, z3, lz, epi(), 1, s);                                // g_h3 from the bottleneck
     // density head on the view mean of h3
     dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);
     gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
-    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 1, gb2);          // g_h3 += g_hm / NV
-    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, h3, R * 128);                   // g_z3
+    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 1, z3, lz);       // g_h3 += g_hm / NV
+    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, z3, lz, h3, 128, R);                 // g_z3
     // layer 3 on [h2 | x0]
-    dw_gemm(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128 + K0, gb[3], part, s);
-    if (g_pre) hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, gb2, 128L, g_pre + 128, 256L, R, 128);
+    dw_gemm(128, 128, (int)R, z3, lz, h2, 128, gw[3], 128 + K0, gb[3], part, s);
     for (int i = 0; i < 3; ++i) {
         if (g_pre && i == 1) continue;
-        dw_gemm(128, kin[i], (int)R, gb2, 128, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, nullptr, part, s);
-        if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, gb2, 128, w[3] + 128 + off[i], 128 + K0, g_in[i], kin[i], epi(), 1, s);
+        dw_gemm(128, kin[i], (int)R, z3, lz, in[i], kin[i], gw[3] + 128 + off[i], 128 + K0, nullptr, part, s);
+        if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, z3, lz, w[3] + 128 + off[i], 128 + K0, g_in[i], kin[i], epi(), 1, s);
     }
-    gemm<false, true>((int)R, 128, 128, gb2, 128, w[3], 128 + K0, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);    // g_z2 = (g_z3 W3a) relu'(h2)
+    gemm<false, true>((int)R, 128, 128, z3, lz, w[3], 128 + K0, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);      // g_z2 = (g_z3 W3a) relu'(h2)
     // layer 2
     dw_gemm(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, gb[2], part, s);
     gemm<false, true>((int)R, 128, 128, ga, 128, w[2], 128, gb2, 128, epi(nullptr, 0, 0, h1, 128), 1, s);         // g_z1
     // layer 1
     dw_gemm(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, gb[1], part, s);
-    gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, ga, 128, epi(nullptr, 0, 0, h0, 128), 1, s);         // g_z0
+    gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, z0, lz, epi(nullptr, 0, 0, h0, 128), 1, s);          // g_z0
     // layer 0
-    if (g_pre) hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, ga, 128L, g_pre, 256L, R, 128);
     for (int i = 0; i < 3; ++i) {
         if (g_pre && i == 1) continue;
-        dw_gemm(128, kin[i], (int)R, ga, 128, in[i], kin[i], gw[0] + off[i], K0, i == 0 ? gb[0] : nullptr, part, s);
-        if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, ga, 128, w[0] + off[i], K0, g_in[i], kin[i], epi(nullptr, 0, 1), 1, s);
+        dw_gemm(128, kin[i], (int)R, z0, lz, in[i], kin[i], gw[0] + off[i], K0, i == 0 ? gb[0] : nullptr, part, s);
+        if (g_in[i]) gemm<false, true>((int)R, kin[i], 128, z0, lz, w[0] + off[i], K0, g_in[i], kin[i], epi(nullptr, 0, 1), 1, s);
     }
 }
 
@@ -917,7 +924,7 @@ void launch_vanilla_train_backward(const float* const* w, const float* x0, const
     gemm<false, true>(M, 256, 256, ga, 256, w[9], 256, gb2, 256, epi(), 1, s);
     dw_gemm(1, 256, M, g_sigma, 1, h[7], 256, gw[10], 256, gb[10], part, s);
     gemm<false, true>(M, 256, 1, g_sigma, 1, w[10], 256, gb2, 256, epi(nullptr, 0, 1), 1, s);
-    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 256)), dim3(256), 0, s, gb2, h[7], R * 256);                  // g_z7
+    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 256)), dim3(256), 0, s, gb2, 256L, h[7], 256, R);                  // g_z7
     float* cur = gb2;
     float* nxt = ga;
     for (int i = 7; i >= 1; --i) {
