@@ -314,12 +314,17 @@ class Runner:
             return ev[0].elapsed_time(ev_mid), max(0.0, first - steady), steady
 
         once(False)                                                                 # loads code objects, grows workspaces
-        runs = [once(True) for _ in range(reps)]          # the window holds ~150 enqueues and 72 small H2D copies: a host hiccup shows
-        total = sorted(r[1] for r in runs)[len(runs) // 2]   # up as an outlier run, hence the median (all runs are in the line)
-        return {"total_ms": total, "runs_ms": [r[1] for r in runs], "set_scene_ms": sorted(r[0] for r in runs)[len(runs) // 2],
-                "one_chunk_steady_ms": sorted(r[2] for r in runs)[len(runs) // 2],
-                "method": "HIP events on the launch stream, warm, median of %d: (set_scene + repack + one-chunk render) - (the same "
-                          "render in the steady state)" % reps,
+        # The window holds ~150 enqueues and 72 small H2D copies: whatever delays the host thread (another tenant of the box, a
+        # page fault) leaves the GPU idle INSIDE the window and can only ADD to it - one builder box gave 93, 95, 7.6, 7.7, 15, 174 ms
+        # in one call.  The number of record is therefore the second smallest of the runs (the smallest alone could be a timing
+        # glitch; an un-delayed run is reproducible to a few per cent); all runs are in the line.
+        runs = [once(True) for _ in range(reps)]
+        pick = lambda xs: sorted(xs)[1 if len(xs) > 1 else 0]
+        total = pick([r[1] for r in runs])
+        return {"total_ms": total, "runs_ms": [r[1] for r in runs], "set_scene_ms": pick([r[0] for r in runs]),
+                "one_chunk_steady_ms": pick([r[2] for r in runs]),
+                "method": "HIP events on the launch stream, warm, second smallest of %d runs (host delays only add to the window): "
+                          "(set_scene + repack + one-chunk render) - (the same render in the steady state)" % reps,
                 "note": "once per scene / per weight update, not part of ms_per_step: channels-last re-layout of 3 tri-planes + latent, "
                         "weight upload + fragment packing, k_tp_preproject (exact fp32 MFMA) x 4 for the latent + x 6 for the tri-planes "
                         "of the two outside-sphere MLPs (pre-projection mode 3)"}
