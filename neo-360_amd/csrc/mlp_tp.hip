@@ -26,6 +26,19 @@
 #include "tp_common.h"
 #include "tp_hp_layout.h"
 
+#ifndef NEO_TP32_RING
+#define NEO_TP32_RING 4       // items (4 tap loads each) in flight per lane in the projected-map gather of k_tp_mlp
+#endif
+#ifndef NEO_TP32_TRACE
+#define NEO_TP32_TRACE 0      // 1: per-phase s_memtime sums of wave 0 of every workgroup -> g_tp32_trace (tools/bench_tp_kernel.py TRACE=f32)
+#endif
+#if NEO_TP32_TRACE
+__device__ unsigned long long g_tp32_trace[16];
+#define TP32_MARK(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tr_[k] += now_ - tlast_; tlast_ = now_; } while (0)
+#else
+#define TP32_MARK(k) do { } while (0)
+#endif
+
 namespace neo {
 
 namespace {
@@ -177,8 +190,12 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
     // PROJ = 0 keeps the reference's operation order throughout.
     constexpr bool FOLD = PROJ >= 1;
 
+#if NEO_TP32_TRACE
+    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
+#endif
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     __syncthreads();
+    TP32_MARK(0);
 
     f32x16 hsum[2], ysum;
 #pragma unroll
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
                 if (FOLD && v > 0) *d += val; else *d = val;
             });
         __syncthreads();
+        TP32_MARK(1);
 
         // ---- streamed-input GEMM: [L0 | L3 skip half] (256 outputs) over 703 / 724 features ----
         f32x16 accx[2][2];
@@ -281,42 +299,57 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
             //      MFMA D layout, hp::proj_index) and are added to the accumulators: the structure of mlp_tp_hpp.hip ----
             if constexpr (PROJ >= 1) {
                 constexpr int NM = PROJ == 2 ? 4 : 1;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                // One ITEM = the four taps of one (chunk c, row group q, map mp): 4 loads, one blend.  Items run through a ring of
+                // NEO_TP32_RING slots: item i + RING is requested as soon as item i's registers are free, so RING - 1 .. RING items
+                // (12-16 loads per lane) stay in flight THROUGH the row / chunk boundaries.  The first version issued the 4 NM loads of
+                // a row, drained them to zero while blending, and only then issued the next row's: 16 exposed round trips per view
+                // (profiles/r05_exact_f32_experiments.log: this phase was 39 % of a tile, 58 k cycles per view; now 36 k).
+                constexpr int RING = NEO_TP32_RING, ITEMS = 16 * NM;
+                f32x4 ring[RING][4];
+                f32x4 sum = {0.0f, 0.0f, 0.0f, 0.0f};
+                auto item_addr = [&](int it, int& c, int& q, int& mp) { mp = it % NM; q = (it / NM) & 3; c = it / (4 * NM); };
+                auto issue = [&](auto itc) {
+                    constexpr int it = decltype(itc)::value;
+                    int c, q, mp;
+                    item_addr(it, c, q, mp);
+                    const int row = rg + 16 * q;
+                    const float* base = mp == 0 ? proj : pp.p[mp == 0 ? 0 : mp - 1];
+                    const int di = mp == 0 ? row * 4 : ((mp - 1) * TM + row) * 4;
+                    const int4 off = *reinterpret_cast<const int4*>((mp == 0 ? loc_off : pl_off) + di);
+                    ring[it % RING][0] = tp::load_tap(base, (uint32_t)off.x + lane_b + 256u * c);
+                    ring[it % RING][1] = tp::load_tap(base, (uint32_t)off.y + lane_b + 256u * c);
+                    ring[it % RING][2] = tp::load_tap(base, (uint32_t)off.z + lane_b + 256u * c);
+                    ring[it % RING][3] = tp::load_tap(base, (uint32_t)off.w + lane_b + 256u * c);
+                };
+                hp::static_for<0, (RING < ITEMS ? RING : ITEMS)>([&](auto itc) { issue(itc); });
+                hp::static_for<0, ITEMS>([&](auto itc) {
+                    constexpr int it = decltype(itc)::value;
+                    int c, q, mp;
+                    item_addr(it, c, q, mp);
+                    const int row = rg + 16 * q;
+                    const int di = mp == 0 ? row * 4 : ((mp - 1) * TM + row) * 4;
+                    const f32x4 val = blend4(ring[it % RING], *reinterpret_cast<const f32x4*>((mp == 0 ? loc_w : pl_w) + di));
+                    if (mp == 0) sum = val; else sum = sum + val;
+                    if constexpr (it + RING < ITEMS) issue(std::integral_constant<int, it + RING>());
                     float* fb = act + (c & 1) * (TM * XB_LD);
+                    if (mp == NM - 1) write_x(fb, row, sum);
+                    if (mp == NM - 1 && q == 3) {
+                        __syncthreads();
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = rg + 16 * q;
-                        f32x4 sum;
+                        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int mp = 0; mp < NM; ++mp) {
-                            const float* base = mp == 0 ? proj : pp.p[mp == 0 ? 0 : mp - 1];
-                            const int di = mp == 0 ? row * 4 : ((mp - 1) * TM + row) * 4;
-                            const int4 off = *reinterpret_cast<const int4*>((mp == 0 ? loc_off : pl_off) + di);
-                            f32x4 t4[4];
-                            t4[0] = tp::load_tap(base, (uint32_t)off.x + lane_b + 256u * c);
-                            t4[1] = tp::load_tap(base, (uint32_t)off.y + lane_b + 256u * c);
-                            t4[2] = tp::load_tap(base, (uint32_t)off.z + lane_b + 256u * c);
-                            t4[3] = tp::load_tap(base, (uint32_t)off.w + lane_b + 256u * c);
-                            const f32x4 val = blend4(t4, *reinterpret_cast<const f32x4*>((mp == 0 ? loc_w : pl_w) + di));
-                            if (mp == 0) sum = val; else sum = sum + val;
-                        }
-                        write_x(fb, row, sum);
+                            for (int gg = 0; gg < 2; ++gg) {
+                                const int trow = mt * 32 + L.l31;
+                                const int piece = L.wv * 4 + gg * 2 + L.half;
+                                const f32x4 tv = *reinterpret_cast<const f32x4*>(fb + trow * XB_LD + ((piece ^ (trow & 15)) << 2));
+                                const int g0 = 2 * (c & 1);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += tv[e];
+                            }
                     }
-                    __syncthreads();
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int gg = 0; gg < 2; ++gg) {
-                            const int row = mt * 32 + L.l31;
-                            const int piece = L.wv * 4 + gg * 2 + L.half;
-                            const f32x4 val = *reinterpret_cast<const f32x4*>(fb + row * XB_LD + ((piece ^ (row & 15)) << 2));
-                            const int g0 = 2 * (c & 1);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += val[e];
-                        }
-                }
+                });
                 __syncthreads();      // the transposition tiles are the streamed-input tiles: chunk 3 has been consumed
+                TP32_MARK(2);
             }
             constexpr int S0 = PROJ == 0 ? 0 : PROJ == 1 ? 8 : 10;       // first streamed stage: 0 local, 8 world, 10 pos_enc
             // prologue: stage S0
@@ -356,6 +389,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
             }
         }
 
+        TP32_MARK(3);
         // ---- L0 epilogue, L1, L2 ------------------------------------------------
         f32x16 acc[1][2];
         store_tile<ACT_LD, 15, true>(accx[0][0], act, L.wv, 0, L);
@@ -371,6 +405,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
             store_tile<ACT_LD, 15, true>(acc[0][1], act, L.wv, 1, L);
             __syncthreads();
         }
+        TP32_MARK(4);
         // ---- L3 = skip half (already in accx[1]) + W3[:, :128] h2 ; ReLU; accumulate the view mean ----
         acc[0][0] = accx[1][0];
         acc[0][1] = accx[1][1];
@@ -381,6 +416,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
             hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
             hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
         }
+        TP32_MARK(5);
         if constexpr (!FOLD) {
         store_tile<ACT_LD, 15, true>(acc[0][0], act, L.wv, 0, L);
         store_tile<ACT_LD, 15, true>(acc[0][1], act, L.wv, 1, L);
@@ -477,6 +513,14 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
                                   colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));
         }
     }
+#if NEO_TP32_TRACE
+    TP32_MARK(6);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_tp32_trace[k], tr_[k]);
+        atomicAdd(&g_tp32_trace[7], 1ull);
+    }
+#endif
 }
 
 // ---- weight packing -------------------------------------------------------------
@@ -515,6 +559,17 @@ __global__ void k_to_channels_last(const float* __restrict__ src, int C, int HW,
 }
 
 }  // namespace
+
+#if NEO_TP32_TRACE
+extern "C" void neo_debug_tp32_trace(unsigned long long* host16, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_tp32_trace), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tp32_trace), z, sizeof(z));
+    }
+}
+#endif
 
 void pack_block(const float* src, int ld, int rows, int KC, int nt0, PackSegs sg, float* dst, hipStream_t s) {
     const int total = (rows / 32) * KC * 256;

@@ -75,11 +75,13 @@ if os.environ.get("TRACE"):
     lib = _lib.load()
     buf = (ctypes.c_ulonglong * 16)()
     hpp = os.environ["TRACE"] == "hpp"
-    read = lib.neo_debug_tpp_trace if hpp else lib.neo_debug_tp_trace
+    f32 = os.environ["TRACE"] == "f32"          # library built -DNEO_TP32_TRACE=1: the exact-fp32 evaluator k_tp_mlp (PREC=f32)
+    read = lib.neo_debug_tp32_trace if f32 else lib.neo_debug_tpp_trace if hpp else lib.neo_debug_tp_trace
     read(buf, 1)                 # reset (drops warm-up + timed launches above)
     net.eval_mlp(SLOT, rays, t, far=far)
     read(buf, 0)
-    names = (["setup", "descriptors + pos_enc", "work list + prologue", "gather + pos_enc k-steps + adds", "L0 epi + L1..L3", "tail"] if hpp else
+    names = (["setup", "descriptors", "projected maps: gather + add", "streamed stages (pos_enc)", "L0 epi + L1 + L2", "L3 + view sums", "tail"] if f32 else
+             ["setup", "descriptors + pos_enc", "work list + prologue", "gather + pos_enc k-steps + adds", "L0 epi + L1..L3", "tail"] if hpp else
              ["setup", "descriptors", "G gather+consume", "planes (+X ks0-3)", "X ks4.. + pos_enc", "L0 epi + L1..L3", "tail"])
     n = max(int(buf[7]), 1)
     tot = sum(int(buf[k]) for k in range(len(names)))
