@@ -401,11 +401,11 @@ def test_bench_plain_form_scene_setup_from_events():
     ss = out["scene_setup"]
     runs = ss["runs_ms"]
     assert len(runs) == 7 and out["scene_setup_ms"] == ss["total_ms"]
-    assert 1.0 < ss["total_ms"] < 60.0, ss
-    # the number of record is the second smallest run: host delays only ADD to the event window (~150 enqueues, 72 small H2D
-    # copies; a loaded box gave 93, 95, 7.6, 7.7, 15, 174 ms in one call), and an un-delayed run repeats: the two smallest agree
-    low = sorted(runs)[:2]
-    assert ss["total_ms"] == low[1] and low[1] - low[0] <= 0.2 * low[0] + 0.3, runs
+    # The number of record is the second smallest run.  No bound on its size or on the runs' agreement here: the event window holds
+    # ~150 enqueues and 72 small H2D copies issued by the host thread, and the box decides how long those take - the builder's boxes
+    # gave 7.2-7.7 ms on most, 93 / 95 / 7.6 / 7.7 / 15 / 174 ms within one call on a loaded one, and a steady 94-100 ms on another
+    # (GPU work in the window: ~5 ms in rocprofv3).  A test that asserted either would fail the whole suite on such a box.
+    assert ss["total_ms"] == sorted(runs)[1] and 0.5 < ss["total_ms"] < 5000.0, ss
 
 
 # ---- the training call's fused point / activation operators (round 5) ------------------------------------------------------
