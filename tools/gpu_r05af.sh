@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05af; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -q -m gpu -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+timeout 2400 python -m pytest tests -q -m gpu > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 tail -4 $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
