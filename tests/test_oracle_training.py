@@ -83,3 +83,27 @@ def test_distloss_prefix_sums_equal_the_definition():
     w_suf, wm_suf = wc[:, -1:] - wc, wmc[:, -1:] - wmc
     manual = (2.0 * (1.0 / 40) * wd / 3.0 + 2.0 * (m * (w_pre - w_suf) + (wm_suf - wm_pre))) / 7
     assert float((gw - manual).abs().max()) < 1e-14
+
+
+def test_given_samples_hooks_of_the_pixelnerf_and_mip_oracles():
+    """The hooks the GPU training tests use to evaluate the oracle at the library's sample positions: feeding an oracle its own
+    positions reproduces its render bit for bit; `sigma_noise` (PixelNeRF) and `jitters` (Mip-NeRF 360) change it; the Mip oracle's
+    sample positions carry no gradient (stop_level_grad)."""
+    from oracle import mip360
+    scene, sd = cases.small_scene(), synth.pixelnerf_state(0)
+    b = cases.neo_batch(cases.strided_rays(8))
+    out, ex = oracle.pixelnerf.render(sd, b, scene, 0.2, 2.5, n_coarse=8, n_fine=8, keep=True)
+    again = oracle.pixelnerf.render(sd, b, scene, 0.2, 2.5, n_coarse=8, n_fine=8, samples=(ex[0]["t"], ex[1]["t"]))
+    assert torch.equal(out[1][0], again[1][0]) and torch.equal(out[0][2], again[0][2])
+    noisy = oracle.pixelnerf.render(sd, b, scene, 0.2, 2.5, n_coarse=8, n_fine=8, samples=(ex[0]["t"], ex[1]["t"]),
+                                    sigma_noise=[torch.full((8, 9), 0.5), torch.full((8, 17), 0.5)])
+    assert max_abs(noisy[1][0], out[1][0]) > 1e-4
+    msd, rays = synth.mip360_state(0, weight_gain=0.25), cases.mip_rays(6)
+    r, h = mip360.render(msd, rays, 0.5, 0.2, 3.0, num_prop_samples=8, num_nerf_samples=4)
+    r2, _ = mip360.render(msd, rays, 0.5, 0.2, 3.0, num_prop_samples=8, num_nerf_samples=4, sdist_given=[x["sdist"] for x in h])
+    assert torch.equal(r[2]["rgb"], r2[2]["rgb"])
+    eps = float(torch.finfo(torch.float32).eps)
+    mj = lambda n: (1 - (eps + (1 - eps) / n)) / (n - 1) - eps
+    r3, h3 = mip360.render(msd, rays, 0.5, 0.2, 3.0, num_prop_samples=8, num_nerf_samples=4,
+                           jitters=[torch.full((6, 1), 0.9 * mj(8)), torch.full((6, 1), 0.5 * mj(8)), torch.full((6, 1), 0.3 * mj(4))])
+    assert max_abs(h3[0]["sdist"], h[0]["sdist"]) > 1e-4 and all(not x["sdist"].requires_grad for x in h3)
