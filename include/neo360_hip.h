@@ -73,6 +73,14 @@ int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits);
  * device, hipStreamWaitEvent, never on the host - for an event recorded behind that previous call.  stream_waits:
  * how many such cross-stream waits this context has inserted (0 for the usual one-stream caller). */
 int neo_ctx_stream_waits(neo_ctx* ctx, uint64_t* cross_stream_waits);
+/* Scratch lanes (round 6).  The reference drives the module as 300 calls of 1024 rays per frame (render_rays_test,
+ * neo360/model.py:861-907); launched back to back on one stream every call ends on a partly filled machine (2,064 tiles
+ * of a coarse launch on 512 workgroup slots).  A context therefore owns TWO sets of render scratch: neo_ctx_set_lane picks
+ * the set the next calls use (0, the default, or 1).  neo_tp_render writes its lane's scratch only and reads the shared
+ * weights / maps, so two renders on different lanes AND different streams are not ordered against each other and overlap
+ * on the device; every other entry point (uploads, set_scene, evaluator / training calls) stays ordered against all
+ * earlier calls of the context, on any lane.  A one-lane, one-stream caller sees no difference. */
+int neo_ctx_set_lane(neo_ctx* ctx, int lane);
 
 /* Arithmetic of the per-point MLP GEMMs of every renderer (vanilla, NeRF_TP, Mip-NeRF 360, PixelNeRF).
  * 1 (the context default, and the default of the Python modules, "f16x3"): fp16 MFMA with every fp32

@@ -41,6 +41,7 @@ SIGNATURES = {
     "neo_ctx_take_flags": (_i, [_vp, _i, _vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(_i)]),
     "neo_ctx_sync_count": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "neo_ctx_stream_waits": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
+    "neo_ctx_set_lane": (_i, [_vp, _i]),
     "neo_ctx_set_precision": (_i, [_vp, _i]),
     "neo_linspace_host": (None, [_f, _f, _i, c_float_p]),
     "neo_raygen": (_i, [_vp, _i, _i, _f, c_float_p, _vp, _vp, _vp, _vp, _vp]),
@@ -164,3 +165,13 @@ def linspace(start, end, steps):
     buf = (ctypes.c_float * steps)()
     load().neo_linspace_host(start, end, steps, buf)
     return list(buf)
+
+
+# Bumped by every library call that overwrites a caller's EXISTING tensor through its data pointer (the `out=` forms of ops.py):
+# such a write does not advance the tensor's autograd version counter, and models.CallOverlap keys its fork points on versions.
+write_epoch = 0
+
+
+def note_external_write():
+    global write_epoch
+    write_epoch += 1

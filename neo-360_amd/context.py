@@ -95,6 +95,12 @@ class Context:
         _lib.check(self.lib.neo_ctx_stream_waits(self.handle, ctypes.byref(n)))
         return n.value
 
+    def set_lane(self, lane):
+        """Scratch lane (0 / 1) the next calls of this context use (neo_ctx_set_lane)."""
+        if getattr(self, "_lane", 0) != lane:
+            _lib.check(self.lib.neo_ctx_set_lane(self.handle, int(lane)))
+            self._lane = lane
+
     def set_precision(self, mode):
         """'f32' (exact fp32 MFMA) or 'f16x3' (fp16 MFMA, hi/lo-split operands, fp32-equivalent)."""
         code = {"f32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]
@@ -129,6 +135,75 @@ class Context:
             self._finalizer.detach()
             self.lib.neo_ctx_destroy(self.handle)
             self.handle = None
+
+
+class CallOverlap:
+    """Lets consecutive whole-chunk calls of one module overlap on the device (round 6, VERDICT r5 task 4).
+
+    The reference renders a frame as 300 `model(chunk)` calls of 1024 rays (neo360/model.py:861-907).  On one stream each
+    call's four evaluator launches end on a partly filled machine and the next call cannot start before the last workgroup of
+    this one has finished.  Here call i runs on side stream i % 2 with scratch lane i % 2 of the context, so call i + 1's
+    kernels fill the CUs call i's tail leaves idle.  Stream semantics towards the CALLER are unchanged:
+
+    * fork: the side stream waits for an event of the caller's stream.  A fresh event is recorded at every call, EXCEPT when
+      the call's ray tensors are views of the very tensor objects (weak identity), at the very versions, of the call the last
+      fresh event was recorded for, on the same caller stream and with no `out=` write of this library in between - then
+      everything these rays depend on was already enqueued before that event and it is reused.  (A fresh event at call
+      i + 1 would sit behind the join of call i and serialise the two.)  Any converted / copied input takes a fresh event.
+    * join: before the call returns, the caller's stream waits for the call's completion event, so anything enqueued on it
+      afterwards sees the outputs - exactly as if the kernels had run there.
+    * memory: outputs are allocated under the side stream and `record_stream`-ed to the caller's stream, inputs are
+      `record_stream`-ed to the side stream: the caching allocator will not hand a block to another stream while the other
+      side may still touch it.
+    """
+
+    def __init__(self, device):
+        self.device = device
+        self.streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+        self.done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.calls = 0
+        self.fresh_forks = 0
+        self._fork_ev = None
+        self._fork_key = None
+        self._fork_bases = ()
+
+    def _key(self, raw, conv, cur):
+        bases, ks = [], []
+        for a, b in zip(raw, conv):
+            if a is not b:
+                return None, ()
+            base = a._base if a._base is not None else a
+            bases.append(base)
+            ks.append((base._version, a.untyped_storage().data_ptr()))
+        return (tuple(ks), cur.cuda_stream, _lib.write_epoch), tuple(bases)
+
+    def begin(self, raw, conv):
+        """-> (side stream, lane, caller's stream).  The side stream is ordered behind everything the inputs depend on."""
+        cur = torch.cuda.current_stream(self.device)
+        lane = self.calls & 1
+        self.calls += 1
+        side = self.streams[lane]
+        key, bases = self._key(raw, conv, cur)
+        reuse = (key is not None and key == self._fork_key and len(bases) == len(self._fork_bases)
+                 and all(r() is b for r, b in zip(self._fork_bases, bases)))
+        if not reuse:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._fork_ev, self._fork_key = ev, key
+            self._fork_bases = tuple(weakref.ref(b) for b in bases)
+            self.fresh_forks += 1
+        side.wait_event(self._fork_ev)
+        for t in conv:
+            t.record_stream(side)
+        return side, lane, cur
+
+    def end(self, lane, cur, outputs):
+        """Completion event on the side stream; the caller's stream waits for it; outputs may be used (and freed) there."""
+        ev = self.done[lane]
+        ev.record(self.streams[lane])
+        cur.wait_event(ev)
+        for t in outputs:
+            t.record_stream(cur)
 
 
 def get_context(device):

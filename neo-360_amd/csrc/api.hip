@@ -85,18 +85,42 @@ const float* neo_ctx::get_edges(int n, float near, float far, hipStream_t s) {
     return buf.as<float>();
 }
 
-int neo_ctx::order_begin(hipStream_t s) {
+static int order_wait(neo_ctx* c, hipStream_t s, neo_ctx::OrderPoint& p) {
+    if (!p.valid || p.stream == s) return NEO_OK;      // same stream: already in order
+    if (hipStreamWaitEvent(s, p.ev, 0) != hipSuccess) return neo_host::fail(NEO_ERR_HIP, "hipStreamWaitEvent failed");
+    c->order_waits += 1;
+    return NEO_OK;
+}
+int neo_ctx::order_begin(hipStream_t s, bool lane_call) {
     // nested scopes (neo_tp_render -> tp_launch, an upload inside a render call): only the OUTERMOST one waits and records
-    if (order_depth == 0 && order_valid && s != order_stream) {
-        if (hipStreamWaitEvent(s, order_ev, 0) != hipSuccess) return neo_host::fail(NEO_ERR_HIP, "hipStreamWaitEvent failed");
-        order_waits += 1;
+    if (order_depth == 0) {
+        order_is_lane = lane_call;
+        shared_dirty = false;
+        if (int rc = order_wait(this, s, order_excl)) return rc;
+        if (lane_call) {
+            if (int rc = order_wait(this, s, order_lane[lane])) return rc;
+        } else {
+            for (auto& p : order_lane)
+                if (int rc = order_wait(this, s, p)) return rc;
+        }
     }
     order_depth += 1;
     return NEO_OK;
 }
+int neo_ctx::touch_shared(hipStream_t s) {
+    if (order_depth == 0 || !order_is_lane || shared_dirty) return NEO_OK;
+    shared_dirty = true;
+    for (auto& p : order_lane)
+        if (int rc = order_wait(this, s, p)) return rc;
+    return NEO_OK;
+}
 void neo_ctx::order_end(hipStream_t s) {
-    if (!order_ev && hipEventCreateWithFlags(&order_ev, hipEventDisableTiming) != hipSuccess) { order_ev = nullptr; return; }
-    if (hipEventRecord(order_ev, s) == hipSuccess) { order_stream = s; order_valid = true; }
+    const bool excl = !order_is_lane || shared_dirty;
+    OrderPoint& p = excl ? order_excl : order_lane[lane];
+    if (!p.ev && hipEventCreateWithFlags(&p.ev, hipEventDisableTiming) != hipSuccess) { p.ev = nullptr; return; }
+    if (hipEventRecord(p.ev, s) == hipSuccess) { p.stream = s; p.valid = true; }
+    if (excl)                              // everything earlier is behind this point now
+        for (auto& l : order_lane) l.valid = false;
 }
 
 neo_order_scope::~neo_order_scope() {
@@ -163,7 +187,7 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     ctx->mip_basis.release();
     for (auto& b : ctx->mip_lws) b.release();
     for (auto& kv : ctx->edges) kv.second.release();
-    for (auto& b : ctx->ws) b.release();
+    for (auto& set : ctx->ws_sets) for (auto& b : set) b.release();
     for (auto& sl : ctx->tp) sl.release();
     for (auto& sl : ctx->pix) sl.release();
     ctx->pix_latent.release();
@@ -173,12 +197,13 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     ctx->enc_axes.release();
     for (auto& b : ctx->enc_ws) b.release();
     ctx->latent.release();
-    ctx->tp_dirsum.release();
+    for (auto& b : ctx->tp_dirsum_sets) b.release();
     ctx->train_scratch.release();
     for (auto& b : ctx->plane) b.release();
     for (auto& sp : ctx->spans) { (void)hipEventDestroy(sp.first); (void)hipEventDestroy(sp.second); }
     for (auto& ev : ctx->flag_ev) if (ev) (void)hipEventDestroy(ev);
-    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
+    if (ctx->order_excl.ev) (void)hipEventDestroy(ctx->order_excl.ev);
+    for (auto& l : ctx->order_lane) if (l.ev) (void)hipEventDestroy(l.ev);
     if (ctx->flag_host) (void)hipHostFree(ctx->flag_host);
     if (ctx->flags) (void)hipFree(ctx->flags);
     delete ctx;
@@ -259,6 +284,15 @@ int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits) {
     ENTER(ctx);
     REQUIRE(blocking_waits != nullptr, "null out pointer");
     *blocking_waits = ctx->blocking_waits;
+    return NEO_OK;
+}
+
+int neo_ctx_set_lane(neo_ctx* ctx, int lane) {
+    ENTER(ctx);
+    REQUIRE(lane >= 0 && lane < neo_ctx::LANES, "lane must be 0 or 1");
+    ctx->lane = lane;
+    ctx->ws = ctx->ws_sets[lane];
+    ctx->tp_dirsum = &ctx->tp_dirsum_sets[lane];
     return NEO_OK;
 }
 

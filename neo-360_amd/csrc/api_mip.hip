@@ -183,7 +183,7 @@ int neo_mip_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const
     const float anneal = static_cast<float>((10.0 * train_frac) / (9.0 * train_frac + 1.0));
     const int nmax = n_prop > n_nerf ? n_prop : n_nerf;
     ORDERED(ctx, static_cast<hipStream_t>(stream));
-    auto& W = ctx->ws;
+    auto* W = ctx->ws;
     const size_t r = static_cast<size_t>(R);
     // two ping-pong sets of (sdist, tdist, weights, rgbdens) + the level-0 seed histogram
     for (int k = 0; k < 2; ++k)

@@ -38,10 +38,12 @@ int ensure_projections(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, bool p
     const size_t need = neo::tp_proj_bytes(t_lat + (planes ? 3 * t_pl : 0)) + neo::tp_proj_pad_bytes();
     REQUIRE(need <= 4294967295UL, "projected maps too large for 32-bit byte offsets");
     if (need > sl.proj.cap) {          // growing re-allocates: everything in the buffer has to be made again
+        if (int rc = ctx->touch_shared(s)) return rc;
         if (sl.proj.reserve(need)) return NEO_ERR_NOMEM;
         sl.proj_weights = sl.proj_scene = sl.projpl_weights = sl.projpl_scene = 0;
     }
     if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->scene_epoch) {
+        if (int rc = ctx->touch_shared(s)) return rc;      // shared by both scratch lanes: this call ends as an exclusive one
         neo::launch_tp_preproject(sc.latent, t_lat, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch), sl.proj.as<float>(), s);
         // split arithmetic: a projected map is a STATIC operand of the evaluator (its blends are added to the layer-0 / skip
         // pre-activations, whose hi/lo split the epilogue guards) - checked once per (scene, weights) here, so that a latent the
@@ -52,6 +54,7 @@ int ensure_projections(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, bool p
         sl.proj_scene = ctx->scene_epoch;
     }
     if (planes && (sl.projpl_weights != sl.weights_epoch || sl.projpl_scene != ctx->scene_epoch)) {
+        if (int rc = ctx->touch_shared(s)) return rc;
         for (int j = 0; j < 3; ++j)
             neo::launch_tp_preproject(sc.plane[j], t_pl, sl.wpack.as<float>(), neo::tp_kc_x(sl.input_ch),
                                       sl.proj.as<float>() + plane_base[j] * 256, s, 256, 128, 64);
@@ -89,16 +92,16 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             neo::TpMlpHDev mh{sl.wpack_hp.p, sl.bias_hp.as<float>(), sl.heads.as<float>(), ctx->flags};
             // the view-direction encodings enter the MLP only through their mean over the views, and they depend on the
             // ray alone: summed once per ray here instead of once per sample and view inside the evaluator
-            if (ctx->tp_dirsum.reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
-            neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum.as<float>(), s);
+            if (ctx->tp_dirsum->reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
+            neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum->as<float>(), s);
             ctx->span_kernel_next = planes ? 2 : 1;
             ctx->span_begin(s);
             if (planes)
                 neo::launch_tp_mlp_hpp(sl.input_ch, mh, sl.proj.as<float>(), plane_base, sc, views, rays_o, rays_d, viewdirs, tvals, far,
-                                       R, N, chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
+                                       R, N, chunk, ctx->flags, out, ctx->tp_dirsum->as<float>(), s);
             else
                 neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
-                                      chunk, ctx->flags, out, ctx->tp_dirsum.as<float>(), s);
+                                      chunk, ctx->flags, out, ctx->tp_dirsum->as<float>(), s);
         } else {
             guard_split_weights(sl, sl.wpack_h.p, neo::tp_wpack_h_bytes(sl.input_ch), ctx->flags, s);
             if (ctx->latent_checked != ctx->scene_epoch) {
@@ -271,9 +274,9 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const 
     const float* u = ctx->get_quantiles(n_fine, s);
     if (!edges || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
 
-    // workspaces
-    ORDERED(ctx, s);
-    auto& W = ctx->ws;
+    // workspaces: this lane's set (neo_ctx_set_lane); the call reads shared weights / maps and writes lane scratch only
+    ORDERED_LANE(ctx, s);
+    auto* W = ctx->ws;
     const size_t r = static_cast<size_t>(R);
     if (W[0].reserve(r * 4) || W[1].reserve(r * N0 * 4) || W[2].reserve(r * N0 * 4) || W[3].reserve(r * N1 * 16) ||
         W[4].reserve(r * N1 * 16) || W[5].reserve(r * N0 * 4) || W[6].reserve(r * N0 * 4) || W[7].reserve(r * N1 * 4) ||

@@ -253,7 +253,7 @@ int neo_tp_render_train(neo_ctx* ctx, const float* rays_o, const float* rays_d, 
     const float* u_det = ctx->get_quantiles(n_fine, s);
     if (!edges || !u_det) return fail(NEO_ERR_HIP, "constant table upload failed");
     ORDERED(ctx, static_cast<hipStream_t>(stream));
-    auto& W = ctx->ws;
+    auto* W = ctx->ws;
     const size_t r = static_cast<size_t>(R);
     const size_t nu = seed ? r * (N0 > n_fine ? N0 : n_fine) * 4 : 4;
     if (W[0].reserve(r * 4) || W[1].reserve(r * N0 * 4) || W[2].reserve(r * N0 * 4) || W[3].reserve(r * N1 * 16) ||

@@ -123,6 +123,9 @@ struct neo_order_scope {
 #define ORDERED(ctx, s)                                   \
     if (int rc_ = (ctx)->order_begin(s)) return rc_;      \
     neo_order_scope order_scope_{(ctx), (s)}
+#define ORDERED_LANE(ctx, s)                              \
+    if (int rc_ = (ctx)->order_begin(s, true)) return rc_; \
+    neo_order_scope order_scope_{(ctx), (s)}
 
 extern "C" void neo_linspace_host(float start, float end, int steps, float* out);
 
@@ -144,7 +147,14 @@ struct neo_ctx {
     bool scene_ready = false;
     uint64_t scene_epoch = 0;          // bumped by every neo_tp_set_scene
     uint64_t planes_checked = 0, latent_checked = 0;   // scene_epoch whose maps passed the split range check
-    neo_host::DevBuf tp_dirsum;        // (rays, 32): view-summed direction encodings of the current launch (k_tp_mlp_hp)
+    // Scratch LANES (round 6): two sets of the render workspaces and of the per-launch direction table.  A caller that drives the
+    // module chunk by chunk (the reference's render_rays_test loop, neo360/model.py:861-907) alternates lanes - and streams -
+    // so that chunk i + 1's evaluators start while chunk i's last workgroups drain (models.py: NeRF_TP overlap).  `lane`
+    // selects the set the NEXT calls use (neo_ctx_set_lane); everything else in the context is shared by both lanes.
+    static constexpr int LANES = 2;
+    int lane = 0;
+    neo_host::DevBuf tp_dirsum_sets[LANES];
+    neo_host::DevBuf* tp_dirsum = &tp_dirsum_sets[0];   // (rays, 32): view-summed direction encodings of the current launch (k_tp_mlp_hp)
     int preproject = 3;                // 0 off; 1 gather the latent pre-projected through the first-layer weights; 2 the tri-planes too; 3 (default): planes for the outside-sphere slots only
     // PixelNeRF scene latent: its own buffer / descriptor / ready flag (a context may hold both decoders)
     neo_host::DevBuf pix_latent;
@@ -155,7 +165,8 @@ struct neo_ctx {
     int pix_preproject = 1;            // PixelNeRF: gather the latent pre-projected through pts_linears.0 (mlp_pix_h.hip)
     std::map<int, neo_host::DevBuf> quantiles;                    // n_new -> linspace(0, fl32(1-2^-32), n_new)
     std::map<std::pair<int, uint64_t>, neo_host::DevBuf> edges;   // (n, near/far bits) -> level-0 t row
-    neo_host::DevBuf ws[12];                                      // render workspaces (grow-only)
+    neo_host::DevBuf ws_sets[LANES][12];                          // render workspaces (grow-only), one set per lane
+    neo_host::DevBuf* ws = ws_sets[0];                            // the current lane's set
     neo_host::DevBuf boxes;                                       // neo_aabb_multi: box frames + bounds
     // pillar stage of the scene encoder (neo_enc_*): packed weights, biases (6x512), scorer heads (3x512), workspaces
     neo_host::MlpSlot enc;
@@ -176,12 +187,19 @@ struct neo_ctx {
     // Context-owned scratch (tp_dirsum, train_scratch, ws[]) is rewritten by every launch on whatever stream the caller
     // passes: launches of one context are therefore ORDERED across streams - a call on a stream other than the previous
     // call's first waits (device-side, hipStreamWaitEvent) for the event recorded behind that call.
-    hipStream_t order_stream = nullptr;
-    hipEvent_t order_ev = nullptr;
-    bool order_valid = false;
+    // Round 6: two ordering domains.  An EXCLUSIVE call (ORDERED: uploads, set_scene, evaluator / training / gather calls -
+    // anything that may write shared context memory) is ordered behind every earlier call of the context and every later
+    // call behind it.  A LANE call (ORDERED_LANE: the whole-chunk renders, which write only their lane's scratch and READ the
+    // shared weights / maps) is ordered behind the last exclusive call and the previous call of ITS lane only - two lane calls
+    // on different lanes and streams run concurrently.  A lane call that turns out to write shared memory after all (lazy
+    // pre-projection, a first-use range check: `touch_shared()`) ends as an exclusive one.
+    struct OrderPoint { hipStream_t stream = nullptr; hipEvent_t ev = nullptr; bool valid = false; };
+    OrderPoint order_excl, order_lane[LANES];
     uint64_t order_waits = 0;                    // cross-stream waits inserted (tests)
     int order_depth = 0;                         // live ORDERED scopes of the current call (only the outermost waits / records)
-    int order_begin(hipStream_t s);
+    bool order_is_lane = false, shared_dirty = false;
+    int touch_shared(hipStream_t s);            // a lane call is about to WRITE shared context memory: wait for the other lanes, end as exclusive
+    int order_begin(hipStream_t s, bool lane_call = false);
     void order_end(hipStream_t s);
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;

@@ -65,7 +65,10 @@
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
 // tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
-// 64 no barriers inside the view loop, 128 no layer-epilogue stores
+// 64 no barriers inside the view loop, 128 no layer-epilogue stores; round 6 (energy budget of the gather half): 256 every tap
+// reads texel 0 of its map (the loads stay, all L1 hits, one 256-B run per instruction: what is left is the instruction / L1
+// path, what went is the L2 -> L1 traffic and the divergent-address cost), 512 the loads are replaced by undefined registers
+// (blends, LDS transposition and adds stay)
 #define NEO_TP_ABLATE 0
 #endif
 #ifndef NEO_TP_TIMELINE
@@ -263,11 +266,17 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     constexpr int c = i / 4;
                     [[maybe_unused]] constexpr int q = i % 4;
 #if NEO_TP_DPF
-                    const int4 off = d_off[i & 1];
+                    int4 off = d_off[i & 1];
 #else
                     const int row = rg + 16 * q;
-                    const int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
+                    int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
 #endif
+                    if constexpr ((NEO_TP_ABLATE & 256) != 0) off = int4{0, 0, 0, 0};
+                    if constexpr ((NEO_TP_ABLATE & 512) != 0) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "=v"(taps[i % RING][t]));
+                        return;
+                    }
                     taps[i % RING][0] = tp::load_tap(proj, (uint32_t)off.x + lane_b + 256u * c);
                     taps[i % RING][1] = tp::load_tap(proj, (uint32_t)off.y + lane_b + 256u * c);
                     taps[i % RING][2] = tp::load_tap(proj, (uint32_t)off.z + lane_b + 256u * c);
@@ -276,11 +285,17 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     constexpr int w = i - 16, s2 = w / 12, j = w % 3;
                     [[maybe_unused]] constexpr int q = (w % 12) / 3;
 #if NEO_TP_DPF
-                    const int4 off = d_off[i & 1];
+                    int4 off = d_off[i & 1];
 #else
                     const int row = rg + 16 * q;
-                    const int4 off = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
+                    int4 off = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
 #endif
+                    if constexpr ((NEO_TP_ABLATE & 256) != 0) off = int4{0, 0, 0, 0};
+                    if constexpr ((NEO_TP_ABLATE & 512) != 0) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) asm volatile("" : "=v"(taps[i % RING][t]));
+                        return;
+                    }
                     taps[i % RING][0] = tp::load_tap(sc.plane[j], (uint32_t)off.x + lane_b + 256u * s2);
                     taps[i % RING][1] = tp::load_tap(sc.plane[j], (uint32_t)off.y + lane_b + 256u * s2);
                     taps[i % RING][2] = tp::load_tap(sc.plane[j], (uint32_t)off.z + lane_b + 256u * s2);

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .context import f32, new_context, ptr
+from .context import CallOverlap, f32, new_context, ptr
 
 
 def _xavier_linear(n_in, n_out, xavier=True):
@@ -585,11 +585,28 @@ class NeRF_TP(_HipModule):
         with torch.no_grad():
             return self._forward_eval(rays, randomized, white_bkgd, chunk)
 
+    # Consecutive evaluation calls overlap on the device (context.CallOverlap: two side streams x two scratch lanes; the
+    # caller's stream semantics are unchanged).  What it is for: the reference's own chunk loop - 300 forward calls of 1024
+    # rays per frame, neo360/model.py:861-907 - whose calls would otherwise each end on a partly filled machine.
+    # False / $NEO360_OVERLAP=0: every call runs on the caller's stream, as before round 6.
+    overlap_calls = os.environ.get("NEO360_OVERLAP", "1") != "0"
+
+    def _overlap(self, dev):
+        if not self.overlap_calls:
+            return None
+        table = self.__dict__.setdefault("_overlap_state", {})
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        ov = table.get(key)
+        if ov is None:
+            ov = table[key] = CallOverlap(torch.device("cuda", key))
+        return ov
+
     def _forward_eval(self, rays, randomized, white_bkgd, chunk=None):
         self._check_mode(randomized)
-        rays_o = f32(rays["rays_o"], "rays_o")
-        rays_d = f32(rays["rays_d"], "rays_d")
-        viewdirs = f32(rays["viewdirs"], "viewdirs")
+        raw = (rays["rays_o"], rays["rays_d"], rays["viewdirs"])
+        rays_o = f32(raw[0], "rays_o")
+        rays_d = f32(raw[1], "rays_d")
+        viewdirs = f32(raw[2], "viewdirs")
         dev = rays_o.device
         ctx = self._context(dev)
         self._ensure_scene(rays, dev)
@@ -599,18 +616,30 @@ class NeRF_TP(_HipModule):
         self._before_call(ctx)
         B = rays_o.shape[0]
         host_poses, NV, focal, cx, cy = self._camera_args(rays)
-        levels, structs = [], []
-        for _ in range(2):
-            t = dict(rgb=torch.empty(B, 3, device=dev), fg_rgb=torch.empty(B, 3, device=dev),
-                     bg_rgb=torch.empty(B, 3, device=dev), fg_acc=torch.empty(B, device=dev),
-                     bg_lambda=torch.empty(B, 1, device=dev), depth=torch.empty(B, device=dev))
-            levels.append(t)
-            structs.append(_lib.TpLevelOut(*(t[k].data_ptr() for k in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth"))))
-        _lib.check(ctx.lib.neo_tp_render(
-            ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
-            self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
-            ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
-        self._after_call(ctx)
+        ov = self._overlap(dev)
+        if ov is not None:
+            side, lane, cur = ov.begin(raw, (rays_o, rays_d, viewdirs))
+        else:
+            side, lane = torch.cuda.current_stream(dev), 0
+        ctx.set_lane(lane)
+        try:
+            with torch.cuda.stream(side):
+                levels, structs = [], []
+                for _ in range(2):
+                    t = dict(rgb=torch.empty(B, 3, device=dev), fg_rgb=torch.empty(B, 3, device=dev),
+                             bg_rgb=torch.empty(B, 3, device=dev), fg_acc=torch.empty(B, device=dev),
+                             bg_lambda=torch.empty(B, 1, device=dev), depth=torch.empty(B, device=dev))
+                    levels.append(t)
+                    structs.append(_lib.TpLevelOut(*(t[k].data_ptr() for k in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth"))))
+                _lib.check(ctx.lib.neo_tp_render(
+                    ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
+                    self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
+                    ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
+                self._after_call(ctx)
+        finally:
+            ctx.set_lane(0)
+            if ov is not None:
+                ov.end(lane, cur, [v for t in levels for v in t.values()] if 'levels' in locals() else [])
         return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]
 
 

@@ -26,6 +26,7 @@ def get_ray_directions_and_rays(H, W, focal, c2w, ctx=None, device="cuda", ray_r
     n = hi - lo
     if out is not None and out[0].shape[0] == n:
         rays_o, viewdirs, rays_d, radii = out
+        _lib.note_external_write()      # same tensor objects, same version counters, new contents
     else:
         rays_o = torch.empty(n, 3, device=dev)
         viewdirs = torch.empty(n, 3, device=dev)

@@ -97,6 +97,17 @@ def _cap(lib, dv):
     return None
 
 
+def _energy_uj(lib, dv):
+    """The socket's energy accumulator in microjoules (rsmi_dev_energy_count_get: counter x resolution), or None."""
+    e, res, ts = ctypes.c_uint64(0), ctypes.c_float(0.0), ctypes.c_uint64(0)
+    try:
+        if lib.rsmi_dev_energy_count_get(dv, ctypes.byref(e), ctypes.byref(res), ctypes.byref(ts)) == 0 and res.value > 0:
+            return e.value * float(res.value)
+    except AttributeError:
+        pass
+    return None
+
+
 class Sampler:
     """with Sampler(device_index) as s: ... timed region ...; s.summary() -> means over the samples taken inside."""
 
@@ -104,6 +115,8 @@ class Sampler:
         self.period = period_s
         self.power, self.sclk = [], []
         self.cap = None
+        self.energy_j = None            # socket energy accumulator over the region (round 6): joules, not power x time
+        self._e0 = self._t0 = self.wall_s = None
         self._stop = threading.Event()
         self._thread = None
         self._lib = _load()
@@ -112,6 +125,7 @@ class Sampler:
     def __enter__(self):
         if self._lib is not None:
             self.cap = _cap(self._lib, self._dv)
+            self._e0, self._t0 = _energy_uj(self._lib, self._dv), time.perf_counter()
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
         return self
@@ -126,6 +140,11 @@ class Sampler:
             self._stop.wait(self.period)
 
     def __exit__(self, *exc):
+        if self._lib is not None and self._e0 is not None:
+            e1 = _energy_uj(self._lib, self._dv)
+            self.wall_s = time.perf_counter() - self._t0
+            if e1 is not None and e1 >= self._e0:
+                self.energy_j = (e1 - self._e0) * 1e-6
         self._stop.set()
         if self._thread is not None:
             self._thread.join(timeout=2.0)
@@ -139,5 +158,7 @@ class Sampler:
         return {"sclk_mhz_mean": mean(self.sclk), "sclk_mhz_min": min(self.sclk) if self.sclk else None,
                 "power_w_mean": mean(self.power), "power_w_max": max(self.power) if self.power else None,
                 "power_limit_w": self.cap, "telemetry_samples": len(self.power),
+                "energy_j": self.energy_j, "energy_window_s": self.wall_s,
+                "power_w_from_energy": (self.energy_j / self.wall_s) if self.energy_j and self.wall_s else None,
                 "telemetry": "librocm_smi64 (rsmi_dev_power_get, rsmi_dev_gpu_clk_freq_get SYS), polled every %d ms from a "
                              "thread of the bench process during the timed steps" % int(self.period * 1e3)}

@@ -1,0 +1,141 @@
+"""GPU: round-6 host-side behaviour of the drop-in modules.
+
+* consecutive evaluation calls of NeRF_TP overlap on the device (context.CallOverlap: two side streams x two scratch lanes of
+  the context) - the reference's own chunk loop, 300 forward calls of 1024 rays (neo360/model.py:861-907) - while the
+  caller's stream semantics stay those of a single-stream call;
+* the advisor's round-5 findings (gather_map geometry check, forward-only callers outside no_grad).
+"""
+import pytest
+import torch
+
+import cases
+from neo360_amd import _lib, models, ops, render, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+PER_RAY = ("rays_o", "rays_d", "viewdirs")
+
+
+def _tp_net(scene, n_coarse=16, n_fine=32, **kw):
+    net = models.NeRF_TP(num_coarse_samples=n_coarse, num_fine_samples=n_fine, num_src_views=cases.NV, **kw).to(DEV)
+    net.load_state_dict(synth.nerf_tp_state(0))
+    net.set_scene(scene["plane_xz"].to(DEV), scene["plane_xy"].to(DEV), scene["plane_yz"].to(DEV), scene["latent"].to(DEV),
+                  scene["image_wh"])
+    return net
+
+
+def _batch(n):
+    return {k: v.to(DEV) for k, v in cases.neo_batch(cases.strided_rays(n)).items()}
+
+
+def _chunk_loop(net, batch, chunk):
+    """The reference's render_rays_test loop, verbatim in shape: slices per-ray keys, passes src_* whole, cats at the end."""
+    n = batch["rays_o"].shape[0]
+    rgb, depth = [], []
+    for i in range(0, n, chunk):
+        part = {k: (v[i:i + chunk] if k in PER_RAY else v) for k, v in batch.items()}
+        res = net(part, False, False, 0.0, 0.0, out_depth=True)
+        rgb.append(res[1][0])
+        depth.append(res[1][5])
+    return torch.cat(rgb), torch.cat(depth)
+
+
+def test_chunk_loop_frame_is_bitwise_the_whole_frame_call():
+    """300-call-style loop (overlapped: lanes + side streams) == ONE library call with the chunk passed down == the same loop
+    with overlap switched off.  Bitwise: the same kernels on the same operands, whatever runs concurrently."""
+    sc = cases.small_scene()
+    net = _tp_net(sc)
+    batch = _batch(2348)                      # 1024 + 1024 + a short 300
+    whole = render.render_rays_test(net, batch, chunk=1024)
+    ctx = net._context(torch.device(DEV))
+    ov = net._overlap(torch.device(DEV))
+    calls0, fresh0 = ov.calls, ov.fresh_forks
+    rgb, depth = _chunk_loop(net, batch, 1024)
+    net.check_flags()
+    assert ov.calls - calls0 == 3
+    assert ov.fresh_forks - fresh0 <= 1, "calls 2 and 3 slice the same ray tensors: they reuse call 1's fork point"
+    assert torch.equal(rgb, whole["rgb"]) and torch.equal(depth, whole["depth"])
+    net.overlap_calls = False
+    rgb2, depth2 = _chunk_loop(net, batch, 1024)
+    net.check_flags()
+    assert torch.equal(rgb2, rgb) and torch.equal(depth2, depth)
+    assert ctx.sync_count() >= 0
+
+
+def test_overlapped_calls_keep_the_callers_stream_semantics():
+    """Outputs are consumed on the caller's stream straight after each call (no synchronisation), inputs are produced on it
+    just before (a fresh tensor per call: every call forks from a fresh event), and freed output blocks are recycled while
+    later calls are still in flight.  Many short calls; every result must equal the one-call-at-a-time result."""
+    sc = cases.small_scene()
+    net = _tp_net(sc)
+    base = _batch(256 * 12)
+    want = []
+    net.overlap_calls = False
+    for i in range(12):
+        part = {k: (v[256 * i:256 * (i + 1)] if k in PER_RAY else v) for k, v in base.items()}
+        want.append(net(part, False, False, 0.0, 0.0, out_depth=True)[1][0].clone())
+    net.check_flags()
+    net.overlap_calls = True
+    ov = net._overlap(torch.device(DEV))
+    fresh0 = ov.fresh_forks
+    acc = []
+    for rep in range(3):
+        for i in range(12):
+            # inputs made on the caller's stream right before the call (copies: new tensor objects every time)
+            part = {k: ((v[256 * i:256 * (i + 1)] * 1.0) if k in PER_RAY else v) for k, v in base.items()}
+            res = net(part, False, False, 0.0, 0.0, out_depth=True)
+            acc.append(res[1][0] * 1.0)          # consumed on the caller's stream, no sync; `res` is freed right here
+            del res, part
+    net.check_flags()
+    torch.cuda.synchronize()
+    assert ov.fresh_forks - fresh0 == 36, "fresh input tensors: no fork point may be reused"
+    for j, got in enumerate(acc):
+        assert torch.equal(got, want[j % 12]), j
+
+
+def test_fork_point_is_not_reused_across_rewritten_rays():
+    """Same tensor objects, new contents: an in-place torch write bumps the version, an `out=` write of this library bumps
+    the library's write epoch - either way the next call takes a fresh fork event (and sees the new rays)."""
+    sc = cases.small_scene()
+    net = _tp_net(sc)
+    b = _batch(512)
+    ov = net._overlap(torch.device(DEV))
+    r1 = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0].clone()
+    f0 = ov.fresh_forks
+    r1b = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0].clone()
+    assert ov.fresh_forks == f0 and torch.equal(r1, r1b)
+    b["viewdirs"].copy_(torch.nn.functional.normalize(b["viewdirs"] + 0.25, dim=-1))     # in place: version + 1
+    r2 = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0].clone()
+    assert ov.fresh_forks == f0 + 1 and not torch.equal(r1, r2)
+    e0 = _lib.write_epoch
+    H = W = 16
+    rays = ops.get_ray_directions_and_rays(H, W, 12.8, synth.look_at_origin(40.0))
+    ops.get_ray_directions_and_rays(H, W, 12.8, synth.look_at_origin(75.0), out=rays)
+    assert _lib.write_epoch == e0 + 1
+    net.check_flags()
+
+
+def test_uploads_stay_ordered_against_both_lanes():
+    """A weight change between two overlapped calls: the upload is an exclusive call of the context (waits for both lanes, and
+    both lanes wait for it) - the call before it sees the old weights, the call after it the new ones."""
+    sc = cases.small_scene()
+    net = _tp_net(sc)
+    b = _batch(1024)
+    net.overlap_calls = False
+    old = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0].clone()
+    st = synth.nerf_tp_state(0)
+    st2 = {k: (v * 1.25 if "rgb_layer.weight" in k else v) for k, v in st.items()}
+    net.load_state_dict(st2)
+    new = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0].clone()
+    net.check_flags()
+    assert not torch.equal(old, new)
+    net.overlap_calls = True
+    for _ in range(4):
+        net.load_state_dict(st)
+        a1 = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0]
+        a2 = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0]
+        net.load_state_dict(st2)
+        c1 = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0]
+        c2 = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0]
+        net.check_flags()
+        assert torch.equal(a1, old) and torch.equal(a2, old) and torch.equal(c1, new) and torch.equal(c2, new)

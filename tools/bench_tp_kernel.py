@@ -64,10 +64,11 @@ for SLOT in SLOTS:
     ts = tel.summary()
     pe = 63 if SLOT < 2 else 84
     macs = NV * ((pe + 640) * 128 + 2 * 128 * 128 + (pe + 640 + 128) * 128 + 128 * 128 + 155 * 64) + 128 + 64 * 64 + 64 * 3
-    print("%s %s pp=%s slot %d R=%d N=%d  %.3f ms  %.1f algorithmic TFLOP/s  checksum %.6f  sclk %s MHz  power %s W (%s samples)" % (
+    print("%s %s pp=%s slot %d R=%d N=%d  %.3f ms  %.1f algorithmic TFLOP/s  checksum %.6f  sclk %s MHz  power %s W (%s samples)  energy/launch %s J (accumulator)  %s J (power x time)" % (
         os.environ.get("TAG", ""), PREC, int(net.preproject), SLOT, R, N, dt * 1e3, R * N * macs * 2 / dt / 1e12, float(out.double().sum()),
         ("%.0f" % ts["sclk_mhz_mean"]) if ts.get("sclk_mhz_mean") else "?", ("%.0f" % ts["power_w_mean"]) if ts.get("power_w_mean") else "?",
-        ts.get("telemetry_samples", 0)), flush=True)
+        ts.get("telemetry_samples", 0), ("%.3f" % (ts["energy_j"] / REPS)) if ts.get("energy_j") else "?",
+        ("%.3f" % (ts["power_w_mean"] * dt)) if ts.get("power_w_mean") else "?"), flush=True)
 if os.environ.get("TRACE"):
     # variant built with -DNEO_TP_TRACE=1: per-phase s_memtime sums of wave 0 of every workgroup (k_tp_mlp_hp; TRACE=hpp: k_tp_mlp_hpp)
     import ctypes
