@@ -367,6 +367,7 @@ class Runner:
         kern = self.ctx.read_timing()
         self.spans = self.ctx.read_spans()          # every evaluator launch of the timed steps: (ms, kernel, points, flops)
         self.ctx.set_timing(False)
+        self.local_dt = dt
         if self.dist is not None:
             tmax = torch.tensor([dt], device=self.dev, dtype=torch.float64)
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
@@ -636,11 +637,67 @@ class FakeRunner:
         if self.dist is not None:
             self.dist.barrier()
         dt = time.perf_counter() - t0
+        self.local_dt = dt
         if self.dist is not None:
             tmax = torch.tensor([dt], dtype=torch.float64)
             self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
             dt = float(tmax.item())
         return dt, None, frame
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa_node(local_rank, fake=False):
+    """One process per GPU: pin this rank's host threads to the CPUs of the NUMA node its GPU hangs off (the launch thread and the
+    telemetry thread then stay next to the device's PCIe root).  Best effort: returns what was done, never fails the run."""
+    info = {"numa_node": None, "cpus_bound": None}
+    try:
+        if fake:
+            bdf = os.environ.get("NEO360_FAKE_BDF")            # tests: any PCI device of the box, or nothing
+        else:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        info["pci"] = bdf
+        if not bdf:
+            return info
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        info["numa_node"] = node
+        if node < 0:
+            return info
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            cpus = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info["cpus_bound"] = len(cpus)
+    except Exception as e:                                       # no sysfs entry, container without NUMA: say so
+        info["numa_note"] = "%s: %s" % (type(e).__name__, e)
+    return info
+
+
+def rank_records(dist, world, rank, local_rank, dev, ms_local, numa):
+    """What every rank saw, gathered to all: answers 'did the collective really span N ranks / N distinct GPUs' from the line."""
+    if dev is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        device = {"name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None), "torch_index": dev.index}
+    else:
+        device = {"name": "cpu (fake renderer)", "pci_bus_id": None, "torch_index": None}
+    rec = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "ms_per_step": ms_local,
+           "world_size_seen": dist.get_world_size() if dist is not None else 1,
+           "backend": dist.get_backend() if dist is not None else None, **device, **(numa or {})}
+    if dist is None:
+        return [rec]
+    out = [None] * world
+    dist.all_gather_object(out, rec)
+    return out
 
 
 def self_spawn(n, argv):
@@ -697,6 +754,9 @@ def main():
 
     # one process per GPU.  Under torch.distributed.run the ranks exist already (RANK set); a plain `python bench.py --gpus N`
     # with N > 1 starts them itself - the driver's N = 1 command line with another N must not die on an assertion
+    if not args.fake and args.gpus > max(torch.cuda.device_count(), 0):
+        sys.exit("bench.py: --gpus %d but this node shows %d GPU%s (torch.cuda.device_count()); nothing was launched"
+                 % (args.gpus, torch.cuda.device_count(), "" if torch.cuda.device_count() == 1 else "s"))
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_spawn(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
@@ -711,19 +771,23 @@ def main():
         if world > 1 or "RANK" in os.environ:
             import torch.distributed as dist
             dist.init_process_group("gloo")
+        numa = bind_to_gpu_numa_node(local_rank, fake=True)
         run = FakeRunner(world, rank, dist)
         dt, _, frame = run.timed(args.steps, args.warmup)
+        ranks = rank_records(dist, world, rank, local_rank, None, run.local_dt / args.steps * 1e3, numa)
         if rank == 0:
             ok = bool(torch.equal(frame[:, 0], torch.arange(run.R, dtype=torch.float32))) if dist is not None else True
             print(json.dumps({"metric": "plumbing test (no measurement)", "fake": True, "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "frame_rows": int(frame.shape[0]), "frame_in_order": ok,
                               "rank_column": sorted(set(frame[:, 4].tolist())) if dist is not None else [0.0],
-                              "self_spawned": bool(os.environ.get("NEO360_BENCH_SELF_SPAWNED")), "value": run.R * args.steps / dt}))
+                              "self_spawned": bool(os.environ.get("NEO360_BENCH_SELF_SPAWNED")), "value": run.R * args.steps / dt,
+                              "ranks": ranks}))
         if dist is not None:
             dist.destroy_process_group()
         return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    numa = bind_to_gpu_numa_node(local_rank)
     if args.workload == "neo360_train":
         if world != 1:
             sys.exit("bench.py: --workload neo360_train is a single-GPU line")
@@ -742,6 +806,7 @@ def main():
     run = Runner(args.workload, args.precision, dev, world, rank, dist, setup_timing=bool(args.setup_timing))
     dt, kern, frame = run.timed(args.steps, args.warmup)
     R = run.R
+    ranks = rank_records(dist, world, rank, local_rank, dev, run.local_dt / args.steps * 1e3, numa)
 
     if rank == 0:
         out = {
@@ -755,6 +820,9 @@ def main():
                                                "(rgb,depth,acc) tiles" if world > 1 else ""),
                        "rays_per_frame": R, "parallelism": "ray-shard x%d" % world},
             "roofline": run.roofline(kern),
+            # one record per rank, gathered over the process group: the world size each rank saw, its GPU (name, PCI bus), the NUMA
+            # node its host threads were bound to and its OWN time per step (`ms_per_step` above is the max over ranks)
+            "ranks": ranks,
         }
         if args.workload == "neo360" and world == 1 and args.chunk_loop:
             # what a run.py user gets without touching the reference's chunk loop (VERDICT r5 task 4)

@@ -345,13 +345,15 @@ int neo_tp_activate_backward(neo_ctx* ctx, const float* raw_rgb, const float* ra
  * forms G = latent . [W0_loc | W3_loc]^T per TEXEL (a plain (texels, 512) x (512, 256) GEMM under autograd), gathers 256 instead of
  * 512 channels and hands them to the MLP as `pre` (NV*P, 256) = the local features' contribution to the pre-activations of layer 0
  * and of the skip half of layer 3.  neo_tp_gather_map / _backward: the lookup (and its scatter-add backward) in a CALLER-OWNED
- * channels-last map (NV Hf Wf, C), C % 64 == 0, at get_local_feats' taps of the scene geometry set with neo_tp_set_scene.
+ * channels-last map (NV Hf Wf, C), C % 64 == 0, at get_local_feats' taps of the scene geometry set with neo_tp_set_scene;
+ * `texels` = rows of the caller's map (and of g_map): it MUST equal NV Hf Wf of the uploaded geometry, anything else is rejected
+ * (the kernels index the map from the context's geometry - a map of another resolution would be read and scattered out of bounds).
  * neo_tp_mlp_train_forward_pre / _backward_pre: as neo_tp_mlp_train_forward / _backward with `pre` in place of the local feature
  * rows; the backward returns g_pre (NV*P, 256) = [dL/dz0 | dL/dz3] and leaves the local columns of gw[0] / gw[3] untouched (their
  * gradient is formed in texel space by the caller's GEMM). */
-int neo_tp_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+int neo_tp_gather_map(neo_ctx* ctx, const float* map, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
                       float cx, float cy, float* out, void* stream);
-int neo_tp_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+int neo_tp_gather_map_backward(neo_ctx* ctx, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
                                float cy, const float* g_out, float* g_map, void* stream);
 int neo_tp_mlp_train_forward_pre(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x_enc,
                                  const float* pre, const float* world_feat, const float* cond, int NV, long P, float* tape,
@@ -370,9 +372,9 @@ int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float
 int neo_linear_input_grad(neo_ctx* ctx, long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw,
                           int accumulate, float* gx, long ldx, void* stream);
 /* neo_tp_gather_map / _backward at the PixelNeRF decoder's taps (scene geometry of neo_pix_set_scene). */
-int neo_pix_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+int neo_pix_gather_map(neo_ctx* ctx, const float* map, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
                        float cx, float cy, float* out, void* stream);
-int neo_pix_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+int neo_pix_gather_map_backward(neo_ctx* ctx, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
                                 float cy, const float* g_out, float* g_map, void* stream);
 
 /* Weight (and bias) gradient of a linear layer y = x W^T + b over K rows - what autograd forms for every nn.Linear of the

@@ -72,10 +72,10 @@ SIGNATURES = {
     "neo_tp_train_points": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, c_float_p, _i, _vp, _vp, _vp]),
     "neo_tp_activate": (_i, [_vp, _vp, _vp, _vp, _f, ctypes.c_long, _vp, _vp]),
     "neo_tp_activate_backward": (_i, [_vp, _vp, _vp, _vp, _f, ctypes.c_long, _vp, _vp, _vp, _vp]),
-    "neo_tp_gather_map": (_i, [_vp, _vp, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
-    "neo_tp_gather_map_backward": (_i, [_vp, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
-    "neo_pix_gather_map": (_i, [_vp, _vp, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
-    "neo_pix_gather_map_backward": (_i, [_vp, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "neo_tp_gather_map": (_i, [_vp, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
+    "neo_tp_gather_map_backward": (_i, [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "neo_pix_gather_map": (_i, [_vp, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
+    "neo_pix_gather_map_backward": (_i, [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
     "neo_tp_mlp_train_forward_pre": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp,
                                           _vp, _vp]),
     "neo_tp_mlp_train_backward_pre": (_i, [_vp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp,

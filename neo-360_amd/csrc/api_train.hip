@@ -167,7 +167,7 @@ int neo_tp_gather_backward(neo_ctx* ctx, const float* pts, long P, const float* 
     return check_launch();
 }
 
-int neo_tp_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+int neo_tp_gather_map(neo_ctx* ctx, const float* map, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
                       float cx, float cy, float* out, void* stream) {
     ENTER(ctx);
     REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
@@ -175,6 +175,8 @@ int neo_tp_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, l
     REQUIRE(map && pts && src_poses && out, "null pointer");
     if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_tp_set_scene)");
     REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    REQUIRE(texels == static_cast<long>(ctx->scene.nv) * ctx->scene.Hf * ctx->scene.Wf,
+            "map rows differ from NV*Hf*Wf of the uploaded scene geometry (stale scene, or a map of another resolution)");
     neo::TpViews views{};
     fill_views(src_poses, NV, views);
     neo::TpScene sc = ctx->scene;
@@ -183,7 +185,7 @@ int neo_tp_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, l
     return check_launch();
 }
 
-int neo_tp_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+int neo_tp_gather_map_backward(neo_ctx* ctx, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
                                float cy, const float* g_out, float* g_map, void* stream) {
     ENTER(ctx);
     REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
@@ -191,6 +193,8 @@ int neo_tp_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, co
     REQUIRE(pts && src_poses && g_out && g_map, "null pointer");
     if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_tp_set_scene)");
     REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    REQUIRE(texels == static_cast<long>(ctx->scene.nv) * ctx->scene.Hf * ctx->scene.Wf,
+            "map rows differ from NV*Hf*Wf of the uploaded scene geometry (stale scene, or a map of another resolution)");
     neo::TpViews views{};
     fill_views(src_poses, NV, views);
     neo::TpScene sc = ctx->scene;
@@ -200,7 +204,7 @@ int neo_tp_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, co
 }
 
 // the same lookup at the PixelNeRF decoder's taps (geometry of neo_pix_set_scene: (f, f) projection, model_pixel.py:198-206)
-int neo_pix_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
+int neo_pix_gather_map(neo_ctx* ctx, const float* map, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
                       float cx, float cy, float* out, void* stream) {
     ENTER(ctx);
     REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
@@ -208,6 +212,8 @@ int neo_pix_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, 
     REQUIRE(map && pts && src_poses && out, "null pointer");
     if (!ctx->pix_scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_pix_set_scene)");
     REQUIRE(NV == ctx->pix_scene.nv, "NV differs from the uploaded scene");
+    REQUIRE(texels == static_cast<long>(ctx->pix_scene.nv) * ctx->pix_scene.Hf * ctx->pix_scene.Wf,
+            "map rows differ from NV*Hf*Wf of the uploaded scene geometry (stale scene, or a map of another resolution)");
     neo::TpViews views{};
     fill_views(src_poses, NV, views);
     neo::TpScene sc = ctx->pix_scene;
@@ -216,7 +222,7 @@ int neo_pix_gather_map(neo_ctx* ctx, const float* map, int C, const float* pts, 
     return check_launch();
 }
 
-int neo_pix_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
+int neo_pix_gather_map_backward(neo_ctx* ctx, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
                                float cy, const float* g_out, float* g_map, void* stream) {
     ENTER(ctx);
     REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0, "bad shape (C a multiple of 64, <= 1024)");
@@ -224,6 +230,8 @@ int neo_pix_gather_map_backward(neo_ctx* ctx, int C, const float* pts, long P, c
     REQUIRE(pts && src_poses && g_out && g_map, "null pointer");
     if (!ctx->pix_scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_pix_set_scene)");
     REQUIRE(NV == ctx->pix_scene.nv, "NV differs from the uploaded scene");
+    REQUIRE(texels == static_cast<long>(ctx->pix_scene.nv) * ctx->pix_scene.Hf * ctx->pix_scene.Wf,
+            "map rows differ from NV*Hf*Wf of the uploaded scene geometry (stale scene, or a map of another resolution)");
     neo::TpViews views{};
     fill_views(src_poses, NV, views);
     neo::TpScene sc = ctx->pix_scene;

@@ -220,13 +220,29 @@ class _HipModule(nn.Module):
         kernels for as long as this key stays the same."""
         return (tuple((p.data_ptr(), p._version) for p in self.parameters()), getattr(self, "_scene_serial", 0))
 
-    def _wants_grad(self):
+    def _wants_grad(self, randomized=True):
+        """randomized: the call's own flag.  An AUTOMATIC switch to the operator chain on a deterministic call (the shape of a
+        forward-only caller that merely forgot torch.no_grad(): nn.Module parameters default to requires_grad=True) is announced
+        once per module - such a caller wants `module.differentiable = False` or no_grad; a training loop that
+        really differentiates a deterministic call sets `module.differentiable = True` and never sees the message."""
         if self.differentiable is not None:
             return bool(self.differentiable)
         if not torch.is_grad_enabled():
             return False
-        return (any(p.requires_grad for p in self.parameters())
+        auto = (any(p.requires_grad for p in self.parameters())
                 or any(t is not None and t.requires_grad for t in self._scene_tensors_for_grad()))
+        if auto and not randomized and not getattr(self, "_warned_auto_chain", False):
+            self._warned_auto_chain = True
+            warnings.warn("%s: autograd is on and a parameter / scene tensor requires grad, so this deterministic forward runs on "
+                          "the differentiable operator chain (activation tapes, one synchronisation per call) instead of the fused "
+                          "kernels.  Forward-only callers: wrap the call in torch.no_grad() or set module.differentiable = False; "
+                          "training code: set module.differentiable = True to silence this." % type(self).__name__,
+                          RuntimeWarning, stacklevel=3)
+        return auto
+
+    def _auto_chain(self):
+        """True when the operator chain would be taken by the automatic rule only (nobody asked for it explicitly)."""
+        return self.differentiable is None
 
 
 class NeRF(_HipModule):
@@ -261,7 +277,7 @@ class NeRF(_HipModule):
         vanilla_nerf/model.py:281-283) runs on the differentiable operators of training.py (nerf_render_train: NeRFMLP
         with a native backward, samplers on the counter-based generator, compositing with a native backward);
         the deterministic no-grad call is ONE fused library call."""
-        if randomized or self._wants_grad():
+        if randomized or self._wants_grad(randomized):
             from . import training
             return training.nerf_render_train(self, rays, randomized, white_bkgd, near, far, seed)
         with torch.no_grad():
@@ -577,9 +593,18 @@ class NeRF_TP(_HipModule):
         compositing) instead of the fused no-grad kernels; same return tuple, same samples for one seed at any `chunk`."""
         if not out_depth:
             # density_noise (model.py:381-384) exists on the operator chain only: a randomized call with it takes that path
-            if self._wants_grad() or (randomized and self.density_noise != 0.0):
+            if self._wants_grad(randomized) or (randomized and self.density_noise != 0.0):
                 from . import training
-                return training.tp_render_train(self, rays, randomized, white_bkgd, self._maps_for_grad(rays), chunk, seed)
+                maps = None
+                try:
+                    maps = self._maps_for_grad(rays)
+                except _lib.NeoError:
+                    # the scene tensors are gone (weak references): only an EXPLICIT request for gradients makes that an error; a
+                    # deterministic call that got here by the automatic rule falls back to the fused kernels (ADVICE r5)
+                    if randomized or not self._auto_chain():
+                        raise
+                if maps is not None:
+                    return training.tp_render_train(self, rays, randomized, white_bkgd, maps, chunk, seed)
             with torch.no_grad():
                 return self._forward_train(rays, randomized, white_bkgd, chunk, seed)
         with torch.no_grad():
@@ -795,11 +820,24 @@ class PixelNeRF(_HipModule):
         """randomized=True (stratified sampling, `noise_std`) or a call that wants gradients (`_wants_grad()`: the reference's
         training_step) runs on the operator chain of training.pix_render_train - every matrix product on the library's GEMMs,
         gradients to all 18 parameter tensors of each MLP and to the latent; otherwise the fused no-grad kernels."""
-        if randomized or self._wants_grad():
+        if randomized or self._wants_grad(randomized):
             from . import training
-            if chunk is not None and chunk < rays["rays_o"].shape[0]:
+            # A deterministic call that reached the chain by the AUTOMATIC rule alone keeps working where only the fused path can
+            # serve it (a chunked frame; a set_scene latent the caller no longer holds): these calls worked before round 5 made
+            # the chain the automatic choice (ADVICE r5) - they fall back to the fused kernels instead of raising.
+            fallback = not randomized and self._auto_chain()
+            chunked = chunk is not None and chunk < rays["rays_o"].shape[0]
+            if chunked and not fallback:
                 raise NotImplementedError("the training call renders its rays as ONE reference chunk")
-            return training.pix_render_train(self, rays, randomized, white_bkgd, near, far, self._latent_for_grad(rays), seed)
+            latent = None
+            if not chunked:
+                try:
+                    latent = self._latent_for_grad(rays)
+                except _lib.NeoError:
+                    if not fallback:
+                        raise
+            if latent is not None:
+                return training.pix_render_train(self, rays, randomized, white_bkgd, near, far, latent, seed)
         with torch.no_grad():
             return self._forward_fused(rays, white_bkgd, near, far, chunk)
 
@@ -913,7 +951,7 @@ class MipNeRF360(_HipModule):
         encodings and compositing native, every matrix product on the library's GEMMs, gradients to all parameters through the
         colours and the interval weights; otherwise the fused no-grad kernels.  `is_train` only selects how the reference
         evaluates the contraction's Jacobian (helper.py:45-66); both of its forms are the closed form used here."""
-        if randomized or self._wants_grad():
+        if randomized or self._wants_grad(randomized):
             from . import training
             return training.mip_render_train(self, batch, train_frac, randomized, near, far, seed)
         with torch.no_grad():

@@ -267,7 +267,9 @@ class _MapGather(torch.autograd.Function):
         P, C = pts.shape[0], gmap.shape[1]
         out = torch.empty(NV * P, C, device=pts.device)
         fn = c.lib.neo_pix_gather_map if kind == "pix" else c.lib.neo_tp_gather_map
-        _lib.check(fn(c.handle, ptr(gmap), C, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
+        # the row count travels with the pointer: the library rejects a map that is not NV*Hf*Wf rows of the geometry uploaded in
+        # this module's context (it used to be indexed - and, in the backward, scattered into - unchecked)
+        _lib.check(fn(c.handle, ptr(gmap), gmap.shape[0], C, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
         ctx_.save_for_backward(pts)
         ctx_.meta = (c, host_poses, NV, focal, cx, cy, tuple(gmap.shape), kind)
         return out
@@ -280,7 +282,7 @@ class _MapGather(torch.autograd.Function):
         g_map = torch.zeros(mshape, device=pts.device)
         g = f32(g_out.contiguous(), "g_out")
         fn = c.lib.neo_pix_gather_map_backward if kind == "pix" else c.lib.neo_tp_gather_map_backward
-        _lib.check(fn(c.handle, mshape[1], ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy, ptr(g), ptr(g_map), c.stream()))
+        _lib.check(fn(c.handle, mshape[0], mshape[1], ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy, ptr(g), ptr(g_map), c.stream()))
         return None, g_map, None, None, None
 
 
@@ -305,6 +307,11 @@ class _TrainMLPPre(torch.autograd.Function):
         for name, t, width in (("cond_rows", cond_rows, 27), ("world_feat", world_feat, 128), ("pre", pre, 256)):
             if tuple(t.shape) != (nv * npts, width):
                 raise ValueError("%s must be (NV*P, %d) = (%d, %d), got %s" % (name, width, nv * npts, width, tuple(t.shape)))
+        want = [(128, pe + 640), (128, 128), (128, 128), (128, 128 + pe + 640), (64, 155), (64, 64), (128, 128), (1, 128), (3, 64)]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if tuple(w.shape) != want[i] or tuple(b.shape) != (want[i][0],):
+                raise ValueError("layer %d: weight %s / bias %s, expected %s / (%d,)"
+                                 % (i, tuple(w.shape), tuple(b.shape), want[i], want[i][0]))
         xe = f32(x_enc, "x_enc").reshape(-1, pe)
         pf, wf, cond = f32(pre, "pre"), f32(world_feat, "world_feat"), f32(cond_rows, "cond_rows")
         c = _ctx(xe, lib_ctx)

@@ -139,3 +139,47 @@ def test_uploads_stay_ordered_against_both_lanes():
         c2 = net(b, False, False, 0.0, 0.0, out_depth=True)[1][0]
         net.check_flags()
         assert torch.equal(a1, old) and torch.equal(a2, old) and torch.equal(c1, new) and torch.equal(c2, new)
+
+
+# ---- advisor, round 5 ---------------------------------------------------------------------------------------------------------
+def test_gather_map_rejects_a_map_of_another_geometry():
+    """training.gather_map indexes the caller's map from the geometry uploaded in the module's context: a map with another row
+    count (stale scene, another resolution) used to be read - and scattered into - out of bounds; now the library refuses it."""
+    from neo360_amd import training
+    sc = cases.small_scene()
+    net = _tp_net(sc)
+    b = _batch(64)
+    nv, _, hf, wf = sc["latent"].shape
+    pts = (torch.rand(200, 3, device=DEV) - 0.5)
+    good = torch.randn(nv * hf * wf, 64, device=DEV, requires_grad=True)
+    out = training.gather_map(net, good, pts, b)
+    out.sum().backward()
+    assert good.grad is not None and good.grad.shape == good.shape
+    for rows in (nv * hf * wf - wf, nv * hf * wf + 1, nv * (hf // 2) * (wf // 2)):
+        bad = torch.randn(rows, 64, device=DEV)
+        with pytest.raises(_lib.NeoError, match="map rows differ"):
+            training.gather_map(net, bad, pts, b)
+
+
+def test_forward_only_caller_outside_no_grad_is_told_once_and_chunked_pixelnerf_still_works():
+    """parameters default to requires_grad=True, so a deterministic forward outside no_grad lands on the operator
+    chain by the automatic rule.  It says so once per module; and where only the fused path can serve the call (PixelNeRF with
+    `chunk`, a set_scene latent the caller dropped) the automatic rule falls back to it instead of raising."""
+    import warnings
+    sc = cases.small_scene()
+    pix = models.PixelNeRF(num_src_views=cases.NV).to(DEV)
+    pix.load_state_dict(synth.pixelnerf_state(0))
+    pix.set_scene(sc["latent"].to(DEV), sc["image_wh"])          # the caller keeps no reference: the module's is weak
+    b = _batch(96)
+    with torch.no_grad():
+        want = pix(b, False, False, 0.2, 3.0, chunk=32)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        got = pix(b, False, False, 0.2, 3.0, chunk=32)            # grad mode on, deterministic, chunked: fused fallback
+        got2 = pix(b, False, False, 0.2, 3.0)                     # latent tensor is gone: fused fallback as well
+    assert torch.equal(got[1][0], want[1][0])
+    assert got2[1][0].shape == want[1][0].shape and not got2[1][0].requires_grad
+    assert sum("differentiable operator chain" in str(w.message) for w in seen) == 1
+    pix.differentiable = True                                      # an explicit request keeps the strict behaviour
+    with pytest.raises(NotImplementedError):
+        pix(b, False, False, 0.2, 3.0, chunk=32)
