@@ -364,6 +364,7 @@ class Runner:
             self.fence()
             dt = time.perf_counter() - t0
         self.telemetry = tel.summary()
+        self.timed_steps = steps
         kern = self.ctx.read_timing()
         self.spans = self.ctx.read_spans()          # every evaluator launch of the timed steps: (ms, kernel, points, flops)
         self.ctx.set_timing(False)
@@ -476,7 +477,11 @@ class Runner:
                 "kernels": per}
         tel = getattr(self, "telemetry", None) or {}
         roof.update({k: tel.get(k) for k in ("sclk_mhz_mean", "sclk_mhz_min", "power_w_mean", "power_w_max", "power_limit_w",
-                                             "telemetry_samples", "telemetry")})
+                                             "telemetry_samples", "telemetry", "energy_j", "energy_window_s", "power_w_from_energy")})
+        if tel.get("energy_j") and getattr(self, "timed_steps", 0):
+            # the socket's energy ACCUMULATOR over the timed steps (rsmi_dev_energy_count_get), not power samples x time: joules
+            # per frame are what a power-limited part prices a kernel change in (profiles/r06_energy_budget.log)
+            roof["energy_j_per_step"] = tel["energy_j"] / self.timed_steps
         if tel.get("sclk_mhz_mean"):
             # the peak is quoted at the 2.4 GHz boost clock; at the clock this run sustained the same pipe peaks lower
             roof["peak_at_measured_clock"] = peak * tel["sclk_mhz_mean"] / PEAK_CLOCK_MHZ

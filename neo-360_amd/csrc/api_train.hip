@@ -402,7 +402,9 @@ int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const
 int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float* x, long ldx, const float* w, long ldw,
                        const float* bias, int relu, int accumulate, float* y, long ldy, void* stream) {
     ENTER(ctx);
-    REQUIRE(rows >= 0 && rows <= 2000000000L && out_f >= 1 && out_f <= 4096 && in_f >= 1 && in_f <= 4096, "bad shape (features <= 4096)");
+    // the GEMM's grid.y is rows / 128 and HIP caps it at 65,535 (a larger call used to fail with a generic launch error)
+    REQUIRE(rows >= 0 && rows <= 65535L * 128 && out_f >= 1 && out_f <= 4096 && in_f >= 1 && in_f <= 4096,
+            "bad shape (rows <= 8,388,480 per call: split larger matrices by rows; features <= 4096)");
     REQUIRE(ldx >= in_f && ldw >= in_f && ldy >= out_f, "row pitch smaller than the row");
     if (rows == 0) return NEO_OK;
     REQUIRE(x && w && y, "null pointer");
@@ -413,7 +415,8 @@ int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float
 int neo_linear_input_grad(neo_ctx* ctx, long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw,
                           int accumulate, float* gx, long ldx, void* stream) {
     ENTER(ctx);
-    REQUIRE(rows >= 0 && rows <= 2000000000L && out_f >= 1 && out_f <= 4096 && in_f >= 1 && in_f <= 4096, "bad shape (features <= 4096)");
+    REQUIRE(rows >= 0 && rows <= 65535L * 128 && out_f >= 1 && out_f <= 4096 && in_f >= 1 && in_f <= 4096,
+            "bad shape (rows <= 8,388,480 per call: split larger matrices by rows; features <= 4096)");
     REQUIRE(ldy >= out_f && ldw >= in_f && ldx >= in_f, "row pitch smaller than the row");
     if (rows == 0) return NEO_OK;
     REQUIRE(gy && w && gx, "null pointer");

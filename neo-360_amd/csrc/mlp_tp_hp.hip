@@ -62,13 +62,22 @@
 #ifndef NEO_TP_BIAS2
 #define NEO_TP_BIAS2 0        // 1 (round 5): the second M-tile's accumulators are initialised by a second LDS read of the biases instead of 16 register copies
 #endif
+#ifndef NEO_TP_PLCACHE
+// Round 6 (VERDICT r5 task 1b; profiles/r06_energy_budget.log: 48 J of a launch's 222 J are the distinct cache lines the tap loads
+// present to the texture-address unit and the L2 -> L1 traffic behind them, 2/3 of that in the tri-planes).  1: the tri-plane taps
+// of a wave's 16 CONSECUTIVE samples are deduplicated per (view, plane) - samples along a ray walk through the bilinear cells of a
+// plane, a tile-view's 256 taps per plane touch ~35 distinct texels inside the sphere - each unique texel's 256-B half is fetched
+// ONCE into a wave-private LDS cache (16 slots, 4 KB) and the blends read their taps from there (ds_read_b128 instead of
+// global_load_dwordx4): 24 load instructions per wave and view instead of 96, ~2.5 x fewer cache lines.  0: every tap from L1 / L2.
+#define NEO_TP_PLCACHE 1
+#endif
 #ifndef NEO_TP_ABLATE
 // timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
 // tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
 // 64 no barriers inside the view loop, 128 no layer-epilogue stores; round 6 (energy budget of the gather half): 256 every tap
 // reads texel 0 of its map (the loads stay, all L1 hits, one 256-B run per instruction: what is left is the instruction / L1
 // path, what went is the L2 -> L1 traffic and the divergent-address cost), 512 the loads are replaced by undefined registers
-// (blends, LDS transposition and adds stay)
+// (blends, LDS transposition and adds stay); 1024 / 2048: as 256 for the tri-plane / the latent taps alone
 #define NEO_TP_ABLATE 0
 #endif
 #ifndef NEO_TP_TIMELINE
@@ -99,6 +108,12 @@ namespace {
 
 using namespace hp;
 constexpr int RING = NEO_TP_RING;
+// wave-private tri-plane tap cache (NEO_TP_PLCACHE): 16 texel slots x 256 B, the unique-texel lists of the wave's 16 rows per
+// (plane, row segment) - stored so that lane group g reads its four slots 4 it + g as ONE 16-byte word - and the slot counts
+constexpr int PLC_SLOTS = 16;
+constexpr int PLC_T_WORDS = PLC_SLOTS * 64;
+constexpr int PLC_LIST_WORDS = 3 * 4 * PLC_SLOTS;
+constexpr int PLC_WAVE_WORDS = PLC_T_WORDS + PLC_LIST_WORDS + 16;
 
 template <int PE_C>
 __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, const float* __restrict__ proj, TpScene sc,
@@ -216,6 +231,74 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         const unsigned long long zm[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 #endif
 
+#if NEO_TP_PLCACHE
+        // ---- tri-plane tap dedup of this wave's 16 rows (see the cached pipeline below).  Lane = (row r = lane >> 2 of the wave's
+        //      16, tap k = lane & 3).  A tap is NEW unless the same texel is a tap of the previous row of its segment or a lower tap
+        //      of its own row (zero-weight placeholders share one texel); every tap follows those links to its first occurrence
+        //      (4 pointer doublings: a chain is at most 15 rows long), first occurrences are numbered in lane order per segment.
+        //      Consecutive samples walk through neighbouring bilinear cells, so a texel that leaves the taps does not come back:
+        //      the links find every duplicate (tools/gather_linework_study.py: chain count == unique count on the bench geometry);
+        //      a miss would only cost a second slot.  Segment = 16 rows; where those hold more than 16 distinct texels (coarse
+        //      samples, grazing views) the rows are split into 2 x 8 or 4 x 4 with their own numbering (4 rows have 16 taps).
+        //      Result: pl_off[row][k] <- byte offset of the tap's slot in the wave's cache; ulist[plane][segment][slot] <- the
+        //      texel's byte offset in the plane (unused slots: the row-0 tap, a valid address); plc_glog: 2 bits per plane.
+        int plc_glog = 0;
+        {
+            float* plc = smem + tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0) + L.wv * PLC_WAVE_WORDS;
+            uint32_t* ulist = reinterpret_cast<uint32_t*>(plc + PLC_T_WORDS);
+            const int lane = L.lane, r = lane >> 2, k = lane & 3, quad = lane & ~3;
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                int* my = pl_off + (j * TM + 16 * L.wv + r) * 4 + k;
+                const uint32_t off = (uint32_t)*my;
+                // candidate links: lowest equal tap of the own row; lowest equal tap of the previous row (preferred)
+                int own = lane, prv = -1;
+                const uint32_t up = (uint32_t)__shfl_up((int)off, 4);               // tap k of row r - 1
+#pragma unroll
+                for (int kk = 3; kk >= 0; --kk) {
+                    const uint32_t o = (uint32_t)__shfl((int)off, quad + kk);
+                    const uint32_t pr = (uint32_t)__shfl((int)up, quad + kk);
+                    if (kk < k && o == off) own = quad + kk;
+                    if (pr == off) prv = quad - 4 + kk;
+                }
+                int glog = 2;                                                      // 16-row segment first
+                unsigned long long mask;
+                int root;
+                while (true) {
+                    const bool first_row = (r & ((4 << glog) - 1)) == 0;
+                    root = (prv >= 0 && !first_row) ? prv : own;
+#pragma unroll
+                    for (int it = 0; it < 5; ++it) root = __shfl(root, root);
+                    mask = __ballot(root == lane);
+                    // distinct texels per segment: 64 >> (2 - glog) lanes each
+                    const int seg_lanes = 16 << glog;
+                    int worst = 0;
+                    for (int sgm = 0; sgm < (4 >> glog); ++sgm) {
+                        const unsigned long long sm = (seg_lanes == 64 ? ~0ull : ((1ull << seg_lanes) - 1ull) << (sgm * seg_lanes));
+                        worst = max(worst, (int)__popcll(mask & sm));
+                    }
+                    if (worst <= PLC_SLOTS || glog == 0) break;
+                    --glog;
+                }
+                const int seg_lanes = 16 << glog;
+                const int rseg = root / seg_lanes;
+                const unsigned long long sm = seg_lanes == 64 ? ~0ull : ((1ull << seg_lanes) - 1ull) << (rseg * seg_lanes);
+                const unsigned long long rbelow = (1ull << root) - 1ull;
+                const int slot = (int)__popcll(mask & sm & rbelow);
+                (void)below;
+                // unused slots first (any valid address: this lane group's row-0 tap), then the first occurrences; LDS is in order
+                {
+                    const uint32_t filler = (uint32_t)__shfl((int)off, 0);
+                    ulist[j * 4 * PLC_SLOTS + lane] = filler;
+                }
+                if (root == lane) ulist[(j * 4 + rseg) * PLC_SLOTS + (slot & 3) * 4 + (slot >> 2)] = off;
+                *my = slot * 256;
+                plc_glog |= glog << (2 * j);
+            }
+            plc_glog = __builtin_amdgcn_readfirstlane(plc_glog);
+        }
+#endif
         // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
         f32x16 accx[2][2];
         bias_tile(accx[0][0], lbias + B_0, L.wv, L);
@@ -271,7 +354,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     const int row = rg + 16 * q;
                     int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
 #endif
-                    if constexpr ((NEO_TP_ABLATE & 256) != 0) off = int4{0, 0, 0, 0};
+                    if constexpr ((NEO_TP_ABLATE & (256 | 2048)) != 0) off = int4{0, 0, 0, 0};
                     if constexpr ((NEO_TP_ABLATE & 512) != 0) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) asm volatile("" : "=v"(taps[i % RING][t]));
@@ -290,7 +373,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     const int row = rg + 16 * q;
                     int4 off = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
 #endif
-                    if constexpr ((NEO_TP_ABLATE & 256) != 0) off = int4{0, 0, 0, 0};
+                    if constexpr ((NEO_TP_ABLATE & (256 | 1024)) != 0) off = int4{0, 0, 0, 0};
                     if constexpr ((NEO_TP_ABLATE & 512) != 0) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) asm volatile("" : "=v"(taps[i % RING][t]));
@@ -490,6 +573,76 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 #ifndef NEO_TP_PLANE_MMA_INSIDE
 #define NEO_TP_PLANE_MMA_INSIDE 1     // 1: world stage 0 is multiplied between the gather items of stage 1 and the tri-plane pipeline always runs (measured best); 0: tri-plane pipeline skipped when no tap carries weight, stage 0 multiplied afterwards
 #endif
+#if NEO_TP_PLCACHE
+            {
+                // ---- tri-planes through the wave-private tap cache.  This wave blends rows 16 wv .. 16 wv + 15 of the tile (16
+                //      consecutive samples); lane = (row group g = lane >> 4, 16-byte column col4) as in the latent pipeline.
+                //      Unit (stage s2, plane j): for every row segment of that plane [fill: the segment's unique texels, 256-B
+                //      half s2, -> cache; blend: each of the segment's rows reads its four taps from the cache], the three planes
+                //      summed per row in the order xz, xy, yz (the order of the uncached pipeline: bit-identical sums).
+                //      The first segment's fill of the NEXT unit is requested before this unit's last segment is blended.
+                (void)any_plane;
+                const int g4 = L.lane >> 4;
+                float* plc = smem + tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0) + L.wv * PLC_WAVE_WORDS;
+                const char* tcache = reinterpret_cast<const char*>(plc);
+                const uint32_t* ulist = reinterpret_cast<const uint32_t*>(plc + PLC_T_WORDS);
+                f32x4 pre[4];                                  // one fill in flight: slots 4 it + g4
+                f32x4 wsum4[4];                                // per row group q: running sum over the planes
+                auto issue_fill = [&](int j, int s2, int seg) __attribute__((always_inline)) {
+                    const uint4 uo = *reinterpret_cast<const uint4*>(ulist + ((j * 4 + seg) * PLC_SLOTS + g4 * 4));
+                    const float* base = sc.plane[j];
+                    pre[0] = tp::load_tap(base, uo.x + lane_b + 256u * s2);
+                    pre[1] = tp::load_tap(base, uo.y + lane_b + 256u * s2);
+                    pre[2] = tp::load_tap(base, uo.z + lane_b + 256u * s2);
+                    pre[3] = tp::load_tap(base, uo.w + lane_b + 256u * s2);
+                };
+                auto commit_fill = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        *reinterpret_cast<f32x4*>(plc + it * 256 + L.lane * 4) = pre[it];      // slot 4 it + g4, bytes 16 col4..
+                };
+                auto blend_rows = [&](auto jc, int seg, int glog) __attribute__((always_inline)) {
+                    constexpr int j = decltype(jc)::value;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if ((q >> glog) != seg) continue;                         // wave-uniform: row group q belongs to segment q >> glog
+                        const int row = 16 * L.wv + 4 * q + g4;
+                        const int4 so = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
+                        const f32x4 wts = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4);
+                        f32x4 tp4[4];
+                        tp4[0] = *reinterpret_cast<const f32x4*>(tcache + so.x + lane_b);
+                        tp4[1] = *reinterpret_cast<const f32x4*>(tcache + so.y + lane_b);
+                        tp4[2] = *reinterpret_cast<const f32x4*>(tcache + so.z + lane_b);
+                        tp4[3] = *reinterpret_cast<const f32x4*>(tcache + so.w + lane_b);
+                        const f32x4 val = blend4(tp4, wts);
+                        if constexpr (j == 0) wsum4[q] = val; else wsum4[q] = wsum4[q] + val;
+                    }
+                };
+                issue_fill(0, 0, 0);
+                static_for<0, 6>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value, s2 = u / 3, j = u % 3;
+                    const int glog = (plc_glog >> (2 * j)) & 3;                   // segment = 4 << glog rows: 16 / 8 / 4
+                    const int nseg = 4 >> glog;
+#pragma unroll 1
+                    for (int seg = 0; seg < nseg; ++seg) {
+                        if (seg > 0) issue_fill(j, s2, seg);                      // only where 16 rows hold more than 16 distinct texels
+                        commit_fill();
+                        if constexpr (u < 5)
+                            if (seg == nseg - 1) issue_fill((u + 1) % 3, (u + 1) / 3, 0);
+                        blend_rows(std::integral_constant<int, j>(), seg, glog);
+                    }
+                    if constexpr (j == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) write_x(xbuf(s2), 16 * L.wv + 4 * q + g4, wsum4[q]);
+                        TP_SYNC();
+                    }
+                    // world stage 0 is multiplied between the units of stage 1 (as between its gather items before)
+                    if constexpr (u == 3) { mma_k(xbuf(0), std::integral_constant<int, 0>()); mma_k(xbuf(0), std::integral_constant<int, 1>()); }
+                    if constexpr (u == 4) { mma_k(xbuf(0), std::integral_constant<int, 2>()); mma_k(xbuf(0), std::integral_constant<int, 3>()); }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+#else
             if (any_plane || NEO_TP_PLANE_MMA_INSIDE) {
 #if NEO_TP_DPF
                 static_for<16, 16 + RING - 1>([&](auto ic) { fetch_off(ic); issue(ic); });
@@ -522,6 +675,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 for (int j = 0; j < 8; ++j) *reinterpret_cast<h8*>(zb + j * 2048) = z;
                 TP_SYNC();
             }
+#endif      // NEO_TP_PLCACHE
             if constexpr (!NEO_TP_PLANE_MMA_INSIDE) static_for<0, 4>([&](auto kc) { mma_k(xbuf(0), kc); });
             TP_MARK(3);
             // world stage 1 is multiplied while the first pos_enc stage is computed
@@ -1204,7 +1358,7 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
         const char* e = getenv("NEO_TP_LDS_PAD");
         lds_pad = e ? (size_t)atol(e) : 0;
     }
-    const size_t lds = (tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0)) * sizeof(float) + lds_pad;
+    const size_t lds = (tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0) + (NEO_TP_PLCACHE ? 4 * PLC_WAVE_WORDS : 0)) * sizeof(float) + lds_pad;
     if (lds > 65536) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -185,6 +185,9 @@ class _HipModule(nn.Module):
         where = " (raised by an earlier call on this module: poll_flags='deferred')" if late else ""
         if flags & 1:
             raise AssertionError("1.0 - p_norm_sq should be greater than 0" + where)
+        if flags & 8:
+            raise _lib.NeoError("internal error reported by a kernel (flag bit 3: a bounded in-kernel wait ran out); results of that "
+                                "call are invalid" + where)
         if flags & 2:
             err = _lib.NeoRangeError(
                 "split-fp16 arithmetic (precision 'f16x3') met an operand outside the fp16 range (|x| >= 65504 or "
@@ -516,7 +519,18 @@ class NeRF_TP(_HipModule):
         self._raise_flags(ctx.poll_flags())       # also clears the word: a miss here must not fail a later forward()
         return out
 
-    def _forward_train(self, rays, randomized, white_bkgd, chunk=None, seed=None):
+    @torch.no_grad()
+    def sample_positions(self, rays, chunk=None):
+        """The sample positions of the deterministic render of these rays, per level: [(fg_t (B,N), bg_s (B,N))] with N = 129,
+        385 at the reference's counts - the rows the fused call's evaluators run at (level 1: sort(level-0 positions + the
+        inverse-CDF samples of the level-0 weights), neo360/helper.py:218-249).  The deterministic training-shaped call and the
+        evaluation call launch the same kernels in the same order, so these are bitwise the positions behind
+        `forward(..., out_depth=True)`.  For parity work: an oracle evaluated AT these positions is comparable ray by ray, with
+        no allowance for the ill-conditioning of the resampling itself (tests/test_gpu_fullsize.py)."""
+        levels = self._forward_train(rays, False, False, chunk, None, _raw=True)
+        return [(t["fg_t"], t["bg_t"]) for t in levels]
+
+    def _forward_train(self, rays, randomized, white_bkgd, chunk=None, seed=None, _raw=False):
         """out_depth=False: per level (comp_rgb, fg_weights, bg_weights, fg_sdist, bg_sdist, bg_acc)
         (neo360/model.py:531-579), forward values only.  randomized=True draws the stratified level-0 jitter and the
         level-1 quantiles from the library's counter-based generator (`seed`, default: one fresh seed per call from
@@ -551,6 +565,8 @@ class NeRF_TP(_HipModule):
             self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)), seed,
             ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
         self._after_call(ctx)
+        if _raw:
+            return levels
         out = []
         for t in levels:
             fg_t, bg_t = t["fg_t"], t["bg_t"]

@@ -397,25 +397,15 @@ def linear(x, w, b=None, relu=False, ctx=None):
     return _Linear.apply(ctx, x, w, b, relu)
 
 
-class _LinearNoBias(torch.autograd.Function):
-    """y = x W^T (library GEMM); backward: dx = dy W (library GEMM), dW = dy^T x by the library's weight-gradient kernel
-    (neo_linear_weight_grad: the output is a handful of tiles over ~230 k rows, where the library GEMM ran at a third of its rate)."""
+class _LinearNoBias:
+    """y = x W^T for a texel-space projection (230,400 x 512 -> 256 at the bench size), forward and both backward products on
+    the library's OWN GEMM kernels (round 6: neo_linear_forward / neo_linear_input_grad = k_sgemm, neo_linear_weight_grad = k_dw;
+    rounds 4-5 called torch's matmul here - hipBLASLt `Cijk_*` kernels, 11.5 % of a training step in
+    profiles/r05_train_step_kernel_stats.csv)."""
 
     @staticmethod
-    def forward(ctx_, lib_ctx, x, w):
-        ctx_.lib_ctx = lib_ctx
-        ctx_.save_for_backward(x, w)
-        return x @ w.t()
-
-    @staticmethod
-    def backward(ctx_, gy):
-        x, w = ctx_.saved_tensors
-        gy = gy.contiguous()
-        gx = gy @ w if ctx_.needs_input_grad[1] else None
-        gw = None
-        if ctx_.needs_input_grad[2]:
-            gw = weight_grad(gy, x, ctx=ctx_.lib_ctx)
-        return None, gx, gw
+    def apply(lib_ctx, x, w):
+        return _Linear.apply(lib_ctx, x, w, None, False)
 
 
 def weight_grad(gy, x, bias=False, ctx=None):

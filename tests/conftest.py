@@ -131,9 +131,13 @@ FLIP_MARGIN = 1e-6      # ~16 ulps of a cdf in [0,1]: what faithful fp32 evaluat
 
 
 CDF_CALIB = 5.4e-7      # median cdf self-displacement of the reference on the fixture FLIP_MARGIN was calibrated on (g4_neo_full_noise)
-FLIP_PRONE_MAX_FRAC = 0.125   # a fixture with more flip-prone rays than this would make the exemption the rule: fail instead (observed: 52-67 of 1024 on the random-init chunks, 111 on the sharp one b5)
-ABOVE_TOL_MAX_FRAC = 0.01    # rays that may exceed 1e-4 at all (observed over 9 fixtures x both arithmetics: 0 .. 6 of 1024 = 0.59 % on full-size
-                             # chunk b1, identically in the split and the exact kernels; profiles/r04_parity_report.json)
+# Both constants are tied to what the fixtures show (VERDICT r5 task 5), not to round numbers:
+FLIP_PRONE_MAX_FRAC = 0.13    # flip-prone rays a fixture may hold before the exemption would be the rule: the maximum observed (111 of 1024 on
+                              # the sharp chunk b5; 52-67 on the random-init chunks - a property of the FIXTURE, computed from the reference's own
+                              # margins, the same on every GPU) + 20 %
+ABOVE_TOL_MAX_FRAC = 0.007    # rays that may exceed 1e-4 at all under the per-ray rule: the maximum observed over 9 fixtures x both arithmetics
+                              # (7 of 1024 = 0.68 % on full-size chunk b1, 6 in the exact kernels; profiles/r05_parity_report.json).  The test that
+                              # allows NO such ray is test_gpu_fullsize.py::test_neo360_full_size_every_ray_at_the_gpus_own_positions.
 
 
 def check_vs_reference_noise(got, g, noise, label, tol=1e-4, flip=None):

@@ -129,6 +129,47 @@ def test_neo360_full_size_chunk_vs_reference(neo_full, golden, golden_optional, 
         assert torch.equal(batch["rays_o"][idx], gb["rays_o"]) and max_abs(batch["rays_d"][idx], gb["rays_d"]) < 3e-7
 
 
+@pytest.mark.parametrize("tag", ["", "b5"])
+def test_neo360_full_size_every_ray_at_the_gpus_own_positions(neo_full, tag):
+    """The 1e-4 contract on EVERY ray of a full-size C3 chunk, no margin / flip / distribution rule (VERDICT r5 task 5).
+    The rules of test_neo360_full_size_chunk_vs_reference exist because the reference's level-1 POSITIONS are ill-conditioned
+    (an ulp of the coarse cdf moves a sample across a bin; its own fp32 and fp64 runs disagree on b5 by more than 1e-4).  Here
+    the positions are taken out of the comparison: the GPU renders, exposes the level-1 positions it used
+    (`sample_positions`), and the pinned oracle (tests/test_oracle_fullsize.py: == the reference <= 5e-6 at this size)
+    evaluates the reference's fp32 arithmetic AT those positions on the host.  Everything else - lookups, encodings, the four
+    MLPs, the view-direction tiling, compositing, merge - is compared at 1e-4 on all eight outputs of all 1024 rays, for the
+    bench chunk ("") and for the trained-like one (b5, density gain 8)."""
+    import oracle
+    state, net, scene, batch = neo_full
+    if tag:
+        net = _net_variant(tag)
+    sc_cpu, cb = cases.full_case(tag, 1024)
+    gb = {k: v.to(DEV) for k, v in cb.items()}
+    res = net(gb, False, False, 0.0, 0.0, out_depth=True)
+    pos = net.sample_positions(gb)
+    net.check_flags()
+    got = _outputs(res)
+    # the positions really are those of the evaluation call: its level-1 colour is the training-shaped call's, bitwise
+    again = net(gb, False, False, 0.0, 0.0, out_depth=False)
+    assert torch.equal(again[1][0], res[1][0]) and torch.equal(again[0][0], res[0][0])
+    fg_t1, bg_s1 = pos[1][0].cpu(), pos[1][1].cpu()
+    assert fg_t1.shape == (1024, 385) and bool((fg_t1[:, 1:] >= fg_t1[:, :-1]).all()) and bool((bg_s1[:, 1:] <= bg_s1[:, :-1]).all())
+    params = synth.nerf_tp_state(0, density_gain=cases.full_gain(tag))
+    torch.set_num_threads(max(1, min(64, (torch.get_num_threads() or 1))))
+    want = oracle.neo360.render(params, cb, sc_cpu, 128, 256, fine_samples=(fg_t1, bg_s1))
+    want = dict(rgb0=want[0][0], depth0=want[0][5], rgb1=want[1][0], fg1=want[1][1], bg1=want[1][2], fgacc1=want[1][3],
+                lam1=want[1][4], depth1=want[1][5])
+    worst = {}
+    for k in want:
+        e = (got[k].double() - want[k].double()).abs()
+        e = e.reshape(e.shape[0], -1).amax(dim=1)
+        worst[k] = (float(e.max()), int((e >= 1e-4).sum()))
+    record_parity("neo360_full_size_C3%s/every_ray_at_gpu_positions" % ("_" + tag if tag else ""),
+                  rays=1024, **{"max_" + k: v[0] for k, v in worst.items()}, rays_above_1e4=sum(v[1] for v in worst.values()))
+    for k, (mx, n) in worst.items():
+        assert n == 0 and mx < 1e-4, (tag, k, mx, n)
+
+
 def test_mip360_full_frame_and_strip():
     state = synth.mip360_state(0, weight_gain=0.5)
     net = models.MipNeRF360(num_prop_samples=64, num_nerf_samples=32).to(DEV)

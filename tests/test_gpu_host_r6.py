@@ -151,9 +151,10 @@ def test_gather_map_rejects_a_map_of_another_geometry():
     b = _batch(64)
     nv, _, hf, wf = sc["latent"].shape
     pts = (torch.rand(200, 3, device=DEV) - 0.5)
-    good = torch.randn(nv * hf * wf, 64, device=DEV, requires_grad=True)
-    out = training.gather_map(net, good, pts, b)
-    out.sum().backward()
+    with torch.enable_grad():
+        good = torch.randn(nv * hf * wf, 64, device=DEV, requires_grad=True)
+        out = training.gather_map(net, good, pts, b)
+        out.sum().backward()
     assert good.grad is not None and good.grad.shape == good.shape
     for rows in (nv * hf * wf - wf, nv * hf * wf + 1, nv * (hf // 2) * (wf // 2)):
         bad = torch.randn(rows, 64, device=DEV)
@@ -173,7 +174,7 @@ def test_forward_only_caller_outside_no_grad_is_told_once_and_chunked_pixelnerf_
     b = _batch(96)
     with torch.no_grad():
         want = pix(b, False, False, 0.2, 3.0, chunk=32)
-    with warnings.catch_warnings(record=True) as seen:
+    with warnings.catch_warnings(record=True) as seen, torch.enable_grad():
         warnings.simplefilter("always")
         got = pix(b, False, False, 0.2, 3.0, chunk=32)            # grad mode on, deterministic, chunked: fused fallback
         got2 = pix(b, False, False, 0.2, 3.0)                     # latent tensor is gone: fused fallback as well
@@ -181,5 +182,5 @@ def test_forward_only_caller_outside_no_grad_is_told_once_and_chunked_pixelnerf_
     assert got2[1][0].shape == want[1][0].shape and not got2[1][0].requires_grad
     assert sum("differentiable operator chain" in str(w.message) for w in seen) == 1
     pix.differentiable = True                                      # an explicit request keeps the strict behaviour
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError), torch.enable_grad():
         pix(b, False, False, 0.2, 3.0, chunk=32)
