@@ -24,7 +24,7 @@ int mip_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* ray
                          (ctx->mip_layered == 1 || (ctx->mip_layered < 0 && static_cast<long>(R) * n >= 8192));
     const int cap = neo::MIP_LAYERED_BATCH;
     if (layered && (ctx->mip_lws[0].reserve(neo::mip_layered_x0_bytes(cap)) || ctx->mip_lws[1].reserve(neo::mip_layered_y_bytes(cap)) ||
-                    ctx->mip_lws[2].reserve(neo::mip_layered_y_bytes(cap)) || ctx->mip_lws[3].reserve(neo::mip_layered_sync_bytes(cap))))
+                    ctx->mip_lws[2].reserve(neo::mip_layered_y_bytes(cap))))
         return NEO_ERR_NOMEM;
     // span ids (neo_ctx_read_spans): 5 fused split evaluator of a proposal MLP, 6 of the NeRF MLP, 7 the NeRF MLP layer by layer
     // (k_mip_ipe_h + 8 x k_mip_gemm_h + the fused evaluator's tail per batch), 8 exact fp32 evaluator
@@ -36,7 +36,7 @@ int mip_mlp_launch(neo_ctx* ctx, int slot, const float* rays_o, const float* ray
                            sl.bias_hp.as<float>()};
         if (layered) {
             const neo::MipLayeredWs ws{static_cast<char*>(ctx->mip_lws[0].p), static_cast<char*>(ctx->mip_lws[1].p),
-                                       static_cast<char*>(ctx->mip_lws[2].p), cap, static_cast<unsigned*>(ctx->mip_lws[3].p)};
+                                       static_cast<char*>(ctx->mip_lws[2].p), cap};
             rc = neo::launch_mip_mlp_h_layered(mh, ws, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);
         } else {
             rc = neo::launch_mip_mlp_h(sh[0], sh[1], sh[2], mh, rays_o, rays_d, viewdirs, radii, tdist, R, n, out, s);

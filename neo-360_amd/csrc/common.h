@@ -138,48 +138,6 @@ __device__ __forceinline__ void sincos_pair(float a, float& s, float& c) {
     c = (q1 & 2) ? -rc : rc;
 }
 
-// TWO consecutive octaves of one coordinate - arguments a0 and a1 = 2 a0 (exact) - for the price of one argument reduction and one
-// pair of polynomials (round 5): (s0, c0) exactly as sincos_pair(a0) returns them, bit for bit; the second octave by angle
-// DOUBLING from the true sine / cosine of a0,
-//     sin 2a = 2 sin a cos a,   cos 2a = 1 - 2 sin^2 a,
-// followed by the same first-order correction for the reference's rounded phase add (c1 = sin(fl32(a1 + fl32(pi/2))) =
-// cos(a1 + d1) ~ cos a1 - d1 sin a1, d1 from TwoSum).  A doubling step doubles the absolute error of its input (angle error
-// x 2): max abs error of (s1, c1) 2.7e-7 / rms 7.5e-8 against 8.4e-8 / 3.5e-8 of a direct evaluation (2e6 arguments, octaves
-// 0..9 of |x| <= 3.5, fp64 truth) - 2 ulp of a feature of magnitude 1, which enters a layer whose fp32 accumulation over 192
-// terms carries more.  ~14 VALU instructions for the second pair instead of ~38.  Beyond |a1| = 4096: four full evaluations.
-__device__ __forceinline__ void sincos_pair2(float a0, float& s0, float& c0, float& s1, float& c1) {
-    const float a1 = a0 + a0;
-    const float b0 = a0 + HALF_PI_F32, b1 = a1 + HALF_PI_F32;
-    if (!(fabsf(a1) <= 4096.0f)) {
-        s0 = sin_cw(a0); c0 = sin_cw(b0);
-        s1 = sin_cw(a1); c1 = sin_cw(b1);
-        return;
-    }
-    const float k = rintf(a0 * 0.636619772f);
-    float r = fmaf(-k, 1.57079625129699707031f, a0);
-    r = fmaf(-k, 7.54978941586159635335e-8f, r);
-    r = fmaf(-k, 5.39030252995776476554e-15f, r);
-    const int q = (int)k, q1 = q + 1;
-    float sn, cs;
-    sincos_poly(r, sn, cs);
-    const float rs = (q & 1) ? cs : sn, rc = (q1 & 1) ? cs : sn;
-    const float st = (q & 2) ? -rs : rs;                            // sin a0
-    const float ct = (q1 & 2) ? -rc : rc;                           // cos a0 = sin(a0 + pi/2)
-    const float bb0 = b0 - a0;                                      // TwoSum: a0 + HP = b0 + err0 exactly
-    const float err0 = (a0 - (b0 - bb0)) + (HALF_PI_F32 - bb0);
-    const float d0 = 4.371139000186243e-08f - err0;
-    s0 = st;
-    c0 = fmaf(-d0, st, ct);                                         // = sincos_pair's fma(d, cs, sn) / fma(-d, sn, cs) after its selects
-    const float t2 = st + st;
-    const float s1t = t2 * ct;
-    const float c1t = fmaf(-t2, st, 1.0f);
-    const float bb1 = b1 - a1;
-    const float err1 = (a1 - (b1 - bb1)) + (HALF_PI_F32 - bb1);
-    const float d1 = 4.371139000186243e-08f - err1;
-    s1 = s1t;
-    c1 = fmaf(-d1, s1t, c1t);
-}
-
 // Positional encoding of one scalar at one octave: sin(x*2^k), sin(x*2^k + fl32(pi/2)).
 // x*2^k is exact; the phase add rounds in fp32 exactly as the reference's does
 // (neo360/helper.py:123-124).

@@ -138,7 +138,7 @@ struct neo_ctx {
     neo_host::MlpSlot pix[2];          // PixelNeRF coarse / fine
     int mip_shape[3][3] = {};          // width, depth, rgb per slot
     neo_host::DevBuf mip_basis;
-    neo_host::DevBuf mip_lws[4];       // layer-by-layer NeRF MLP (mip_layered.h): encoding fragments + two activation buffers + the chain kernel's slab counters
+    neo_host::DevBuf mip_lws[3];       // layer-by-layer NeRF MLP (mip_layered.h): encoding fragments + two activation buffers
     int mip_layered = -1;              // 1: NeRF MLP layer by layer, 0: fused evaluator, -1 (default): layer by layer from 8192 intervals
     std::map<int, neo_host::DevBuf> centre_quantiles;             // n -> linspace(1/2n, 1-1/2n-eps, n)
     // NeO-360 scene features, channels-last, context-owned

@@ -204,72 +204,6 @@ __global__ __launch_bounds__(MG_THREADS, 2) void k_mip_gemm_h(MipGemmArgs a) {
     range_commit(L, a.flags);
 }
 
-// ---- the whole trunk in ONE launch (round 5) ----------------------------------------------------------------------------------
-// Layer l + 1 of an interval slab (256 intervals) needs layer l's 1024 outputs of THAT slab only - the four workgroups
-// (slab_i, slab_o = 0..3), which the id -> tile map above places on one XCD at the same time.  k_mip_chain_h keeps each workgroup
-// on its tile through all the layers and replaces the seven kernel boundaries (a launch gap + a drained GPU + a cold prologue
-// each: ~8 of ~78 us per layer at 16,384 intervals per batch) by a four-workgroup barrier: every thread releases its stores
-// (agent scope), one thread counts the workgroup in on the slab's counter of that layer and polls until all four are in, and every
-// wave drops its stale L1 lines of the ping-pong buffers (acquire fence) before it reads the other workgroups' outputs.
-// Progress: a workgroup that polls holds its CU, so the siblings it waits for must be resident or become resident.  They do: the
-// dispatcher hands out workgroup ids in order, a slab's four ids lie inside one aligned block of 32 ids, and every block before it
-// is complete - its workgroups finish and free their CUs whatever the later ones do.  (One workgroup per CU: 8 waves x 236 VGPRs.)
-// Belt and braces: a poll that has not succeeded after ~4 s raises flag bit 3 (NEO_FLAG_INTERNAL) and gives up instead of hanging.
-struct MipChainArgs {
-    const char* w[8];     // per layer: 32 output tiles x ks x 2 KB
-    int ks0[8], ks1[8];   // k-steps from the previous layer's output (layer 0: from the encoding) / from the encoding (skip layer)
-    const float* bias;    // 8 x 1024
-    const char* x0;       // the batch's encoding fragments
-    char* y[2];           // ping-pong activation buffers: layer l writes y[l & 1] and reads y[(l + 1) & 1]
-    int n_it, layers;
-    uint32_t* flags;
-    unsigned* arrive;     // [n_it / 8 interval slabs][8 layers], zero before the launch
-};
-constexpr uint32_t FLAG_INTERNAL = 8u;
-
-__device__ __forceinline__ void mip_slab_barrier(unsigned* ctr, unsigned expect, uint32_t* flags) {
-    __threadfence();                                    // release: this thread's activation stores are visible at agent scope
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned polls = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < expect) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++polls > (1u << 24)) {
-                atomicOr(flags, FLAG_INTERNAL);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // the other workgroups' outputs: no stale L1 lines of the buffer read next
-}
-
-template <bool RELU>
-__global__ __launch_bounds__(MG_THREADS, 2) void k_mip_chain_h(MipChainArgs c) {
-    extern __shared__ __attribute__((aligned(16))) char mg_lds[];
-    LaneCtx L;
-    L.init();
-    const int id = blockIdx.x;
-    const int slab_i = ((id >> 5) << 3) | (id & 7);
-#pragma unroll 1
-    for (int l = 0; l < c.layers; ++l) {
-        MipGemmArgs a;
-        a.w = c.w[l];
-        a.bias = c.bias + l * 1024;
-        a.x0 = l == 0 ? c.x0 : c.y[(l + 1) & 1];
-        a.x1 = c.ks1[l] ? c.x0 : nullptr;
-        a.y = c.y[l & 1];
-        a.ks0 = c.ks0[l];
-        a.ks1 = c.ks1[l];
-        a.n_it = c.n_it;
-        a.flags = c.flags;
-        mip_gemm_tile<RELU, false>(a, id, mg_lds, L);
-        if (l + 1 < c.layers) mip_slab_barrier(c.arrive + slab_i * 8 + l, 4u, c.flags);
-    }
-    range_commit(L, c.flags);
-}
-
 // grid for a batch of n_it interval tiles (n_it % 64 == 0): 4 output slabs x n_it / 8 interval slabs
 inline unsigned mip_gemm_grid(int n_it) { return (unsigned)(n_it / 8 * 4); }
 

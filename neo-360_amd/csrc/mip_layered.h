@@ -12,9 +12,7 @@ struct MipLayeredWs {
     char* ya;
     char* yb;
     int cap;
-    unsigned* arrive = nullptr;   // k_mip_chain_h's slab counters, mip_layered_sync_bytes(cap); nullptr: one launch per layer
 };
-inline size_t mip_layered_sync_bytes(int cap) { return static_cast<size_t>(cap / 256) * 8 * sizeof(unsigned); }
 constexpr int MIP_LAYERED_BATCH = 16384;
 inline size_t mip_layered_x0_bytes(int cap) { return static_cast<size_t>(cap) * 2048; }
 inline size_t mip_layered_y_bytes(int cap) { return static_cast<size_t>(cap) * 4096; }

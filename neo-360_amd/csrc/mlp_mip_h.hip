@@ -25,9 +25,6 @@
 #include "mip_layered.h"
 #include "split_tile.h"
 
-#ifndef NEO_MIP_PROP64
-#define NEO_MIP_PROP64 0        // 1: proposal MLPs on 64-row tiles (k_mip_prop_h) - measured 4 % SLOWER than the 32-row evaluator k_mip_mlp_h<256, 4, false, 8> (profiles/r04_mip_gemm_experiments.log 2c); kept as an experiment branch
-#endif
 #ifndef NEO_MIP_H_WAVES
 #define NEO_MIP_H_WAVES 16      // waves per workgroup of the 1024-wide evaluator: 16 (4 per SIMD) measured +3-4 % over 8
 #endif
@@ -485,115 +482,6 @@ __global__ __launch_bounds__(NWV * 64, (NWV == 16 ? 4 : (W == 1024 ? 2 : 4))) vo
     }
 }
 
-// EXPERIMENT (NEO_MIP_PROP64, off): proposal MLP (4 x 256, density only: model.py:131-136) on 64-ROW tiles: 8 waves, wave = one
-// N-tile x two M-tiles, so a weight fragment feeds 6 MFMAs instead of 3 (the 32-row evaluator asks 85 B/clk of the CU's 64 B/clk
-// vector-memory path for this MLP too; its activations are 1 KB per row, so 64 rows fit: 64 KB + 32 KB of encoding stages).
-// Same arithmetic, same k order as k_mip_mlp_h<256, 4, false, 8>.  Measured: 44.5 ms per launch against 42.8 - the 110 KB of
-// LDS leave ONE workgroup (2 waves per SIMD) per CU where the 32-row evaluator runs two (4 waves per SIMD), and the
-// encoding's VALU work and the barriers want those waves more than the weight stream wants the rows.
-constexpr int PR = 64;
-constexpr size_t PROP_LDS_BYTES = (size_t)(2 * PR * 256 + 4 * PR * 64) * sizeof(_Float16) + (size_t)(PR * 44 + PR * 12) * sizeof(float);
-__global__ __launch_bounds__(512, 2) void k_mip_prop_h(MipMlpHDev m, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                       const float* __restrict__ radii, const float* __restrict__ tdist, int R, int n,
-                                                       float4* __restrict__ out) {
-    constexpr int W = 256, DEPTH = 4, NT = 512, KSW = W / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* hb = reinterpret_cast<_Float16*>(smem);
-    const HT act{hb, hb + PR * W};                                               // [64][256] x 2 planes
-    _Float16* xb = hb + 2 * PR * W;
-    auto xbuf = [&](int b) { return HT{xb + b * (2 * PR * 64), xb + b * (2 * PR * 64) + PR * 64}; };   // 2 x [64][64] x 2 planes
-    float* lift = reinterpret_cast<float*>(xb + 4 * PR * 64);
-    float* rowz = lift + PR * 44;
-    LaneCtx L;
-    L.init();
-    int tid = threadIdx.x;
-    const long P = (long)R * n;
-    const long tile0 = (long)blockIdx.x * PR;
-    const h8* wp = reinterpret_cast<const h8*>(m.wpack);
-    if (tid < PR) {
-        long g = tile0 + tid;
-        if (g >= P) g = P - 1;
-        const int ray = (int)(g / n), i = (int)(g - (long)ray * n);
-        row_gaussian(rays_o, rays_d, radii, tdist, ray, i, n, rowz + tid * 12);
-    }
-    __syncthreads();
-    lift_rows(m.basis, rowz, lift, tid, NT, PR);
-    __syncthreads();
-    // 64 packed features (32 pairs) of stage s: thread = (row, 8 consecutive features = chunk q of the stage)
-    auto produce = [&](int s, const HT& buf) {
-        const int row = tid & 63, q = tid >> 6;
-        h8 vh, vl;
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            float f0, f1;
-            ipe_pair(lift, row, (s * 64 + q * 8 + e) >> 1, f0, f1);
-            _Float16 h, l;
-            split(f0, h, l);
-            vh[e] = h; vl[e] = l;
-            split(f1, h, l);
-            vh[e + 1] = h; vl[e + 1] = l;
-        }
-        const int o = chunk_off<64>(row, q);
-        *reinterpret_cast<h8*>(buf.hi + o) = vh;
-        *reinterpret_cast<h8*>(buf.lo + o) = vl;
-    };
-    f32x16 acc[1][2];
-    const int nts[1] = {L.wv};
-#pragma unroll 1
-    for (int layer = 0; layer < DEPTH; ++layer) {
-        asm volatile("" : "+v"(tid));          // per-lane indices re-derived from an opaque lane id (no swizzled addresses in scratch)
-        L.lane = tid & 63;
-        L.half = L.lane >> 5;
-        L.l31 = L.lane & 31;
-        L.key = L.lane & 15;
-        const h8* wl = wp + (size_t)woff_of(W, layer) * 1;       // woff_of is in h8 units
-        bias_tile(acc[0][0], m.bias + layer * W, L.wv, L);
-        acc[0][1] = acc[0][0];
-        if (layer == 0) {
-            produce(0, xbuf(0));
-            __syncthreads();
-#pragma unroll 1
-            for (int s = 0; s < 8; ++s) {
-                if (s + 1 < 8) produce(s + 1, xbuf((s + 1) & 1));
-                gemm2h<1, 64>(acc, wl, 32, nts, s * 4, 0, 4, xbuf(s & 1), L);
-                __syncthreads();
-            }
-        } else {
-            gemm2h<1, W>(acc, wl, KSW, nts, 0, 0, KSW, act, L);
-            __syncthreads();
-        }
-        store_tile_h<true, W>(acc[0][0], act, L.wv, 0, L);
-        store_tile_h<true, W>(acc[0][1], act, L.wv, 1, L);
-        __syncthreads();
-    }
-    // density head: 16 lanes per row, 2 chunks of 8 channels each (the 32-row evaluator's order), two passes of 32 rows
-    range_commit(L, m.flags);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 32 + (tid >> 4), part = tid & 15;
-        float sacc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int chunk = part * 2 + ((c + part) % 2);
-            const int o = chunk_off<W>(row, chunk);
-            const h8 vh = *reinterpret_cast<const h8*>(act.hi + o);
-            const h8 vl = *reinterpret_cast<const h8*>(act.lo + o);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(m.heads + chunk * 8);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(m.heads + chunk * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float w = e < 4 ? w0[e] : w1[e - 4];
-                sacc = __builtin_fmaf((float)vh[e], w, sacc);
-                sacc = __builtin_fmaf((float)vl[e], w, sacc);
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
-        const long gi = tile0 + row;
-        if (part == 0 && gi < P) out[gi] = make_float4(0.0f, 0.0f, 0.0f, density_act(sacc + m.heads[hd_db(W)]));   // disable_rgb: zeros
-    }
-}
-
 // Encoding producer of the layer-by-layer path: one interval tile (32 intervals) of the batch that starts at interval p0 per
 // workgroup; the 504 features (+ 8 zeros) as fragments of 32 k-steps.  Thread (row, q) makes features 64 s + 8 q + 0..7 of
 // stage s = chunk q of that stage = k-step 4 s + q/2, fragment half q & 1: one 16-byte store per plane.  Same feature
@@ -718,14 +606,8 @@ int launch_mip_mlp_h(int width, int depth, int rgb, const MipMlpHDev& m, const f
         hipLaunchKernelGGL((k_mip_mlp_h<1024, 8, true, NEO_MIP_H_WAVES>), dim3((unsigned)tiles), dim3(NEO_MIP_H_WAVES * 64), lds_bytes<1024>(), s, m,
                            rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));
     else if (width == 256 && depth == 4 && !rgb) {
-#if NEO_MIP_PROP64
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_prop_h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PROP_LDS_BYTES);
-        hipLaunchKernelGGL(k_mip_prop_h, dim3((unsigned)((P + PR - 1) / PR)), dim3(512), PROP_LDS_BYTES, s, m, rays_o, rays_d, radii, tdist,
-                           R, n, reinterpret_cast<float4*>(out));
-#else
         hipLaunchKernelGGL((k_mip_mlp_h<256, 4, false, 8>), dim3((unsigned)tiles), dim3(512), lds_bytes<256>(), s, m,
                            rays_o, rays_d, viewdirs, radii, tdist, R, n, reinterpret_cast<float4*>(out));
-#endif
     }
     else
         return -1;
@@ -748,28 +630,6 @@ int launch_mip_mlp_h_layered(const MipMlpHDev& m, const MipLayeredWs& ws, const 
         const long pb = P - p0 < ws.cap ? P - p0 : ws.cap;
         const int n_it = (int)((pb + 2047) / 2048) * 64;            // the GEMM's grid wants whole groups of 64 interval tiles
         hipLaunchKernelGGL(k_mip_ipe_h, dim3((unsigned)n_it), dim3(256), 0, s, m.basis, rays_o, rays_d, radii, tdist, R, n, p0, ws.x0);
-#ifndef NEO_MIP_CHAIN
-#define NEO_MIP_CHAIN 0           // 1: the eight trunk layers as ONE launch with slab-local barriers (mip_gemm_h.h:k_mip_chain_h) - bitwise the same, measured 1.9x SLOWER (agent-scope release / acquire per layer and workgroup writes back and invalidates the XCD's L2: profiles/r05_mip_chain_experiments.log); experiment branch
-#endif
-        if (NEO_MIP_CHAIN && ws.arrive) {
-            MipChainArgs c{};
-            for (int l = 0; l < DEPTH; ++l) {
-                c.w[l] = wbase + (size_t)woff_of(W, l) * 16;
-                c.ks0[l] = l == 0 ? 32 : W / 16;
-                c.ks1[l] = l == 5 ? 32 : 0;                         // skip concat [h | encoding] (model.py:76-79)
-            }
-            c.bias = m.bias;
-            c.x0 = ws.x0;
-            c.y[0] = bufs[0];
-            c.y[1] = bufs[1];
-            c.n_it = n_it;
-            c.layers = DEPTH;
-            c.flags = m.flags;
-            c.arrive = ws.arrive;
-            (void)hipMemsetAsync(ws.arrive, 0, mip_layered_sync_bytes(ws.cap), s);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mip_chain_h<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS_BYTES);
-            hipLaunchKernelGGL(k_mip_chain_h<true>, dim3(mip_gemm_grid(n_it)), dim3(MG_THREADS), MG_LDS_BYTES, s, c);
-        } else
         for (int l = 0; l < DEPTH; ++l) {
             MipGemmArgs a{};
             a.w = wbase + (size_t)woff_of(W, l) * 16;

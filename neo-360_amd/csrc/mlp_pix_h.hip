@@ -21,9 +21,6 @@
 #define NEO_GATHER_WAVES_PER_SIMD 3
 #endif
 
-#ifndef NEO_PIX_FOLDB
-#define NEO_PIX_FOLDB 1
-#endif
 
 namespace neo {
 
@@ -417,16 +414,6 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_pix_mlp_h(Tp
     //      view layer 0 reads the view-mean trunk itself ----
     f32x16 ysum[1][2];
     {
-#if !NEO_PIX_FOLDB
-        f32x16 acc[1][2];
-        bias_tile(acc[0][0], m.bias + B_B, L.wv, L);
-        acc[0][1] = acc[0][0];
-        gemm2h<1, 128>(acc, wp + PX_B, 8, nts_1, 0, 0, 8, act, L);
-        __syncthreads();
-        store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
-        store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
-        __syncthreads();
-#endif
         bias_tile(ysum[0][0], m.bias + B_V0, L.wv, L);
         ysum[0][1] = ysum[0][0];
         gemm2h<1, 128>(ysum, wp + PX_V0, 10, nts_1, 0, 0, 8, act, L);
@@ -513,12 +500,10 @@ void launch_pix_pack_h(const float* const* w, const float* const* b, void* wpack
     (void)hipMemsetAsync(heads, 0, HEADS_FLOATS * sizeof(float), s);
     cp(b[0], 128, bias + B_0); cp(b[1], 128, bias + B_1); cp(b[2], 128, bias + B_2); cp(b[3], 128, bias + B_3);
     cp(b[6], 128, bias + B_B); cp(b[4], 128, bias + B_V0); cp(b[5], 128, bias + B_V1);
-#if NEO_PIX_FOLDB
     // after the plain copies: [W_v0[:, :128] . W_b | W_v0[:, 128:]] into fold_ws (packed above - stream order: the fold kernel is
     // enqueued here, so the view layer is packed AGAIN below from the folded matrix), folded bias over B_V0
     launch_fold_bottleneck(w[4], w[6], b[6], b[4], 128, 128, 128, 27, fold_ws, bias + B_V0, s);
     pack_h(fold_ws, 155, 128, 10, 0, v0, base + (size_t)PX_V0 * 8, s);
-#endif
     cp(w[7], 128, heads + HD_DW); cp(b[7], 1, heads + HD_DB); cp(w[8], 384, heads + HD_RW); cp(b[8], 3, heads + HD_RB);
 }
 

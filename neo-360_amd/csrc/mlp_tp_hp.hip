@@ -35,63 +35,17 @@
 #ifndef NEO_TP_STAGGER_DEFAULT
 #define NEO_TP_STAGGER_DEFAULT 0      // x 64 cycles; $NEO_TP_STAGGER overrides (see k_tp_mlp_hp)
 #endif
-#ifndef NEO_TP_LDS_BIAS
-#define NEO_TP_LDS_BIAS 1     // biases / head weights staged in LDS once per workgroup
-#endif
 #ifndef NEO_TP_XSTREAM
-#define NEO_TP_XSTREAM 2      // streamed-stage weight fragments in a ring this many k-steps ahead (0: the one-k-step scheme)
-#endif
-#ifndef NEO_TP_TSTREAM
-#define NEO_TP_TSTREAM 6      // the tail GEMMs (bottleneck, view layers) as one weight stream this many k-steps ahead (0: per-stage loops)
-#endif
-#ifndef NEO_TP_LSTREAM
-#define NEO_TP_LSTREAM 4      // L1..L3 as one weight stream requested this many k-steps ahead across the layer barriers (0: per-layer loops)
-#endif
-#ifndef NEO_TP_HALFPIPE
-#define NEO_TP_HALFPIPE 0     // 1: L0 epilogue .. L3 pipelined by half tiles (measured SLOWER: profiles/r03_tp_hp_experiments.log); kept as an experiment branch
-#endif
-#ifndef NEO_TP_ZSKIP
-#define NEO_TP_ZSKIP 1        // skip a view's latent / tri-plane gather pipeline when no row of the tile has a non-zero tap weight in it
-#endif
-#ifndef NEO_TP_DPF
-#define NEO_TP_DPF 1          // 1: a gather item's tap offsets / weights are read from LDS ONE ITEM AHEAD of their use (the ISA of the plain form waits out a full LDS round trip twice per item: ds_read offsets -> s_waitcnt -> 4 loads, ds_read weights -> s_waitcnt -> blend)
-#endif
-#ifndef NEO_TP_PLANE_FMA
-#define NEO_TP_PLANE_FMA 0    // 1 (round 5): the blends of a row group's three tri-planes are chained through the running sum (fma onto the sum) instead of blend + add
-#endif
-#ifndef NEO_TP_BIAS2
-#define NEO_TP_BIAS2 0        // 1 (round 5): the second M-tile's accumulators are initialised by a second LDS read of the biases instead of 16 register copies
-#endif
-#ifndef NEO_TP_PLCACHE
-// Round 6 (VERDICT r5 task 1b; profiles/r06_energy_budget.log: 48 J of a launch's 222 J are the distinct cache lines the tap loads
-// present to the texture-address unit and the L2 -> L1 traffic behind them, 2/3 of that in the tri-planes).  1: the tri-plane taps
-// of a wave's 16 CONSECUTIVE samples are deduplicated per (view, plane) - samples along a ray walk through the bilinear cells of a
-// plane, a tile-view's 256 taps per plane touch ~35 distinct texels inside the sphere - each unique texel's 256-B half is fetched
-// ONCE into a wave-private LDS cache (16 slots, 4 KB) and the blends read their taps from there (ds_read_b128 instead of
-// global_load_dwordx4): 24 load instructions per wave and view instead of 96, ~2.5 x fewer cache lines.  0: every tap from L1 / L2.
-#define NEO_TP_PLCACHE 1
+#define NEO_TP_XSTREAM 2      // streamed-stage weight fragments in a ring this many k-steps ahead
 #endif
 #ifndef NEO_TP_ABLATE
-// timing experiments only (results wrong by construction; tools/build_variant.py): 1 no latent-chunk gathers, 2 no
-// tri-plane gathers, 4 no pos_enc, 8 no streamed-stage MFMAs, 16 no L1/L2/L3 GEMMs, 32 descriptors for view 0 only,
-// 64 no barriers inside the view loop, 128 no layer-epilogue stores; round 6 (energy budget of the gather half): 256 every tap
-// reads texel 0 of its map (the loads stay, all L1 hits, one 256-B run per instruction: what is left is the instruction / L1
-// path, what went is the L2 -> L1 traffic and the divergent-address cost), 512 the loads are replaced by undefined registers
-// (blends, LDS transposition and adds stay); 1024 / 2048: as 256 for the tri-plane / the latent taps alone
+// timing / energy probes only (results wrong by construction; tools/build_variant.py; profiles/r06_energy_budget.log):
+// 1 no latent-chunk gathers, 2 no tri-plane gathers, 4 no pos_enc; 256 every tap reads texel 0 of its map (the loads stay, all L1
+// hits on one line: what goes is the divergent-address work and the L2 -> L1 traffic), 1024 / 2048 the same for the tri-plane /
+// the latent taps alone; 512 the loads are replaced by undefined registers (blends, LDS transposition and adds stay)
 #define NEO_TP_ABLATE 0
 #endif
-#ifndef NEO_TP_TIMELINE
-#define NEO_TP_TIMELINE 0     // 1: s_memtime before / after every barrier of every wave of one workgroup -> g_tp_stamps (tools/tp_timeline.py)
-#endif
-#if NEO_TP_TIMELINE
-__device__ unsigned long long g_tp_stamps[4 * 1024];
-__device__ int g_tp_stamp_block = 1000;
-#define TP_STAMP() do { if (stamp_on_) { if ((threadIdx.x & 63) == 0 && stamp_n_ < 1024) g_tp_stamps[(threadIdx.x >> 6) * 1024 + stamp_n_] = __builtin_amdgcn_s_memtime(); ++stamp_n_; } } while (0)
-#define TP_SYNC() do { TP_STAMP(); __syncthreads(); TP_STAMP(); } while (0)
-#else
-#define TP_STAMP() do { } while (0)
-#define TP_SYNC() do { if (!(NEO_TP_ABLATE & 64)) __syncthreads(); } while (0)
-#endif
+#define TP_SYNC() __syncthreads()
 #ifndef NEO_TP_TRACE
 #define NEO_TP_TRACE 0        // 1: per-phase s_memtime sums of wave 0 of every workgroup -> g_tp_trace (tools/tp_phase_trace.py)
 #endif
@@ -108,12 +62,6 @@ namespace {
 
 using namespace hp;
 constexpr int RING = NEO_TP_RING;
-// wave-private tri-plane tap cache (NEO_TP_PLCACHE): 16 texel slots x 256 B, the unique-texel lists of the wave's 16 rows per
-// (plane, row segment) - stored so that lane group g reads its four slots 4 it + g as ONE 16-byte word - and the slot counts
-constexpr int PLC_SLOTS = 16;
-constexpr int PLC_T_WORDS = PLC_SLOTS * 64;
-constexpr int PLC_LIST_WORDS = 3 * 4 * PLC_SLOTS;
-constexpr int PLC_WAVE_WORDS = PLC_T_WORDS + PLC_LIST_WORDS + 16;
 
 template <int PE_C>
 __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, const float* __restrict__ proj, TpScene sc,
@@ -157,25 +105,15 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
 #if NEO_TP_TRACE
     unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-#if NEO_TP_TIMELINE
-    const bool stamp_on_ = (int)blockIdx.x == g_tp_stamp_block;
-    int stamp_n_ = 0;
-    TP_STAMP();
-#endif
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags);
     float* dens_w = smem + tp::OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
-#if NEO_TP_LDS_BIAS
     // biases and head weights are read from LDS: an accumulator initialisation is on the critical path of every layer
     float* lbias_w = smem + tp::LDS_WORDS;
     for (int i = tid; i < 768; i += 256) lbias_w[i] = m.bias[i];
     for (int i = tid; i < HD_RB + 3; i += 256) lbias_w[768 + i] = m.heads[i];
     const float* lbias = lbias_w;
     const float* lheads = lbias_w + 768;
-#else
-    const float* lbias = m.bias;
-    const float* lheads = m.heads;
-#endif
     float* dsum = smem + tp::OFF_DIR;          // [64][32] fp32: sum over the views of each point's direction encoding (same 8 KB as dsm)
     TP_SYNC();                                 // point_setup has recorded which ray's direction every row carries
     {
@@ -208,118 +146,30 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
-        if (!(NEO_TP_ABLATE & 32) || v == 0)
         tp::view_descriptors<PROJ_TEXEL_BYTES, false>(S, L, sc, rot, trn, v, [](int, int, float) {});
         TP_SYNC();
         TP_MARK(1);
-#if NEO_TP_ZSKIP
-        // Which rows have any non-zero tap weight, per map (0 = latent, 1..3 = planes): samples outside a feature map
-        // blend to exactly zero (grid_sample's zero padding).  (Skipping single gather items was measured first: loads
-        // under a branch cost the software pipeline its exact vmcnt bookkeeping, and zero-weight taps are cheap on the
-        // memory path anyway - all lanes read texel 0, one cache line, ~3 cycles instead of 16-23: tools/ta_cost.hip.)
-        unsigned long long zm[4];       // bit p: row p of the tile has a non-zero weight in map m (wave-uniform, SGPRs)
+        // Does any row carry a non-zero tap weight in the latent?  Samples outside a source image blend to exactly zero
+        // (grid_sample's zero padding).  (Skipping single gather items was measured first: loads under a branch cost the software
+        // pipeline its exact vmcnt bookkeeping, and zero-weight taps are cheap on the memory path anyway - all lanes read texel 0,
+        // one cache line.)  Wave-uniform and identical in all four waves: the barriers stay uniform.
+        unsigned long long zm0;
         {
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(loc_w + L.lane * 4);
-            zm[0] = __ballot(w0[0] != 0.0f || w0[1] != 0.0f || w0[2] != 0.0f || w0[3] != 0.0f);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4 wj = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + L.lane) * 4);
-                zm[1 + j] = __ballot(wj[0] != 0.0f || wj[1] != 0.0f || wj[2] != 0.0f || wj[3] != 0.0f);
-            }
+            zm0 = __ballot(w0[0] != 0.0f || w0[1] != 0.0f || w0[2] != 0.0f || w0[3] != 0.0f);
         }
-#else
-        const unsigned long long zm[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-#endif
 
-#if NEO_TP_PLCACHE
-        // ---- tri-plane tap dedup of this wave's 16 rows (see the cached pipeline below).  Lane = (row r = lane >> 2 of the wave's
-        //      16, tap k = lane & 3).  A tap is NEW unless the same texel is a tap of the previous row of its segment or a lower tap
-        //      of its own row (zero-weight placeholders share one texel); every tap follows those links to its first occurrence
-        //      (4 pointer doublings: a chain is at most 15 rows long), first occurrences are numbered in lane order per segment.
-        //      Consecutive samples walk through neighbouring bilinear cells, so a texel that leaves the taps does not come back:
-        //      the links find every duplicate (tools/gather_linework_study.py: chain count == unique count on the bench geometry);
-        //      a miss would only cost a second slot.  Segment = 16 rows; where those hold more than 16 distinct texels (coarse
-        //      samples, grazing views) the rows are split into 2 x 8 or 4 x 4 with their own numbering (4 rows have 16 taps).
-        //      Result: pl_off[row][k] <- byte offset of the tap's slot in the wave's cache; ulist[plane][segment][slot] <- the
-        //      texel's byte offset in the plane (unused slots: the row-0 tap, a valid address); plc_glog: 2 bits per plane.
-        int plc_glog = 0;
-        {
-            float* plc = smem + tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0) + L.wv * PLC_WAVE_WORDS;
-            uint32_t* ulist = reinterpret_cast<uint32_t*>(plc + PLC_T_WORDS);
-            const int lane = L.lane, r = lane >> 2, k = lane & 3, quad = lane & ~3;
-            const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                int* my = pl_off + (j * TM + 16 * L.wv + r) * 4 + k;
-                const uint32_t off = (uint32_t)*my;
-                // candidate links: lowest equal tap of the own row; lowest equal tap of the previous row (preferred)
-                int own = lane, prv = -1;
-                const uint32_t up = (uint32_t)__shfl_up((int)off, 4);               // tap k of row r - 1
-#pragma unroll
-                for (int kk = 3; kk >= 0; --kk) {
-                    const uint32_t o = (uint32_t)__shfl((int)off, quad + kk);
-                    const uint32_t pr = (uint32_t)__shfl((int)up, quad + kk);
-                    if (kk < k && o == off) own = quad + kk;
-                    if (pr == off) prv = quad - 4 + kk;
-                }
-                int glog = 2;                                                      // 16-row segment first
-                unsigned long long mask;
-                int root;
-                while (true) {
-                    const bool first_row = (r & ((4 << glog) - 1)) == 0;
-                    root = (prv >= 0 && !first_row) ? prv : own;
-#pragma unroll
-                    for (int it = 0; it < 5; ++it) root = __shfl(root, root);
-                    mask = __ballot(root == lane);
-                    // distinct texels per segment: 64 >> (2 - glog) lanes each
-                    const int seg_lanes = 16 << glog;
-                    int worst = 0;
-                    for (int sgm = 0; sgm < (4 >> glog); ++sgm) {
-                        const unsigned long long sm = (seg_lanes == 64 ? ~0ull : ((1ull << seg_lanes) - 1ull) << (sgm * seg_lanes));
-                        worst = max(worst, (int)__popcll(mask & sm));
-                    }
-                    if (worst <= PLC_SLOTS || glog == 0) break;
-                    --glog;
-                }
-                const int seg_lanes = 16 << glog;
-                const int rseg = root / seg_lanes;
-                const unsigned long long sm = seg_lanes == 64 ? ~0ull : ((1ull << seg_lanes) - 1ull) << (rseg * seg_lanes);
-                const unsigned long long rbelow = (1ull << root) - 1ull;
-                const int slot = (int)__popcll(mask & sm & rbelow);
-                (void)below;
-                // unused slots first (any valid address: this lane group's row-0 tap), then the first occurrences; LDS is in order
-                {
-                    const uint32_t filler = (uint32_t)__shfl((int)off, 0);
-                    ulist[j * 4 * PLC_SLOTS + lane] = filler;
-                }
-                if (root == lane) ulist[(j * 4 + rseg) * PLC_SLOTS + (slot & 3) * 4 + (slot >> 2)] = off;
-                *my = slot * 256;
-                plc_glog |= glog << (2 * j);
-            }
-            plc_glog = __builtin_amdgcn_readfirstlane(plc_glog);
-        }
-#endif
         // ---- [L0 | L3 skip half] pre-activations: bias + pre-projected latent (adds) + world / pos_enc GEMM ----
         f32x16 accx[2][2];
         bias_tile(accx[0][0], lbias + B_0, L.wv, L);
         bias_tile(accx[1][0], lbias + B_3, L.wv, L);
-#if NEO_TP_BIAS2 && NEO_TP_LDS_BIAS
-        {
-            int z = 0;                               // an opaque zero: without it the compiler merges the two reads and copies registers
-            asm volatile("" : "+v"(z));
-            bias_tile(accx[0][1], lbias + B_0 + z, L.wv, L);
-            bias_tile(accx[1][1], lbias + B_3 + z, L.wv, L);
-        }
-#else
         accx[0][1] = accx[0][0];
         accx[1][1] = accx[1][0];
-#endif
         {
             const int col4 = tid & 15, rg = tid >> 4;
             const uint32_t lane_b = 16u * col4;
             f32x4 taps[RING][4];
             f32x4 wsum;                                    // running sum over the three planes of one row group
-#if NEO_TP_DPF
             int4 d_off[2];                                 // tap byte offsets of the item that is REQUESTED next (slot = item & 1)
             f32x4 d_w[2];                                  // tap weights of the item that is BLENDED next
             // item -> its descriptor row in LDS (offsets and weights share the layout)
@@ -338,7 +188,6 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 if constexpr (i < 16) d_w[i & 1] = *reinterpret_cast<const f32x4*>(loc_w + desc_index(ic));
                 else if constexpr (i < 40) d_w[i & 1] = *reinterpret_cast<const f32x4*>(pl_w + desc_index(ic));
             };
-#endif
             // item i: 0..15 = pre-projected latent (chunk i / 4, row group i % 4); 16..39 = tri-planes
             // (stage (i - 16) / 12, row group ((i - 16) % 12) / 3, plane (i - 16) % 3)
             constexpr int NI = 40;
@@ -348,12 +197,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 } else if constexpr (i < 16) {
                     constexpr int c = i / 4;
                     [[maybe_unused]] constexpr int q = i % 4;
-#if NEO_TP_DPF
                     int4 off = d_off[i & 1];
-#else
-                    const int row = rg + 16 * q;
-                    int4 off = *reinterpret_cast<const int4*>(loc_off + row * 4);
-#endif
                     if constexpr ((NEO_TP_ABLATE & (256 | 2048)) != 0) off = int4{0, 0, 0, 0};
                     if constexpr ((NEO_TP_ABLATE & 512) != 0) {
 #pragma unroll
@@ -367,12 +211,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 } else if constexpr (i < NI) {
                     constexpr int w = i - 16, s2 = w / 12, j = w % 3;
                     [[maybe_unused]] constexpr int q = (w % 12) / 3;
-#if NEO_TP_DPF
                     int4 off = d_off[i & 1];
-#else
-                    const int row = rg + 16 * q;
-                    int4 off = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
-#endif
                     if constexpr ((NEO_TP_ABLATE & (256 | 1024)) != 0) off = int4{0, 0, 0, 0};
                     if constexpr ((NEO_TP_ABLATE & 512) != 0) {
 #pragma unroll
@@ -399,26 +238,14 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 } else if constexpr (i < 16) {
                     constexpr int c = i / 4, q = i % 4;
                     const int row = rg + 16 * q;
-#if NEO_TP_DPF
                     const f32x4 val = blend4(taps[i % RING], d_w[i & 1]);
-#else
-                    const f32x4 val = blend4(taps[i % RING], *reinterpret_cast<const f32x4*>(loc_w + row * 4));
-#endif
                     *reinterpret_cast<f32x4*>(fbuf(c & 1) + row * 64 + ((col4 ^ (row & 15)) << 2)) = val;
                 } else {
                     constexpr int w = i - 16, s2 = w / 12, q = (w % 12) / 3, j = w % 3;
                     const int row = rg + 16 * q;
-#if NEO_TP_DPF
                     const f32x4 wts = d_w[i & 1];
-#else
-                    const f32x4 wts = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4);
-#endif
-#if NEO_TP_PLANE_FMA
-                    if constexpr (j == 0) wsum = blend4(taps[i % RING], wts); else wsum = tp::blend4_acc(taps[i % RING], wts, wsum);
-#else
                     const f32x4 val = blend4(taps[i % RING], wts);
                     if constexpr (j == 0) wsum = val; else wsum = wsum + val;
-#endif
                     if constexpr (j == 2) write_x(xbuf(s2), row, wsum);
                 }
             };
@@ -450,12 +277,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                 const int ch = pstage * 8 + chs;               // chunk of the whole encoding
                 float f[8];
                 h8 vh, vl;
-#if NEO_PE_PAIR2
-                pe2_chunk<PE_C>(xv, ch, vh, vl, L);             // doubling order (tp_hp_layout.h): two octaves of one coordinate per half-chunk
-                if (false) {
-#else
                 if (ch * 4 < 10 * PE_C) {                      // pairs (C = 3: chunk 7 holds pairs 28, 29 and the identity features)
-#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         if (PE_C == 3 && jj >= 2 && ch == 7) {  // pairs 30, 31 do not exist: positions 60..63 = x, y, z, 0
@@ -477,7 +299,7 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                         }
                         sincos_pair(ldexpf(x, oct), f[2 * jj], f[2 * jj + 1]);
                     }
-                } else if (!NEO_PE_PAIR2) {                     // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
+                } else {                                        // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = 0.0f;
                     if (ch * 4 == 10 * PE_C) {
@@ -485,7 +307,6 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                         f[0] = xv[0]; f[1] = xv[1]; f[2] = xv[2]; f[3] = xv[3];
                     }
                 }
-#if !NEO_PE_PAIR2
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     h2 h, l;
@@ -493,9 +314,6 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     vh[e] = h[0]; vh[e + 1] = h[1];
                     vl[e] = l[0]; vl[e + 1] = l[1];
                 }
-#else
-                (void)f;
-#endif
                 const int o = chunk_off<64>(row, chs);
                 *reinterpret_cast<h8*>(buf.hi + o) = vh;
                 *reinterpret_cast<h8*>(buf.lo + o) = vl;
@@ -536,30 +354,23 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                     }
                 load_wk(std::integral_constant<int, ks + XD>());
             };
-            // ---- gathers: two software pipelines (items 0..15 pre-projected latent, 16..39 tri-planes), each skipped as a
-            //      whole when NO row of the tile has a non-zero tap weight in its maps for this view.  That is the normal
+            // ---- gathers: two software pipelines (items 0..15 pre-projected latent, 16..39 tri-planes); the latent one is skipped
+            //      as a whole when NO row of the tile has a non-zero tap weight in the latent for this view.  That is the normal
             //      case outside the unit sphere (half of all points): the far samples project outside every source image
             //      and lie outside the [-1,1]^3 tri-plane volume of the view (profiles/r03_tile_footprint.json: the median
             //      background tile-view touches ONE texel per map, i.e. only the zero-weight placeholder).  Their features are
             //      exactly zero (grid_sample zero padding), so the latent adds, the 8 world k-steps of the streamed GEMM and
-            //      their weight fragments are skipped too.  zm[] is identical in all four waves: the barriers stay uniform.
-            const bool any_latent = !NEO_TP_ZSKIP || zm[0] != 0ull;
-            const bool any_plane = !NEO_TP_ZSKIP || (zm[1] | zm[2] | zm[3]) != 0ull;
+            //      their weight fragments are skipped too.
+            const bool any_latent = zm0 != 0ull;
             if (any_latent) {
-#if NEO_TP_DPF
                 static_for<0, RING - 1>([&](auto ic) { fetch_off(ic); issue(ic); });
                 fetch_off(std::integral_constant<int, RING - 1>());
                 fetch_w(std::integral_constant<int, 0>());
-#else
-                static_for<0, RING - 1>([&](auto ic) { issue(ic); });
-#endif
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-#if NEO_TP_DPF
                     // descriptors one item ahead: offsets of the item requested in the NEXT pass, weights of the item blended in it
                     if constexpr (i + RING < 16) fetch_off(std::integral_constant<int, i + RING>());
                     if constexpr (i + 1 < 16) fetch_w(std::integral_constant<int, i + 1>());
-#endif
                     if constexpr (i + RING - 1 < 16) issue(std::integral_constant<int, i + RING - 1>());
                     if constexpr (i == 4 || i == 8 || i == 12) consume_chunk(std::integral_constant<int, i / 4 - 1>());
                     finish(ic);
@@ -570,122 +381,29 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             }
             TP_MARK(2);
             static_for<0, XD>([&](auto kc) { load_wk(kc); });
-#ifndef NEO_TP_PLANE_MMA_INSIDE
-#define NEO_TP_PLANE_MMA_INSIDE 1     // 1: world stage 0 is multiplied between the gather items of stage 1 and the tri-plane pipeline always runs (measured best); 0: tri-plane pipeline skipped when no tap carries weight, stage 0 multiplied afterwards
-#endif
-#if NEO_TP_PLCACHE
-            {
-                // ---- tri-planes through the wave-private tap cache.  This wave blends rows 16 wv .. 16 wv + 15 of the tile (16
-                //      consecutive samples); lane = (row group g = lane >> 4, 16-byte column col4) as in the latent pipeline.
-                //      Unit (stage s2, plane j): for every row segment of that plane [fill: the segment's unique texels, 256-B
-                //      half s2, -> cache; blend: each of the segment's rows reads its four taps from the cache], the three planes
-                //      summed per row in the order xz, xy, yz (the order of the uncached pipeline: bit-identical sums).
-                //      The first segment's fill of the NEXT unit is requested before this unit's last segment is blended.
-                (void)any_plane;
-                const int g4 = L.lane >> 4;
-                float* plc = smem + tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0) + L.wv * PLC_WAVE_WORDS;
-                const char* tcache = reinterpret_cast<const char*>(plc);
-                const uint32_t* ulist = reinterpret_cast<const uint32_t*>(plc + PLC_T_WORDS);
-                f32x4 pre[4];                                  // one fill in flight: slots 4 it + g4
-                f32x4 wsum4[4];                                // per row group q: running sum over the planes
-                auto issue_fill = [&](int j, int s2, int seg) __attribute__((always_inline)) {
-                    const uint4 uo = *reinterpret_cast<const uint4*>(ulist + ((j * 4 + seg) * PLC_SLOTS + g4 * 4));
-                    const float* base = sc.plane[j];
-                    pre[0] = tp::load_tap(base, uo.x + lane_b + 256u * s2);
-                    pre[1] = tp::load_tap(base, uo.y + lane_b + 256u * s2);
-                    pre[2] = tp::load_tap(base, uo.z + lane_b + 256u * s2);
-                    pre[3] = tp::load_tap(base, uo.w + lane_b + 256u * s2);
-                };
-                auto commit_fill = [&]() __attribute__((always_inline)) {
-#pragma unroll
-                    for (int it = 0; it < 4; ++it)
-                        *reinterpret_cast<f32x4*>(plc + it * 256 + L.lane * 4) = pre[it];      // slot 4 it + g4, bytes 16 col4..
-                };
-                auto blend_rows = [&](auto jc, int seg, int glog) __attribute__((always_inline)) {
-                    constexpr int j = decltype(jc)::value;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if ((q >> glog) != seg) continue;                         // wave-uniform: row group q belongs to segment q >> glog
-                        const int row = 16 * L.wv + 4 * q + g4;
-                        const int4 so = *reinterpret_cast<const int4*>(pl_off + (j * TM + row) * 4);
-                        const f32x4 wts = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + row) * 4);
-                        f32x4 tp4[4];
-                        tp4[0] = *reinterpret_cast<const f32x4*>(tcache + so.x + lane_b);
-                        tp4[1] = *reinterpret_cast<const f32x4*>(tcache + so.y + lane_b);
-                        tp4[2] = *reinterpret_cast<const f32x4*>(tcache + so.z + lane_b);
-                        tp4[3] = *reinterpret_cast<const f32x4*>(tcache + so.w + lane_b);
-                        const f32x4 val = blend4(tp4, wts);
-                        if constexpr (j == 0) wsum4[q] = val; else wsum4[q] = wsum4[q] + val;
-                    }
-                };
-                issue_fill(0, 0, 0);
-                static_for<0, 6>([&](auto uc) {
-                    constexpr int u = decltype(uc)::value, s2 = u / 3, j = u % 3;
-                    const int glog = (plc_glog >> (2 * j)) & 3;                   // segment = 4 << glog rows: 16 / 8 / 4
-                    const int nseg = 4 >> glog;
-#pragma unroll 1
-                    for (int seg = 0; seg < nseg; ++seg) {
-                        if (seg > 0) issue_fill(j, s2, seg);                      // only where 16 rows hold more than 16 distinct texels
-                        commit_fill();
-                        if constexpr (u < 5)
-                            if (seg == nseg - 1) issue_fill((u + 1) % 3, (u + 1) / 3, 0);
-                        blend_rows(std::integral_constant<int, j>(), seg, glog);
-                    }
-                    if constexpr (j == 2) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) write_x(xbuf(s2), 16 * L.wv + 4 * q + g4, wsum4[q]);
-                        TP_SYNC();
-                    }
-                    // world stage 0 is multiplied between the units of stage 1 (as between its gather items before)
-                    if constexpr (u == 3) { mma_k(xbuf(0), std::integral_constant<int, 0>()); mma_k(xbuf(0), std::integral_constant<int, 1>()); }
-                    if constexpr (u == 4) { mma_k(xbuf(0), std::integral_constant<int, 2>()); mma_k(xbuf(0), std::integral_constant<int, 3>()); }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
-#else
-            if (any_plane || NEO_TP_PLANE_MMA_INSIDE) {
-#if NEO_TP_DPF
+            {   // the tri-plane pipeline always runs: world stage 0 is multiplied between the gather items of stage 1 (measured best, round 3)
                 static_for<16, 16 + RING - 1>([&](auto ic) { fetch_off(ic); issue(ic); });
                 fetch_off(std::integral_constant<int, 16 + RING - 1>());
                 fetch_w(std::integral_constant<int, 16>());
-#else
-                static_for<16, 16 + RING - 1>([&](auto ic) { issue(ic); });
-#endif
                 static_for<16, NI>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-#if NEO_TP_DPF
                     if constexpr (i + RING < NI) fetch_off(std::integral_constant<int, i + RING>());
                     if constexpr (i + 1 < NI) fetch_w(std::integral_constant<int, i + 1>());
-#endif
                     if constexpr (i + RING - 1 < NI) issue(std::integral_constant<int, i + RING - 1>());
-                    if constexpr (NEO_TP_PLANE_MMA_INSIDE && i >= 28 && (i - 28) % 3 == 0)
+                    if constexpr (i >= 28 && (i - 28) % 3 == 0)
                         mma_k(xbuf(0), std::integral_constant<int, (i - 28) / 3>());
                     finish(ic);
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (i == 27 || i == 39) TP_SYNC();
                 });
-            } else {
-                // no tap of any tri-plane carries weight: the world features of this view are exactly zero.  Both stage
-                // tiles are cleared and the same k-steps run on them (one instruction stream on both paths keeps the 64
-                // accumulator registers out of scratch); the 24 gather items, their blends and a barrier are saved.
-                if (any_latent) TP_SYNC();                             // chunk 3 of the latent is still being read
-                const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                _Float16* zb = hbase + tid * 8;                        // the act area (32 KB) as 2048 x 16 B: 8 chunks per thread
-#pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<h8*>(zb + j * 2048) = z;
-                TP_SYNC();
             }
-#endif      // NEO_TP_PLCACHE
-            if constexpr (!NEO_TP_PLANE_MMA_INSIDE) static_for<0, 4>([&](auto kc) { mma_k(xbuf(0), kc); });
             TP_MARK(3);
             // world stage 1 is multiplied while the first pos_enc stage is computed
             static_for<4, 8>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
                 mma_k(xbuf(1), kc);
                 if constexpr (ks & 1) {
-                    if (NEO_PE_PAIR2) __builtin_amdgcn_sched_barrier(0);      // keeps the encoding's temporaries out of the k-steps' live ranges
                     finish_pe(xbuf(0), 0, (ks - 4) >> 1);
-                    if (NEO_PE_PAIR2) __builtin_amdgcn_sched_barrier(0);
                 }
             });
             TP_SYNC();
@@ -702,122 +420,9 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             }
         }
         TP_MARK(4);
-#if NEO_TP_HALFPIPE
-        // ---- L0 epilogue, L1, L2, L3 pipelined by HALF TILES (the two M-tiles of 32 points) ----------------------------
-        // Seven segments separated by one barrier each; in segment s one M-tile runs the 8 k-steps of a layer on the
-        // matrix pipe while the OTHER M-tile's previous-layer epilogue (ReLU, hi/lo split, 8-byte plane stores) issues in
-        // the shadow of those MFMAs, two values per k-step:
-        //     S0            epi L0(m0)        S1  L1(m0) | epi L0(m1)      S2  L1(m1) | epi L1(m0)
-        //     S3  L2(m0) | epi L1(m1)         S4  L2(m1) | epi L2(m0)      S5  L3(m0) | epi L2(m1)
-        //     S6  L3(m1) | sum_v relu(L3)(m0)                         then      sum_v relu(L3)(m1)
-        // A segment reads activation rows of one M-tile and writes rows of the other, so ONE barrier per segment orders
-        // the in-place tile.  Each k-step accumulates hi*hi into A and the two cross terms into B (summed at the
-        // end): consecutive MFMAs on one accumulator are back to back (forwarded), and VALU work placed between A and
-        // B never sits inside a dependent pair.
-#ifndef NEO_TP_HP_LD
-#define NEO_TP_HP_LD 4            // weight prefetch distance in k-steps (ring of LD + 1 fragment pairs, 8 VGPRs each)
-#endif
-#ifndef NEO_TP_HP_BPF
-#define NEO_TP_HP_BPF 1           // 1: the activation fragments of k-step ks + 1 are read before the MFMAs of k-step ks
-#endif
-        // weight fragments: ONE stream of 48 k-steps (every layer twice: once per M-tile), LD k-steps ahead across the
-        // segment barriers, in a ring of LD + 1 slots
-        constexpr int LD = NEO_TP_HP_LD, LS = LD + 1;
-        h8 lwh[LS], lwl[LS];
-        const char* lwb = reinterpret_cast<const char*>(wp);
-        const uint32_t lw_off = (uint32_t)(L.wv * 8 * 128 + L.lane) * 16u;
-        auto load_lw = [&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;          // 0..47: segment g / 8 (layer = segment / 2), k-step g % 8
-            if constexpr (g < 48) {
-                constexpr int layer = g / 16, ks = g % 8;
-                constexpr uint32_t base = (uint32_t)(layer == 0 ? hoff_1(PE_C) : layer == 1 ? hoff_2(PE_C) : hoff_3a(PE_C)) * 16u;
-                lwh[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks));
-                lwl[g % LS] = *reinterpret_cast<const h8*>(lwb + (base + lw_off + 2048u * ks + 1024u));
-            }
-        };
-        static_for<0, LD>([&](auto gc) { load_lw(gc); });
-        // EPI: 0 none, 1 ReLU + split + store rows `emt` of act (columns of N-tile wv), 2 hsum[emt] += relu
-        auto segment = [&](auto sc_, auto ec, f32x16& A, f32x16& Bc, const f32x16& src) __attribute__((always_inline)) {
-            constexpr int seg = decltype(sc_)::value, mt = seg & 1, EPI = decltype(ec)::value, emt = mt ^ 1;
-            h8 bh[2], bl[2];
-            if constexpr (NEO_TP_HP_BPF) {
-                const int o = chunk_off<128>(mt * 32 + L.l31, L.half);
-                bh[0] = *reinterpret_cast<const h8*>(act.hi + o);
-                bl[0] = *reinterpret_cast<const h8*>(act.lo + o);
-            }
-            h4 th, tl;
-            static_for<0, 8>([&](auto kc) {
-                constexpr int ks = decltype(kc)::value, g = seg * 8 + ks;
-                if constexpr (NEO_TP_HP_BPF ? ks < 7 : true) {
-                    constexpr int kr = NEO_TP_HP_BPF ? ks + 1 : ks;
-                    const int o = chunk_off<128>(mt * 32 + L.l31, (kr << 1) + L.half);
-                    bh[kr & 1] = *reinterpret_cast<const h8*>(act.hi + o);
-                    bl[kr & 1] = *reinterpret_cast<const h8*>(act.lo + o);
-                }
-                A = NEO_MFMA_H(lwh[g % LS], bh[ks & 1], A);
-                if constexpr (EPI == 1) {
-                    constexpr int gq = ks >> 1, e0 = 2 * (ks & 1);
-#pragma unroll
-                    for (int e = e0; e < e0 + 2; ++e) {
-                        const float x = fmaxf(src[4 * gq + e], 0.0f);
-                        range_see(L, x);
-                        _Float16 h, l;
-                        split(x, h, l);
-                        th[e] = h;
-                        tl[e] = l;
-                    }
-                } else if constexpr (EPI == 2) {
-                    hsum[emt][2 * ks] += fmaxf(src[2 * ks], 0.0f);
-                    hsum[emt][2 * ks + 1] += fmaxf(src[2 * ks + 1], 0.0f);
-                }
-                Bc = NEO_MFMA_H_LH(lwl[g % LS], bh[ks & 1], Bc);
-                Bc = NEO_MFMA_H_HL(lwh[g % LS], bl[ks & 1], Bc);
-                load_lw(std::integral_constant<int, g + LD>());
-                if constexpr (EPI == 1 && (ks & 1)) {
-                    constexpr int gq = ks >> 1;
-                    const int o = chunk_off<128>(emt * 32 + L.l31, L.wv * 4 + gq) + 4 * L.half;
-                    *reinterpret_cast<h4*>(act.hi + o) = th;
-                    *reinterpret_cast<h4*>(act.lo + o) = tl;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-#pragma unroll
-            for (int r = 0; r < 16; ++r) A[r] += Bc[r];
-        };
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        auto SG = [](auto c) { return c; };
-        f32x16 a0, a1, bq;
-        auto zero16 = [&](f32x16& z) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-        };
-        store_tile_h<true>(accx[0][0], act, L.wv, 0, L);                                        // S0
-        TP_SYNC();
-        bias_tile(a0, lbias + B_1, L.wv, L); zero16(bq);
-        segment(std::integral_constant<int, 0>(), I1(), a0, bq, accx[0][1]);                     // S1: L1(m0) | epi L0(m1)
-        TP_SYNC();
-        bias_tile(a1, lbias + B_1, L.wv, L); zero16(bq);
-        segment(std::integral_constant<int, 1>(), I1(), a1, bq, a0);                             // S2: L1(m1) | epi L1(m0)
-        TP_SYNC();
-        bias_tile(a0, lbias + B_2, L.wv, L); zero16(bq);
-        segment(std::integral_constant<int, 2>(), I1(), a0, bq, a1);                             // S3: L2(m0) | epi L1(m1)
-        TP_SYNC();
-        bias_tile(a1, lbias + B_2, L.wv, L); zero16(bq);
-        segment(std::integral_constant<int, 3>(), I1(), a1, bq, a0);                             // S4: L2(m1) | epi L2(m0)
-        TP_SYNC();
-        zero16(bq);
-        segment(std::integral_constant<int, 4>(), I1(), accx[1][0], bq, a1);                     // S5: L3(m0) = skip half + W3a h2 | epi L2(m1)
-        TP_SYNC();
-        zero16(bq);
-        segment(std::integral_constant<int, 5>(), I2(), accx[1][1], bq, accx[1][0]);             // S6: L3(m1) | sum_v relu(L3)(m0)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hsum[1][r] += fmaxf(accx[1][1][r], 0.0f);
-        (void)SG;
-#elif NEO_TP_LSTREAM
         // ---- L0 epilogue; L1, L2, L3 as ONE weight stream of 24 k-steps (N-tile = wave) requested LD k-steps ahead
         //      across the layer boundaries: the weights of the next layer do not wait for the barriers ----
-        constexpr int LD = NEO_TP_LSTREAM, LS = LD + 1;
+        constexpr int LD = 4, LS = LD + 1;
         h8 lwh[LS], lwl[LS];
         const char* lwb = reinterpret_cast<const char*>(wp);
         const uint32_t lw_off = (uint32_t)(L.wv * 8 * 128 + L.lane) * 16u;
@@ -835,22 +440,13 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
         store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
         TP_SYNC();
-        if (NEO_TP_PRIO) __builtin_amdgcn_s_setprio(NEO_TP_PRIO);      // L1..L3: this wave issues almost only MFMAs
         static_for<0, 24>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int layer = g / 8, ks = g % 8;
             if constexpr (ks == 0) {
                 if constexpr (layer < 2) {
                     bias_tile(acc[0][0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
-#if NEO_TP_BIAS2 && NEO_TP_LDS_BIAS
-                    {
-                        int z = 0;
-                        asm volatile("" : "+v"(z));
-                        bias_tile(acc[0][1], lbias + (layer == 0 ? B_1 : B_2) + z, L.wv, L);
-                    }
-#else
                     acc[0][1] = acc[0][0];
-#endif
                 } else {
                     acc[0][0] = accx[1][0];
                     acc[0][1] = accx[1][1];
@@ -886,37 +482,6 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (NEO_TP_PRIO) __builtin_amdgcn_s_setprio(0);
-#else
-        // ---- L0 epilogue, L1, L2 ----
-        f32x16 acc[1][2];
-        if (!(NEO_TP_ABLATE & 128)) {
-            store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
-            store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
-        }
-        TP_SYNC();
-#pragma unroll 1
-        for (int layer = 0; layer < 2; ++layer) {
-            bias_tile(acc[0][0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
-            acc[0][1] = acc[0][0];
-            if (!(NEO_TP_ABLATE & 16)) gemm2h<1, 128>(acc, wp + (layer == 0 ? hoff_1(PE_C) : hoff_2(PE_C)), 8, nts_1, 0, 0, 8, act, L);
-            TP_SYNC();
-            if (!(NEO_TP_ABLATE & 128)) {
-                store_tile_h<true>(acc[0][0], act, L.wv, 0, L);
-                store_tile_h<true>(acc[0][1], act, L.wv, 1, L);
-            }
-            TP_SYNC();
-        }
-        // ---- L3 = skip half (in accx[1]) + W3[:, :128] h2; ReLU; accumulate over the views ----
-        acc[0][0] = accx[1][0];
-        acc[0][1] = accx[1][1];
-        if (!(NEO_TP_ABLATE & 16)) gemm2h<1, 128>(acc, wp + hoff_3a(PE_C), 8, nts_1, 0, 0, 8, act, L);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            hsum[0][r] += fmaxf(acc[0][0][r], 0.0f);
-            hsum[1][r] += fmaxf(acc[0][1][r], 0.0f);
-        }
-#endif
         TP_SYNC();           // every wave is done reading this view's tiles
         TP_MARK(5);
     }
@@ -955,12 +520,11 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
         sg += __shfl_xor(sg, 2, 64);
         raw_sigma = sg + lheads[HD_DB];
     }
-#if NEO_TP_FOLDB
     // ---- tail GEMMs as one weight stream of 14 k-steps, TD ahead across the stage boundary: view layer 0 WITH THE BOTTLENECK FOLDED
     //      IN (tp_hp_layout.h) on [mean trunk | mean dir enc] (N-tile vnt, M-tile vmt, 8 + 2 k-steps), then 64 x 64 (4 k-steps) ----
     {
         const char* twb = reinterpret_cast<const char*>(wp);
-        constexpr int TD = NEO_TP_TSTREAM ? NEO_TP_TSTREAM : 6, TS = TD + 1;
+        constexpr int TD = 6, TS = TD + 1;
         h8 twh[TS], twl[TS];
         auto load_t = [&](auto gc) __attribute__((always_inline)) {
             constexpr int g = decltype(gc)::value;
@@ -1007,111 +571,6 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
             __builtin_amdgcn_sched_barrier(0);
         });
     }
-#elif NEO_TP_TSTREAM
-    // ---- tail GEMMs as one weight stream of 22 k-steps, TD ahead across the stage boundaries:
-    //      bottleneck of the view mean (N-tile cw, 8 k-steps, both M-tiles), view layer 0 on [mean bottleneck | mean dir enc]
-    //      (N-tile vnt, M-tile vmt, 8 + 2 k-steps), 64 x 64 (4 k-steps) ----
-    {
-        const char* twb = reinterpret_cast<const char*>(wp);
-        constexpr int TD = NEO_TP_TSTREAM, TS = TD + 1;
-        h8 twh[TS], twl[TS];
-        auto load_t = [&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;
-            if constexpr (g < 22) {
-                constexpr int stage = g < 8 ? 0 : g < 18 ? 1 : 2;
-                constexpr int ks = stage == 0 ? g : stage == 1 ? g - 8 : g - 18;
-                constexpr int KS = stage == 0 ? 8 : stage == 1 ? 10 : 4;
-                constexpr uint32_t base = (uint32_t)(stage == 0 ? hoff_b(PE_C) : stage == 1 ? hoff_v0(PE_C) : hoff_v1(PE_C)) * 16u;
-                const int nt = stage == 0 ? L.wv : vnt;
-                const uint32_t off = base + (uint32_t)((nt * KS + ks) * 128 + L.lane) * 16u;
-                twh[g % TS] = *reinterpret_cast<const h8*>(twb + off);
-                twl[g % TS] = *reinterpret_cast<const h8*>(twb + off + 1024u);
-            }
-        };
-        static_for<0, TD>([&](auto gc) { load_t(gc); });
-        f32x16 acc2[2], y;
-        static_for<0, 22>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            load_t(std::integral_constant<int, g + TD>());
-            if constexpr (g < 8) {
-                if constexpr (g == 0) {
-                    bias_tile(acc2[0], lbias + B_B, L.wv, L);
-                    acc2[1] = acc2[0];
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int o = chunk_off<128>(mt * 32 + L.l31, (g << 1) + L.half);
-                    const h8 bh = *reinterpret_cast<const h8*>(act.hi + o);
-                    const h8 bl = *reinterpret_cast<const h8*>(act.lo + o);
-                    acc2[mt] = NEO_MFMA_H_LH(twl[g % TS], bh, acc2[mt]);
-                    acc2[mt] = NEO_MFMA_H_HL(twh[g % TS], bl, acc2[mt]);
-                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bh, acc2[mt]);
-                }
-                if constexpr (g == 7) {
-                    TP_SYNC();
-                    store_tile_h<false>(acc2[0], act, L.wv, 0, L);
-                    store_tile_h<false>(acc2[1], act, L.wv, 1, L);
-                    TP_SYNC();
-                }
-            } else {
-                constexpr bool v0 = g < 18;
-                constexpr int ks = v0 ? g - 8 : g - 18;
-                if constexpr (ks == 0) bias_tile(y, lbias + (v0 ? B_V0 : B_V1), vnt, L);
-                h8 bh, bl;
-                if constexpr (v0 && ks >= 8) {
-                    const int o = chunk_off<32>(vmt * 32 + L.l31, ((ks - 8) << 1) + L.half);
-                    bh = *reinterpret_cast<const h8*>(dsm.hi + o);
-                    bl = *reinterpret_cast<const h8*>(dsm.lo + o);
-                } else {
-                    const int o = chunk_off<128>(vmt * 32 + L.l31, (ks << 1) + L.half);
-                    bh = *reinterpret_cast<const h8*>(act.hi + o);
-                    bl = *reinterpret_cast<const h8*>(act.lo + o);
-                }
-                y = NEO_MFMA_H_LH(twl[g % TS], bh, y);
-                y = NEO_MFMA_H_HL(twh[g % TS], bl, y);
-                y = NEO_MFMA_H(twh[g % TS], bh, y);
-                if constexpr (g == 17) {
-                    TP_SYNC();
-                    store_tile_h<true>(y, act, vnt, vmt, L);
-                    TP_SYNC();
-                }
-                if constexpr (g == 21) {
-                    TP_SYNC();
-                    store_tile_h<true>(y, act, vnt, vmt, L);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
-#else
-    // ---- bottleneck of the view mean (no activation) ----
-    {
-        f32x16 acc[1][2];
-        bias_tile(acc[0][0], lbias + B_B, L.wv, L);
-        acc[0][1] = acc[0][0];
-        gemm2h<1, 128>(acc, wp + hoff_b(PE_C), 8, nts_1, 0, 0, 8, act, L);
-        TP_SYNC();
-        store_tile_h<false>(acc[0][0], act, L.wv, 0, L);
-        store_tile_h<false>(acc[0][1], act, L.wv, 1, L);
-        TP_SYNC();
-    }
-    // ---- view layer 0 on [mean bottleneck | mean dir enc] -> 64 ----
-    f32x16 ysum;
-    bias_tile(ysum, lbias + B_V0, vnt, L);
-    gemm1h<128>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 0, 8, act, L);
-    gemm1h<32>(ysum, wp + hoff_v0(PE_C), 10, vnt, vmt, 8, 2, dsm, L);
-    TP_SYNC();
-    // ---- ReLU -> 64x64 -> ReLU -> rgb head ----
-    store_tile_h<true>(ysum, act, vnt, vmt, L);
-    TP_SYNC();
-    {
-        f32x16 y;
-        bias_tile(y, lbias + B_V1, vnt, L);
-        gemm1h<128>(y, wp + hoff_v1(PE_C), 4, vnt, vmt, 0, 4, act, L);
-        TP_SYNC();
-        store_tile_h<true>(y, act, vnt, vmt, L);
-    }
-#endif
     TP_SYNC();
     {
         const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;
@@ -1141,7 +600,6 @@ __global__ __launch_bounds__(256, NEO_TP_WPS) void k_tp_mlp_hp(TpMlpHDev m, cons
                                   colour_act(b + lheads[HD_RB + 2]), density_act(raw_sigma));
         }
     }
-    TP_STAMP();
 #if NEO_TP_TRACE
     TP_MARK(6);
     if (threadIdx.x == 0) {
@@ -1248,15 +706,6 @@ __global__ __launch_bounds__(256, 2) void k_tp_preproject(const float* __restric
 
 }  // namespace
 
-#if NEO_TP_TIMELINE
-extern "C" void neo_debug_tp_stamps(unsigned long long* host4096, int block) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(g_tp_stamps), sizeof(unsigned long long) * 4096);
-    unsigned long long z[4096] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tp_stamps), z, sizeof(z));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tp_stamp_block), &block, sizeof(int));
-}
-#endif
 #if NEO_TP_TRACE
 extern "C" void neo_debug_tp_trace(unsigned long long* host16, int reset) {
     (void)hipDeviceSynchronize();
@@ -1279,13 +728,8 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, const float* const* 
     // w / b order: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
     // biases of the pre-projected evaluators = the shared bias block with view layer 0's entry replaced by the folded one
     (void)hipMemcpyAsync(bias_hp, bias_src, 768 * sizeof(float), hipMemcpyDeviceToDevice, s);
-#if NEO_TP_FOLDB
     launch_fold_bottleneck(w[4], w[6], b[6], b[4], 64, 128, 128, 27, fold_ws, bias_hp + B_V0, s);
     const float* w_v0 = fold_ws;
-#else
-    (void)fold_ws; (void)b;
-    const float* w_v0 = w[4];
-#endif
     _Float16* base = reinterpret_cast<_Float16*>(wpack_hp);
     const int pe = input_ch * 21;
     const int x0w = pe + 512 + 128;
@@ -1298,13 +742,8 @@ void launch_tp_pack_hp(int input_ch, const float* const* w, const float* const* 
     PackPerm px;
     for (int k = 0; k < 256; ++k) px.col[k] = -1;
     for (int k = 0; k < 128; ++k) px.col[k] = (short)(pe + 512 + k);
-#if NEO_PE_PAIR2
-    // doubling order (tp_hp_layout.h:pe2_source_column): half-chunks of two consecutive octaves of one coordinate
-    for (int j = 0; j < pe_ksteps(C) * 16; ++j) px.col[128 + j] = (short)pe2_source_column(C, j);
-#else
     for (int j = 0; j < 20 * C; ++j) px.col[128 + j] = (short)(C + ((j & 1) ? 10 * C : 0) + (j >> 1));
     for (int a = 0; a < C; ++a) px.col[128 + 20 * C + a] = (short)a;
-#endif
     pack_h_perm(w[0], x0w, 128, ksx, 0, px, base + (long)hoff_x() * 8, s);
     PackPerm px3 = px;
     for (int k = 0; k < 256; ++k)
@@ -1358,7 +797,7 @@ void launch_tp_mlp_hp(int input_ch, const TpMlpHDev& m, const float* proj, const
         const char* e = getenv("NEO_TP_LDS_PAD");
         lds_pad = e ? (size_t)atol(e) : 0;
     }
-    const size_t lds = (tp::LDS_WORDS + (NEO_TP_LDS_BIAS ? 768 + 336 : 0) + (NEO_TP_PLCACHE ? 4 * PLC_WAVE_WORDS : 0)) * sizeof(float) + lds_pad;
+    const size_t lds = (tp::LDS_WORDS + 768 + 336) * sizeof(float) + lds_pad;
     if (lds > 65536) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_mlp_hp<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -19,8 +19,7 @@
 // sphere that is the normal case - so per tile-view the kernel lists the (row group, map) pairs in which ANY row carries a
 // weight (6 of 16 on average outside the sphere, 14 inside: tools/footprint_study.py) and the pipeline runs over that list,
 // padded to a multiple of RING with zero-weight entries so the ring slots stay compile-time constants; every load of the
-// loop is unconditional, so its s_waitcnt bookkeeping stays exact.  NEO_TPP_WORKLIST=0: the round-4 first version, four
-// compile-time pipelines (all maps / planes / latent / none) chosen per tile-view.
+// loop is unconditional, so its s_waitcnt bookkeeping stays exact.
 // The only matrix work left before the L0 epilogue - the pos_enc k-steps (4 inside / 6 outside the sphere) - is issued
 // between the chunks.  L1, L2, L3, view-mean linearity and the heads are those of mlp_tp_hp.hip.
 #include <hip/hip_fp16.h>
@@ -45,21 +44,6 @@
 #endif
 #ifndef NEO_TPP_TD
 #define NEO_TPP_TD 6           // tail weight stream prefetch distance
-#endif
-#ifndef NEO_TPP_WORKLIST
-#define NEO_TPP_WORKLIST 1     // gather pipeline over the list of (row group, map) pairs that carry weight (0: whole-map variants)
-#endif
-#ifndef NEO_TPP_SKIPEMPTY
-#define NEO_TPP_SKIPEMPTY 3    // work list: a tile-view in which NO tap of any map carries weight (21 % of the fine tile-views outside the sphere) skips the gather and the adds.  1: the whole gather under one branch, pos_enc k-steps in front of it; 3: zero-trip gather loops, k-steps stay between the chunks; 0: off
-#endif
-#ifndef NEO_TPP_PE_WCACHE
-#define NEO_TPP_PE_WCACHE 0    // outside the sphere the 4th encoded coordinate is 1 / r, the same in every source view: its 10 (sin, cos) pairs are computed for view 0 only
-#endif
-#ifndef NEO_TPP_ZSKIP
-#define NEO_TPP_ZSKIP 1        // gather only the maps in which some row of the tile has a weighted tap (latent / planes)
-#endif
-#ifndef NEO_TPP_MMA_INSIDE
-#define NEO_TPP_MMA_INSIDE 2   // pos_enc k-steps: 1 between the gather items of every pipeline variant, 2 only inside the all-maps pipeline (after the pipeline otherwise), 0 always after the pipeline
 #endif
 #define TPP_SYNC() __syncthreads()
 #ifndef NEO_TP_TRACE
@@ -127,7 +111,6 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
     [[maybe_unused]] int* loc_off = S.loc_off;
     float* loc_w = S.loc_w;
     [[maybe_unused]] int* pl_off = S.pl_off;
-    float* pl_w = S.pl_w;
 
     LaneCtx L;
     L.init();
@@ -197,12 +180,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 const int ch = pstage * 8 + chs;               // chunk of the whole encoding
                 float f[8];
                 h8 vh, vl;
-#if NEO_PE_PAIR2
-                pe2_chunk<PE_C>(xv, ch, vh, vl, L);             // doubling order (tp_hp_layout.h): two octaves of one coordinate per half-chunk
-                if (false) {
-#else
                 if (ch * 4 < 10 * PE_C) {                      // pairs (C = 3: chunk 7 holds pairs 28, 29 and the identity features)
-#endif
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
                         if (PE_C == 3 && jj >= 2 && ch == 7) {  // pairs 30, 31 do not exist: positions 60..63 = x, y, z, 0
@@ -214,9 +192,6 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         float x;
                         int oct;
                         if constexpr (PE_C == 4) {
-                            // coordinate 3 = 1 / r does not depend on the source view: its pairs are computed for view 0 and stay
-                            // in the tile (the later views store only the first 12 bytes of a chunk)
-                            if (NEO_TPP_PE_WCACHE && jj == 3 && v > 0) { f[6] = 0.0f; f[7] = 0.0f; continue; }
                             x = xv[jj];
                             oct = ch;
                         } else {
@@ -227,7 +202,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         }
                         sincos_pair(ldexpf(x, oct), f[2 * jj], f[2 * jj + 1]);
                     }
-                } else if (!NEO_PE_PAIR2) {                     // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
+                } else {                                        // C = 4: chunk 10 = x, y, z, 1/r; chunk 11 = padding
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = 0.0f;
                     if (ch * 4 == 10 * PE_C) {
@@ -235,7 +210,6 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         f[0] = xv[0]; f[1] = xv[1]; f[2] = xv[2]; f[3] = xv[3];
                     }
                 }
-#if !NEO_PE_PAIR2
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     h2 h, l;
@@ -243,20 +217,9 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                     vh[e] = h[0]; vh[e + 1] = h[1];
                     vl[e] = l[0]; vl[e + 1] = l[1];
                 }
-#else
-                (void)f;
-#endif
                 const int o = chunk_off<LDH>(row, chs);
-                if (NEO_TPP_PE_WCACHE && PE_C == 4 && v > 0 && ch * 4 < 10 * PE_C) {      // an octave chunk of a later view: x, y, z pairs only
-                    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 ph = __builtin_bit_cast(u32x4, vh), pl = __builtin_bit_cast(u32x4, vl);
-                    *reinterpret_cast<u32x3*>(buf.hi + o) = u32x3{ph[0], ph[1], ph[2]};
-                    *reinterpret_cast<u32x3*>(buf.lo + o) = u32x3{pl[0], pl[1], pl[2]};
-                } else {
-                    *reinterpret_cast<h8*>(buf.hi + o) = vh;
-                    *reinterpret_cast<h8*>(buf.lo + o) = vl;
-                }
+                *reinterpret_cast<h8*>(buf.hi + o) = vh;
+                *reinterpret_cast<h8*>(buf.lo + o) = vl;
             };
             pe_chunk(std::integral_constant<int, 64>(), xpe0, 0, 0);
             pe_chunk(std::integral_constant<int, 64>(), xpe0, 0, 1);
@@ -264,46 +227,14 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
         }
         TPP_SYNC();
         TPP_MARK(1);
-#if NEO_TPP_WORKLIST
         // (the work list below decides per (row group, map) what is gathered)
-#elif NEO_TPP_ZSKIP
-        // Which maps carry any weight for this tile (samples outside a feature map blend to exactly zero: grid_sample's zero
-        // padding).  Outside the unit sphere the far samples project outside every source image (71 % of the fine tile-views
-        // have no weighted latent tap) and often outside the tri-plane volume as well (21 %): profiles/r03_tile_footprint.json.
-        bool any_latent, any_plane;
-        {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(loc_w + L.lane * 4);
-            any_latent = __ballot(w0[0] != 0.0f || w0[1] != 0.0f || w0[2] != 0.0f || w0[3] != 0.0f) != 0ull;
-            unsigned long long zp = 0ull;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4 wj = *reinterpret_cast<const f32x4*>(pl_w + (j * TM + L.lane) * 4);
-                zp |= __ballot(wj[0] != 0.0f || wj[1] != 0.0f || wj[2] != 0.0f || wj[3] != 0.0f);
-            }
-            any_plane = zp != 0ull;
-        }
-#else
-        const bool any_latent = true, any_plane = true;
-#endif
 
         // ---- [L0 | L3 skip half] pre-activations: bias + four pre-projected maps (adds) + pos_enc GEMM ----
         f32x16 accx[2][2];
-#ifndef NEO_TP_BIAS2
-#define NEO_TP_BIAS2 0        // the second M-tile's accumulators from a second LDS read of the biases instead of 16 register copies (mlp_tp_hp.hip)
-#endif
         bias_tile(accx[0][0], lbias + B_0, L.wv, L);
         bias_tile(accx[1][0], lbias + B_3, L.wv, L);
-#if NEO_TP_BIAS2
-        {
-            int z = 0;                               // an opaque zero: without it the compiler merges the two reads and copies registers
-            asm volatile("" : "+v"(z));
-            bias_tile(accx[0][1], lbias + B_0 + z, L.wv, L);
-            bias_tile(accx[1][1], lbias + B_3 + z, L.wv, L);
-        }
-#else
         accx[0][1] = accx[0][0];
         accx[1][1] = accx[1][0];
-#endif
         {
             const int col4 = tid & 15, rg = tid >> 4;
             const uint32_t lane_b = 16u * col4;
@@ -311,9 +242,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             f32x4 wsum;                                    // running sum over the maps of one (chunk, row group)
             int4 d_off[RING];                              // tap byte offsets of the item REQUESTED next (slot = item & 1; work list: entry % 3)
             [[maybe_unused]] f32x4 d_w[2];                 // tap weights of the item BLENDED next
-#if NEO_TPP_WORKLIST
             f32x4 d_w3[RING];                              // (work-list pipeline: slot = entry % 3, like the taps)
-#endif
             // pos_enc weight fragments: k-steps 8..8+KSP-1 of N-tiles wv (L0) and 4 + wv (L3 skip) of the packed streamed stage
             constexpr int XD = NEO_TPP_XD, XS = XD + 1;
             h8 wh[XS][2], wl[XS][2];
@@ -372,7 +301,6 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                         for (int e = 0; e < 4; ++e) accx[c >> 1][mt][4 * (g0 + gg) + e] += val[e];
                     }
             };
-#if NEO_TPP_WORKLIST
             static_assert(RING == 3 && LIST_MAX % RING == 0, "the work-list pipeline is written for a ring of three");
             // ---- the work list of this tile-view.  Every wave builds its own copy (identical in all four: no barrier). ----
             int n_p;                                         // entries incl. padding: a multiple of RING, 6..18 (wave-uniform)
@@ -388,7 +316,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
 #pragma unroll
                     for (int q = 0; q < 4; ++q) am |= (((z >> (16 * q)) & 0xFFFFull) != 0ull ? 1u : 0u) << (4 * q + mp);
                 }
-                any_w = !NEO_TPP_SKIPEMPTY || am != 0u;
+                any_w = am != 0u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)                  // an empty group keeps ONE entry: the latent's all-zero weights blend
                     if (((am >> (4 * q)) & 0xFu) == 0u) am |= 1u << (4 * q);      // to the zeros the group's rows must receive
@@ -473,125 +401,22 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 if (fin[j].w) *reinterpret_cast<f32x4*>(fstore + (c & 1) * (TM * 64) + fin[j].y * 64) = wsum;
                 __builtin_amdgcn_sched_barrier(0);          // keep the ring RING entries deep: no hoisting of later entries' loads
             };
-#if NEO_TPP_SKIPEMPTY == 1
-            // the pos_enc k-steps in one block, outside any branch (an MFMA on the 64 accumulator registers inside a branch makes
-            // the allocator spill them: profiles/r03_tp_hp_experiments.log); the first two entries' taps are already on their way
-            static_for<0, KSP>([&](auto kc) { mma_k(kc); });
-            if (any_w)
-#elif NEO_TPP_SKIPEMPTY == 2
-            if (!any_w) static_for<0, KSP>([&](auto kc) { mma_k(kc); });       // (experiment: MFMAs in both branches -> 86 / 106 spills)
-            else
-#elif NEO_TPP_SKIPEMPTY == 3
             // an empty tile-view runs the same code with a zero-trip gather loop and without the adds: the pos_enc k-steps keep
             // their places between the chunks and stay outside any branch (the barriers stay too: four cheap ones per view)
             if (!any_w) n_p = 0;
-#endif
             static_for<0, 4>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-#if NEO_TPP_SKIPEMPTY != 1
                 // this chunk's share of the pos_enc k-steps (KSP = 4: one per chunk; 6: 2, 1, 2, 1)
                 static_for<0, KSP>([&](auto kc) {
                     constexpr int kp = decltype(kc)::value;
                     if constexpr ((KSP == 4 ? kp : (kp < 2 ? 0 : kp < 3 ? 1 : kp < 5 ? 2 : 3)) == c) mma_k(kc);
                 });
-#endif
 #pragma unroll 1
                 for (int k = 0; k < n_p; k += RING) static_for<0, RING>([&](auto jc) { step(cc, jc, k); });
                 TPP_SYNC();
-#if NEO_TPP_SKIPEMPTY == 3
                 if (any_w)
-#endif
                 consume_chunk(cc);
             });
-#else
-            // The pipeline for a compile-time set of maps: MASK bit 0 = latent, bit 1 = the three planes.  G maps per
-            // (chunk, row group); item i: group i / G (chunk = group / 4, row group = group % 4), member i % G.
-            auto pipeline = [&](auto mc) __attribute__((always_inline)) {
-                constexpr int MASK = decltype(mc)::value;
-                constexpr int G = (MASK & 1) + 3 * ((MASK >> 1) & 1);
-                constexpr int NI = 16 * G;
-                // pos_enc k-step kp is issued before item mma_item(kp)
-                auto mma_here = [&](auto ic) __attribute__((always_inline)) {
-                    constexpr int i = decltype(ic)::value;
-                    if constexpr ((NEO_TPP_MMA_INSIDE == 1 || (NEO_TPP_MMA_INSIDE == 2 && MASK == 3)) && NI > 0) {
-                        static_for<0, KSP>([&](auto kc) {
-                            constexpr int kp = decltype(kc)::value;
-                            if constexpr (i == ((2 * kp + 1) * NI) / (2 * KSP) + (NI >= 48 ? 2 : 0)) mma_k(kc);
-                        });
-                    }
-                };
-                if constexpr (NI > 0) {
-                    auto map_of = [](int i) constexpr { return (MASK & 1) ? i % G : i % G + 1; };      // 0 latent, 1..3 planes
-                    auto desc_index = [&](auto ic) __attribute__((always_inline)) {
-                        constexpr int i = decltype(ic)::value;
-                        constexpr int mp = map_of(i), q = (i / G) % 4;
-                        if constexpr (mp == 0) return (rg + 16 * q) * 4;
-                        else return ((mp - 1) * TM + rg + 16 * q) * 4;
-                    };
-                    auto fetch_off = [&](auto ic) __attribute__((always_inline)) {
-                        constexpr int i = decltype(ic)::value;
-                        if constexpr (i < NI) {
-                            if constexpr (map_of(i) == 0) d_off[i & 1] = *reinterpret_cast<const int4*>(loc_off + desc_index(ic));
-                            else d_off[i & 1] = *reinterpret_cast<const int4*>(pl_off + desc_index(ic));
-                        }
-                    };
-                    auto fetch_w = [&](auto ic) __attribute__((always_inline)) {
-                        constexpr int i = decltype(ic)::value;
-                        if constexpr (i < NI) {
-                            if constexpr (map_of(i) == 0) d_w[i & 1] = *reinterpret_cast<const f32x4*>(loc_w + desc_index(ic));
-                            else d_w[i & 1] = *reinterpret_cast<const f32x4*>(pl_w + desc_index(ic));
-                        }
-                    };
-                    auto issue = [&](auto ic) __attribute__((always_inline)) {
-                        constexpr int i = decltype(ic)::value;
-                        if constexpr (i < NI) {
-                            constexpr int mp = map_of(i), c = i / (4 * G);
-                            const float* base = proj;          // one buffer: the descriptors carry each map's base
-                            const int4 off = d_off[i & 1];
-                            taps[i % RING][0] = tp::load_tap(base, (uint32_t)off.x + lane_b + 256u * c);
-                            taps[i % RING][1] = tp::load_tap(base, (uint32_t)off.y + lane_b + 256u * c);
-                            taps[i % RING][2] = tp::load_tap(base, (uint32_t)off.z + lane_b + 256u * c);
-                            taps[i % RING][3] = tp::load_tap(base, (uint32_t)off.w + lane_b + 256u * c);
-                        }
-                    };
-                    auto finish = [&](auto ic) __attribute__((always_inline)) {
-                        constexpr int i = decltype(ic)::value;
-                        constexpr int k = i % G, c = i / (4 * G), q = (i / G) % 4;
-                        const f32x4 val = blend4(taps[i % RING], d_w[i & 1]);
-                        if constexpr (k == 0) wsum = val; else wsum = wsum + val;
-                        if constexpr (k == G - 1) {
-                            const int row = rg + 16 * q;
-                            *reinterpret_cast<f32x4*>(fbuf(c & 1) + row * 64 + ((col4 ^ (row & 15)) << 2)) = wsum;
-                        }
-                    };
-                    static_for<0, RING - 1>([&](auto ic) { fetch_off(ic); issue(ic); });
-                    fetch_off(std::integral_constant<int, RING - 1>());
-                    fetch_w(std::integral_constant<int, 0>());
-                    static_for<0, NI>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        // descriptors one item ahead: offsets of the item requested in the NEXT pass, weights of the item blended in it
-                        fetch_off(std::integral_constant<int, i + RING>());
-                        fetch_w(std::integral_constant<int, i + 1>());
-                        issue(std::integral_constant<int, i + RING - 1>());
-                        if constexpr (i % (4 * G) == 0 && i > 0) consume_chunk(std::integral_constant<int, i / (4 * G) - 1>());
-                        mma_here(ic);
-                        finish(ic);
-                        __builtin_amdgcn_sched_barrier(0);      // keep the ring RING items deep: no hoisting of later items' loads
-                        if constexpr (i % (4 * G) == 4 * G - 1) TPP_SYNC();
-                    });
-                    consume_chunk(std::integral_constant<int, 3>());
-                }
-                if constexpr (NEO_TPP_MMA_INSIDE == 1 && NI == 0) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
-            };
-            static_for<0, XD>([&](auto kc) { load_wk(kc); });
-            if (any_latent && any_plane) pipeline(std::integral_constant<int, 3>());
-            else if (any_plane) pipeline(std::integral_constant<int, 2>());
-            else if (any_latent) pipeline(std::integral_constant<int, 1>());
-            else pipeline(std::integral_constant<int, 0>());
-            if constexpr (NEO_TPP_MMA_INSIDE == 0) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
-            if constexpr (NEO_TPP_MMA_INSIDE == 2)
-                if (!(any_latent && any_plane)) static_for<0, KSP>([&](auto kc) { mma_k(kc); });
-#endif
         }
         TPP_SYNC();          // the transposition tiles alias the activation tile: every wave has consumed the last chunk
         TPP_MARK(3);
@@ -616,22 +441,13 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             store_tile_h<true>(accx[0][0], act, L.wv, 0, L);
             store_tile_h<true>(accx[0][1], act, L.wv, 1, L);
             TPP_SYNC();
-            if (NEO_TP_PRIO) __builtin_amdgcn_s_setprio(NEO_TP_PRIO);      // L1..L3: this wave issues almost only MFMAs
             static_for<0, 24>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 constexpr int layer = g / 8, ks = g % 8;
                 if constexpr (ks == 0) {
                     if constexpr (layer < 2) {
                         bias_tile(acc[0], lbias + (layer == 0 ? B_1 : B_2), L.wv, L);
-#if NEO_TP_BIAS2
-                        {
-                            int z = 0;
-                            asm volatile("" : "+v"(z));
-                            bias_tile(acc[1], lbias + (layer == 0 ? B_1 : B_2) + z, L.wv, L);
-                        }
-#else
                         acc[1] = acc[0];
-#endif
                     } else {
                         acc[0] = accx[1][0];
                         acc[1] = accx[1][1];
@@ -667,7 +483,6 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if (NEO_TP_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         TPP_SYNC();           // every wave is done reading this view's tiles
         TPP_MARK(4);
@@ -707,7 +522,6 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
         sg += __shfl_xor(sg, 2, 64);
         raw_sigma = sg + lheads[HD_DB];
     }
-#if NEO_TP_FOLDB
     // ---- tail GEMMs as one weight stream of 14 k-steps, TD ahead across the stage boundary: view layer 0 WITH THE BOTTLENECK FOLDED
     //      IN (tp_hp_layout.h) on [mean trunk | mean dir enc] (N-tile vnt, M-tile vmt, 8 + 2 k-steps), then 64 x 64 (4 k-steps) ----
     {
@@ -759,83 +573,6 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
             __builtin_amdgcn_sched_barrier(0);
         });
     }
-#else
-    // ---- tail GEMMs as one weight stream of 22 k-steps, TD ahead across the stage boundaries:
-    //      bottleneck of the view mean (N-tile wave, 8 k-steps, both M-tiles), view layer 0 on [mean bottleneck | mean dir enc]
-    //      (N-tile vnt, M-tile vmt, 8 + 2 k-steps), 64 x 64 (4 k-steps) ----
-    {
-        const char* twb = reinterpret_cast<const char*>(wp);
-        constexpr int TD = NEO_TPP_TD, TS = TD + 1;
-        h8 twh[TS], twl[TS];
-        auto load_t = [&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;
-            if constexpr (g < 22) {
-                constexpr int stage = g < 8 ? 0 : g < 18 ? 1 : 2;
-                constexpr int ks = stage == 0 ? g : stage == 1 ? g - 8 : g - 18;
-                constexpr int KS = stage == 0 ? 8 : stage == 1 ? 10 : 4;
-                constexpr uint32_t base = (uint32_t)(stage == 0 ? hoff_b(PE_C) : stage == 1 ? hoff_v0(PE_C) : hoff_v1(PE_C)) * 16u;
-                const int nt = stage == 0 ? L.wv : vnt;
-                const uint32_t off = base + (uint32_t)((nt * KS + ks) * 128 + L.lane) * 16u;
-                twh[g % TS] = *reinterpret_cast<const h8*>(twb + off);
-                twl[g % TS] = *reinterpret_cast<const h8*>(twb + off + 1024u);
-            }
-        };
-        static_for<0, TD>([&](auto gc) { load_t(gc); });
-        f32x16 acc2[2], y;
-        static_for<0, 22>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            load_t(std::integral_constant<int, g + TD>());
-            if constexpr (g < 8) {
-                if constexpr (g == 0) {
-                    bias_tile(acc2[0], lbias + B_B, L.wv, L);
-                    acc2[1] = acc2[0];
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int o = chunk_off<128>(mt * 32 + L.l31, (g << 1) + L.half);
-                    const h8 bh = *reinterpret_cast<const h8*>(act.hi + o);
-                    const h8 bl = *reinterpret_cast<const h8*>(act.lo + o);
-                    acc2[mt] = NEO_MFMA_H_LH(twl[g % TS], bh, acc2[mt]);
-                    acc2[mt] = NEO_MFMA_H_HL(twh[g % TS], bl, acc2[mt]);
-                    acc2[mt] = NEO_MFMA_H(twh[g % TS], bh, acc2[mt]);
-                }
-                if constexpr (g == 7) {
-                    TPP_SYNC();
-                    store_tile_h<false>(acc2[0], act, L.wv, 0, L);
-                    store_tile_h<false>(acc2[1], act, L.wv, 1, L);
-                    TPP_SYNC();
-                }
-            } else {
-                constexpr bool v0 = g < 18;
-                constexpr int ks = v0 ? g - 8 : g - 18;
-                if constexpr (ks == 0) bias_tile(y, lbias + (v0 ? B_V0 : B_V1), vnt, L);
-                h8 bh, bl;
-                if constexpr (v0 && ks >= 8) {
-                    const int o = chunk_off<32>(vmt * 32 + L.l31, ((ks - 8) << 1) + L.half);
-                    bh = *reinterpret_cast<const h8*>(dsm.hi + o);
-                    bl = *reinterpret_cast<const h8*>(dsm.lo + o);
-                } else {
-                    const int o = chunk_off<128>(vmt * 32 + L.l31, (ks << 1) + L.half);
-                    bh = *reinterpret_cast<const h8*>(act.hi + o);
-                    bl = *reinterpret_cast<const h8*>(act.lo + o);
-                }
-                y = NEO_MFMA_H_LH(twl[g % TS], bh, y);
-                y = NEO_MFMA_H_HL(twh[g % TS], bl, y);
-                y = NEO_MFMA_H(twh[g % TS], bh, y);
-                if constexpr (g == 17) {
-                    TPP_SYNC();
-                    store_tile_h<true>(y, act, vnt, vmt, L);
-                    TPP_SYNC();
-                }
-                if constexpr (g == 21) {
-                    TPP_SYNC();
-                    store_tile_h<true>(y, act, vnt, vmt, L);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
-#endif
     TPP_SYNC();
     {
         const int pt = L.wv * 16 + (L.lane >> 2), part = L.lane & 3;

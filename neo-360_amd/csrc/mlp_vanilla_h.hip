@@ -108,12 +108,6 @@ __device__ __forceinline__ void put_feat(const HTile& t, int p, int f, float v) 
 #ifndef NEO_VH_TILE_DEFAULT
 #define NEO_VH_TILE_DEFAULT 64   // points per workgroup: 64 (two workgroups per CU) or 128 (one; $NEO_VANILLA_H_TILE)
 #endif
-#ifndef NEO_VH_XLAYER
-#define NEO_VH_XLAYER 1        // the next stage's first weight fragments are requested before this stage's barrier
-#endif
-#ifndef NEO_VH_FOLDB
-#define NEO_VH_FOLDB 1         // the linear bottleneck is folded into the view layer at pack time (launch_vanilla_pack_h): no bottleneck stage
-#endif
 #ifndef NEO_VH_PREFETCH
 #define NEO_VH_PREFETCH 1      // weight fragments are requested this many k-steps ahead of their MFMAs
 #endif
@@ -218,9 +212,6 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NTW][MTW], const float* 
 // for a PAIR of chunks (g, g+1) so that lanes 0-31 own chunk g and lanes 32-63 chunk g+1 of their point: one
 // ds_write_b128 per plane and chunk pair, conflict-free under the XOR swizzle (the 8-byte form was 2-way conflicted:
 // rows r and r+16 of a 32-lane pass share banks).
-#ifndef NEO_VH_STORE128
-#define NEO_VH_STORE128 1
-#endif
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void swap_halves(u32x2& x, u32x2& y) {      // x[lanes 32-63] <-> y[lanes 0-31]
@@ -251,7 +242,6 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][MTW], const H
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-#if NEO_VH_STORE128
 #pragma unroll
             for (int gp = 0; gp < ((NEO_VH_ABLATE & 4) ? 1 : 2); ++gp) {
                 h4 h0, l0, h1, l1;
@@ -265,16 +255,6 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[NTW][MTW], const H
                 *reinterpret_cast<u32x4*>(act.hi + o) = u32x4{xh[0], xh[1], yh[0], yh[1]};
                 *reinterpret_cast<u32x4*>(act.lo + o) = u32x4{xl[0], xl[1], yl[0], yl[1]};
             }
-#else
-#pragma unroll
-            for (int g = 0; g < ((NEO_VH_ABLATE & 4) ? 1 : 4); ++g) {
-                h4 vh, vl;
-                split_quad<RELU>(acc[nt][mt], g, vh, vl, L);
-                const int o = chunk_off<ACT_LDH, 15>((mt0 + mt) * 32 + L.l31, (nt0 + nt) * 4 + g) + 4 * L.half;
-                *reinterpret_cast<h4*>(act.hi + o) = vh;
-                *reinterpret_cast<h4*>(act.lo + o) = vl;
-            }
-#endif
         }
 }
 
@@ -342,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
     f32x16 acc[NTW][MT];
     const int nt0 = L.wv * NTW;
     WRing<NTW> ring;
-    constexpr bool XL = NEO_VH_XLAYER != 0 && (16 % WRing<NTW>::NB) == 0 && (4 % WRing<NTW>::NB) == 0;   // stages end on slot 0
+    constexpr bool XL = (16 % WRing<NTW>::NB) == 0 && (4 % WRing<NTW>::NB) == 0;   // stages end on slot 0
     // ---- L0: 63 -> 256 ----
     init_bias<NTW, MT>(acc, m.bias + stage_b_off(0), nt0, L);
     gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + stage_w_off(0), ST_KS[0], nt0, 0, 0, 4, side, L, ring);
@@ -360,7 +340,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
             if (XL) ring_prime(ring, wp + woff, KS, nt0, 16, L);
             gemm_h<NTW, MT, SIDE_LDH, 7>(acc, wp + woff, KS, nt0, 0, 16, 4, side, L, ring, XL);
         }
-        if (XL && (!NEO_VH_FOLDB || s < 7)) {          // next stage: L(s+1) (its stream is 20 k-steps long for s + 1 == 5), or the bottleneck after L7
+        if (XL && s < 7) {          // next stage: L(s+1) (its stream is 20 k-steps long for s + 1 == 5), or the bottleneck after L7
             const int nwoff = s < 7 ? stage_w_off(1) + s * (8 * 16 * 128) + (s + 1 > 5 ? 8 * 4 * 128 : 0) : stage_w_off(8);
             ring_prime(ring, wp + nwoff, s + 1 == 5 ? 20 : 16, nt0, 0, L);
         }
@@ -413,14 +393,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : MT == 4 ? 1 : 2)) void k_va
         for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o, 64);
         raw_sigma = s + m.heads[HD_DB];
     }
-#if !NEO_VH_FOLDB
-    // ---- bottleneck: 256 -> 256, no activation ----
-    init_bias<NTW, MT>(acc, m.bias + stage_b_off(8), nt0, L);
-    gemm_h<NTW, MT, ACT_LDH, 15>(acc, wp + stage_w_off(8), 16, nt0, 0, 0, 16, act, L, ring, XL);
-    VH_SYNC();
-    store_act<NTW, MT, false>(acc, act, nt0, 0, L);
-    VH_SYNC();
-#endif
     // ---- view layer: [bottleneck | dir enc] 283 -> 128, ReLU (4 N-tiles: split over M as well when NW = 8); with the bottleneck
     //      folded in (NEO_VH_FOLDB) its first 256 inputs are the trunk's last activations themselves ----
     {
@@ -498,15 +470,13 @@ void launch_vanilla_pack_h(const float* const* weights, const float* const* bias
                            const float* bias_src, float* bias_h, hipStream_t s) {
     _Float16* base = reinterpret_cast<_Float16*>(wpack_h);
     (void)hipMemcpyAsync(bias_h, bias_src, (size_t)stage_b_off(NUM_STAGES) * sizeof(float), hipMemcpyDeviceToDevice, s);
-#if NEO_VH_FOLDB
     // bottleneck_layer (256 -> 256, NO activation) feeds views_linear.0 only (vanilla_nerf/model.py:113-121):
     // W_v [W_b h + b_b | d] + b_v = (W_v[:, :256] W_b) h + W_v[:, 256:] d + (W_v[:, :256] b_b + b_v).  The product is formed once
     // per upload (fp64 accumulation) and packed as the view layer; the kernel skips the bottleneck stage (65,536 of 593,408 MACs).
     launch_fold_bottleneck(weights[8], weights[9], biases[9], biases[8], 128, 256, 256, 27, fold_ws, bias_h + stage_b_off(9), s);
-#endif
     for (int st = 0; st < NUM_STAGES; ++st) {
         const int total = (ST_N[st] / 32) * ST_KS[st] * 512;
-        const float* src = (NEO_VH_FOLDB && st == 9) ? fold_ws : weights[ST_SRC[st]];
+        const float* src = st == 9 ? fold_ws : weights[ST_SRC[st]];
         hipLaunchKernelGGL(k_pack_stage_h, dim3((total + 255) / 256), dim3(256), 0, s, src, ST_N[st],
                            ST_KIN[st], ST_KS[st], base + (long)stage_w_off(st) * 8);
     }

@@ -70,24 +70,9 @@ __device__ __forceinline__ void range_commit(const LaneCtx& L, uint32_t* __restr
 // (one instruction instead of cvt_f32_f16 + sub); lo pair packed by a second v_cvt_pk_f16_f32.  Same values bit for
 // bit as split(): hi = fp16(x), lo = fp16(x - hi) (the subtraction is exact).  The compiler's own lowering of the
 // scalar form costs 5 instructions per value (separate conversions, a re-widening and a pack).
-#ifndef NEO_SPLIT_MIXLO
-#define NEO_SPLIT_MIXLO 0     // 1 (round 5): the lo pair by v_fma_mixlo_f16 + v_fma_mixhi_f16 - 3 instructions per pair of values instead of 4
-#endif
 __device__ __forceinline__ void split2(float x0, float x1, h2& hi, h2& lo) {
     const f32x2 v = {x0, x1};
     hi = __builtin_convertvector(v, h2);
-#if NEO_SPLIT_MIXLO
-    // lo = fp16(x - hi) straight into the two halves of one register: the mixed-precision fma reads the fp16 hi out of the
-    // packed pair (op_sel picks the half), subtracts it from the fp32 x EXACTLY (x - fp16(x) is representable) and rounds once
-    // to fp16 - bit for bit what v_fma_mix_f32 + v_cvt_pk_f16_f32 produced (tools/split2_check.hip).  This is the explicit,
-    // operand-by-operand use of the instruction; what tests/test_build_cpu.py keeps out of the library is the COMPILER folding
-    // float(fp16(a * b)) into it with a different rounding of hi.
-    unsigned packed;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(packed) : "v"(hi), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(packed) : "v"(hi), "v"(x1));
-    lo = __builtin_bit_cast(h2, packed);
-    return;
-#endif
     float r0, r1;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
@@ -129,9 +114,6 @@ __device__ __forceinline__ float relu1(float x) {
 // v_permlane32_swap exchanges the halves of a PAIR of chunks (2gp, 2gp + 1), lanes 0-31 then own chunk 2gp and lanes 32-63
 // chunk 2gp + 1 of their point: one ds_write_b128 per plane and chunk pair (lane groups of 8 consecutive lanes = 8 rows with
 // 8 distinct slot residues under the XOR swizzle: conflict-free), as mlp_vanilla_h.hip does since round 2.  Same bits in LDS.
-#ifndef NEO_SPLIT_STORE128
-#define NEO_SPLIT_STORE128 0
-#endif
 typedef unsigned su32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void swap_halves32(su32x2& x, su32x2& y) {      // x[lanes 32-63] <-> y[lanes 0-31]
@@ -144,30 +126,6 @@ __device__ __forceinline__ void swap_halves32(su32x2& x, su32x2& y) {      // x[
 }
 template <bool RELU, int LDH = 128>
 __device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, int nt, int mt, const LaneCtx& L) {
-#if NEO_SPLIT_STORE128
-#pragma unroll
-    for (int gp = 0; gp < 2; ++gp) {
-        h4 vh[2], vl[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = acc[4 * (2 * gp + u) + e];
-                v[e] = RELU ? relu1(x) : x;
-            }
-            range_see4(L, v);
-            split4(v, vh[u], vl[u]);
-        }
-        su32x2 xh = __builtin_bit_cast(su32x2, vh[0]), yh = __builtin_bit_cast(su32x2, vh[1]);
-        su32x2 xl = __builtin_bit_cast(su32x2, vl[0]), yl = __builtin_bit_cast(su32x2, vl[1]);
-        swap_halves32(xh, yh);      // lanes < 32: (xh | yh) = chunk 2gp; lanes >= 32: chunk 2gp + 1
-        swap_halves32(xl, yl);
-        const int o = chunk_off<LDH>(mt * 32 + L.l31, nt * 4 + 2 * gp + L.half);
-        *reinterpret_cast<su32x4*>(act.hi + o) = su32x4{xh[0], xh[1], yh[0], yh[1]};
-        *reinterpret_cast<su32x4*>(act.lo + o) = su32x4{xl[0], xl[1], yl[0], yl[1]};
-    }
-#else
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 v;
@@ -183,7 +141,6 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, const HT& act, i
         *reinterpret_cast<h4*>(act.hi + o) = vh;
         *reinterpret_cast<h4*>(act.lo + o) = vl;
     }
-#endif
 }
 
 

@@ -305,94 +305,6 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
     }
 }
 
-// Row-streaming GEMM for the 128-deep layers of the training chains: C[M][N] (+)= A[M][128] . op(B)^T with N = 32 NTW (64 / 128).
-// The whole weight matrix (<= 64 KB) sits in LDS as [n][k] for the life of a PERSISTENT workgroup (2 per CU); each wave takes 32
-// rows of A per tile straight from global memory into MFMA operand registers (16 bytes per lane and k-quad: lane = row, no LDS, no
-// barrier in the loop), the next tile's 16 fragments in flight while this one is multiplied.  k_sgemm staged both operands through
-// LDS with a barrier per 32-deep K step - at K = 128 that is four steps of pipeline fill per tile (55 % of the fp32 matrix peak).
-// MEASURED NEGATIVE (default off, NEO_ROWGEMM): correct (all gradient tests green) and 13 % slower per training step than k_sgemm.
-// D rows = m (first MFMA operand), lanes = n: a store instruction writes 32 consecutive floats of two rows.
-//   BT = false: B stored [N][K] (forward, B = W)      BT = true: B stored [K][N] (dX = dZ W)
-template <bool BT, int NTW>
-__global__ __launch_bounds__(256, 2) void k_rowgemm(int M, const float* __restrict__ A, long lda, const float* __restrict__ B, long ldb,
-                                                    float* __restrict__ C, long ldc, GemmEpi ep) {
-    constexpr int K = 128, KQ = K / 8, N = 32 * NTW, PW = K + 4;
-    __shared__ __attribute__((aligned(16))) float Ws[N * PW];
-    LaneCtx L;
-    L.init();
-    const int tid = threadIdx.x;
-    if (!BT) {
-        for (int i = tid; i < N * (K / 4); i += 256) {
-            const int n = i / (K / 4), k4 = (i % (K / 4)) * 4;
-            *reinterpret_cast<f32x4*>(Ws + n * PW + k4) = *reinterpret_cast<const f4u*>(B + (long)n * ldb + k4);
-        }
-    } else {
-        for (int i = tid; i < K * (N / 4); i += 256) {
-            const int k = i / (N / 4), n4 = (i % (N / 4)) * 4;
-            const f32x4 v = *reinterpret_cast<const f4u*>(B + (long)k * ldb + n4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Ws[(n4 + e) * PW + k] = v[e];
-        }
-    }
-    __syncthreads();
-    const int ntiles = (M + 127) / 128;
-    const int stride = gridDim.x;
-    auto load_a = [&](int t, f32x4 (&a)[KQ]) {
-        int row = t * 128 + L.wv * 32 + L.l31;
-        row = row < M ? row : M - 1;
-        const float* p = A + (long)row * lda + 4 * L.half;
-#pragma unroll
-        for (int c = 0; c < KQ; ++c) a[c] = *reinterpret_cast<const f4u*>(p + 8 * c);
-    };
-    auto tile = [&](int t, const f32x4 (&a)[KQ]) {
-        f32x16 acc[NTW];
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < KQ; ++c) {
-            f32x4 b[NTW];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(Ws + (32 * nt + L.l31) * PW + 8 * c + 4 * L.half);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[nt] = NEO_MFMA(a[c][e], b[nt][e], acc[nt]);
-        }
-        // epilogue: registers 4 g + e = row 8 g + 4 half + e of this wave's 32, lane l31 = column 32 nt + l31
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int gn = 32 * nt + L.l31;
-            const float bs = ep.bias ? ep.bias[gn] : 0.0f;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int gm = t * 128 + L.wv * 32 + 8 * g + 4 * L.half + e;
-                    if (gm >= M) continue;
-                    float* dst = C + (long)gm * ldc + gn;
-                    float x = acc[nt][4 * g + e] * ep.scale + bs;
-                    if (ep.accumulate == 1) x = *dst + x;
-                    if (ep.relu) x = fmaxf(x, 0.0f);
-                    if (ep.mask && !(ep.mask[(long)gm * ep.ldm + gn] > 0.0f)) x = 0.0f;
-                    *dst = x;
-                }
-        }
-    };
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
-    f32x4 a0[KQ], a1[KQ];
-    load_a(t, a0);
-    for (; t < ntiles; t += 2 * stride) {
-        const int t1 = t + stride, t2 = t1 + stride;
-        if (t1 < ntiles) load_a(t1, a1);
-        tile(t, a0);
-        if (t2 < ntiles) load_a(t2, a0);
-        if (t1 < ntiles) tile(t1, a1);
-    }
-}
-
 // Weight gradient of one layer segment, with the bias gradient fused: W[M][N] += Z^T X, db[M] += colsum(Z) over the K = rows
 // slice of this workgroup (Z = dZ stored [K][M], X stored [K][N]: both with the reduction index slowest).  128 x NT tiles -
 // a 128 x 128 layer is ONE tile, so every row of Z and of X is read once (k_sgemm<true, true> read Z once per 64 columns of X
@@ -620,15 +532,6 @@ __global__ void k_colsum(const float* __restrict__ g, long M, int C, float* __re
     atomicAdd(out + c, s);
 }
 
-#ifndef NEO_SGEMM_WIDE
-#define NEO_SGEMM_WIDE 0        // 1: 128 x 128 tiles for N > 64 - measured: no gain (37.2 vs 37.6 ms per training step, profiles/r05_train_dw.log): the chain is not bound by the A rows
-#endif
-inline bool wide_tile(int N) { return NEO_SGEMM_WIDE && N > 64; }
-
-#ifndef NEO_ROWGEMM
-#define NEO_ROWGEMM 0           // 1: k_rowgemm for the 128 x 128 layers - measured SLOWER (41.9 against 37.1 ms per training step,
-                                // profiles/r05_train_dw.log): 32-byte-per-row fragment loads thrash the 32 KB L1; kept as an experiment
-#endif
 template <bool AT, bool BT>
 void gemm(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, const GemmEpi& ep,
           int splits, hipStream_t s) {
@@ -636,21 +539,8 @@ void gemm(int M, int N, int K, const float* A, long lda, const float* B, long ld
     int kps = (K + splits - 1) / splits;
     kps = ((kps + GK - 1) / GK) * GK;
     const int nz = (K + kps - 1) / kps;
-    if constexpr (!AT) {
-        // 128-deep layers with 64 / 128 outputs (most of the NeRFPPMLP chain): the row-streaming kernel
-        // (N = 64 stays on k_sgemm: the two-tile instance of this kernel spills 84 registers under hipcc 7.2)
-        if (NEO_ROWGEMM && K == 128 && N == 128 && splits == 1 && ep.accumulate != 2) {
-            const int tiles = (M + 127) / 128;
-            hipLaunchKernelGGL((k_rowgemm<BT, 4>), dim3(tiles < 512 ? tiles : 512), dim3(256), 0, s, M, A, lda, B, ldb, C, ldc, ep);
-            return;
-        }
-    }
     const GemmSegs none{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, {0, 0, 0, 0}, 0};
-    if (wide_tile(N))
-        hipLaunchKernelGGL((k_sgemm<AT, BT, 128>), dim3((N + 127) / 128, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
-                           ldb, C, ldc, ep, kps, none);
-    else
-        hipLaunchKernelGGL((k_sgemm<AT, BT, GTN>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
+    hipLaunchKernelGGL((k_sgemm<AT, BT, GTN>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, nz), dim3(256), 0, s, M, N, K, A, lda, B,
                            ldb, C, ldc, ep, kps, none);
 }
 
@@ -662,11 +552,7 @@ void gemm_cat(int M, int N, const Seg* segs, int nseg, const float* B, long ldb,
     GemmSegs sg{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}, {0, 0, 0, 0}, nseg};
     int K = 0;
     for (int i = 0; i < nseg; ++i) { sg.a[i] = segs[i].a; sg.lda[i] = segs[i].k; sg.k[i] = segs[i].k; K += segs[i].k; }
-    if (wide_tile(N))
-        hipLaunchKernelGGL((k_sgemm<false, false, 128>), dim3((N + 127) / 128, (M + GTM - 1) / GTM, 1), dim3(256), 0, s, M, N, K,
-                           segs[0].a, (long)segs[0].k, B, ldb, C, ldc, ep, K, sg);
-    else
-        hipLaunchKernelGGL((k_sgemm<false, false, GTN>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, 1), dim3(256), 0, s, M, N, K,
+    hipLaunchKernelGGL((k_sgemm<false, false, GTN>), dim3((N + GTN - 1) / GTN, (M + GTM - 1) / GTM, 1), dim3(256), 0, s, M, N, K,
                            segs[0].a, (long)segs[0].k, B, ldb, C, ldc, ep, K, sg);
 }
 
@@ -680,11 +566,7 @@ inline unsigned blocks(long n) { return (unsigned)((n + 255) / 256); }
 // split-K of a weight-gradient GEMM (C (M x N) += A^T B over K = rows): enough K slices that the grid holds >= ~1024 workgroups
 // whatever the layer's shape - a 128 x 128 layer is 2 output tiles, and 71 slices of 8192 rows (round 3's rule) left 142 workgroups
 // on 256 CUs; each slice keeps >= 1024 rows so the atomically accumulated partial tiles stay few
-#ifndef NEO_TRAIN_SPLITK
-#define NEO_TRAIN_SPLITK 1
-#endif
 inline int split_k(int M, int N, long K) {
-    if (!NEO_TRAIN_SPLITK) return (int)((K + 8191) / 8192);
     const long tiles = (long)((N + GTN - 1) / GTN) * ((M + GTM - 1) / GTM);
     long nz = (1024 + tiles - 1) / tiles;
     const long cap = K / 1024 > 0 ? K / 1024 : 1;
@@ -695,20 +577,12 @@ inline int split_k(int M, int N, long K) {
 
 // W (M x N, row pitch ldw) += Z^T X over K rows, db (M) += column sums of Z (null: a later segment of the same layer);
 // enough K slices for one resident wave of workgroups (2 per CU), each at least 1024 rows
-#ifndef NEO_TRAIN_DW
-#define NEO_TRAIN_DW 1          // 0: k_sgemm<true, true> + k_colsum (rounds 3-4; A/B)
-#endif
 // part: DW_PART_FLOATS of scratch (the slices' partial tiles and bias sums)
 constexpr long DW_PART_TILES = 520;        // slices x tiles of one call: <= 512 + tiles - 1, tiles <= 8 (256 x 256: 4)
 constexpr long DW_PART_FLOATS = DW_PART_TILES * (128 * 128 + 128);
 void dw_gemm(int M, int N, int K, const float* Z, long ldz, const float* X, long ldx, float* W, long ldw, float* db, float* part,
              hipStream_t s) {
     if (M <= 0 || N <= 0 || K <= 0) return;
-    if (!NEO_TRAIN_DW) {
-        gemm<true, true>(M, N, K, Z, ldz, X, ldx, W, ldw, epi(nullptr, 0, 2), split_k(M, N, K), s);
-        if (db) hipLaunchKernelGGL(k_colsum, dim3((M + 127) / 128, blocks(K)), dim3(M < 128 ? 64 : 128), 0, s, Z, (long)K, M, db);
-        return;
-    }
     const int NT = N > 64 ? 128 : 64;
     const int tx = (N + NT - 1) / NT, ty = (M + 127) / 128, tiles = tx * ty;
     long nz = (512 + tiles - 1) / tiles;

@@ -305,24 +305,13 @@ constexpr int GRUN = 16;
 // channel order of a 16-lane group's 64-channel piece: 1 = lane c holds channels c, c + 16, c + 32, c + 48 (one atomic instruction of
 // the group = one 64-byte sector of the texel; with 0 = 4 consecutive channels per lane, every one of the 4 instructions touched
 // all 4 sectors)
-#ifndef NEO_SCATTER_LANE_MAJOR
-#define NEO_SCATTER_LANE_MAJOR 1
-#endif
-#ifndef NEO_SCATTER_SCOPE_WG
-#define NEO_SCATTER_SCOPE_WG 0      // 1: workgroup-scope atomics - a TIMING PROBE only (sums from different XCDs may be lost)
-#endif
 __device__ __forceinline__ int scatter_channel(int piece64, int c, int e) {
-    return NEO_SCATTER_LANE_MAJOR ? piece64 * 64 + 16 * e + c : piece64 * 64 + 4 * c + e;
+    return piece64 * 64 + 16 * e + c;
 }
 __device__ __forceinline__ void scatter_add(float* dst, float v) {
-#if NEO_SCATTER_SCOPE_WG
-    __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
     atomicAdd(dst, v);
-#endif
 }
 __device__ __forceinline__ f32x4 scatter_grad(const float* row, int piece64, int c) {
-    if (!NEO_SCATTER_LANE_MAJOR) return *reinterpret_cast<const f32x4*>(row + piece64 * 64 + 4 * c);
     f32x4 g;
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = row[piece64 * 64 + 16 * e + c];
@@ -642,15 +631,8 @@ void launch_gather_bwd(const TpScene& sc, const TpViews& views, const float* pts
                        hipStream_t s) {
     const long rows = P * sc.nv;
     if (rows <= 0) return;
-#ifndef NEO_GATHER_BWD_RUNS
-#define NEO_GATHER_BWD_RUNS 1          // 1 (round 5): atomics merged over runs of consecutive rows in one texel cell (k_gather_bwd_runs); 0: one atomic per (row, tap, channel)
-#endif
-    if (NEO_GATHER_BWD_RUNS)
-        hipLaunchKernelGGL(k_gather_bwd_runs, dim3((unsigned)((rows + 16 * GRUN - 1) / (16 * GRUN))), dim3(256), 0, s, sc, views, pts, P,
-                           g_world, g_local, g_plane_xz, g_plane_xy, g_plane_yz, g_latent);
-    else
-        hipLaunchKernelGGL((k_gather<true>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, sc, views, pts, P,
-                           const_cast<float*>(g_world), const_cast<float*>(g_local), g_plane_xz, g_plane_xy, g_plane_yz, g_latent);
+    hipLaunchKernelGGL(k_gather_bwd_runs, dim3((unsigned)((rows + 16 * GRUN - 1) / (16 * GRUN))), dim3(256), 0, s, sc, views, pts, P,
+                       g_world, g_local, g_plane_xz, g_plane_xy, g_plane_yz, g_latent);
 }
 
 }  // namespace neo
