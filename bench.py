@@ -273,6 +273,7 @@ class Runner:
         if workload == "neo360" and self.split and getattr(self.net, "preproject", False):
             self.kernel_name = "k_tp_mlp_hpp" if self.net.preproject == 2 and self.net.preproject is not True else "k_tp_mlp_hp"
         self.c2w = synth.look_at_origin(40.0)
+        self.ray_grid = os.environ.get("NEO360_RAY_GRID", "1") != "0"      # frame API's pixel-grid hint (8 x 8 ray patches)
         self.R = H * W
         self.lo, self.hi = shard_bounds(self.R, world, rank, unit=CHUNK)
         self.ctx = self.net._context(dev)
@@ -342,7 +343,8 @@ class Runner:
 
     def step(self):
         return self.render.render_frame_sharded(self.net, self.shard_rays(), self.world, self.rank, chunk=CHUNK,
-                                                n_rays=self.R, always_gather=self.dist is not None, **self.kw)
+                                                n_rays=self.R, always_gather=self.dist is not None,
+                                                image_width=W if self.ray_grid else None, **self.kw)
 
     def fence(self):
         if self.dist is not None:

@@ -42,6 +42,7 @@ SIGNATURES = {
     "neo_ctx_sync_count": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "neo_ctx_stream_waits": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
     "neo_ctx_set_lane": (_i, [_vp, _i]),
+    "neo_ctx_set_ray_grid": (_i, [_vp, _i, ctypes.c_long]),
     "neo_ctx_set_precision": (_i, [_vp, _i]),
     "neo_linspace_host": (None, [_f, _f, _i, c_float_p]),
     "neo_raygen": (_i, [_vp, _i, _i, _f, c_float_p, _vp, _vp, _vp, _vp, _vp]),

@@ -101,6 +101,13 @@ class Context:
             _lib.check(self.lib.neo_ctx_set_lane(self.handle, int(lane)))
             self._lane = lane
 
+    def set_ray_grid(self, width, first_ray=0):
+        """Pixel-grid hint for the next whole-frame renders (neo_ctx_set_ray_grid); width 0 removes it."""
+        key = (int(width), int(first_ray) if width else 0)
+        if getattr(self, "_ray_grid", (0, 0)) != key:
+            _lib.check(self.lib.neo_ctx_set_ray_grid(self.handle, key[0], key[1]))
+            self._ray_grid = key
+
     def set_precision(self, mode):
         """'f32' (exact fp32 MFMA) or 'f16x3' (fp16 MFMA, hi/lo-split operands, fp32-equivalent)."""
         code = {"f32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]

@@ -296,6 +296,14 @@ int neo_ctx_set_lane(neo_ctx* ctx, int lane) {
     return NEO_OK;
 }
 
+int neo_ctx_set_ray_grid(neo_ctx* ctx, int width, long first_ray) {
+    ENTER(ctx);
+    REQUIRE(width >= 0 && width % 8 == 0 && first_ray >= 0, "width must be a multiple of 8 (0: no hint), first_ray >= 0");
+    ctx->ray_grid_w = width;
+    ctx->ray_grid_first = width ? first_ray : 0;
+    return NEO_OK;
+}
+
 int neo_ctx_stream_waits(neo_ctx* ctx, uint64_t* cross_stream_waits) {
     ENTER(ctx);
     REQUIRE(cross_stream_waits != nullptr, "null out pointer");

@@ -267,6 +267,8 @@ int neo_tp_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const 
     fill_views(src_poses, NV, views);
     neo::TpScene sc = ctx->scene;
     sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    sc.grid_w = ctx->ray_grid_w;              // pixel-grid hint of the frame API: the evaluators walk the rays in 8 x 8 patches
+    sc.grid_first = ctx->ray_grid_first;
 
     const int N0 = n_coarse + 1, N1 = N0 + n_fine;
     const float near = 1e-4f;                                         // model.py:277

@@ -155,6 +155,8 @@ struct neo_ctx {
     int lane = 0;
     neo_host::DevBuf tp_dirsum_sets[LANES];
     neo_host::DevBuf* tp_dirsum = &tp_dirsum_sets[0];   // (rays, 32): view-summed direction encodings of the current launch (k_tp_mlp_hp)
+    int ray_grid_w = 0;                // neo_ctx_set_ray_grid: the next renders' rays are row-major pixels of an image this wide ...
+    long ray_grid_first = 0;           // ... ray 0 of a render = pixel ray_grid_first of the frame (0 = no hint: caller's ray order)
     int preproject = 3;                // 0 off; 1 gather the latent pre-projected through the first-layer weights; 2 the tri-planes too; 3 (default): planes for the outside-sphere slots only
     // PixelNeRF scene latent: its own buffer / descriptor / ready flag (a context may hold both decoders)
     neo_host::DevBuf pix_latent;

@@ -663,6 +663,10 @@ class NeRF_TP(_HipModule):
         else:
             side, lane = torch.cuda.current_stream(dev), 0
         ctx.set_lane(lane)
+        # pixel-grid hint (render.render_rays_test / render_frame_sharded set `ray_grid` around a frame): a scheduling hint for
+        # the evaluators' tile order, bitwise-neutral; only meaningful for a call that spans whole bands of 8 image rows
+        grid = getattr(self, "ray_grid", None)
+        ctx.set_ray_grid(*(grid if grid and grid[0] % 8 == 0 and B >= 8 * grid[0] else (0, 0)))
         try:
             with torch.cuda.stream(side):
                 levels, structs = [], []
@@ -679,6 +683,7 @@ class NeRF_TP(_HipModule):
                 self._after_call(ctx)
         finally:
             ctx.set_lane(0)
+            ctx.set_ray_grid(0)
             if ov is not None:
                 ov.end(lane, cur, [v for t in levels for v in t.values()] if 'levels' in locals() else [])
         return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]

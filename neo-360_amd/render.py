@@ -60,7 +60,7 @@ def _render_exact(model, batch, chunk, white_bkgd, near, far, train_frac):
 
 @torch.no_grad()
 def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3.0, train_frac=1.0, check=True,
-                     on_range="retry_f32"):
+                     on_range="retry_f32", image_width=None, first_ray=0):
     """Fine-level rgb / depth of every ray in `batch` (one image), as the reference's
     render_rays_test returns them: dict(rgb (R,3), depth (R,)) plus `target` /
     `instance_mask` passed through when present.  check=True waits for the frame and raises what the device-side
@@ -79,6 +79,16 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
     marks such frames; `model.last_precision_used` holds the arithmetic of the last frame either way."""
     if on_range not in ("retry_f32", "raise"):
         raise ValueError("on_range must be 'retry_f32' or 'raise', got %r" % (on_range,))
+    if image_width and isinstance(model, models.NeRF_TP):
+        # image_width (+ first_ray: the frame index of this batch's first ray, for a rank's shard): the rays are the row-major
+        # pixels of an image - the evaluators then walk them in 8 x 8 pixel patches (neo_ctx_set_ray_grid: L2 locality in both
+        # image directions, bitwise the same frame)
+        prev_grid = getattr(model, "ray_grid", None)
+        model.ray_grid = (int(image_width), int(first_ray))
+        try:
+            return render_rays_test(model, batch, chunk, white_bkgd, near, far, train_frac, check, on_range)
+        finally:
+            model.ray_grid = prev_grid
     latch = getattr(model, "_range_latch", None)
     if latch is not None and on_range == "retry_f32" and check and (model.precision or model.default_precision) != "f32":
         if latch == model.operands_key():
@@ -116,7 +126,7 @@ def render_rays_test(model, batch, chunk=1024, white_bkgd=False, near=0.2, far=3
 @torch.no_grad()
 def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False, near=0.2, far=3.0, group=None,
                          gather=True, train_frac=1.0, n_rays=None, out=None, reuse=False, check=True, always_gather=False,
-                         info=None):
+                         info=None, image_width=None):
     """This rank renders its contiguous range of whole chunks; `gather=True` reassembles
     the full (R,5) = (rgb, depth, acc) frame on every rank with one all-gather.
     `batch` holds the whole frame's rays, or - with n_rays = R given - only this rank's shard
@@ -137,7 +147,7 @@ def render_frame_sharded(model, batch, world, rank, chunk=1024, white_bkgd=False
         lo, hi = shard_bounds(R, world, rank, unit=chunk)
         assert batch["rays_o"].shape[0] == hi - lo, "batch must hold exactly this rank's shard"
         mine = batch
-    part = render_rays_test(model, mine, chunk, white_bkgd, near, far, train_frac, check=check)
+    part = render_rays_test(model, mine, chunk, white_bkgd, near, far, train_frac, check=check, image_width=image_width, first_ray=lo)
     tile = torch.cat([part["rgb"], part["depth"][:, None], part["acc"][:, None]], dim=1)
     used = part.get("precision_used") or getattr(model, "last_precision_used", None) or model.precision or model.default_precision
     if info is not None:

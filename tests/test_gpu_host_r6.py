@@ -184,3 +184,29 @@ def test_forward_only_caller_outside_no_grad_is_told_once_and_chunked_pixelnerf_
     pix.differentiable = True                                      # an explicit request keeps the strict behaviour
     with pytest.raises(NotImplementedError), torch.enable_grad():
         pix(b, False, False, 0.2, 3.0, chunk=32)
+
+
+def test_ray_patch_order_is_bitwise_neutral():
+    """The pixel-grid hint of the frame API (neo_ctx_set_ray_grid: rays walked in 8 x 8 pixel patches inside whole bands of 8
+    image rows) is pure scheduling: the frame, and any shard of it - band-aligned or with ragged ends - is bitwise the frame
+    rendered in the caller's ray order."""
+    sc = cases.small_scene()
+    net = _tp_net(sc)
+    Hs, Ws = 48, 64
+    ro, vd, rd, _ = ops.get_ray_directions_and_rays(Hs, Ws, 0.8 * Ws, synth.look_at_origin(40.0))
+    extra = {k: v for k, v in _batch(8).items() if k.startswith("src_")}
+    frame = dict(rays_o=ro, rays_d=rd, viewdirs=vd, **extra)
+    plain = render.render_rays_test(net, frame, chunk=1024)
+    hinted = render.render_rays_test(net, frame, chunk=1024, image_width=Ws)
+    assert torch.equal(plain["rgb"], hinted["rgb"]) and torch.equal(plain["depth"], hinted["depth"])
+    ctx = net._context(torch.device(DEV))
+    assert getattr(ctx, "_ray_grid", (0, 0)) == (0, 0), "the hint must not outlive the frame call"
+    for lo, hi in ((1024, 3072), (300, 2348), (0, 1000)):
+        # Q1 (view-direction tiling) depends on chunk membership: shards start on chunk boundaries in the real sharded render;
+        # here the whole shard is ONE chunk on both sides, so any range is comparable
+        part = {k: (v[lo:hi] if k in PER_RAY else v) for k, v in frame.items()}
+        a = render.render_rays_test(net, part, chunk=hi - lo)
+        b = render.render_rays_test(net, part, chunk=hi - lo, image_width=Ws, first_ray=lo)
+        assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["depth"], b["depth"]), (lo, hi)
+    with pytest.raises(_lib.NeoError):
+        ctx.set_ray_grid(60)                 # not a multiple of 8
