@@ -83,11 +83,12 @@ int neo_ctx_stream_waits(neo_ctx* ctx, uint64_t* cross_stream_waits);
 int neo_ctx_set_lane(neo_ctx* ctx, int lane);
 /* Pixel-grid hint for whole-frame renders (round 6).  When the rays handed to the next neo_tp_render calls are the pixels of a
  * row-major image `width` wide (ray 0 of a call = pixel `first_ray` of the frame: a rank's shard starts in the middle), the
- * evaluators visit the rays of every whole band of 8 image rows in 8 x 8 pixel patches instead of row by row: the workgroups
- * resident on an XCD then cover a compact piece of the image and share feature texels in that XCD's L2 in both image directions
- * (fabric traffic of an inside-sphere launch: see profiles/).  Pure scheduling: every output value is bitwise the one without the
- * hint.  width = 0 (default) removes it; width must be a multiple of 8.  The reference has no counterpart (its chunk loop renders
- * 1024 consecutive rays at a time, datasets/ray_utils.py:96-104 defines the row-major order). */
+ * evaluators visit the rays of every whole band of image rows in small pixel patches (2 x 2 inside the unit sphere, 8 x 8 outside)
+ * instead of row by row: the workgroups resident on an XCD then cover a compact piece of the image and share feature texels in that
+ * XCD's L2 in both image directions - fabric-side traffic of a full-frame launch 59.8 -> 41.7 GB inside, 11.6 -> 1.8 GB outside
+ * (profiles/r06_ray_patch_order.log).  Pure scheduling: every output value is bitwise the one without the hint.  width = 0
+ * (default) removes it; width must be a multiple of 8.  The reference has no counterpart (its chunk loop renders 1024 consecutive
+ * rays at a time; datasets/ray_utils.py:96-104 defines the row-major order). */
 int neo_ctx_set_ray_grid(neo_ctx* ctx, int width, long first_ray);
 
 /* Arithmetic of the per-point MLP GEMMs of every renderer (vanilla, NeRF_TP, Mip-NeRF 360, PixelNeRF).

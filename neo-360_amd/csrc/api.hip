@@ -185,7 +185,8 @@ int neo_ctx_destroy(neo_ctx* ctx) {
     for (auto& kv : ctx->centre_quantiles) kv.second.release();
     for (auto& sl : ctx->mip) sl.release();
     ctx->mip_basis.release();
-    for (auto& b : ctx->mip_lws) b.release();
+    for (auto& set : ctx->mip_lws_sets) for (auto& b : set) b.release();
+    for (auto& kv : ctx->mip_seed) kv.second.release();
     for (auto& kv : ctx->edges) kv.second.release();
     for (auto& set : ctx->ws_sets) for (auto& b : set) b.release();
     for (auto& sl : ctx->tp) sl.release();
@@ -293,6 +294,7 @@ int neo_ctx_set_lane(neo_ctx* ctx, int lane) {
     ctx->lane = lane;
     ctx->ws = ctx->ws_sets[lane];
     ctx->tp_dirsum = &ctx->tp_dirsum_sets[lane];
+    ctx->mip_lws = ctx->mip_lws_sets[lane];
     return NEO_OK;
 }
 
@@ -542,7 +544,7 @@ int neo_vanilla_render(neo_ctx* ctx, const float* rays_o, const float* viewdirs,
     const float* t0 = ctx->get_edges(n_coarse, near, far, s);
     const float* u = ctx->get_quantiles(n_fine, s);
     if (!t0 || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
-    ORDERED(ctx, static_cast<hipStream_t>(stream));
+    ORDERED_LANE(ctx, static_cast<hipStream_t>(stream));      // writes this lane's workspaces only, reads the packed weights
     if (ctx->ws[0].reserve(static_cast<size_t>(R) * N0 * 16)) return NEO_ERR_NOMEM;
     if (ctx->ws[1].reserve(static_cast<size_t>(R) * N0 * 4)) return NEO_ERR_NOMEM;
     if (ctx->ws[2].reserve(static_cast<size_t>(R) * N1 * 4)) return NEO_ERR_NOMEM;

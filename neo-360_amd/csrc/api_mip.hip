@@ -182,23 +182,27 @@ int neo_mip_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const
     // anneal = bias(train_frac, slope 10) = 10 tf / (9 tf + 1)   (model.py:286-290), python double -> fp32 scalar
     const float anneal = static_cast<float>((10.0 * train_frac) / (9.0 * train_frac + 1.0));
     const int nmax = n_prop > n_nerf ? n_prop : n_nerf;
-    ORDERED(ctx, static_cast<hipStream_t>(stream));
-    auto* W = ctx->ws;
+    // level-0 histogram: sdist = [0, 1], weights = [1]  (model.py:240-256; near_anneal_rate=None) - a constant table per ray
+    // count, made once (round 6: it used to be uploaded, with a stream synchronisation, by every call)
     const size_t r = static_cast<size_t>(R);
+    auto seed_it = ctx->mip_seed.find(R);
+    if (seed_it == ctx->mip_seed.end()) {
+        DevBuf& sb = ctx->mip_seed[R];
+        if (sb.reserve(r * 3 * 4)) return NEO_ERR_NOMEM;
+        std::vector<float> h(r * 3);
+        for (size_t i = 0; i < r; ++i) { h[i * 2] = 0.0f; h[i * 2 + 1] = 1.0f; h[2 * r + i] = 1.0f; }
+        HIP_TRY(hipMemcpyAsync(sb.p, h.data(), r * 3 * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                     // h goes out of scope; first use of this ray count only
+        seed_it = ctx->mip_seed.find(R);
+    }
+    ORDERED_LANE(ctx, static_cast<hipStream_t>(stream));      // writes this lane's workspaces / activation buffers only
+    auto* W = ctx->ws;
     // two ping-pong sets of (sdist, tdist, weights, rgbdens) + the level-0 seed histogram
     for (int k = 0; k < 2; ++k)
         if (W[k * 4 + 0].reserve(r * (nmax + 1) * 4) || W[k * 4 + 1].reserve(r * (nmax + 1) * 4) ||
             W[k * 4 + 2].reserve(r * nmax * 4) || W[k * 4 + 3].reserve(r * nmax * 16))
             return NEO_ERR_NOMEM;
-    if (W[8].reserve(r * 3 * 4)) return NEO_ERR_NOMEM;
-    // level-0 histogram: sdist = [0, 1], weights = [1]  (model.py:240-256; near_anneal_rate=None)
-    float* seed = W[8].as<float>();
-    {
-        std::vector<float> h(r * 3);
-        for (size_t i = 0; i < r; ++i) { h[i * 2] = 0.0f; h[i * 2 + 1] = 1.0f; h[2 * r + i] = 1.0f; }
-        HIP_TRY(hipMemcpyAsync(seed, h.data(), r * 3 * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
+    const float* seed = seed_it->second.as<float>();
     const float* s_prev = seed;
     const float* w_prev = seed + 2 * r;
     int n_prev = 1;

@@ -49,6 +49,7 @@ int pix_launch(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo::TpView
         // latent pre-projected through this slot's pts_linears.0 latent columns (exact fp32 MFMA): rebuilt only when the
         // scene or the slot's weights changed since the last launch
         if (sl.proj_weights != sl.weights_epoch || sl.proj_scene != ctx->pix_scene_epoch) {
+            if (int rc = ctx->touch_shared(s)) return rc;          // shared by both scratch lanes
             const long texels = static_cast<long>(sc.nv) * sc.Hf * sc.Wf;
             if (sl.proj.reserve(static_cast<size_t>(texels) * 512)) return NEO_ERR_NOMEM;
             neo::launch_tp_preproject(sc.latent, texels, sl.wpack.as<float>(), neo::pix_kc_x(), sl.proj.as<float>(), s, 128);
@@ -170,7 +171,7 @@ int neo_pix_render(neo_ctx* ctx, const float* rays_o, const float* rays_d, const
     const float* t0 = ctx->get_edges(n_coarse, near, far, s);
     const float* u = ctx->get_quantiles(n_fine, s);
     if (!t0 || !u) return fail(NEO_ERR_HIP, "constant table upload failed");
-    ORDERED(ctx, static_cast<hipStream_t>(stream));
+    ORDERED_LANE(ctx, static_cast<hipStream_t>(stream));      // writes this lane's workspaces only (a lazy pre-projection: touch_shared)
     if (ctx->ws[0].reserve(static_cast<size_t>(R) * N0 * 16)) return NEO_ERR_NOMEM;
     if (ctx->ws[1].reserve(static_cast<size_t>(R) * N0 * 4)) return NEO_ERR_NOMEM;
     if (ctx->ws[2].reserve(static_cast<size_t>(R) * N1 * 4)) return NEO_ERR_NOMEM;

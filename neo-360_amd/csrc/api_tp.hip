@@ -72,6 +72,21 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
               float* out, hipStream_t s) {
     ORDERED(ctx, s);      // context scratch (tp_dirsum, projected maps, ws[]) is shared by all streams
     const int slot_index = static_cast<int>(&sl - ctx->tp);
+    // Patch shape of the ray-patch tile order (neo_ctx_set_ray_grid), per region - measured fabric-side bytes per full-frame launch
+    // (profiles/r06_ray_patch_order.log): inside the sphere a ray's footprint is ~2 MB of projected texels, so only the nearest
+    // neighbours of a ray are still in the XCD's 4 MB L2: 2 x 2 patches (59.8 -> 41.7 GB; 4 x 4: 45.3, 8 x 8: 51.5); outside, where
+    // most taps are the zero-weight placeholder, 8 x 8 (11.6 -> 1.8 GB).  $NEO_TP_PATCH = "<log2 w>,<log2 h>" overrides both.
+    neo::TpScene scp = sc;
+    if (scp.grid_w > 0) {
+        static int epw = -2, eph = -2;
+        if (epw == -2) {
+            epw = eph = -1;
+            if (const char* e = getenv("NEO_TP_PATCH")) (void)sscanf(e, "%d,%d", &epw, &eph);
+        }
+        scp.grid_pw = epw >= 0 ? epw : (slot_index < 2 ? 1 : 3);
+        scp.grid_ph = eph >= 0 ? eph : (slot_index < 2 ? 1 : 3);
+        if (scp.grid_w % (1 << scp.grid_pw) != 0) scp.grid_w = 0;
+    }
     long plane_base[3] = {0, 0, 0};          // first texel of each projected tri-plane inside sl.proj
     if (ctx->precision == 1) {
         // range guard of the split arithmetic: tri-planes are summed over three maps before they are split
@@ -97,10 +112,10 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             ctx->span_kernel_next = planes ? 2 : 1;
             ctx->span_begin(s);
             if (planes)
-                neo::launch_tp_mlp_hpp(sl.input_ch, mh, sl.proj.as<float>(), plane_base, sc, views, rays_o, rays_d, viewdirs, tvals, far,
+                neo::launch_tp_mlp_hpp(sl.input_ch, mh, sl.proj.as<float>(), plane_base, scp, views, rays_o, rays_d, viewdirs, tvals, far,
                                        R, N, chunk, ctx->flags, out, ctx->tp_dirsum->as<float>(), s);
             else
-                neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
+                neo::launch_tp_mlp_hp(sl.input_ch, mh, sl.proj.as<float>(), scp, views, rays_o, rays_d, viewdirs, tvals, far, R, N,
                                       chunk, ctx->flags, out, ctx->tp_dirsum->as<float>(), s);
         } else {
             guard_split_weights(sl, sl.wpack_h.p, neo::tp_wpack_h_bytes(sl.input_ch), ctx->flags, s);
@@ -111,7 +126,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             neo::TpMlpHDev mh{sl.wpack_h.p, sl.bias.as<float>(), sl.heads.as<float>(), ctx->flags};
             ctx->span_kernel_next = 3;
             ctx->span_begin(s);
-            neo::launch_tp_mlp_h(sl.input_ch, mh, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
+            neo::launch_tp_mlp_h(sl.input_ch, mh, scp, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s);
         }
     } else {
         // exact fp32 MFMA; with pre-projection on, the same algorithm as the split default in the reference's arithmetic: the
@@ -125,7 +140,7 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
         const neo::TpPlaneProj pp{{pbase + plane_base[0] * 256, pbase + plane_base[1] * 256, pbase + plane_base[2] * 256}};
         ctx->span_kernel_next = 4;
         ctx->span_begin(s);
-        neo::launch_tp_mlp(sl.input_ch, m, sc, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s,
+        neo::launch_tp_mlp(sl.input_ch, m, scp, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s,
                            ctx->preproject ? sl.proj.as<float>() : nullptr, planes ? &pp : nullptr);
     }
     ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(sl.input_ch, sc.nv));

@@ -138,7 +138,9 @@ struct neo_ctx {
     neo_host::MlpSlot pix[2];          // PixelNeRF coarse / fine
     int mip_shape[3][3] = {};          // width, depth, rgb per slot
     neo_host::DevBuf mip_basis;
-    neo_host::DevBuf mip_lws[3];       // layer-by-layer NeRF MLP (mip_layered.h): encoding fragments + two activation buffers
+    neo_host::DevBuf mip_lws_sets[2][3];   // layer-by-layer NeRF MLP (mip_layered.h): encoding fragments + two activation buffers, per scratch lane
+    neo_host::DevBuf* mip_lws = mip_lws_sets[0];
+    std::map<int, neo_host::DevBuf> mip_seed;   // R -> the level-0 histogram of neo_mip_render (sdist = [0, 1], weights = [1]) for R rays
     int mip_layered = -1;              // 1: NeRF MLP layer by layer, 0: fused evaluator, -1 (default): layer by layer from 8192 intervals
     std::map<int, neo_host::DevBuf> centre_quantiles;             // n -> linspace(1/2n, 1-1/2n-eps, n)
     // NeO-360 scene features, channels-last, context-owned

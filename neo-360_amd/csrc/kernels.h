@@ -109,11 +109,13 @@ struct TpScene {                     // channels-last feature maps owned by the 
     float fy_sign = -1.0f;          // v = (-y/z) * (fy_sign * focal) + cy: -1 for NeRF_TP (model.py:243), +1 for the
                                     // PixelNeRF baseline, which passes (f, f) (vanilla_nerf/model_pixel.py:203-206)
     // Ray-patch tile order (round 6, neo_ctx_set_ray_grid): when the rays of a launch are pixels of a row-major image of width
-    // grid_w (ray 0 of the launch = pixel grid_first of the frame), the evaluators walk the rays of every whole band of 8 image
-    // rows in 8 x 8 pixel PATCHES instead of row by row, so the ~64 tiles resident on an XCD cover a compact piece of the image and
-    // share feature texels in that XCD's L2 in both image directions.  0: rays in the caller's order.  Results do not depend on it.
+    // grid_w (ray 0 of the launch = pixel grid_first of the frame), the evaluators walk the rays of every whole band of 2^grid_ph
+    // image rows in 2^grid_pw x 2^grid_ph pixel PATCHES instead of row by row, so the ~64 tiles resident on an XCD cover a compact
+    // piece of the image and share feature texels in that XCD's L2 in both image directions (shape chosen per region in
+    // api_tp.hip:tp_launch).  0: rays in the caller's order.  Results do not depend on it.
     int grid_w = 0;
     long grid_first = 0;
+    int grid_pw = 3, grid_ph = 3;   // log2 of the patch width / height in pixels (bands are 2^grid_ph image rows)
 };
 struct TpViews {                     // world -> camera per source view (neo360/util.py:52-70)
     float rot[TP_MAX_VIEWS][9];     // c2w[:3,:3]^T, row-major

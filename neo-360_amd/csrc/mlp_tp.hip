@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
 #if NEO_TP32_TRACE
     unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, false, sc.grid_w, sc.grid_first);
+    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, false, sc.grid_w, sc.grid_first, sc.grid_pw, sc.grid_ph);
     __syncthreads();
     TP32_MARK(0);
 
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
         g += __shfl_xor(g, 1, 64); g += __shfl_xor(g, 2, 64);
         b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
         const long gv = tile0 + pt;
-        const long gi = tp::patch_point(gv, N, R, sc.grid_w, sc.grid_first);
+        const long gi = tp::patch_point(gv, N, R, sc.grid_w, sc.grid_first, sc.grid_pw, sc.grid_ph);
         if (part == 0 && gv < P) {
             out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
                                   colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));

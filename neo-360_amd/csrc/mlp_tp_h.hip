@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
     constexpr int KSX = ks_x(PE_C);
     constexpr int NST = PE_C == 3 ? 11 : 12;   // streamed stages of 64 features: 8 local, 2 world, 1-2 pos_enc
 
-    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, false, sc.grid_w, sc.grid_first);
+    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, false, sc.grid_w, sc.grid_first, sc.grid_pw, sc.grid_ph);
     __syncthreads();
 
     // View means by linearity.  Everything after relu(L3_v) is linear up to the view mean: the density head acts on
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, NEO_GATHER_WAVES_PER_SIMD) void k_tp_mlp_h(TpM
         b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
         range_commit(L, m.flags);
         const long gv = tile0 + pt;
-        const long gi = tp::patch_point(gv, N, R, sc.grid_w, sc.grid_first);
+        const long gi = tp::patch_point(gv, N, R, sc.grid_w, sc.grid_first, sc.grid_pw, sc.grid_ph);
         if (part == 0 && gv < P) {
             out[gi] = make_float4(colour_act(r + m.heads[HD_RB]), colour_act(g + m.heads[HD_RB + 1]),
                                   colour_act(b + m.heads[HD_RB + 2]), density_act(raw_sigma));

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
 #if NEO_TP_TRACE
     unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_amdgcn_s_memtime();
 #endif
-    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, false, sc.grid_w, sc.grid_first);
+    tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, false, sc.grid_w, sc.grid_first, sc.grid_pw, sc.grid_ph);
     float* dens_w = smem + PP_OFF_DENSW;
     if (tid < 128) dens_w[tid] = m.heads[HD_DW + tid];
     if (tid < DESC_BLOCK) {                            // the all-zero descriptor block (offset 0 = the buffer's first texel, weight 0)
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256, NEO_TPP_WPS) void k_tp_mlp_hpp(TpMlpHDev m, co
         b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64);
         range_commit(L, m.flags);
         const long gv = tile0 + pt;
-        const long gi = tp::patch_point(gv, N, R, sc.grid_w, sc.grid_first);
+        const long gi = tp::patch_point(gv, N, R, sc.grid_w, sc.grid_first, sc.grid_pw, sc.grid_ph);
         if (part == 0 && gv < P) {
             out[gi] = make_float4(colour_act(r + lheads[HD_RB]), colour_act(g + lheads[HD_RB + 1]),
                                   colour_act(b + lheads[HD_RB + 2]), density_act(raw_sigma));

@@ -134,19 +134,19 @@ __device__ __forceinline__ float pe_feature(const float* x, int f) {
 
 
 // Virtual point index (tile order) -> the point it stands for: identity unless the launch carries a pixel-grid hint
-// (TpScene::grid_w), then the rays of every WHOLE band of 8 image rows inside the launch are visited patch by patch
-// (8 x 8 pixels, patches left to right): virtual ray k of a band -> patch k / 64, pixel (k % 64) / 8 rows down, (k % 64) % 8 across.
-// A bijection on the launch's points; rays outside whole bands (a shard's ragged ends) keep their place.
-__device__ __forceinline__ long patch_point(long gv, int N, int R, int grid_w, long grid_first) {
+// (TpScene::grid_w), then the rays of every WHOLE band of 2^ph image rows inside the launch are visited patch by patch
+// (2^pw x 2^ph pixels, row-major inside a patch, patches left to right).  A bijection on the launch's points; rays outside whole
+// bands (a shard's ragged ends) keep their place.
+__device__ __forceinline__ long patch_point(long gv, int N, int R, int grid_w, long grid_first, int pw = 3, int ph = 3) {
     if (grid_w <= 0) return gv;
     const long rayv = gv / N;
     const int s = (int)(gv - rayv * N);
-    const long band = 8L * grid_w;
+    const long band = (long)grid_w << ph;
     const long G = grid_first + rayv;
     const long b = G / band;
     if (b * band < grid_first || (b + 1) * band > grid_first + R) return gv;
-    const int k = (int)(G - b * band), r = k & 63;
-    const long Gt = b * band + (long)(r >> 3) * grid_w + (long)(k >> 6) * 8 + (r & 7);
+    const int k = (int)(G - b * band), r = k & ((1 << (pw + ph)) - 1);
+    const long Gt = b * band + (long)(r >> pw) * grid_w + ((long)(k >> (pw + ph)) << pw) + (r & ((1 << pw) - 1));
     return (Gt - grid_first) * N + s;
 }
 
@@ -157,14 +157,14 @@ __device__ __forceinline__ void point_setup_row(const Scratch& S, int tid, long 
                                                 const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                 const float* __restrict__ viewdirs, const float* __restrict__ tvals,
                                                 const float* __restrict__ far_arr, uint32_t* __restrict__ flags,
-                                                bool t_shared = false, int grid_w = 0, long grid_first = 0) {
+                                                bool t_shared = false, int grid_w = 0, long grid_first = 0, int pw = 3, int ph = 3) {
     float* pe_world = S.pe_world;
     float* feat_world = S.feat_world;
     float* vdir_world = S.vdir_world;
     {
         long g = tile0 + tid;
         if (g >= P) g = P - 1;
-        g = patch_point(g, N, R, grid_w, grid_first);
+        g = patch_point(g, N, R, grid_w, grid_first, pw, ph);
         const int ray = (int)(g / N);
         const int s = (int)(g - (long)ray * N);
         const int c0 = (ray / chunk) * chunk;                    // first ray of this ray's reference chunk
@@ -231,9 +231,9 @@ __device__ __forceinline__ void point_setup(const Scratch& S, int tid, long tile
                                             const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                             const float* __restrict__ viewdirs, const float* __restrict__ tvals,
                                             const float* __restrict__ far_arr, uint32_t* __restrict__ flags,
-                                            bool t_shared = false, int grid_w = 0, long grid_first = 0) {
+                                            bool t_shared = false, int grid_w = 0, long grid_first = 0, int pw = 3, int ph = 3) {
     if (tid < TM)
-        point_setup_row<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, t_shared, grid_w, grid_first);
+        point_setup_row<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, t_shared, grid_w, grid_first, pw, ph);
 }
 
 // ---- per-view descriptors (all 4 waves; lane = row) ---------------------------------------------------

@@ -214,6 +214,41 @@ class _HipModule(nn.Module):
     _range_latch = None            # render.render_rays_test: operands_key() of the (weights, scene) whose STATIC operands tripped the range guard
     last_precision_used = None     # arithmetic of the last frame render.render_rays_test produced on this module
 
+    # Consecutive fused evaluation calls of one module overlap on the device (context.CallOverlap: two side streams x two scratch
+    # lanes of the library context; the caller's stream semantics are unchanged).  What it is for: the reference's own chunk loops
+    # - 300 forward calls of 1024 rays per frame (neo360/model.py:861-907, vanilla_nerf/model.py:336-363, model_pixel.py:356-383,
+    # mipnerf360/model.py:471-505) - whose calls would otherwise each end on a partly filled machine.
+    # False / $NEO360_OVERLAP=0: every call runs on the caller's stream, as before round 6.
+    overlap_calls = os.environ.get("NEO360_OVERLAP", "1") != "0"
+
+    def _overlap(self, dev):
+        if not self.overlap_calls:
+            return None
+        table = self.__dict__.setdefault("_overlap_state", {})
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        ov = table.get(key)
+        if ov is None:
+            ov = table[key] = CallOverlap(torch.device("cuda", key))
+        return ov
+
+    def _launch_overlapped(self, ctx, dev, raw, conv, launch):
+        """Run `launch()` - output allocation + ONE fused library call + the flag post - on this call's side stream and scratch
+        lane (or on the caller's stream when overlap is off); `launch` returns the list of output tensors.  raw / conv: the ray
+        tensors as the caller passed them / as the library reads them (fork-point reuse: CallOverlap.begin)."""
+        ov = self._overlap(dev)
+        if ov is None:
+            return launch()
+        side, lane, cur = ov.begin(raw, conv)
+        ctx.set_lane(lane)
+        outs = []
+        try:
+            with torch.cuda.stream(side):
+                outs = launch()
+        finally:
+            ctx.set_lane(0)
+            ov.end(lane, cur, outs)
+        return outs
+
     def _scene_tensors_for_grad(self):
         return ()
 
@@ -287,22 +322,27 @@ class NeRF(_HipModule):
             return self._forward_fused(rays, white_bkgd, near, far)
 
     def _forward_fused(self, rays, white_bkgd, near, far):
-        rays_o = f32(rays["rays_o"], "rays_o")
-        viewdirs = f32(rays["viewdirs"], "viewdirs")
-        rays_d = f32(rays["rays_d"], "rays_d")
+        raw = (rays["rays_o"], rays["viewdirs"], rays["rays_d"])
+        rays_o = f32(raw[0], "rays_o")
+        viewdirs = f32(raw[1], "viewdirs")
+        rays_d = f32(raw[2], "rays_d")
         dev = rays_o.device
         ctx = self._context(dev)
         self._sync_weights(ctx)
         self._before_call(ctx)
         B = rays_o.shape[0]
-        outs = [(torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
-                for _ in range(2)]
-        _lib.check(ctx.lib.neo_vanilla_render(
-            ctx.handle, ptr(rays_o), ptr(viewdirs), ptr(rays_d), B, float(near), float(far),
-            self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
-            ptr(outs[0][0]), ptr(outs[0][1]), ptr(outs[0][2]), ptr(outs[1][0]), ptr(outs[1][1]), ptr(outs[1][2]),
-            ctx.stream()))
-        self._after_call(ctx)
+        outs = []
+
+        def launch():
+            outs.extend((torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)) for _ in range(2))
+            _lib.check(ctx.lib.neo_vanilla_render(
+                ctx.handle, ptr(rays_o), ptr(viewdirs), ptr(rays_d), B, float(near), float(far),
+                self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
+                ptr(outs[0][0]), ptr(outs[0][1]), ptr(outs[0][2]), ptr(outs[1][0]), ptr(outs[1][1]), ptr(outs[1][2]),
+                ctx.stream()))
+            self._after_call(ctx)
+            return [t for lv in outs for t in lv]
+        self._launch_overlapped(ctx, dev, raw, (rays_o, viewdirs, rays_d), launch)
         return outs
 
     @torch.no_grad()
@@ -626,22 +666,6 @@ class NeRF_TP(_HipModule):
         with torch.no_grad():
             return self._forward_eval(rays, randomized, white_bkgd, chunk)
 
-    # Consecutive evaluation calls overlap on the device (context.CallOverlap: two side streams x two scratch lanes; the
-    # caller's stream semantics are unchanged).  What it is for: the reference's own chunk loop - 300 forward calls of 1024
-    # rays per frame, neo360/model.py:861-907 - whose calls would otherwise each end on a partly filled machine.
-    # False / $NEO360_OVERLAP=0: every call runs on the caller's stream, as before round 6.
-    overlap_calls = os.environ.get("NEO360_OVERLAP", "1") != "0"
-
-    def _overlap(self, dev):
-        if not self.overlap_calls:
-            return None
-        table = self.__dict__.setdefault("_overlap_state", {})
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
-        ov = table.get(key)
-        if ov is None:
-            ov = table[key] = CallOverlap(torch.device("cuda", key))
-        return ov
-
     def _forward_eval(self, rays, randomized, white_bkgd, chunk=None):
         self._check_mode(randomized)
         raw = (rays["rays_o"], rays["rays_d"], rays["viewdirs"])
@@ -657,35 +681,30 @@ class NeRF_TP(_HipModule):
         self._before_call(ctx)
         B = rays_o.shape[0]
         host_poses, NV, focal, cx, cy = self._camera_args(rays)
-        ov = self._overlap(dev)
-        if ov is not None:
-            side, lane, cur = ov.begin(raw, (rays_o, rays_d, viewdirs))
-        else:
-            side, lane = torch.cuda.current_stream(dev), 0
-        ctx.set_lane(lane)
         # pixel-grid hint (render.render_rays_test / render_frame_sharded set `ray_grid` around a frame): a scheduling hint for
         # the evaluators' tile order, bitwise-neutral; only meaningful for a call that spans whole bands of 8 image rows
         grid = getattr(self, "ray_grid", None)
         ctx.set_ray_grid(*(grid if grid and grid[0] % 8 == 0 and B >= 8 * grid[0] else (0, 0)))
+        levels = []
+
+        def launch():
+            structs = []
+            for _ in range(2):
+                t = dict(rgb=torch.empty(B, 3, device=dev), fg_rgb=torch.empty(B, 3, device=dev),
+                         bg_rgb=torch.empty(B, 3, device=dev), fg_acc=torch.empty(B, device=dev),
+                         bg_lambda=torch.empty(B, 1, device=dev), depth=torch.empty(B, device=dev))
+                levels.append(t)
+                structs.append(_lib.TpLevelOut(*(t[k].data_ptr() for k in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth"))))
+            _lib.check(ctx.lib.neo_tp_render(
+                ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
+                self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
+                ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
+            self._after_call(ctx)
+            return [v for t in levels for v in t.values()]
         try:
-            with torch.cuda.stream(side):
-                levels, structs = [], []
-                for _ in range(2):
-                    t = dict(rgb=torch.empty(B, 3, device=dev), fg_rgb=torch.empty(B, 3, device=dev),
-                             bg_rgb=torch.empty(B, 3, device=dev), fg_acc=torch.empty(B, device=dev),
-                             bg_lambda=torch.empty(B, 1, device=dev), depth=torch.empty(B, device=dev))
-                    levels.append(t)
-                    structs.append(_lib.TpLevelOut(*(t[k].data_ptr() for k in ("rgb", "fg_rgb", "bg_rgb", "fg_acc", "bg_lambda", "depth"))))
-                _lib.check(ctx.lib.neo_tp_render(
-                    ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
-                    self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
-                    ctypes.byref(structs[0]), ctypes.byref(structs[1]), ctx.stream()))
-                self._after_call(ctx)
+            self._launch_overlapped(ctx, dev, raw, (rays_o, rays_d, viewdirs), launch)
         finally:
-            ctx.set_lane(0)
             ctx.set_ray_grid(0)
-            if ov is not None:
-                ov.end(lane, cur, [v for t in levels for v in t.values()] if 'levels' in locals() else [])
         return [(t["rgb"], t["fg_rgb"], t["bg_rgb"], t["fg_acc"], t["bg_lambda"], t["depth"]) for t in levels]
 
 
@@ -863,9 +882,10 @@ class PixelNeRF(_HipModule):
             return self._forward_fused(rays, white_bkgd, near, far, chunk)
 
     def _forward_fused(self, rays, white_bkgd, near, far, chunk=None):
-        rays_o = f32(rays["rays_o"], "rays_o")
-        rays_d = f32(rays["rays_d"], "rays_d")
-        viewdirs = f32(rays["viewdirs"], "viewdirs")
+        raw = (rays["rays_o"], rays["rays_d"], rays["viewdirs"])
+        rays_o = f32(raw[0], "rays_o")
+        rays_d = f32(raw[1], "rays_d")
+        viewdirs = f32(raw[2], "viewdirs")
         dev = rays_o.device
         ctx = self._context(dev)
         self._ensure_scene(rays)
@@ -875,12 +895,17 @@ class PixelNeRF(_HipModule):
         self._before_call(ctx)
         B = rays_o.shape[0]
         host_poses, NV, focal, cx, cy = self._camera_args(rays)
-        lv = [(torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)) for _ in range(2)]
-        _lib.check(ctx.lib.neo_pix_render(
-            ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
-            float(near), float(far), self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
-            ptr(lv[0][0]), ptr(lv[0][1]), ptr(lv[0][2]), ptr(lv[1][0]), ptr(lv[1][1]), ptr(lv[1][2]), ctx.stream()))
-        self._after_call(ctx)
+        lv = []
+
+        def launch():
+            lv.extend((torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)) for _ in range(2))
+            _lib.check(ctx.lib.neo_pix_render(
+                ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), B, int(chunk or max(B, 1)), host_poses, NV, focal, cx, cy,
+                float(near), float(far), self.num_coarse_samples, self.num_fine_samples, int(bool(white_bkgd)),
+                ptr(lv[0][0]), ptr(lv[0][1]), ptr(lv[0][2]), ptr(lv[1][0]), ptr(lv[1][1]), ptr(lv[1][2]), ctx.stream()))
+            self._after_call(ctx)
+            return [t for l in lv for t in l]
+        self._launch_overlapped(ctx, dev, raw, (rays_o, rays_d, viewdirs), launch)
         return lv
 
 
@@ -979,22 +1004,28 @@ class MipNeRF360(_HipModule):
             return self._forward_fused(batch, train_frac, near, far)
 
     def _forward_fused(self, batch, train_frac, near, far):
-        rays_o, rays_d = f32(batch["rays_o"], "rays_o"), f32(batch["rays_d"], "rays_d")
-        viewdirs, radii = f32(batch["viewdirs"], "viewdirs"), f32(batch["radii"], "radii")
+        raw = (batch["rays_o"], batch["rays_d"], batch["viewdirs"], batch["radii"])
+        rays_o, rays_d = f32(raw[0], "rays_o"), f32(raw[1], "rays_d")
+        viewdirs, radii = f32(raw[2], "viewdirs"), f32(raw[3], "radii")
         dev = rays_o.device
         ctx = self._context(dev)
         self._sync_weights(ctx)
         self._before_call(ctx)
         B = rays_o.shape[0]
         counts = (self.num_prop_samples, self.num_prop_samples, self.num_nerf_samples)
-        bufs = [dict(rgb=torch.empty(B, 3, device=dev), sdist=torch.empty(B, n + 1, device=dev),
-                     weights=torch.empty(B, n, device=dev), rgbdens=torch.empty(B, n, 4, device=dev)) for n in counts]
-        arr = (_lib.MipLevelOut * 3)(*[_lib.MipLevelOut(*(b[k].data_ptr() for k in ("rgb", "sdist", "weights", "rgbdens")))
-                                       for b in bufs])
-        _lib.check(ctx.lib.neo_mip_render(ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), B,
-                                          float(train_frac), float(near), float(far), self.num_prop_samples,
-                                          self.num_nerf_samples, arr, ctx.stream()))
-        self._after_call(ctx)
+        bufs = []
+
+        def launch():
+            bufs.extend(dict(rgb=torch.empty(B, 3, device=dev), sdist=torch.empty(B, n + 1, device=dev),
+                             weights=torch.empty(B, n, device=dev), rgbdens=torch.empty(B, n, 4, device=dev)) for n in counts)
+            arr = (_lib.MipLevelOut * 3)(*[_lib.MipLevelOut(*(b[k].data_ptr() for k in ("rgb", "sdist", "weights", "rgbdens")))
+                                           for b in bufs])
+            _lib.check(ctx.lib.neo_mip_render(ctx.handle, ptr(rays_o), ptr(rays_d), ptr(viewdirs), ptr(radii), B,
+                                              float(train_frac), float(near), float(far), self.num_prop_samples,
+                                              self.num_nerf_samples, arr, ctx.stream()))
+            self._after_call(ctx)
+            return [t for b in bufs for t in b.values()]
+        self._launch_overlapped(ctx, dev, raw, (rays_o, rays_d, viewdirs, radii), launch)
         renderings = [{"rgb": b["rgb"]} for b in bufs]
         history = [dict(density=b["rgbdens"][..., 3], rgb=b["rgbdens"][..., :3], sdist=b["sdist"], weights=b["weights"])
                    for b in bufs]

@@ -210,3 +210,49 @@ def test_ray_patch_order_is_bitwise_neutral():
         assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["depth"], b["depth"]), (lo, hi)
     with pytest.raises(_lib.NeoError):
         ctx.set_ray_grid(60)                 # not a multiple of 8
+
+
+@pytest.mark.parametrize("which", ["vanilla", "pixelnerf", "mip360"])
+def test_other_renderers_chunk_loops_overlap_and_stay_bitwise(which):
+    """The reference drives every renderer chunk by chunk (vanilla_nerf/model.py:336-363, model_pixel.py:356-383,
+    mipnerf360/model.py:471-505).  Their fused evaluation calls take the same side-stream / scratch-lane overlap as NeRF_TP's:
+    the overlapped loop's frame is bitwise the serial loop's."""
+    n, chunk = 1536, 256
+    if which == "vanilla":
+        net = models.NeRF().to(DEV)
+        net.load_state_dict(synth.vanilla_state(0))
+        batch = {k: v.to(DEV) for k, v in cases.strided_rays(n).items()}
+        call = lambda part: net(part, False, False, 0.2, 3.0)[1][0]
+    elif which == "pixelnerf":
+        sc = cases.small_scene()
+        net = models.PixelNeRF(num_src_views=cases.NV).to(DEV)
+        net.load_state_dict(synth.pixelnerf_state(0))
+        latent = sc["latent"].to(DEV)
+        net.set_scene(latent, sc["image_wh"])
+        batch = _batch(n)
+        call = lambda part: net(part, False, False, 0.2, 3.0)[1][0]
+    else:
+        net = models.MipNeRF360(num_prop_samples=16, num_nerf_samples=8).to(DEV)
+        net.load_state_dict(synth.mip360_state(0, weight_gain=0.5))
+        batch = {k: v.to(DEV) for k, v in cases.mip_rays(n).items()}
+        call = lambda part: net(part, 1.0, False, False, 0.2, 3.0)[0][-1]["rgb"]
+    per_ray = PER_RAY + ("radii",)
+
+    def loop():
+        out = []
+        for i in range(0, n, chunk):
+            part = {k: (v[i:i + chunk] if k in per_ray else v) for k, v in batch.items()}
+            out.append(call(part))
+        res = torch.cat(out)
+        net.check_flags()
+        return res
+    net.overlap_calls = False
+    want = loop()
+    net.overlap_calls = True
+    ov = net._overlap(torch.device(DEV))
+    c0, f0 = ov.calls, ov.fresh_forks
+    got = loop()
+    assert ov.calls - c0 == n // chunk and ov.fresh_forks - f0 <= 1
+    assert torch.equal(got, want)
+    got2 = loop()
+    assert torch.equal(got2, want)

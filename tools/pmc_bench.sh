@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_${W}_${P}
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $REPO/bench.py --workload $W --precision $P --steps 1 --warmup 0 --cpu-rays 0 --others 0 --exact-f32 0 --setup-timing 0"
+CMD="python $REPO/bench.py --workload $W --precision $P --steps 1 --warmup 0 --cpu-rays 0 --others 0 --exact-f32 0 --setup-timing 0 --chunk-loop 0"
 timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 i=0
