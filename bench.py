@@ -696,8 +696,12 @@ def _parse_cpulist(text):
 
 
 def bind_to_gpu_numa_node(local_rank, fake=False):
-    """One process per GPU: pin this rank's host threads to the CPUs of the NUMA node its GPU hangs off (the launch thread and the
-    telemetry thread then stay next to the device's PCIe root).  Best effort: returns what was done, never fails the run."""
+    """One process per GPU: which NUMA node does this rank's GPU hang off - reported in the rank's record - and, only with
+    $NEO360_NUMA_BIND=1, pin this rank's host threads to that node's CPUs.  The pinning is OFF by default because it was measured
+    to hurt (round 6, tools/gpu_r06j.sh, one MI355X box with 128 of 256 logical CPUs on the GPU's node): frame throughput is
+    unchanged (493.5 k vs 492.4 k rays/s) but the once-per-scene set-up window - ~150 enqueues and 72 small pageable
+    host-to-device copies - goes from 7.4 ms to 406 ms (every small copy waits ~5 ms for a runtime helper thread that the
+    affinity mask moved).  Best effort: returns what was found / done, never fails the run."""
     info = {"numa_node": None, "cpus_bound": None}
     try:
         if fake:
@@ -711,7 +715,7 @@ def bind_to_gpu_numa_node(local_rank, fake=False):
         with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
             node = int(f.read().strip())
         info["numa_node"] = node
-        if node < 0:
+        if node < 0 or os.environ.get("NEO360_NUMA_BIND", "0") != "1":
             return info
         with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
             cpus = _parse_cpulist(f.read()) & os.sched_getaffinity(0)
@@ -861,7 +865,8 @@ def main():
                        "rays_per_frame": R, "parallelism": "ray-shard x%d" % world},
             "roofline": run.roofline(kern),
             # one record per rank, gathered over the process group: the world size each rank saw, its GPU (name, PCI bus), the NUMA
-            # node its host threads were bound to and its OWN time per step (`ms_per_step` above is the max over ranks)
+            # node it hangs off (host threads are pinned there only with $NEO360_NUMA_BIND=1: measured harmful, see
+            # bind_to_gpu_numa_node) and its OWN time per step (`ms_per_step` above is the max over ranks)
             "ranks": ranks,
         }
         if args.workload == "neo360" and world == 1 and args.chunk_loop:
