@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT; T=${1:-r06z}; O=gpurun_out/$T; rm -rf $O; mkdir -p $O
 rm -f gpurun_out/parity_report.json
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -q -m gpu --durations=10 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+timeout 2400 python -m pytest tests -q -m gpu --durations=5 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 bash tools/pmc_bench.sh neo360 f16x3 "k_tp_mlp_hp<" "k_tp_mlp_hpp<" > $O/pmc_bench.log 2>&1
 cp gpurun_out/pmc_neo360_f16x3/summary.json profiles/r06_pmc_neo360_f16x3.json
