@@ -116,3 +116,23 @@ def alter_gather_cat(outputs, key, image_sizes, group=None):
             ret.append(part.reshape(h, w))
         curr += h * w
     return ret
+
+
+def ray_patch_order(n_rays, width, first_ray=0, pw_log2=1, ph_log2=1):
+    """Host mirror of csrc/tp_common.h:patch_point at ray granularity (documentation + CPU test; the device function is what runs):
+    the order in which the NeO-360 evaluators visit the rays of a launch that carries the pixel-grid hint (neo_ctx_set_ray_grid).
+    Returns a LongTensor `order` with order[k] = the ray (0 .. n_rays-1) visited k-th: inside every WHOLE band of 2^ph image rows
+    that lies inside [first_ray, first_ray + n_rays) the rays go patch by patch (2^pw x 2^ph pixels, row-major inside a patch,
+    patches left to right); rays outside whole bands keep their place.  A permutation for every (n_rays, first_ray)."""
+    import torch
+    k = torch.arange(n_rays, dtype=torch.long)
+    if width <= 0 or width % (1 << pw_log2) != 0:
+        return k
+    band = width << ph_log2
+    G = first_ray + k
+    b = G // band
+    whole = (b * band >= first_ray) & ((b + 1) * band <= first_ray + n_rays)
+    kk = G - b * band
+    r = kk & ((1 << (pw_log2 + ph_log2)) - 1)
+    Gt = b * band + (r >> pw_log2) * width + ((kk >> (pw_log2 + ph_log2)) << pw_log2) + (r & ((1 << pw_log2) - 1))
+    return torch.where(whole, Gt - first_ray, k)

@@ -198,3 +198,28 @@ def test_alter_gather_cat_single_process_is_the_identity_gather():
     assert torch.equal(got[0], outs[0]["rgb"].reshape(2, 3, 3)) and torch.equal(got[1], outs[1]["rgb"].reshape(1, 4, 3))
     d = parallel.alter_gather_cat([{"depth": torch.arange(10, dtype=torch.float32)}], "depth", sizes)
     assert torch.equal(d[0], torch.arange(6, dtype=torch.float32).reshape(2, 3)) and d[1].shape == (1, 4)
+
+
+def test_ray_patch_order_is_a_permutation_for_any_shard():
+    """The evaluators' ray-patch tile order (neo_ctx_set_ray_grid; host mirror parallel.ray_patch_order of tp_common.h:patch_point)
+    permutes the rays of a launch - whole frame, band-aligned shard, shard with ragged ends, any patch shape."""
+    import torch
+    from neo360_amd.parallel import ray_patch_order, shard_bounds
+    W, H = 640, 480
+    for pw, ph in ((1, 1), (3, 3), (2, 2), (0, 3), (1, 3)):
+        o = ray_patch_order(W * H, W, 0, pw, ph)
+        assert torch.equal(torch.sort(o).values, torch.arange(W * H))
+        # first patch of the frame: 2^pw x 2^ph pixels, row-major
+        want = torch.tensor([y * W + x for y in range(1 << ph) for x in range(1 << pw)])
+        assert torch.equal(o[:want.numel()], want)
+    for world in (2, 3, 8):
+        for rank in range(world):
+            lo, hi = shard_bounds(W * H, world, rank, unit=1024)
+            o = ray_patch_order(hi - lo, W, lo, 1, 1)
+            assert torch.equal(torch.sort(o).values, torch.arange(hi - lo)), (world, rank)
+            # rays outside whole bands of the shard keep their place
+            band = W << 1
+            head = (-lo) % band
+            assert torch.equal(o[:head], torch.arange(head))
+    assert torch.equal(ray_patch_order(1000, 0), torch.arange(1000))          # no hint
+    assert torch.equal(ray_patch_order(1000, 60, 0, 3, 3), torch.arange(1000))   # width not a multiple of the patch width
