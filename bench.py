@@ -322,7 +322,9 @@ class Runner:
         runs = [once(True) for _ in range(reps)]
         pick = lambda xs: sorted(xs)[1 if len(xs) > 1 else 0]
         total = pick([r[1] for r in runs])
-        return {"total_ms": total, "runs_ms": [r[1] for r in runs], "set_scene_ms": pick([r[0] for r in runs]),
+        import statistics
+        return {"total_ms": total, "median_ms": statistics.median(r[1] for r in runs), "runs_ms": [r[1] for r in runs],
+                "set_scene_ms": pick([r[0] for r in runs]),
                 "one_chunk_steady_ms": pick([r[2] for r in runs]),
                 "method": "HIP events on the launch stream, warm, second smallest of %d runs (host delays only add to the window): "
                           "(set_scene + repack + one-chunk render) - (the same render in the steady state)" % reps,
