@@ -1,3 +1,4 @@
+# NOTE: the NEO_TP32_STAGGER switch this script drives was removed after the measurement (no effect; profiles/r06_f32_stagger.log)
 # round 6: exact-fp32 NeO-360 evaluator - start offset of the second workgroup generation (anti-phase of the two co-resident workgroups)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r06k; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
