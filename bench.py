@@ -404,11 +404,14 @@ class Runner:
         try:
             frame()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(frames):
+            times = []
+            for _ in range(frames):                      # frame by frame: the loop is host-paced, a delayed host thread shows as an outlier
+                t0 = time.perf_counter()
                 out = frame()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / frames
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            dt = sorted(times)[len(times) // 2] if len(times) > 2 else sum(times) / len(times)
+            self.loop_times_ms = [t * 1e3 for t in times]
         finally:
             net.overlap_calls = prev
         return dt, out
@@ -873,11 +876,13 @@ def main():
         }
         if args.workload == "neo360" and world == 1 and args.chunk_loop:
             # what a run.py user gets without touching the reference's chunk loop (VERDICT r5 task 4)
-            dt_o, (rgb_o, depth_o) = run.chunk_loop(2, overlap=True)
+            dt_o, (rgb_o, depth_o) = run.chunk_loop(5, overlap=True)
+            loop_ms = list(run.loop_times_ms)
             dt_s, (rgb_s, depth_s) = run.chunk_loop(2, overlap=False)
             out["chunk_loop"] = {
                 "value": R / dt_o, "unit": "rays/s", "ms_per_frame": dt_o * 1e3, "frac_of_headline": (R / dt_o) / out["value"],
-                "calls_per_frame": (R + CHUNK - 1) // CHUNK, "rays_per_call": CHUNK, "frames": 2,
+                "calls_per_frame": (R + CHUNK - 1) // CHUNK, "rays_per_call": CHUNK, "frames": 5, "frames_ms": loop_ms,
+                "statistic": "median of 5 frames timed one by one (the loop is host-paced: 300 Python calls per frame)",
                 "serial_calls": {"value": R / dt_s, "ms_per_frame": dt_s * 1e3, "frac_of_headline": (R / dt_s) / out["value"]},
                 "bitwise_equal_to_whole_frame_call": bool(torch.equal(rgb_o, frame[:, :3]) and torch.equal(depth_o, frame[:, 3])
                                                           and torch.equal(rgb_s, rgb_o) and torch.equal(depth_s, depth_o)),

@@ -290,7 +290,7 @@ int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits) {
 
 int neo_ctx_set_lane(neo_ctx* ctx, int lane) {
     ENTER(ctx);
-    REQUIRE(lane >= 0 && lane < neo_ctx::LANES, "lane must be 0 or 1");
+    REQUIRE(lane >= 0 && lane < neo_ctx::LANES, "lane out of range (0 .. 3)");
     ctx->lane = lane;
     ctx->ws = ctx->ws_sets[lane];
     ctx->tp_dirsum = &ctx->tp_dirsum_sets[lane];

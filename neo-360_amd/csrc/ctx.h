@@ -138,7 +138,7 @@ struct neo_ctx {
     neo_host::MlpSlot pix[2];          // PixelNeRF coarse / fine
     int mip_shape[3][3] = {};          // width, depth, rgb per slot
     neo_host::DevBuf mip_basis;
-    neo_host::DevBuf mip_lws_sets[2][3];   // layer-by-layer NeRF MLP (mip_layered.h): encoding fragments + two activation buffers, per scratch lane
+    neo_host::DevBuf mip_lws_sets[4][3];   // layer-by-layer NeRF MLP (mip_layered.h): encoding fragments + two activation buffers, per scratch lane
     neo_host::DevBuf* mip_lws = mip_lws_sets[0];
     std::map<int, neo_host::DevBuf> mip_seed;   // R -> the level-0 histogram of neo_mip_render (sdist = [0, 1], weights = [1]) for R rays
     int mip_layered = -1;              // 1: NeRF MLP layer by layer, 0: fused evaluator, -1 (default): layer by layer from 8192 intervals
@@ -153,7 +153,7 @@ struct neo_ctx {
     // module chunk by chunk (the reference's render_rays_test loop, neo360/model.py:861-907) alternates lanes - and streams -
     // so that chunk i + 1's evaluators start while chunk i's last workgroups drain (models.py: NeRF_TP overlap).  `lane`
     // selects the set the NEXT calls use (neo_ctx_set_lane); everything else in the context is shared by both lanes.
-    static constexpr int LANES = 2;
+    static constexpr int LANES = 4;
     int lane = 0;
     neo_host::DevBuf tp_dirsum_sets[LANES];
     neo_host::DevBuf* tp_dirsum = &tp_dirsum_sets[0];   // (rays, 32): view-summed direction encodings of the current launch (k_tp_mlp_hp)
