@@ -75,8 +75,8 @@ int neo_ctx_sync_count(neo_ctx* ctx, uint64_t* blocking_waits);
 int neo_ctx_stream_waits(neo_ctx* ctx, uint64_t* cross_stream_waits);
 /* Scratch lanes (round 6).  The reference drives the module as 300 calls of 1024 rays per frame (render_rays_test,
  * neo360/model.py:861-907); launched back to back on one stream every call ends on a partly filled machine (2,064 tiles
- * of a coarse launch on 512 workgroup slots).  A context therefore owns TWO sets of render scratch: neo_ctx_set_lane picks
- * the set the next calls use (0, the default, or 1).  neo_tp_render writes its lane's scratch only and reads the shared
+ * of a coarse launch on 512 workgroup slots).  A context therefore owns FOUR sets of render scratch (grown on first use): neo_ctx_set_lane
+ * picks the set the next calls use (0, the default, .. 3).  neo_tp_render writes its lane's scratch only and reads the shared
  * weights / maps, so two renders on different lanes AND different streams are not ordered against each other and overlap
  * on the device; every other entry point (uploads, set_scene, evaluator / training calls) stays ordered against all
  * earlier calls of the context, on any lane.  A one-lane, one-stream caller sees no difference. */

@@ -149,7 +149,7 @@ struct neo_ctx {
     bool scene_ready = false;
     uint64_t scene_epoch = 0;          // bumped by every neo_tp_set_scene
     uint64_t planes_checked = 0, latent_checked = 0;   // scene_epoch whose maps passed the split range check
-    // Scratch LANES (round 6): two sets of the render workspaces and of the per-launch direction table.  A caller that drives the
+    // Scratch LANES (round 6): four sets (grown on first use; the Python host keeps two calls in flight) of the render workspaces and of the per-launch direction table.  A caller that drives the
     // module chunk by chunk (the reference's render_rays_test loop, neo360/model.py:861-907) alternates lanes - and streams -
     // so that chunk i + 1's evaluators start while chunk i's last workgroups drain (models.py: NeRF_TP overlap).  `lane`
     // selects the set the NEXT calls use (neo_ctx_set_lane); everything else in the context is shared by both lanes.
