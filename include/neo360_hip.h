@@ -380,6 +380,31 @@ int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float
                        const float* bias, int relu, int accumulate, float* y, long ldy, void* stream);
 int neo_linear_input_grad(neo_ctx* ctx, long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw,
                           int accumulate, float* gx, long ldx, void* stream);
+/* PixelNeRF's late-fusion MLP under autograd as ONE chain each way (round 6; vanilla_nerf/model_pixel.py:96-131 inside the training
+ * step :255-300): rows R = NV * P view-major; x_enc (R, 63) camera-frame encodings, pre (R, 128) = the gathered PROJECTED latent
+ * W0[:, 63:575] f (the 512-wide product is formed per texel by the caller, as for NeRFPPMLP), cond (R, 27) direction encodings.
+ * w / b: the nine layers in neo_pix_upload_mlp's order.  tape: neo_pix_mlp_train_tape_floats(NV, P) floats kept between forward and
+ * backward.  The backward returns the nine weight / bias gradients (gw / gb ZEROED by the caller; the latent columns of gw[0] stay
+ * untouched: their gradient is the texel-space GEMM's), g_pre (R, 128) = dL/dz0 and, when g_x_enc is not null, dL/dx_enc. */
+long neo_pix_mlp_train_tape_floats(int NV, long P);
+int neo_pix_mlp_train_forward_pre(neo_ctx* ctx, const float* const* w, const float* const* b, const float* x_enc, const float* pre,
+                                  const float* cond, int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, void* stream);
+int neo_pix_mlp_train_backward_pre(neo_ctx* ctx, const float* const* w, const float* x_enc, const float* cond, int NV, long P,
+                                   const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
+                                   float* g_x_enc, float* g_pre, void* stream);
+/* Mip-NeRF 360's MLPs under autograd as ONE chain each way (round 6; mipnerf360/model.py:107-176 inside the training step :236-365):
+ * rows = R rays x n intervals, x0 (rows, 504) integrated encodings (neo_mip_encode; data, no gradient), d_enc (R, 27) one direction
+ * encoding per ray.  width / depth = netwidth / netdepth (256 x 4 proposal, 1024 x 8 NeRF; the layer after index 4 reads [h | x0]),
+ * rgb = 0 for the proposal MLPs (disable_rgb: colour columns zero).  w / b in neo_mip_upload_mlp's order.  rgbdens (rows, 4) =
+ * [sigmoid(raw) (1 + 2 pad) - pad | softplus(raw_density - 1)], activated as the reference returns them.  tape: caller-owned,
+ * neo_mip_mlp_train_tape_floats floats, kept with rgbdens between forward and backward.  Backward: g_rgbdens (rows, 4) = dL/d rgbdens;
+ * gw / gb ZEROED by the caller. */
+long neo_mip_mlp_train_tape_floats(int width, int depth, int rgb, long R, int n);
+int neo_mip_mlp_train_forward(neo_ctx* ctx, int width, int depth, int rgb, const float* const* w, const float* const* b, const float* x0,
+                              const float* d_enc, long R, int n, float* tape, float* rgbdens, void* stream);
+int neo_mip_mlp_train_backward(neo_ctx* ctx, int width, int depth, int rgb, const float* const* w, const float* x0, const float* d_enc,
+                               long R, int n, const float* tape, const float* rgbdens, const float* g_rgbdens, float* const* gw,
+                               float* const* gb, void* stream);
 /* neo_tp_gather_map / _backward at the PixelNeRF decoder's taps (scene geometry of neo_pix_set_scene). */
 int neo_pix_gather_map(neo_ctx* ctx, const float* map, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
                        float cx, float cy, float* out, void* stream);

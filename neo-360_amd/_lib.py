@@ -81,6 +81,14 @@ SIGNATURES = {
                                           _vp, _vp]),
     "neo_tp_mlp_train_backward_pre": (_i, [_vp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp,
                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
+    "neo_pix_mlp_train_tape_floats": (ctypes.c_long, [_i, ctypes.c_long]),
+    "neo_pix_mlp_train_forward_pre": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp, _vp]),
+    "neo_pix_mlp_train_backward_pre": (_i, [_vp, ctypes.POINTER(_vp), _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp,
+                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp]),
+    "neo_mip_mlp_train_tape_floats": (ctypes.c_long, [_i, _i, _i, ctypes.c_long, _i]),
+    "neo_mip_mlp_train_forward": (_i, [_vp, _i, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, ctypes.c_long, _i, _vp, _vp, _vp]),
+    "neo_mip_mlp_train_backward": (_i, [_vp, _i, _i, _i, ctypes.POINTER(_vp), _vp, _vp, ctypes.c_long, _i, _vp, _vp, _vp,
+                                        ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "neo_linear_forward": (_i, [_vp, ctypes.c_long, _i, _i, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _i, _i, _vp, ctypes.c_long, _vp]),
     "neo_linear_input_grad": (_i, [_vp, ctypes.c_long, _i, _i, _vp, ctypes.c_long, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, _vp]),
     "neo_linear_weight_grad": (_i, [_vp, _i, _i, ctypes.c_long, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, ctypes.c_long, _vp, _vp]),

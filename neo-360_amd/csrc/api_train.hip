@@ -399,6 +399,36 @@ int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const
     return check_launch();
 }
 
+long neo_pix_mlp_train_tape_floats(int NV, long P) { return (NV >= 1 && P >= 0) ? (long)neo::pix_train_tape_floats(NV, P) : 0; }
+
+int neo_pix_mlp_train_forward_pre(neo_ctx* ctx, const float* const* w, const float* const* b, const float* x_enc, const float* pre,
+                                  const float* cond, int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, void* stream) {
+    ENTER(ctx);
+    REQUIRE(NV >= 1 && P >= 0, "bad shape");
+    if (P == 0) return NEO_OK;
+    REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
+    REQUIRE(w && b && x_enc && pre && cond && tape && raw_rgb && raw_sigma, "null pointer");
+    for (int i = 0; i < 9; ++i) REQUIRE(w[i] && b[i], "null weight / bias pointer");
+    neo::launch_pix_train_forward(w, b, x_enc, pre, cond, NV, P, tape, raw_rgb, raw_sigma, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_pix_mlp_train_backward_pre(neo_ctx* ctx, const float* const* w, const float* x_enc, const float* cond, int NV, long P,
+                                   const float* tape, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
+                                   float* g_x_enc, float* g_pre, void* stream) {
+    ENTER(ctx);
+    REQUIRE(NV >= 1 && P >= 0, "bad shape");
+    if (P == 0) return NEO_OK;
+    REQUIRE((long)NV * P <= 4190000L, "at most 4.19 M rows (point-views) per call");
+    REQUIRE(w && x_enc && cond && tape && g_rgb && g_sigma && gw && gb && g_pre, "null pointer");
+    for (int i = 0; i < 9; ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
+    if (ctx->train_scratch.reserve(neo::pix_train_scratch_floats(NV, P) * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_pix_train_backward(w, x_enc, cond, NV, P, tape, ctx->train_scratch.as<float>(), g_rgb, g_sigma, gw, gb, g_x_enc, g_pre,
+                                   static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
 int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float* x, long ldx, const float* w, long ldw,
                        const float* bias, int relu, int accumulate, float* y, long ldy, void* stream) {
     ENTER(ctx);
@@ -462,6 +492,40 @@ int neo_vanilla_mlp_train_backward(neo_ctx* ctx, const float* const* w, const fl
     if (ctx->train_scratch.reserve(neo::vanilla_train_scratch_floats(R) * sizeof(float))) return NEO_ERR_NOMEM;
     neo::launch_vanilla_train_backward(w, x0, cond, R, tape, ctx->train_scratch.as<float>(), g_rgb, g_sigma, gw, gb, g_x0, g_cond,
                                        static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+long neo_mip_mlp_train_tape_floats(int width, int depth, int rgb, long R, int n) {
+    return (R >= 0 && n >= 1 && width >= 1 && depth >= 1) ? (long)neo::mip_train_tape_floats(width, depth, rgb, R * n, R) : 0;
+}
+
+static int mip_train_shape_ok(int width, int depth, long R, int n) {
+    return width >= 64 && width <= 1024 && width % 64 == 0 && depth >= 1 && depth <= 8 && R >= 0 && n >= 1 && R * (long)n <= 4190000L;
+}
+
+int neo_mip_mlp_train_forward(neo_ctx* ctx, int width, int depth, int rgb, const float* const* w, const float* const* b, const float* x0,
+                              const float* d_enc, long R, int n, float* tape, float* rgbdens, void* stream) {
+    ENTER(ctx);
+    REQUIRE(mip_train_shape_ok(width, depth, R, n), "width in [64, 1024] (multiple of 64), depth in [1, 8], at most 4.19 M rows (intervals) per call");
+    if (R == 0) return NEO_OK;
+    REQUIRE(w && b && x0 && tape && rgbdens && (!rgb || d_enc), "null pointer");
+    for (int i = 0; i < depth + (rgb ? 4 : 1); ++i) REQUIRE(w[i] && b[i], "null weight / bias pointer");
+    neo::launch_mip_train_forward(width, depth, rgb ? 1 : 0, w, b, x0, d_enc, R, n, tape, rgbdens, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
+int neo_mip_mlp_train_backward(neo_ctx* ctx, int width, int depth, int rgb, const float* const* w, const float* x0, const float* d_enc,
+                               long R, int n, const float* tape, const float* rgbdens, const float* g_rgbdens, float* const* gw,
+                               float* const* gb, void* stream) {
+    ENTER(ctx);
+    REQUIRE(mip_train_shape_ok(width, depth, R, n), "width in [64, 1024] (multiple of 64), depth in [1, 8], at most 4.19 M rows (intervals) per call");
+    if (R == 0) return NEO_OK;
+    REQUIRE(w && x0 && tape && rgbdens && g_rgbdens && gw && gb && (!rgb || d_enc), "null pointer");
+    for (int i = 0; i < depth + (rgb ? 4 : 1); ++i) REQUIRE(w[i] && gw[i] && gb[i], "null weight / gradient pointer");
+    ORDERED(ctx, static_cast<hipStream_t>(stream));
+    if (ctx->train_scratch.reserve(neo::mip_train_scratch_floats(width, rgb ? 1 : 0, R * n, R) * sizeof(float))) return NEO_ERR_NOMEM;
+    neo::launch_mip_train_backward(width, depth, rgb ? 1 : 0, w, x0, d_enc, R, n, tape, ctx->train_scratch.as<float>(), rgbdens, g_rgbdens,
+                                   gw, gb, static_cast<hipStream_t>(stream));
     return check_launch();
 }
 

@@ -20,6 +20,26 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
                               const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc, float* g_local,
                               float* g_world, hipStream_t s, float* g_pre = nullptr);
 
+// PixelNeRF's MLP (vanilla_nerf/model_pixel.py:96-131) on the projected latent: pre (R, 128), x_enc (R, 63), cond (R, 27).
+// w / b order as neo_pix_upload_mlp.
+size_t pix_train_tape_floats(int NV, long P);
+size_t pix_train_scratch_floats(int NV, long P);
+void launch_pix_train_forward(const float* const* w, const float* const* b, const float* x_enc, const float* pre, const float* cond,
+                              int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s);
+void launch_pix_train_backward(const float* const* w, const float* x_enc, const float* cond, int NV, long P, const float* tape,
+                               float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
+                               float* g_x_enc, float* g_pre, hipStream_t s);
+
+// Mip-NeRF 360 MLP (mipnerf360/model.py:107-176): rows = R x n intervals, x0 (rows, 504), d_enc (R, 27); W / D = netwidth / netdepth, rgb = 1 with
+// the colour branch.  w / b order as neo_mip_upload_mlp.  Outputs activated: rgbdens (rows, 4) = [rgb | density].
+size_t mip_train_tape_floats(int W, int D, int rgb, long rows, long R);
+size_t mip_train_scratch_floats(int W, int rgb, long rows, long R);
+void launch_mip_train_forward(int W, int D, int rgb, const float* const* w, const float* const* b, const float* x0, const float* d_enc,
+                              long R, int n, float* tape, float* rgbdens, hipStream_t s);
+void launch_mip_train_backward(int W, int D, int rgb, const float* const* w, const float* x0, const float* d_enc, long R, int n,
+                               const float* tape, float* scratch, const float* rgbdens, const float* g, float* const* gw,
+                               float* const* gb, hipStream_t s);
+
 // vanilla NeRFMLP (vanilla_nerf/model.py:100-125): rows R = rays x samples; x0 (R, 63), cond (R, 27).  w / b order as
 // neo_vanilla_upload_mlp.
 size_t vanilla_train_tape_floats(long R);

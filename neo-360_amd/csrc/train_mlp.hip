@@ -678,6 +678,80 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
     gemm<false, false>((int)P, 3, 64, y1, 64, w[8], 64, raw_rgb, 3, epi(b[8], 0), 1, s);
 }
 
+// PixelNeRF's late-fusion MLP (vanilla_nerf/model_pixel.py:96-131) as the same kind of chain (round 6): the NeRFPPMLP chain without
+// the world features and without the skip (netdepth 4: the skip after layer index 4 never fires).  w / b order as
+// neo_pix_upload_mlp: pts_linears.0..3 (128 x 575, 128 x 128 x 3), views_linear.0 (128 x 155), views_linear.1 (128 x 128), bottleneck, density,
+// rgb.  pre (R, 128) = the gathered PROJECTED latent W0[:, 63:575] f (formed per texel by the caller); tape layout
+// (pix_train_tape_floats): h0 h1 h2 h3 bott y0 (R x 128) hm ym y1 (P x 128).
+// tape / scratch of the PixelNeRF chain (view width 128)
+size_t pix_train_tape_floats(int NV, long P) {
+    const long R = (long)NV * P;
+    return (size_t)(R * (5 * 128 + 128) + P * (128 + 128 + 128));
+}
+size_t pix_train_scratch_floats(int NV, long P) {
+    const long R = (long)NV * P;
+    return (size_t)(R * (2 * 128 + 128) + P * (128 + 128 + 128) + DW_PART_FLOATS);
+}
+
+void launch_pix_train_forward(const float* const* w, const float* const* b, const float* x_enc, const float* pre, const float* cond,
+                              int NV, long P, float* tape, float* raw_rgb, float* raw_sigma, hipStream_t s) {
+    const long R = (long)NV * P;
+    const int pe = 63, K0 = pe + 512, VC = 128;                     // VC: netwidth_condition (model_pixel.py:44)
+    float* h0 = tape; float* h1 = h0 + R * 128; float* h2 = h1 + R * 128; float* h3 = h2 + R * 128;
+    float* bott = h3 + R * 128; float* y0 = bott + R * 128; float* hm = y0 + R * VC; float* ym = hm + P * 128; float* y1 = ym + P * VC;
+    hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, pre, 128L, h0, 128L, R, 128);
+    gemm<false, false>((int)R, 128, pe, x_enc, pe, w[0], K0, h0, 128, epi(b[0], 1, 1), 1, s);                        // relu(pre + x_enc W0_pe + b0)
+    gemm<false, false>((int)R, 128, 128, h0, 128, w[1], 128, h1, 128, epi(b[1], 1), 1, s);
+    gemm<false, false>((int)R, 128, 128, h1, 128, w[2], 128, h2, 128, epi(b[2], 1), 1, s);
+    gemm<false, false>((int)R, 128, 128, h2, 128, w[3], 128, h3, 128, epi(b[3], 1), 1, s);
+    gemm<false, false>((int)R, 128, 128, h3, 128, w[6], 128, bott, 128, epi(b[6], 0), 1, s);                         // bottleneck, per view (:113-114)
+    hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);                   // combine_interleaved "average"
+    gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
+    gemm<false, false>((int)R, VC, 128, bott, 128, w[4], 155, y0, VC, epi(b[4], 0), 1, s);                           // view layer 0 on [bott | cond]
+    gemm<false, false>((int)R, VC, 27, cond, 27, w[4] + 128, 155, y0, VC, epi(nullptr, 0, 1), 1, s);
+    hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * VC)), dim3(256), 0, s, y0, NV, P, VC, 1, ym);                    // mean over views, ReLU
+    gemm<false, false>((int)P, VC, VC, ym, VC, w[5], VC, y1, VC, epi(b[5], 1), 1, s);
+    gemm<false, false>((int)P, 3, VC, y1, VC, w[8], VC, raw_rgb, 3, epi(b[8], 0), 1, s);
+}
+
+// gw / gb ZEROED by the caller; g_pre (R, 128) = dL/dz0 (the lookup's backward carries it into the projected map: the gradient of
+// W0's latent columns is formed in texel space); g_x_enc (R, 63) may be null.  scratch: pix_train_scratch_floats(NV, P).
+void launch_pix_train_backward(const float* const* w, const float* x_enc, const float* cond, int NV, long P, const float* tape,
+                               float* scratch, const float* g_rgb, const float* g_sigma, float* const* gw, float* const* gb,
+                               float* g_x_enc, float* g_pre, hipStream_t s) {
+    const long R = (long)NV * P;
+    const int pe = 63, K0 = pe + 512, VC = 128;                     // VC: netwidth_condition (model_pixel.py:44)
+    const float* h0 = tape; const float* h1 = h0 + R * 128; const float* h2 = h1 + R * 128; const float* h3 = h2 + R * 128;
+    const float* bott = h3 + R * 128; const float* y0 = bott + R * 128; const float* hm = y0 + R * VC;
+    const float* ym = hm + P * 128; const float* y1 = ym + P * VC;
+    (void)y0;
+    float* ga = scratch; float* gb2 = ga + R * 128; float* gy0 = gb2 + R * 128;                 // R-sized
+    float* g_hm = gy0 + R * VC; float* g_y1 = g_hm + P * 128; float* g_ym = g_y1 + P * VC;       // P-sized
+    float* part = g_ym + P * VC;                                                                 // DW_PART_FLOATS (dw_gemm)
+    dw_gemm(3, VC, (int)P, g_rgb, 3, y1, VC, gw[8], VC, gb[8], part, s);                                         // rgb head
+    gemm<false, true>((int)P, VC, 3, g_rgb, 3, w[8], VC, g_y1, VC, epi(nullptr, 0, 0, y1, VC), 1, s);            // x relu'(y1)
+    dw_gemm(VC, VC, (int)P, g_y1, VC, ym, VC, gw[5], VC, gb[5], part, s);                                        // view layer 1
+    gemm<false, true>((int)P, VC, VC, g_y1, VC, w[5], VC, g_ym, VC, epi(nullptr, 0, 0, ym, VC), 1, s);           // x relu'(mean)
+    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * VC)), dim3(256), 0, s, g_ym, NV, P, VC, 0, gy0, (long)VC);        // mean over views -> rows
+    dw_gemm(VC, 128, (int)R, gy0, VC, bott, 128, gw[4], 155, gb[4], part, s);                                    // view layer 0 on [bott | cond]
+    dw_gemm(VC, 27, (int)R, gy0, VC, cond, 27, gw[4] + 128, 155, nullptr, part, s);
+    gemm<false, true>((int)R, 128, VC, gy0, VC, w[4], 155, ga, 128, epi(), 1, s);                                // g_bott
+    dw_gemm(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, gb[6], part, s);                                     // bottleneck
+    gemm<false, true>((int)R, 128, 128, ga, 128, w[6], 128, gb2, 128, epi(), 1, s);                              // g_h3 from the bottleneck
+    dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);                                    // density head on the view mean
+    gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
+    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 1, gb2, 128L);    // g_h3 += g_hm / NV
+    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, 128L, h3, 128, R);              // g_z3
+    dw_gemm(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128, gb[3], part, s);                                    // layer 3
+    gemm<false, true>((int)R, 128, 128, gb2, 128, w[3], 128, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);         // g_z2
+    dw_gemm(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, gb[2], part, s);                                     // layer 2
+    gemm<false, true>((int)R, 128, 128, ga, 128, w[2], 128, gb2, 128, epi(nullptr, 0, 0, h1, 128), 1, s);         // g_z1
+    dw_gemm(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, gb[1], part, s);                                    // layer 1
+    gemm<false, true>((int)R, 128, 128, gb2, 128, w[1], 128, g_pre, 128, epi(nullptr, 0, 0, h0, 128), 1, s);      // g_z0 -> g_pre
+    dw_gemm(128, pe, (int)R, g_pre, 128, x_enc, pe, gw[0], K0, gb[0], part, s);                                  // layer 0, encoding columns
+    if (g_x_enc) gemm<false, true>((int)R, pe, 128, g_pre, 128, w[0], K0, g_x_enc, pe, epi(), 1, s);
+}
+
 // gw / gb: nine weight / bias gradients, ZEROED by the caller (split-K partials are accumulated atomically); each of the
 // three input gradients (R x pe, R x 512, R x 128) may be null
 void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc, const float* local, const float* world,
@@ -817,5 +891,152 @@ void launch_vanilla_train_backward(const float* const* w, const float* x0, const
     dw_gemm(256, 63, M, cur, 256, x0, 63, gw[0], 63, gb[0], part, s);
     if (g_x0) gemm<false, true>(M, 63, 256, cur, 256, w[0], 63, g_x0, 63, epi(nullptr, 0, 1), 1, s);
 }
+
+// ---- Mip-NeRF 360 MLP (mipnerf360/model.py:107-176) as one chain each way (round 6) --------------------------------------
+// rows = R rays x n intervals; x0 (rows, 504) integrated encodings (data: no gradient), d_enc (R, 27) one direction encoding per
+// RAY (the reference tiles it over the intervals; here the direction term of the view layer is formed once per ray and broadcast).
+// W = netwidth (256 proposal / 1024 NeRF), D = netdepth (4 / 8): layer i > 0 with (i - 1) % 4 == 0 and i - 1 > 0 reads [h | x0].
+// w / b order as neo_mip_upload_mlp: pts_linear.0..D-1, density, then (rgb branch) bottleneck (W -> 256), views_linear.0 (283 -> 128), rgb.
+// Outputs ACTIVATED as the reference returns them: rgbdens (rows, 4) = [sigmoid(.) (1 + 2 pad) - pad | softplus(raw - 1)]; the backward
+// reads them back (softplus' = 1 - exp(-density), sigmoid' from the colour), so no raw values are kept.
+// tape (floats): h0..h(D-1) (rows x W each), bott (rows x 256), y (rows x 128, post-ReLU), the rays' direction terms (R x 128)
+namespace {
+constexpr int MIP_POS = 504;
+constexpr float MIP_PAD = 0.001f;
+inline bool mip_skip(int i) { return i > 0 && (i - 1) % 4 == 0 && (i - 1) > 0; }
+
+// y[r n + j][c] = relu(y[..][c] + dterm[r][c])
+__global__ void k_ray_bcast_add_relu(float* __restrict__ y, const float* __restrict__ dterm, long rows, int n, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * C) return;
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    y[i] = fmaxf(y[i] + dterm[(row / n) * C + c], 0.0f);
+}
+// out[r][c] = sum_j g[r n + j][c]
+__global__ void k_ray_group_sum(const float* __restrict__ g, long R, int n, int C, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * C) return;
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    float s = 0.0f;
+    for (int j = 0; j < n; ++j) s += g[((long)r * n + j) * C + c];
+    out[i] = s;
+}
+// in place on (rows, 4): columns 0..2 raw colour -> sigmoid(x) (1 + 2 pad) - pad (zeros without the branch), column 3 raw density ->
+// softplus(x - 1) with torch's threshold (x > 20: x)
+__global__ void k_mip_act(float4* __restrict__ v, long rows, int rgb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    float4 q = v[i];
+    const float x = q.w + (-1.0f);
+    q.w = x > 20.0f ? x : log1pf(expf(x));
+    if (rgb) {
+        q.x = (1.0f / (1.0f + expf(-q.x))) * (1.0f + 2.0f * MIP_PAD) - MIP_PAD;
+        q.y = (1.0f / (1.0f + expf(-q.y))) * (1.0f + 2.0f * MIP_PAD) - MIP_PAD;
+        q.z = (1.0f / (1.0f + expf(-q.z))) * (1.0f + 2.0f * MIP_PAD) - MIP_PAD;
+    } else {
+        q.x = q.y = q.z = 0.0f;
+    }
+    v[i] = q;
+}
+// graw = g x d(activation): from the activated outputs
+__global__ void k_mip_act_bwd(const float4* __restrict__ g, const float4* __restrict__ out, long rows, int rgb, float4* __restrict__ graw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const float4 a = g[i], o = out[i];
+    float4 r;
+    r.w = a.w * (1.0f - expf(-o.w));
+    if (rgb) {
+        const float k = 1.0f + 2.0f * MIP_PAD;
+        const float sx = (o.x + MIP_PAD) / k, sy = (o.y + MIP_PAD) / k, sz = (o.z + MIP_PAD) / k;
+        r.x = a.x * k * sx * (1.0f - sx);
+        r.y = a.y * k * sy * (1.0f - sy);
+        r.z = a.z * k * sz * (1.0f - sz);
+    } else {
+        r.x = r.y = r.z = 0.0f;
+    }
+    graw[i] = r;
+}
+}  // namespace
+
+size_t mip_train_tape_floats(int W, int D, int rgb, long rows, long R) {
+    return (size_t)rows * ((size_t)D * W + (rgb ? 256 + 128 : 0)) + (rgb ? (size_t)R * 128 : 0);
+}
+size_t mip_train_scratch_floats(int W, int rgb, long rows, long R) {
+    return (size_t)rows * (2 * (size_t)W + 4 + (rgb ? 256 + 128 : 0)) + (size_t)R * 128 + DW_PART_FLOATS;
+}
+
+void launch_mip_train_forward(int W, int D, int rgb, const float* const* w, const float* const* b, const float* x0, const float* d_enc,
+                              long R, int n, float* tape, float* rgbdens, hipStream_t s) {
+    const long rows = R * n;
+    const int M = (int)rows;
+    auto h = [&](int i) { return tape + (size_t)i * rows * W; };
+    float* bott = tape + (size_t)D * rows * W;
+    float* y = bott + (size_t)rows * 256;
+    gemm<false, false>(M, W, MIP_POS, x0, MIP_POS, w[0], MIP_POS, h(0), W, epi(b[0], 1), 1, s);
+    for (int i = 1; i < D; ++i) {
+        if (mip_skip(i)) {         // the layer after the concatenation [h | x0] (model.py:118-123): two products into one sum
+            gemm<false, false>(M, W, W, h(i - 1), W, w[i], W + MIP_POS, h(i), W, epi(b[i], 0), 1, s);
+            gemm<false, false>(M, W, MIP_POS, x0, MIP_POS, w[i] + W, W + MIP_POS, h(i), W, epi(nullptr, 1, 1), 1, s);
+        } else {
+            gemm<false, false>(M, W, W, h(i - 1), W, w[i], W, h(i), W, epi(b[i], 1), 1, s);
+        }
+    }
+    gemm<false, false>(M, 1, W, h(D - 1), W, w[D], W, rgbdens + 3, 4, epi(b[D], 0), 1, s);                          // raw density -> column 3
+    if (rgb) {
+        float* dterm = y + (size_t)rows * 128;                                                                        // (R, 128)
+        gemm<false, false>(M, 256, W, h(D - 1), W, w[D + 1], W, bott, 256, epi(b[D + 1], 0), 1, s);
+        gemm<false, false>(M, 128, 256, bott, 256, w[D + 2], 283, y, 128, epi(b[D + 2], 0), 1, s);
+        gemm<false, false>((int)R, 128, 27, d_enc, 27, w[D + 2] + 256, 283, dterm, 128, epi(), 1, s);                 // once per ray
+        hipLaunchKernelGGL(k_ray_bcast_add_relu, dim3(blocks(rows * 128)), dim3(256), 0, s, y, dterm, rows, n, 128);
+        gemm<false, false>(M, 3, 128, y, 128, w[D + 3], 128, rgbdens, 4, epi(b[D + 3], 0), 1, s);                     // raw colour -> columns 0..2
+    }
+    hipLaunchKernelGGL(k_mip_act, dim3(blocks(rows)), dim3(256), 0, s, reinterpret_cast<float4*>(rgbdens), rows, rgb);
+}
+
+// gw / gb ZEROED by the caller (D + 1 or D + 4 tensors); g (rows, 4) = dL/d rgbdens; rgbdens = the forward's output
+void launch_mip_train_backward(int W, int D, int rgb, const float* const* w, const float* x0, const float* d_enc, long R, int n,
+                               const float* tape, float* scratch, const float* rgbdens, const float* g, float* const* gw,
+                               float* const* gb, hipStream_t s) {
+    const long rows = R * n;
+    const int M = (int)rows;
+    auto h = [&](int i) { return tape + (size_t)i * rows * W; };
+    const float* bott = tape + (size_t)D * rows * W;
+    const float* y = bott + (size_t)rows * 256;
+    float* cur = scratch; float* nxt = cur + (size_t)rows * W; float* graw = nxt + (size_t)rows * W;
+    float* gbott = graw + (size_t)rows * 4; float* gy = gbott + (rgb ? (size_t)rows * 256 : 0);
+    float* gdt = gy + (rgb ? (size_t)rows * 128 : 0); float* part = gdt + (size_t)R * 128;
+    hipLaunchKernelGGL(k_mip_act_bwd, dim3(blocks(rows)), dim3(256), 0, s, reinterpret_cast<const float4*>(g),
+                       reinterpret_cast<const float4*>(rgbdens), rows, rgb, reinterpret_cast<float4*>(graw));
+    int acc = 0;
+    if (rgb) {
+        dw_gemm(3, 128, M, graw, 4, y, 128, gw[D + 3], 128, gb[D + 3], part, s);                                      // rgb head
+        gemm<false, true>(M, 128, 3, graw, 4, w[D + 3], 128, gy, 128, epi(nullptr, 0, 0, y, 128), 1, s);              // x relu'(y)
+        dw_gemm(128, 256, M, gy, 128, bott, 256, gw[D + 2], 283, gb[D + 2], part, s);                                 // view layer, bottleneck columns
+        hipLaunchKernelGGL(k_ray_group_sum, dim3(blocks(R * 128)), dim3(256), 0, s, gy, R, n, 128, gdt);
+        dw_gemm(128, 27, (int)R, gdt, 128, d_enc, 27, gw[D + 2] + 256, 283, nullptr, part, s);                         //             direction columns
+        gemm<false, true>(M, 256, 128, gy, 128, w[D + 2], 283, gbott, 256, epi(), 1, s);
+        dw_gemm(256, W, M, gbott, 256, h(D - 1), W, gw[D + 1], W, gb[D + 1], part, s);                                // bottleneck
+        gemm<false, true>(M, W, 256, gbott, 256, w[D + 1], W, cur, W, epi(), 1, s);
+        acc = 1;
+    }
+    dw_gemm(1, W, M, graw + 3, 4, h(D - 1), W, gw[D], W, gb[D], part, s);                                             // density head
+    gemm<false, true>(M, W, 1, graw + 3, 4, w[D], W, cur, W, epi(nullptr, 0, acc), 1, s);
+    hipLaunchKernelGGL(k_relu_mask, dim3(blocks(rows * W)), dim3(256), 0, s, cur, (long)W, h(D - 1), W, rows);         // g_z(D-1)
+    for (int i = D - 1; i >= 1; --i) {
+        if (mip_skip(i)) {
+            dw_gemm(W, W, M, cur, W, h(i - 1), W, gw[i], W + MIP_POS, gb[i], part, s);
+            dw_gemm(W, MIP_POS, M, cur, W, x0, MIP_POS, gw[i] + W, W + MIP_POS, nullptr, part, s);
+            gemm<false, true>(M, W, W, cur, W, w[i], W + MIP_POS, nxt, W, epi(nullptr, 0, 0, h(i - 1), W), 1, s);
+        } else {
+            dw_gemm(W, W, M, cur, W, h(i - 1), W, gw[i], W, gb[i], part, s);
+            gemm<false, true>(M, W, W, cur, W, w[i], W, nxt, W, epi(nullptr, 0, 0, h(i - 1), W), 1, s);
+        }
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    dw_gemm(W, MIP_POS, M, cur, W, x0, MIP_POS, gw[0], MIP_POS, gb[0], part, s);
+}
+
 
 }  // namespace neo

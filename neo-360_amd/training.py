@@ -746,6 +746,68 @@ def nerf_render_train(module, rays, randomized, white_bkgd, near, far, seed=None
 
 
 # ---- PixelNeRF decoder: the training call (vanilla_nerf/model_pixel.py:174-258 under the LitPixelNeRF training_step) ------------
+class _PixTrainMLPPre(torch.autograd.Function):
+    """PixelNeRF's MLP on the projected latent as ONE native chain each way (neo_pix_mlp_train_forward_pre / _backward_pre):
+    activations go layer to layer inside the library, the backward returns all 18 parameter gradients, dL/dpre and - if asked -
+    dL/dx_enc.  The gradient of W0's latent columns flows through `pre` into the texel-space GEMM (project_pixel_latent)."""
+
+    @staticmethod
+    def forward(ctx_, lib_ctx, nv, x_enc, cond_rows, pre, *params):
+        ws, bs = params[:9], params[9:]
+        npts = x_enc.shape[1]
+        if x_enc.dim() != 3 or tuple(x_enc.shape) != (nv, npts, 63):
+            raise ValueError("x_enc must be (NV, P, 63), got %s" % (tuple(x_enc.shape),))
+        for name, t, width in (("cond_rows", cond_rows, 27), ("pre", pre, 128)):
+            if tuple(t.shape) != (nv * npts, width):
+                raise ValueError("%s must be (NV*P, %d) = (%d, %d), got %s" % (name, width, nv * npts, width, tuple(t.shape)))
+        want = [(128, 575), (128, 128), (128, 128), (128, 128), (128, 155), (128, 128), (128, 128), (1, 128), (3, 128)]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if tuple(w.shape) != want[i] or tuple(b.shape) != (want[i][0],):
+                raise ValueError("PixelNeRF MLP layer %d: weight %s / bias %s, expected %s / (%d,)"
+                                 % (i, tuple(w.shape), tuple(b.shape), want[i], want[i][0]))
+        xe = f32(x_enc, "x_enc").reshape(-1, 63)
+        pf, cond = f32(pre, "pre"), f32(cond_rows, "cond_rows")
+        c = _ctx(xe, lib_ctx)
+        wd = [f32(w.detach(), "weight") for w in ws]
+        bd = [f32(b.detach(), "bias") for b in bs]
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        raw_rgb = torch.empty(npts, 3, device=xe.device)
+        raw_sigma = torch.empty(npts, 1, device=xe.device)
+        tape = torch.empty(c.lib.neo_pix_mlp_train_tape_floats(nv, npts), device=xe.device)
+        _lib.check(c.lib.neo_pix_mlp_train_forward_pre(c.handle, tab(wd), tab(bd), ptr(xe), ptr(pf), ptr(cond), nv, npts, ptr(tape),
+                                                       ptr(raw_rgb), ptr(raw_sigma), c.stream()))
+        ctx_.save_for_backward(xe, cond, tape, *wd)
+        ctx_.meta = (c, nv, npts, x_enc.shape, [tuple(w.shape) for w in ws], [tuple(b.shape) for b in bs])
+        return raw_rgb, raw_sigma
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g_rgb, g_sigma):
+        xe, cond, tape, *wd = ctx_.saved_tensors
+        c, nv, npts, xshape, wshapes, bshapes = ctx_.meta
+        if ctx_.needs_input_grad[3]:
+            raise NotImplementedError("pixel_mlp: no gradient for cond_rows (the reference's view directions are data)")
+        dev = xe.device
+        g_rgb = f32(g_rgb.contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(npts, 3, device=dev)
+        g_sigma = f32(g_sigma.contiguous(), "g_sigma") if g_sigma is not None else torch.zeros(npts, 1, device=dev)
+        gw = [torch.zeros(s, device=dev) for s in wshapes]
+        gb = [torch.zeros(s, device=dev) for s in bshapes]
+        gx = torch.empty_like(xe) if ctx_.needs_input_grad[2] else None
+        gpre = torch.empty(nv * npts, 128, device=dev)
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(c.lib.neo_pix_mlp_train_backward_pre(c.handle, tab(wd), ptr(xe), ptr(cond), nv, npts, ptr(tape), ptr(g_rgb), ptr(g_sigma),
+                                                        tab(gw), tab(gb), ptr(gx), ptr(gpre), c.stream()))
+        return (None, None, gx.reshape(xshape) if gx is not None else None, None, gpre, *gw, *gb)
+
+
+def pixel_mlp_fused(mlp, x_enc, cond_rows, pre, nv, ctx=None):
+    """pixel_mlp_projected as one native chain each way (round 6; the analogue of nerfpp_mlp_projected for the PixelNeRF decoder):
+    same inputs, same outputs, gradients to all 18 parameter tensors and to `pre`."""
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    return _PixTrainMLPPre.apply(ctx, nv, x_enc, cond_rows, pre, *params)
+
+
 def pixel_mlp_projected(mlp, x_enc, cond_rows, pre, nv, ctx=None):
     """PixelNeRF's late-fusion MLP (model_pixel.py:96-131) under autograd, every product on the library's exact-fp32 GEMMs
     (`linear`): x_enc (NV,P,63), cond_rows (NV*P,27), pre (NV*P,128) = the gathered latent projected through the local columns
@@ -819,7 +881,9 @@ def pix_render_train(module, rays, randomized, white_bkgd, near, far, latent, se
             cond = d_enc.repeat(1, N, 1).reshape(-1, d_enc.shape[-1])                           # tile (1,N,1) of (NV,1,B,27) (:219-222)
             look, x_enc = train_points(module, 0, rays_o, rays_d, t, None, poses, ctx=c)
         pre = gather_map(module, project_pixel_latent(mlp, latent_cl, ctx=c), look, rays, kind="pix")
-        raw_rgb, raw_sigma = pixel_mlp_projected(mlp, x_enc, cond, pre, NV, ctx=c)
+        # the MLP as one native chain each way (round 6); `module.train_fused = False`: the per-layer operators (pixel_mlp_projected)
+        mlp_fn = pixel_mlp_fused if getattr(module, "train_fused", True) else pixel_mlp_projected
+        raw_rgb, raw_sigma = mlp_fn(mlp, x_enc, cond, pre, NV, ctx=c)
         raw_sigma = raw_sigma.reshape(B, N)
         if noise > 0.0:
             raw_sigma = raw_sigma + rand_uniform(seed, 4 + 2 * level, B, N, ctx=c) * noise
@@ -927,6 +991,75 @@ def mip_mlp(mlp, x0, d_enc, n, ctx=None):
     return density, rgb * (1 + 2 * 0.001) - 0.001
 
 
+class _MipTrainMLP(torch.autograd.Function):
+    """MipNeRF360MLP.forward under autograd as ONE native chain each way (neo_mip_mlp_train_forward / _backward, round 6): trunk,
+    skip layer, heads and both activations inside the library; the backward returns every parameter gradient.  x0 / d_enc are data
+    (sdist is detached: stop_level_grad), so no input gradients."""
+
+    @staticmethod
+    def forward(ctx_, lib_ctx, width, depth, rgb, n, x0, d_enc, *params):
+        nl = depth + (4 if rgb else 1)
+        ws, bs = params[:nl], params[nl:]
+        rows = x0.shape[0]
+        if x0.dim() != 2 or x0.shape[1] != 504 or rows % n:
+            raise ValueError("x0 must be (R n, 504) with n = %d, got %s" % (n, tuple(x0.shape)))
+        R = rows // n
+        if rgb and tuple(d_enc.shape) != (R, 27):
+            raise ValueError("d_enc must be (R, 27) = (%d, 27), got %s" % (R, tuple(d_enc.shape)))
+        want = [(width, 504)] + [(width, width + 504 if (i - 1) % 4 == 0 and i - 1 > 0 else width) for i in range(1, depth)] + [(1, width)]
+        if rgb:
+            want += [(256, width), (128, 283), (3, 128)]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            if tuple(w.shape) != want[i] or tuple(b.shape) != (want[i][0],):
+                raise ValueError("Mip-NeRF 360 MLP layer %d: weight %s / bias %s, expected %s / (%d,)"
+                                 % (i, tuple(w.shape), tuple(b.shape), want[i], want[i][0]))
+        xf = f32(x0, "x0")
+        de = f32(d_enc, "d_enc") if rgb else None
+        c = _ctx(xf, lib_ctx)
+        wd = [f32(w.detach(), "weight") for w in ws]
+        bd = [f32(b.detach(), "bias") for b in bs]
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        out = torch.empty(rows, 4, device=xf.device)
+        tape = torch.empty(c.lib.neo_mip_mlp_train_tape_floats(width, depth, int(rgb), R, n), device=xf.device)
+        _lib.check(c.lib.neo_mip_mlp_train_forward(c.handle, width, depth, int(rgb), tab(wd), tab(bd), ptr(xf), ptr(de), R, n, ptr(tape),
+                                                   ptr(out), c.stream()))
+        ctx_.save_for_backward(xf, tape, out, *wd) if not rgb else ctx_.save_for_backward(xf, tape, out, *wd, de)
+        ctx_.meta = (c, width, depth, bool(rgb), R, n, [tuple(w.shape) for w in ws], [tuple(b.shape) for b in bs])
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g):
+        c, width, depth, rgb, R, n, wshapes, bshapes = ctx_.meta
+        saved = ctx_.saved_tensors
+        xf, tape, out = saved[:3]
+        wd = list(saved[3:3 + len(wshapes)])
+        de = saved[-1] if rgb else None
+        dev = xf.device
+        g = f32(g.contiguous(), "g_rgbdens")
+        gw = [torch.zeros(s, device=dev) for s in wshapes]
+        gb = [torch.zeros(s, device=dev) for s in bshapes]
+        tab = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _lib.check(c.lib.neo_mip_mlp_train_backward(c.handle, width, depth, int(rgb), tab(wd), ptr(xf), ptr(de), R, n, ptr(tape), ptr(out),
+                                                    ptr(g), tab(gw), tab(gb), c.stream()))
+        return (None, None, None, None, None, None, None, *gw, *gb)
+
+
+def mip_mlp_fused(mlp, x0, d_enc, n, ctx=None):
+    """mip_mlp as one native chain each way (round 6): same inputs, same outputs (density (R, n), rgb (R, n, 3)), gradients to
+    every parameter tensor.  Shapes outside the chain's range (width not a multiple of 64 or > 1024, depth > 8, a skip after the last
+    layer) take the per-layer operators."""
+    W, D = mlp.netwidth, len(mlp.pts_linear)
+    if W % 64 or W > 1024 or D > 8 or ((D - 1) % 4 == 0 and D - 1 > 0):
+        return mip_mlp(mlp, x0, d_enc, n, ctx=ctx)
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    out = _MipTrainMLP.apply(ctx, W, D, not mlp.disable_rgb, n, x0, d_enc, *params)
+    R = x0.shape[0] // n
+    out = out.reshape(R, n, 4)
+    return out[..., 3], out[..., :3]
+
+
 def mip_render_train(module, batch, train_frac, randomized, near, far, seed=None):
     """models.MipNeRF360.forward WITH autograd / randomized sampling: (renderings, ray_history) as the reference returns them.
     Per level: proposal resampling on the previous level's detached histogram (neo_mip_resample_u: max-dilation, annealed
@@ -967,7 +1100,8 @@ def mip_render_train(module, batch, train_frac, randomized, near, far, seed=None
                 u, jitter = torch.linspace(pad, 1 - pad - _EPS32, n).to(dev), None
             sdist, tdist = mip_resample_u(sdist, weights.detach(), n, near, far, lvl > 0, dilation, anneal, u, jitter, ctx=c)
             x0 = mip_encode(rays_o, rays_d, radii, tdist, mlp.pos_basis_t, ctx=c)
-        density, rgb = mip_mlp(mlp, x0, d_enc, n, ctx=c)
+        # the level's MLP as one native chain each way (round 6); `module.train_fused = False`: the per-layer operators (mip_mlp)
+        density, rgb = (mip_mlp_fused if getattr(module, "train_fused", True) else mip_mlp)(mlp, x0, d_enc, n, ctx=c)
         weights, colour = mip_composite(rgb, density, tdist, rays_d, 1.0, ctx=c)
         renderings.append({"rgb": colour})
         history.append(dict(density=density, rgb=rgb, sdist=sdist, weights=weights))

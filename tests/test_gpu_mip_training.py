@@ -170,3 +170,32 @@ def test_training_step_gradients_vs_fp64_autograd():
         assert layers == list(range(layers[-1] + 1)), flipped             # from one layer downwards
     record_parity("train_mip360_module_call", max_rel_l2_grad_err_vs_fp64=worst, rays=R, loss_abs_err=abs(float(loss_g) - loss_c),
                   tensors_below_a_flipped_unit=[nm for nm, _, _ in flipped])
+
+
+@pytest.mark.parametrize("lvl", [0, 2])
+def test_fused_chain_equals_the_per_layer_operators(lvl):
+    """neo_mip_mlp_train_forward / _backward (one native chain each way, round 6: trunk, skip layer, heads, softplus / sigmoid inside
+    the library) against mip_mlp (one operator per layer + torch glue) on a proposal MLP (4 x 256, no colour) and the NeRF MLP
+    (8 x 1024): the same exact-fp32 GEMMs, so outputs and every parameter gradient agree to rounding of the summation order."""
+    R, n = 72, 24
+    net = _net()
+    mlp = net.mlps[lvl]
+    g = torch.Generator(device=DEV).manual_seed(3 + lvl)
+    x0 = torch.randn(R * n, 504, device=DEV, generator=g).clamp_(-1, 1)
+    d_enc = torch.randn(R, 27, device=DEV, generator=g)
+    up_d, up_c = torch.randn(R, n, device=DEV, generator=g), torch.randn(R, n, 3, device=DEV, generator=g)
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    res = []
+    with torch.enable_grad():
+        for p in params:
+            p.requires_grad_(True)
+        for fn in (training.mip_mlp_fused, training.mip_mlp):
+            dens, rgb = fn(mlp, x0, d_enc, n)
+            loss = (dens * up_d).sum() + (rgb * up_c).sum() if not mlp.disable_rgb else (dens * up_d).sum()
+            res.append((dens.detach(), rgb.detach(), torch.autograd.grad(loss, params)))
+    (d_a, c_a, g_a), (d_b, c_b, g_b) = res
+    assert d_a.shape == (R, n) and c_a.shape == (R, n, 3)
+    assert max_abs(d_a, d_b) <= 3e-6 * max(1.0, float(d_b.abs().max())) and max_abs(c_a, c_b) <= 3e-6
+    for i, (a, b) in enumerate(zip(g_a, g_b)):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6), (i, float((a - b).abs().max()), float(b.abs().max()))

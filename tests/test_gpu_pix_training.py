@@ -123,3 +123,36 @@ def test_randomized_module_call_and_noise_std():
         assert max_abs(out[lv][0], want[lv][0]) < 1e-4 and max_abs(out[lv][1], want[lv][1]) < 1e-4
     quiet, _, _ = _net(n0, n1, noise_std=0.0)
     assert max_abs(quiet(rays, True, False, 0.2, 2.5, seed=seed)[0][0], a[0][0]) > 1e-5
+
+
+def test_fused_chain_equals_the_per_layer_operators():
+    """neo_pix_mlp_train_forward_pre / _backward_pre (one native chain each way, round 6) against pixel_mlp_projected (one
+    operator per layer + torch glue): same exact-fp32 GEMMs in the same order, so outputs and all 19 gradients agree to rounding
+    of the accumulation order (view means / split-K slices)."""
+    NV, P = 3, 1700
+    net, _, _ = _net()
+    mlp = net.fine_mlp
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x_enc = torch.randn(NV, P, 63, device=DEV, generator=g)
+    cond = torch.randn(NV * P, 27, device=DEV, generator=g)
+    pre0 = torch.randn(NV * P, 128, device=DEV, generator=g) * 0.5
+    up_rgb, up_sigma = torch.randn(P, 3, device=DEV, generator=g), torch.randn(P, 1, device=DEV, generator=g)
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    res = []
+    with torch.enable_grad():
+        for p in params:
+            p.requires_grad_(True)
+        for fn in (training.pixel_mlp_fused, training.pixel_mlp_projected):
+            pre = pre0.clone().requires_grad_(True)
+            rgb, sigma = fn(mlp, x_enc, cond, pre, NV)
+            grads = torch.autograd.grad((rgb * up_rgb).sum() + (sigma * up_sigma).sum(), [pre] + params)
+            res.append((rgb.detach(), sigma.detach(), grads))
+    (rgb_a, sig_a, g_a), (rgb_b, sig_b, g_b) = res
+    assert max_abs(rgb_a, rgb_b) <= 2e-6 * max(1.0, float(rgb_b.abs().max()))
+    assert max_abs(sig_a, sig_b) <= 2e-6 * max(1.0, float(sig_b.abs().max()))
+    for i, (a, b) in enumerate(zip(g_a, g_b)):
+        if i == 1:                                                  # pts_linears.0: the latent columns belong to the texel-space GEMM
+            assert float(a[:, 63:].abs().max()) == 0.0
+            a, b = a[:, :63], b[:, :63]
+        assert float((a - b).abs().max()) <= 5e-6 * max(float(b.abs().max()), 1e-6), i

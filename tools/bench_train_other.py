@@ -41,6 +41,7 @@ def pstep():
     out = pix(batch, True, False, 0.2, 2.5)
     (((out[0][0] - target) ** 2).mean() + ((out[1][0] - target) ** 2).mean()).backward(); popt.step()
 timed("pixelnerf", pstep)
+pix.train_fused = False; timed("pix/layers", pstep); pix.train_fused = True     # the per-layer operators (rounds 4-5)
 # Mip-NeRF 360
 mrays = {k: v.to(dev) for k, v in cases.mip_rays(R).items()}
 mip = models.MipNeRF360().to(dev); mip.load_state_dict(synth.mip360_state(0, weight_gain=0.5))
@@ -50,3 +51,4 @@ def mstep():
     rend, hist = mip(mrays, 0.5, True, True, 0.2, 3.0)
     (((rend[2]["rgb"] - target) ** 2).mean() + 0.01 * sum((h["weights"] ** 2).sum(-1).mean() for h in hist)).backward(); mopt.step()
 timed("mip360", mstep)
+mip.train_fused = False; timed("mip/layers", mstep); mip.train_fused = True
