@@ -364,6 +364,13 @@ int neo_tp_gather_map(neo_ctx* ctx, const float* map, long texels, int C, const 
                       float cx, float cy, float* out, void* stream);
 int neo_tp_gather_map_backward(neo_ctx* ctx, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal, float cx,
                                float cy, const float* g_out, float* g_map, void* stream);
+/* The same lookup in a C-column SLICE of a wider channels-last map (round 6): row pitch `pitch` floats, `map` / `g_map` point at the
+ * slice's first column (16-byte aligned).  One merged texel-space projection (texels, 4 x 256) then serves the four MLPs of NeRF_TP:
+ * each gathers - and scatters its gradient into - its own 256 columns of ONE map / ONE gradient buffer. */
+int neo_tp_gather_map_slice(neo_ctx* ctx, const float* map, long texels, long pitch, int C, const float* pts, long P, const float* src_poses,
+                            int NV, float focal, float cx, float cy, float* out, void* stream);
+int neo_tp_gather_map_slice_backward(neo_ctx* ctx, long texels, long pitch, int C, const float* pts, long P, const float* src_poses, int NV,
+                                     float focal, float cx, float cy, const float* g_out, float* g_map, void* stream);
 int neo_tp_mlp_train_forward_pre(neo_ctx* ctx, int input_ch, const float* const* w, const float* const* b, const float* x_enc,
                                  const float* pre, const float* world_feat, const float* cond, int NV, long P, float* tape,
                                  float* raw_rgb, float* raw_sigma, void* stream);
@@ -380,6 +387,11 @@ int neo_linear_forward(neo_ctx* ctx, long rows, int out_f, int in_f, const float
                        const float* bias, int relu, int accumulate, float* y, long ldy, void* stream);
 int neo_linear_input_grad(neo_ctx* ctx, long rows, int in_f, int out_f, const float* gy, long ldy, const float* w, long ldw,
                           int accumulate, float* gx, long ldx, void* stream);
+/* Schedule of the projected-space NeRFPPMLP training chain (neo_tp_mlp_train_forward_pre / _backward_pre), process-wide: 1 (default) =
+ * everything per row - layers 0..3, bottleneck, view layer 0; backward: the input-gradient chain g_y0 -> g_z0 and g_world - as ONE
+ * kernel each way with the activation tile in LDS and every layer written to HBM once (csrc/train_chain.h); 0 = one GEMM launch per
+ * layer (rounds 3-5).  Same exact-fp32 products in both; mode < 0 only queries.  Returns the previous mode. */
+int neo_train_chain_mode(int mode);
 /* PixelNeRF's late-fusion MLP under autograd as ONE chain each way (round 6; vanilla_nerf/model_pixel.py:96-131 inside the training
  * step :255-300): rows R = NV * P view-major; x_enc (R, 63) camera-frame encodings, pre (R, 128) = the gathered PROJECTED latent
  * W0[:, 63:575] f (the 512-wide product is formed per texel by the caller, as for NeRFPPMLP), cond (R, 27) direction encodings.

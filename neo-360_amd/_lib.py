@@ -75,12 +75,15 @@ SIGNATURES = {
     "neo_tp_activate_backward": (_i, [_vp, _vp, _vp, _vp, _f, ctypes.c_long, _vp, _vp, _vp, _vp]),
     "neo_tp_gather_map": (_i, [_vp, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_gather_map_backward": (_i, [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "neo_tp_gather_map_slice": (_i, [_vp, _vp, ctypes.c_long, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
+    "neo_tp_gather_map_slice_backward": (_i, [_vp, ctypes.c_long, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
     "neo_pix_gather_map": (_i, [_vp, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_pix_gather_map_backward": (_i, [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
     "neo_tp_mlp_train_forward_pre": (_i, [_vp, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp,
                                           _vp, _vp]),
     "neo_tp_mlp_train_backward_pre": (_i, [_vp, _i, ctypes.POINTER(_vp), _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp,
                                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _vp]),
+    "neo_train_chain_mode": (_i, [_i]),
     "neo_pix_mlp_train_tape_floats": (ctypes.c_long, [_i, ctypes.c_long]),
     "neo_pix_mlp_train_forward_pre": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp, _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp, _vp]),
     "neo_pix_mlp_train_backward_pre": (_i, [_vp, ctypes.POINTER(_vp), _vp, _vp, _i, ctypes.c_long, _vp, _vp, _vp,
@@ -159,6 +162,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("NEO360_TRAIN_CHAIN") in ("0", "1"):          # A/B of the fused training chain (neo_train_chain_mode)
+            lib.neo_train_chain_mode(int(os.environ["NEO360_TRAIN_CHAIN"]))
         _lib = lib
         return lib
 

@@ -203,6 +203,45 @@ int neo_tp_gather_map_backward(neo_ctx* ctx, long texels, int C, const float* pt
     return check_launch();
 }
 
+// a C-column slice of a wider map (row pitch `pitch` floats; `map` / `g_map` point at the slice's first column): one merged texel-space
+// projection serves the four MLPs of NeRF_TP (round 6)
+int neo_tp_gather_map_slice(neo_ctx* ctx, const float* map, long texels, long pitch, int C, const float* pts, long P, const float* src_poses,
+                            int NV, float focal, float cx, float cy, float* out, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0 && pitch >= C && pitch % 4 == 0, "bad shape (C a multiple of 64, <= 1024; pitch >= C, a multiple of 4)");
+    if (P == 0) return NEO_OK;
+    REQUIRE(map && pts && src_poses && out, "null pointer");
+    REQUIRE((reinterpret_cast<uintptr_t>(map) & 15) == 0, "the slice must start at a 16-byte boundary");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    REQUIRE(texels == static_cast<long>(ctx->scene.nv) * ctx->scene.Hf * ctx->scene.Wf,
+            "map rows differ from NV*Hf*Wf of the uploaded scene geometry (stale scene, or a map of another resolution)");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_map_gather(sc, views, pts, P, map, C, out, static_cast<hipStream_t>(stream), pitch);
+    return check_launch();
+}
+
+int neo_tp_gather_map_slice_backward(neo_ctx* ctx, long texels, long pitch, int C, const float* pts, long P, const float* src_poses, int NV,
+                                     float focal, float cx, float cy, const float* g_out, float* g_map, void* stream) {
+    ENTER(ctx);
+    REQUIRE(P >= 0 && C >= 64 && C <= 1024 && C % 64 == 0 && pitch >= C, "bad shape (C a multiple of 64, <= 1024; pitch >= C)");
+    if (P == 0) return NEO_OK;
+    REQUIRE(pts && src_poses && g_out && g_map, "null pointer");
+    if (!ctx->scene_ready) return fail(NEO_ERR_STATE, "scene geometry not set (neo_tp_set_scene)");
+    REQUIRE(NV == ctx->scene.nv, "NV differs from the uploaded scene");
+    REQUIRE(texels == static_cast<long>(ctx->scene.nv) * ctx->scene.Hf * ctx->scene.Wf,
+            "map rows differ from NV*Hf*Wf of the uploaded scene geometry (stale scene, or a map of another resolution)");
+    neo::TpViews views{};
+    fill_views(src_poses, NV, views);
+    neo::TpScene sc = ctx->scene;
+    sc.focal = focal; sc.cx = cx; sc.cy = cy;
+    neo::launch_map_gather_bwd(sc, views, pts, P, g_out, C, g_map, static_cast<hipStream_t>(stream), pitch);
+    return check_launch();
+}
+
 // the same lookup at the PixelNeRF decoder's taps (geometry of neo_pix_set_scene: (f, f) projection, model_pixel.py:198-206)
 int neo_pix_gather_map(neo_ctx* ctx, const float* map, long texels, int C, const float* pts, long P, const float* src_poses, int NV, float focal,
                       float cx, float cy, float* out, void* stream) {
@@ -398,6 +437,8 @@ int neo_tp_mlp_train_backward_pre(neo_ctx* ctx, int input_ch, const float* const
                                   g_rgb, g_sigma, gw, gb, g_x_enc, nullptr, g_world, static_cast<hipStream_t>(stream), g_pre);
     return check_launch();
 }
+
+int neo_train_chain_mode(int mode) { return neo::train_chain_mode(mode); }
 
 long neo_pix_mlp_train_tape_floats(int NV, long P) { return (NV >= 1 && P >= 0) ? (long)neo::pix_train_tape_floats(NV, P) : 0; }
 

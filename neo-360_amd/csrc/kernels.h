@@ -44,11 +44,12 @@ struct TpScene;
 struct TpViews;
 void launch_gather(const TpScene& sc, const TpViews& views, const float* pts, long P, float* world, float* local,
                    hipStream_t s);
-// lookup in a caller-owned channels-last map (NV Hf Wf, C) at the latent's taps (C % 64 == 0) and its run-merged scatter backward
+// lookup in a caller-owned channels-last map (NV Hf Wf, C) at the latent's taps (C % 64 == 0) and its run-merged scatter backward;
+// pitch > 0: the map's row pitch in floats (a C-column slice of a wider map: `map` / `g_map` point at the slice's first column)
 void launch_map_gather(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* map, int C, float* out,
-                       hipStream_t s);
+                       hipStream_t s, long pitch = 0);
 void launch_map_gather_bwd(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* g_out, int C, float* g_map,
-                           hipStream_t s);
+                           hipStream_t s, long pitch = 0);
 // training call: lookup points (P,3) + per-view reference-order encodings (NV,P,21 C) of the samples tvals (R,N); input_ch 3 inside /
 // 4 outside the sphere (far required); activations (raw -> (rgb, sigma) packed) with their backward
 void launch_tp_train_points(int input_ch, const float* rays_o, const float* rays_d, const float* tvals, const float* far, int R, int N,

@@ -20,6 +20,10 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
                               const float* g_sigma, float* const* gw, float* const* gb, float* g_x_enc, float* g_local,
                               float* g_world, hipStream_t s, float* g_pre = nullptr);
 
+// 1 (default): the per-row part of the projected-space NeRFPPMLP chain runs as one kernel each way (train_chain.h); 0: layer by layer.
+// mode < 0 only queries.  Returns the previous mode.
+int train_chain_mode(int mode);
+
 // PixelNeRF's MLP (vanilla_nerf/model_pixel.py:96-131) on the projected latent: pre (R, 128), x_enc (R, 63), cond (R, 27).
 // w / b order as neo_pix_upload_mlp.
 size_t pix_train_tape_floats(int NV, long P);

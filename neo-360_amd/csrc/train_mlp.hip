@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
     }
     const float* pa = Z + (long)(kbeg + ka) * ldz + m0 + ra;
     const float* pb = X + (long)(kbeg + kb) * ldx + n0 + rb;
-    f32x4 qa[4], qb[JB];
+    f32x4 qa[2][4], qb[2][JB];                    // two operand sets: a K step's loads have TWO multiply phases to arrive (round 6)
     auto guarded = [&](const float* p, unsigned mask, bool kv) -> f32x4 {
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (kv) {
@@ -358,29 +358,31 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
         }
         return v;
     };
-    // operands of the K step starting at k0 -> registers (FAST: interior tile and a full step, no guards)
-    auto fetch = [&](auto fastc, int k0) {
+    // operands of the K step starting at k0 -> register set S (FAST: interior tile and a full step, no guards); steps are fetched in order
+    auto fetch = [&](auto fastc, auto setc, int k0) {
         constexpr bool FAST = decltype(fastc)::value;
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float* p = pa + (long)(8 * j) * ldz;
-            if constexpr (FAST) qa[j] = *reinterpret_cast<const f4u*>(p);
-            else qa[j] = guarded(p, mka, k0 + ka + 8 * j < kend);
+            if constexpr (FAST) qa[S][j] = *reinterpret_cast<const f4u*>(p);
+            else qa[S][j] = guarded(p, mka, k0 + ka + 8 * j < kend);
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const float* p = pb + (long)((256 / QB) * j) * ldx;
-            if constexpr (FAST) qb[j] = *reinterpret_cast<const f4u*>(p);
-            else qb[j] = guarded(p, mkb, k0 + kb + (256 / QB) * j < kend);
+            if constexpr (FAST) qb[S][j] = *reinterpret_cast<const f4u*>(p);
+            else qb[S][j] = guarded(p, mkb, k0 + kb + (256 / QB) * j < kend);
         }
         pa += (long)GK * ldz;
         pb += (long)GK * ldx;
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](auto setc, int buf) {
+        constexpr int S = decltype(setc)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(As[buf] + (ka + 8 * j) * PA + ra) = qa[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(As[buf] + (ka + 8 * j) * PA + ra) = qa[S][j];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) *reinterpret_cast<f32x4*>(Bs[buf] + (kb + (256 / QB) * j) * PB + rb) = qb[j];
+        for (int j = 0; j < JB; ++j) *reinterpret_cast<f32x4*>(Bs[buf] + (kb + (256 / QB) * j) * PB + rb) = qb[S][j];
     };
     const bool bias_wg = part_db != nullptr && blockIdx.x == 0 && tid < 128;
     float cs = 0.0f;
@@ -408,17 +410,30 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
                     for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = NEO_MFMA(b[mt][e], a[nt][e], acc[mt][nt]);   // D rows = m, D cols = n
         }
     };
-    // nst K steps from k0: one barrier per step
+    // nst K steps from k0: one barrier per step; invariant at the top of the loop: LDS buffer 0 = step i, set 0 = step i + 1,
+    // set 1 = step i + 2 (both in flight)
     auto run = [&](auto fastc, int k0, int nst) {
         if (nst <= 0) return;
-        fetch(fastc, k0);
-        stage(0);
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        fetch(fastc, S0(), k0);
+        stage(S0(), 0);
+        if (nst > 1) fetch(fastc, S0(), k0 + GK);
+        if (nst > 2) fetch(fastc, S1(), k0 + 2 * GK);
         __syncthreads();
-        for (int i = 0; i < nst; ++i) {
-            const bool more = i + 1 < nst;
-            if (more) fetch(fastc, k0 + (i + 1) * GK);
-            compute(i & 1);
-            if (more) stage((i + 1) & 1);
+        int i = 0;
+        for (; i + 1 < nst; i += 2) {
+            compute(0);
+            stage(S0(), 1);                                       // waits for set 0 only: set 1's loads stay in flight
+            if (i + 3 < nst) fetch(fastc, S0(), k0 + (i + 3) * GK);
+            __syncthreads();
+            compute(1);
+            if (i + 2 < nst) stage(S1(), 0);
+            if (i + 4 < nst) fetch(fastc, S1(), k0 + (i + 4) * GK);
+            __syncthreads();
+        }
+        if (i < nst) {
+            compute(0);
             __syncthreads();
         }
     };
@@ -604,6 +619,10 @@ void dw_gemm(int M, int N, int K, const float* Z, long ldz, const float* X, long
     }
 }
 
+#include "train_chain.h"
+
+int g_chain_fused = 1;      // 1: the per-row part of the projected-space NeRFPPMLP chain as one kernel each way (train_chain.h); 0: layer by layer
+
 }  // namespace
 
 // y (rows x out_f) (+)= x (rows x in_f) W^T + b, optional ReLU: one linear layer of a training chain composed by the caller
@@ -627,10 +646,16 @@ size_t tp_train_tape_floats(int NV, long P) {
     const long R = (long)NV * P;
     return (size_t)(R * (5 * 128 + 64) + P * (128 + 64 + 64));
 }
-// scratch of the backward: two R x 128 gradient buffers, one R x 64, three P-sized
+// scratch of the backward: three R x 128 gradient buffers (the third: g_bott of the fused chain), one R x 64, three P-sized
 size_t tp_train_scratch_floats(int NV, long P) {
     const long R = (long)NV * P;
-    return (size_t)(R * (2 * 128 + 64) + P * (128 + 64 + 64) + DW_PART_FLOATS);
+    return (size_t)(R * (3 * 128 + 64) + P * (128 + 64 + 64) + DW_PART_FLOATS);
+}
+
+int train_chain_mode(int mode) {
+    const int old = g_chain_fused;
+    if (mode >= 0) g_chain_fused = mode ? 1 : 0;
+    return old;
 }
 
 // w / b order as neo_tp_upload_mlp: pts_linears.0..3, views_linear.0, views_linear.1, bottleneck, density, rgb
@@ -647,6 +672,20 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
     const int K0 = pe + 640;
     float* h0 = tape; float* h1 = h0 + R * 128; float* h2 = h1 + R * 128; float* h3 = h2 + R * 128;
     float* bott = h3 + R * 128; float* y0 = bott + R * 128; float* hm = y0 + R * 64; float* ym = hm + P * 128; float* y1 = ym + P * 64;
+    if (pre && g_chain_fused && (pe == 63 || pe == 84)) {
+        // one kernel for everything per row (train_chain.h); the view means and the P-sized heads below
+        ChainFwdArgs a{w[0], w[1], w[2], w[3], w[4], w[6], b[0], b[1], b[2], b[3], b[4], b[6], x_enc, world, pre, cond,
+                       h0, h1, h2, h3, bott, y0, R, pe};
+        const dim3 grid((unsigned)((R + CH_ROWS - 1) / CH_ROWS));
+        if (pe == 63) hipLaunchKernelGGL((k_tp_chain_fwd<8>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_tp_chain_fwd<11>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
+        gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
+        hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 64)), dim3(256), 0, s, y0, NV, P, 64, 1, ym);
+        gemm<false, false>((int)P, 64, 64, ym, 64, w[5], 64, y1, 64, epi(b[5], 1), 1, s);
+        gemm<false, false>((int)P, 3, 64, y1, 64, w[8], 64, raw_rgb, 3, epi(b[8], 0), 1, s);
+        return;
+    }
     if (pre) {
         hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, pre, 256L, h0, 128L, R, 128);
         gemm<false, false>((int)R, 128, pe, x_enc, pe, w[0], K0, h0, 128, epi(b[0], 0, 1), 1, s);                    // h0 = pre0 + x_enc W0_pe + b0
@@ -782,6 +821,28 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0, 64L);
     dw_gemm(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, gb[4], part, s);
     dw_gemm(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, nullptr, part, s);
+    if (g_pre && g_chain_fused && (pe == 63 || pe == 84)) {
+        // density head on the view mean of h3, then ONE kernel for the input-gradient chain of every row (train_chain.h), then the
+        // weight-gradient GEMMs on what it wrote: g_bott, g_z3 | g_z0 (the halves of g_pre), g_z2, g_z1
+        float* gbt = part + DW_PART_FLOATS;                                                      // the third R x 128 buffer
+        dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);
+        gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
+        ChainBwdArgs a{w[0], w[1], w[2], w[3], w[4], w[6], h0, h1, h2, h3, gy0, g_hm, gbt, g_pre, ga, gb2, g_world, R, P, pe, NV};
+        hipLaunchKernelGGL(k_tp_chain_bwd, dim3((unsigned)((R + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, a);
+        float* z3 = g_pre + 128;
+        float* z0 = g_pre;
+        dw_gemm(128, 128, (int)R, gbt, 128, h3, 128, gw[6], 128, gb[6], part, s);                                 // bottleneck
+        dw_gemm(128, 128, (int)R, z3, 256, h2, 128, gw[3], 128 + K0, gb[3], part, s);                             // layer 3 on [h2 | x_enc | . | world]
+        dw_gemm(128, pe, (int)R, z3, 256, x_enc, pe, gw[3] + 128, 128 + K0, nullptr, part, s);
+        dw_gemm(128, 128, (int)R, z3, 256, world, 128, gw[3] + 128 + pe + 512, 128 + K0, nullptr, part, s);
+        if (g_x_enc) gemm<false, true>((int)R, pe, 128, z3, 256, w[3] + 128, 128 + K0, g_x_enc, pe, epi(), 1, s);
+        dw_gemm(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, gb[2], part, s);                                  // layer 2
+        dw_gemm(128, 128, (int)R, gb2, 128, h0, 128, gw[1], 128, gb[1], part, s);                                 // layer 1
+        dw_gemm(128, pe, (int)R, z0, 256, x_enc, pe, gw[0], K0, gb[0], part, s);                                  // layer 0 on [x_enc | . | world]
+        dw_gemm(128, 128, (int)R, z0, 256, world, 128, gw[0] + pe + 512, K0, nullptr, part, s);
+        if (g_x_enc) gemm<false, true>((int)R, pe, 128, z0, 256, w[0], K0, g_x_enc, pe, epi(nullptr, 0, 1), 1, s);
+        return;
+    }
     gemm<false, true>((int)R, 128, 64, gy0, 64, w[4], 155, ga, 128, epi(), 1, s);                                // g_bott (R x 128)
     // bottleneck
     dw_gemm(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, gb[6], part, s);

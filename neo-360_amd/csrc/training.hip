@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void k_gather_bwd_runs(TpScene sc, TpViews vie
 // taps those of get_local_feats (row_taps: view 0's intrinsics, the uploaded scene's latent geometry).  Forward: one 16-lane group
 // per row; backward: the run-merged scatter of k_gather_bwd_runs for the one map.
 __global__ __launch_bounds__(256) void k_map_gather(TpScene sc, TpViews views, const float* __restrict__ pts, long P,
-                                                    const float* __restrict__ map, int C, float* __restrict__ out) {
+                                                    const float* __restrict__ map, long pitch, int C, float* __restrict__ out) {
     const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int c = threadIdx.x & 15;
     if (row >= P * sc.nv) return;
@@ -413,13 +413,13 @@ __global__ __launch_bounds__(256) void k_map_gather(TpScene sc, TpViews views, c
         f32x4 tap[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            tap[k] = *reinterpret_cast<const f32x4*>(map + ((long)v * sc.Hf * sc.Wf + t.loc.off[k]) * C + piece * 4);
+            tap[k] = *reinterpret_cast<const f32x4*>(map + ((long)v * sc.Hf * sc.Wf + t.loc.off[k]) * pitch + piece * 4);
         *reinterpret_cast<f32x4*>(out + row * C + piece * 4) = tp::blend4(tap, wv4);
     }
 }
 
 __global__ __launch_bounds__(256) void k_map_gather_bwd_runs(TpScene sc, TpViews views, const float* __restrict__ pts, long P,
-                                                            const float* __restrict__ g_out, int C, float* __restrict__ g_map) {
+                                                            const float* __restrict__ g_out, int C, float* __restrict__ g_map, long pitch) {
     __shared__ int s_off[16][GRUN][4];
     __shared__ float s_w[16][GRUN][4];
     const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void k_map_gather_bwd_runs(TpScene sc, TpViews
         for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto flush = [&](int k) {
             if (cur[k] >= 0) {
-                float* dst = g_map + (long)cur[k] * C;
+                float* dst = g_map + (long)cur[k] * pitch;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) scatter_add(dst + scatter_channel(q, c, e), acc[k][e]);
             }
@@ -547,18 +547,18 @@ __global__ void k_tp_activate_bwd(const float* __restrict__ raw_rgb, const float
 }  // namespace
 
 void launch_map_gather(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* map, int C, float* out,
-                       hipStream_t s) {
+                       hipStream_t s, long pitch) {
     const long rows = P * sc.nv;
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_map_gather, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, sc, views, pts, P, map, C, out);
+    hipLaunchKernelGGL(k_map_gather, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, sc, views, pts, P, map, pitch > 0 ? pitch : (long)C, C, out);
 }
 
 void launch_map_gather_bwd(const TpScene& sc, const TpViews& views, const float* pts, long P, const float* g_out, int C, float* g_map,
-                           hipStream_t s) {
+                           hipStream_t s, long pitch) {
     const long rows = P * sc.nv;
     if (rows <= 0) return;
     hipLaunchKernelGGL(k_map_gather_bwd_runs, dim3((unsigned)((rows + 16 * GRUN - 1) / (16 * GRUN))), dim3(256), 0, s, sc, views, pts, P,
-                       g_out, C, g_map);
+                       g_out, C, g_map, pitch > 0 ? pitch : (long)C);
 }
 
 void launch_tp_train_points(int input_ch, const float* rays_o, const float* rays_d, const float* tvals, const float* far, int R, int N,

@@ -10,6 +10,7 @@ The fused MLP evaluators are inference kernels: these ops cover the parts of the
 the reference's training tuple (forward values) through `neo_tp_render_train`.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -254,43 +255,94 @@ def gather_planes(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
 
 class _MapGather(torch.autograd.Function):
     """Bilinear lookup in a caller-owned channels-last map (NV Hf Wf, C) at get_local_feats' taps, with the run-merged
-    scatter-add as its backward (neo_tp_gather_map / _backward)."""
+    scatter-add as its backward (neo_tp_gather_map / _backward).  `col` / `width`: a column slice of a wider map (round 6:
+    neo_tp_gather_map_slice) whose gradient is scattered into the matching slice of ONE buffer shared by every lookup in that map
+    (`shared`, see project_latent_all): the first lookup to run its backward hands the buffer to autograd, the others add into it."""
 
     @staticmethod
-    def forward(ctx_, module, gmap, pts, rays, kind="tp"):
+    def forward(ctx_, module, gmap, pts, rays, kind="tp", col=None, width=None, shared=None):
         pts = f32(pts, "pts").reshape(-1, 3)
         gmap = f32(gmap, "map")
         if gmap.dim() != 2 or gmap.shape[1] % 64 != 0:
             raise ValueError("map must be (texels, C) with C a multiple of 64, got %s" % (tuple(gmap.shape),))
         c = module._context(pts.device)
         host_poses, NV, focal, cx, cy = module._camera_args(rays)
-        P, C = pts.shape[0], gmap.shape[1]
+        P = pts.shape[0]
+        sliced = col is not None
+        if sliced:
+            if kind != "tp" or width % 64 or col % 4 or col < 0 or col + width > gmap.shape[1] or shared is None:
+                raise ValueError("bad map slice [%s, +%s) of %s (kind %s)" % (col, width, tuple(gmap.shape), kind))
+            C = int(width)
+        else:
+            C = gmap.shape[1]
         out = torch.empty(NV * P, C, device=pts.device)
-        fn = c.lib.neo_pix_gather_map if kind == "pix" else c.lib.neo_tp_gather_map
         # the row count travels with the pointer: the library rejects a map that is not NV*Hf*Wf rows of the geometry uploaded in
         # this module's context (ADVICE r5: it used to be indexed - and, in the backward, scattered into - unchecked)
-        _lib.check(fn(c.handle, ptr(gmap), gmap.shape[0], C, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
+        if sliced:
+            _lib.check(c.lib.neo_tp_gather_map_slice(c.handle, gmap.data_ptr() + 4 * int(col), gmap.shape[0], gmap.shape[1], C, ptr(pts), P,
+                                                     host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
+        else:
+            fn = c.lib.neo_pix_gather_map if kind == "pix" else c.lib.neo_tp_gather_map
+            _lib.check(fn(c.handle, ptr(gmap), gmap.shape[0], C, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(out), c.stream()))
         ctx_.save_for_backward(pts)
-        ctx_.meta = (c, host_poses, NV, focal, cx, cy, tuple(gmap.shape), kind)
+        ctx_.meta = (c, host_poses, NV, focal, cx, cy, tuple(gmap.shape), kind, col, C, shared)
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx_, g_out):
         (pts,) = ctx_.saved_tensors
-        c, host_poses, NV, focal, cx, cy, mshape, kind = ctx_.meta
-        g_map = torch.zeros(mshape, device=pts.device)
+        c, host_poses, NV, focal, cx, cy, mshape, kind, col, C, shared = ctx_.meta
         g = f32(g_out.contiguous(), "g_out")
+        if col is not None:
+            first = shared.get("buf") is None
+            if first:
+                shared["buf"] = torch.zeros(mshape, device=pts.device)
+            buf = shared["buf"]
+            _lib.check(c.lib.neo_tp_gather_map_slice_backward(c.handle, mshape[0], mshape[1], C, ptr(pts), pts.shape[0], host_poses, NV, focal,
+                                                              cx, cy, ptr(g), buf.data_ptr() + 4 * int(col), c.stream()))
+            return None, (buf if first else None), None, None, None, None, None, None
+        g_map = torch.zeros(mshape, device=pts.device)
         fn = c.lib.neo_pix_gather_map_backward if kind == "pix" else c.lib.neo_tp_gather_map_backward
         _lib.check(fn(c.handle, mshape[0], mshape[1], ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy, ptr(g), ptr(g_map), c.stream()))
-        return None, g_map, None, None, None
+        return None, g_map, None, None, None, None, None, None
 
 
-def gather_map(module, gmap, pts, rays, kind="tp"):
+class _GradSink(torch.autograd.Function):
+    """Identity between a merged projected map and its lookups: its backward runs once, after every lookup has scattered into the shared
+    gradient buffer, and releases the buffer so that a second backward through the same graph starts from zeros again."""
+
+    @staticmethod
+    def forward(ctx_, gmap, shared):
+        ctx_.shared = shared
+        return gmap.view_as(gmap)
+
+    @staticmethod
+    def backward(ctx_, g):
+        ctx_.shared["buf"] = None
+        return g, None
+
+
+def gather_map(module, gmap, pts, rays, kind="tp", col=None, width=None, shared=None):
     """Lookup of world points pts (P,3) in a channels-last map gmap (NV*Hf*Wf, C) with the latent's geometry, every source view:
     (NV*P, C) view-major rows.  kind "tp": NeRF_TP's get_local_feats taps (scene of neo_tp_set_scene); "pix": the PixelNeRF decoder's
-    (neo_pix_set_scene).  Differentiable w.r.t. the map."""
-    return _MapGather.apply(module, gmap, pts, rays, kind)
+    (neo_pix_set_scene).  Differentiable w.r.t. the map.  col / width / shared: columns [col, col + width) of a merged map made by
+    project_latent_all (which also returns `shared`)."""
+    return _MapGather.apply(module, gmap, pts, rays, kind, col, width, shared)
+
+
+def _zeros_like_shapes(wshapes, bshapes, dev):
+    """Zeroed weight / bias gradient tensors of a chain as views of ONE buffer: one fill kernel instead of 18 (each view starts at a
+    multiple of 4 floats)."""
+    shapes = list(wshapes) + list(bshapes)
+    sizes = [int(math.prod(sh)) for sh in shapes]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 3) // 4 * 4
+    flat = torch.zeros(total, device=dev)
+    views = [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+    return views[:len(wshapes)], views[len(wshapes):]
 
 
 class _TrainMLPPre(torch.autograd.Function):
@@ -337,8 +389,7 @@ class _TrainMLPPre(torch.autograd.Function):
         dev = xe.device
         g_rgb = f32(g_rgb.contiguous(), "g_rgb") if g_rgb is not None else torch.zeros(npts, 3, device=dev)
         g_sigma = f32(g_sigma.contiguous(), "g_sigma") if g_sigma is not None else torch.zeros(npts, 1, device=dev)
-        gw = [torch.zeros(s, device=dev) for s in wshapes]
-        gb = [torch.zeros(s, device=dev) for s in bshapes]
+        gw, gb = _zeros_like_shapes(wshapes, bshapes, dev)
         gx = torch.empty_like(xe) if ctx_.needs_input_grad[3] else None
         gworld = torch.empty_like(wf) if ctx_.needs_input_grad[5] else None
         gpre = torch.empty(nv * npts, 256, device=dev)
@@ -431,6 +482,20 @@ def project_latent(mlp, latent_cl, ctx=None):
     w0, w3 = mlp.pts_linears[0].weight, mlp.pts_linears[3].weight
     wcat = torch.cat([w0[:, pe:pe + 512], w3[:, 128 + pe:128 + pe + 512]], dim=0)          # (256, 512)
     return _LinearNoBias.apply(ctx, latent_cl, wcat)
+
+
+def project_latent_all(mlps, latent_cl, ctx=None):
+    """project_latent for several MLPs in ONE GEMM each way (round 6): G = F [W0_loc | W3_loc]_mlp0..^T, (texels, 256 len(mlps)); MLP i
+    looks up columns [256 i, 256 i + 256) (gather_map(..., col, width, shared)).  Against one projection per MLP the latent is read
+    once instead of len(mlps) times, its gradient is written once instead of being summed from len(mlps) full-size tensors, and the
+    lookups' backward passes scatter into one buffer.  Returns (map, shared)."""
+    blocks = []
+    for mlp in mlps:
+        pe = mlp.input_ch * 21
+        w0, w3 = mlp.pts_linears[0].weight, mlp.pts_linears[3].weight
+        blocks += [w0[:, pe:pe + 512], w3[:, 128 + pe:128 + pe + 512]]
+    shared = {"buf": None}
+    return _GradSink.apply(_LinearNoBias.apply(ctx, latent_cl, torch.cat(blocks, dim=0)), shared), shared
 
 
 def nerfpp_mlp_projected(mlp, x_enc, cond_rows, world_feat, pre, nv, ctx=None):
@@ -643,7 +708,7 @@ def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws, pr
         u_fg, u_bg = (draws["u_fg"], draws["u_bg"]) if draws is not None else (None, None)
         fg_t, bg_s = sample_level0(far, n0, u_fg, u_bg, ctx=c)
         rot = poses[:, :3, :3].transpose(1, 2)
-        dir_cam = torch.matmul(rot[:, None], viewdirs[None, :, :, None])[..., 0]              # (NV,B,3): model.py:339-341
+        dir_cam = (rot[:, None, :, :] * viewdirs[None, :, None, :]).sum(-1)                    # (NV,B,3) = R_v^T d: model.py:339-341 (3-term sums, no library GEMM)
         d_enc = ops.pos_enc(dir_cam, 0, module.deg_view, ctx=c)                                # (NV,B,27)
     mlps = module._mlps()
     out = []
@@ -658,10 +723,11 @@ def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws, pr
         res = {}
         for name, mlp, look, x_enc in (("fg", mlps[level], fg_p, fg_x), ("bg", mlps[2 + level], bg_lin, bg_x)):
             if proj is not None:
-                if (name, level) not in proj:
-                    proj[(name, level)] = project_latent(mlp, proj["latent_cl"], ctx=c)                  # (texels, 256), once per call
+                if "G" not in proj:                                     # (texels, 4 x 256): one texel-space GEMM for the four MLPs, once per call
+                    proj["G"], proj["shared"] = project_latent_all(mlps, proj["latent_cl"], ctx=c)
                 world = gather_planes(module, look, maps[0], maps[1], maps[2], maps[3], rays)
-                pre = gather_map(module, proj[(name, level)], look, rays)
+                slot = level + (2 if name == "bg" else 0)              # mlps = (fg coarse, fg fine, bg coarse, bg fine)
+                pre = gather_map(module, proj["G"], look, rays, col=256 * slot, width=256, shared=proj["shared"])
                 raw_rgb, raw_sigma = nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, NV, ctx=c)
             else:
                 world, local = gather_features(module, look, maps[0], maps[1], maps[2], maps[3], rays)
@@ -868,7 +934,7 @@ def pix_render_train(module, rays, randomized, white_bkgd, near, far, latent, se
         else:
             t = edges[None, :].expand(B, n0 + 1).contiguous()
         rot = poses[:, :3, :3].transpose(1, 2)                                                  # util.py:45-49: R^T d per view
-        dir_cam = torch.matmul(rot[:, None], viewdirs[None, :, :, None])[..., 0].contiguous()   # (NV,B,3), as tp_render_train
+        dir_cam = (rot[:, None, :, :] * viewdirs[None, :, None, :]).sum(-1)                     # (NV,B,3), as tp_render_train
         d_enc = ops.pos_enc(dir_cam, 0, 4, ctx=c)                                               # (NV,B,27)
     latent_cl = latent.permute(0, 2, 3, 1).reshape(-1, latent.shape[1])                          # (NV Hf Wf, 512) channels-last, under autograd
     if latent_cl.dtype != torch.float32:

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import cases
+from conftest import max_abs
 from neo360_amd import _lib, models, ops, render, synth
 
 pytestmark = pytest.mark.gpu
@@ -256,3 +257,84 @@ def test_other_renderers_chunk_loops_overlap_and_stay_bitwise(which):
     assert torch.equal(got, want)
     got2 = loop()
     assert torch.equal(got2, want)
+
+
+@pytest.mark.parametrize("rows_p,nv,input_ch", [(1000, 3, 3), (37, 2, 3), (4133, 3, 3), (777, 3, 4)])
+def test_fused_training_chain_equals_the_layer_by_layer_chain(rows_p, nv, input_ch):
+    """neo_train_chain_mode: the per-row part of the projected-space NeRFPPMLP chain as ONE kernel each way (csrc/train_chain.h: the
+    activation tile stays in LDS, every layer goes to HBM once) against one GEMM launch per layer - the same exact-fp32 products, so
+    outputs, all 18 parameter gradients, g_world and g_pre agree to rounding of the summation order; ragged last tiles (rows not a
+    multiple of 64) and tiles that straddle two views included."""
+    from neo360_amd import training
+    lib = _lib.load()
+    mlp = models.NeRFPPMLP(0, 10, 4, input_ch=input_ch, num_src_views=nv).to(DEV)              # input_ch 4: the outside-sphere MLPs (84-d encoding)
+    g = torch.Generator(device=DEV).manual_seed(rows_p)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.copy_(torch.randn(p.shape, device=DEV, generator=g) * (0.15 if p.dim() == 2 else 0.05))
+    P = rows_p
+    x_enc = torch.randn(nv, P, 21 * input_ch, device=DEV, generator=g)
+    cond = torch.randn(nv * P, 27, device=DEV, generator=g)
+    world0 = torch.randn(nv * P, 128, device=DEV, generator=g) * 0.5
+    pre0 = torch.randn(nv * P, 256, device=DEV, generator=g) * 0.5
+    up_rgb, up_sigma = torch.randn(P, 3, device=DEV, generator=g), torch.randn(P, 1, device=DEV, generator=g)
+    layers = mlp.ordered_layers()
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    old = lib.neo_train_chain_mode(-1)
+    try:
+        with torch.enable_grad():
+            for p in params:
+                p.requires_grad_(True)
+            # forward in both schedules: same values
+            fwd = {}
+            for mode in (0, 1):
+                lib.neo_train_chain_mode(mode)
+                world, pre = world0.clone().requires_grad_(True), pre0.clone().requires_grad_(True)
+                fwd[mode] = training.nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, nv)
+            # backward in both schedules FROM ONE TAPE (the fused forward's; both schedules keep the same tape layout): a unit whose
+            # pre-activation rounds to +0 in one forward and to a tiny positive number in the other would otherwise take the other
+            # derivative (1 unit in ~6 M here) and move its row's gradients by a finite amount - a property of ReLU, not of a schedule
+            loss = (fwd[1][0] * up_rgb).sum() + (fwd[1][1] * up_sigma).sum()
+            g_a = torch.autograd.grad(loss, [world, pre] + params, retain_graph=True)
+            lib.neo_train_chain_mode(0)
+            g_b = torch.autograd.grad(loss, [world, pre] + params)
+    finally:
+        lib.neo_train_chain_mode(old)
+    for j in (0, 1):
+        assert max_abs(fwd[1][j].detach(), fwd[0][j].detach()) <= 3e-6 * max(1.0, float(fwd[0][j].abs().max()))
+    for i, (a, b) in enumerate(zip(g_a, g_b)):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6), (i, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_merged_projection_shares_one_gradient_buffer_and_survives_a_second_backward():
+    """project_latent_all: one texel-space GEMM for the four MLPs, each lookup reads / scatters into its 256-column slice
+    (neo_tp_gather_map_slice) of ONE map / ONE gradient buffer.  Against one projection + one full-size gradient per MLP: same values,
+    same gradients; and the shared buffer is released after a backward pass, so a second pass over a retained graph gives the same
+    gradients again (not twice the first)."""
+    from neo360_amd import training
+    sc = cases.small_scene()
+    net = _tp_net(sc)
+    batch = _batch(64)
+    mlps = net._mlps()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    latent = sc["latent"].to(DEV)
+    lat_cl = latent.permute(0, 2, 3, 1).reshape(-1, latent.shape[1]).contiguous().requires_grad_(True)
+    pts = (torch.rand(500, 3, device=DEV, generator=g) - 0.5) * 1.2
+    ups = [torch.randn(cases.NV * 500, 256, device=DEV, generator=g) for _ in mlps]
+    with torch.enable_grad():
+        for p in net.parameters():
+            p.requires_grad_(True)
+        gmap, shared = training.project_latent_all(mlps, lat_cl)
+        outs = [training.gather_map(net, gmap, pts + 0.01 * i, batch, col=256 * i, width=256, shared=shared) for i in range(4)]
+        loss = sum((o * u).sum() for o, u in zip(outs, ups))
+        wanted = [lat_cl] + [m.pts_linears[j].weight for m in mlps for j in (0, 3)]
+        g1 = torch.autograd.grad(loss, wanted, retain_graph=True)
+        g2 = torch.autograd.grad(loss, wanted)
+        singles = [training.gather_map(net, training.project_latent(m, lat_cl), pts + 0.01 * i, batch) for i, m in enumerate(mlps)]
+        g3 = torch.autograd.grad(sum((o * u).sum() for o, u in zip(singles, ups)), wanted)
+    assert shared["buf"] is None
+    for o, s in zip(outs, singles):
+        assert max_abs(o.detach(), s.detach()) <= 1e-6 * max(1.0, float(s.abs().max()))
+    for a, b, c in zip(g1, g2, g3):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-6)          # atomics: the order of the adds differs
+        assert float((a - c).abs().max()) <= 2e-5 * max(float(c.abs().max()), 1e-6)
