@@ -271,6 +271,10 @@ int neo_enc_floorplans(neo_ctx* ctx, const float* latent, int NV, int Hf, int Wf
 /* ---- training-side operators ----------------------------------------------------------- */
 /* Counter-based uniforms in [0,1): out[r][c] = (Philox4x32-10(key = seed, counter = (r, c, stream_id, 0))[0] >> 8) 2^-24
  * - the generator behind every randomized=True sampler here (the reference draws torch.rand: helper.py:49, :196). */
+/* dst[b][c][r] = src[b][r][c]: batched 2-D transpose (fp32, tiled through LDS, out of place).  NCHW <-> channels-last of a feature map
+ * under autograd: (NV, C, H W) -> (NV, H W, C) is batch NV, rows C, cols H W; the gradient goes back with rows H W, cols C
+ * (the reference keeps NCHW and permutes inside grid_sample: encoder_tp_fusion_conv.py:180-206). */
+int neo_transpose(neo_ctx* ctx, const float* src, long batch, int rows, int cols, float* dst, void* stream);
 int neo_rand_uniform(neo_ctx* ctx, uint64_t seed, uint32_t stream_id, int rows, int cols, float* out, void* stream);
 
 /* neo360/helper.py:24-75 sample_along_rays for both regions: far (R) from neo_intersect_sphere, near = 1e-4.

@@ -75,6 +75,7 @@ SIGNATURES = {
     "neo_tp_activate_backward": (_i, [_vp, _vp, _vp, _vp, _f, ctypes.c_long, _vp, _vp, _vp, _vp]),
     "neo_tp_gather_map": (_i, [_vp, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_gather_map_backward": (_i, [_vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
+    "neo_transpose": (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp, _vp]),
     "neo_tp_gather_map_slice": (_i, [_vp, _vp, ctypes.c_long, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),
     "neo_tp_gather_map_slice_backward": (_i, [_vp, ctypes.c_long, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp, _vp]),
     "neo_pix_gather_map": (_i, [_vp, _vp, ctypes.c_long, _i, _vp, ctypes.c_long, c_float_p, _i, _f, _f, _f, _vp, _vp]),

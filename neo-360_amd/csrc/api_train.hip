@@ -30,6 +30,15 @@ int neo_tp_eval_region(neo_ctx* ctx, int slot, const neo::TpScene& sc, const neo
 
 extern "C" {
 
+int neo_transpose(neo_ctx* ctx, const float* src, long batch, int rows, int cols, float* dst, void* stream) {
+    ENTER(ctx);
+    REQUIRE(batch >= 0 && batch <= 65535 && rows >= 0 && cols >= 0 && (rows + 63) / 64 <= 65535, "bad shape (batch <= 65535, rows <= 4.19 M)");
+    if (batch == 0 || rows == 0 || cols == 0) return NEO_OK;
+    REQUIRE(src && dst && src != dst, "null pointer / in-place transpose");
+    neo::launch_transpose(src, batch, rows, cols, dst, static_cast<hipStream_t>(stream));
+    return check_launch();
+}
+
 int neo_rand_uniform(neo_ctx* ctx, uint64_t seed, uint32_t stream_id, int rows, int cols, float* out, void* stream) {
     ENTER(ctx);
     REQUIRE(rows >= 0 && cols >= 0, "negative shape");

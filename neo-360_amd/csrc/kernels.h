@@ -33,6 +33,8 @@ int launch_resample(const float* t_prev, int t_prev_stride, const float* weights
 
 // training.hip — training-side operators
 void launch_uniform(uint64_t seed, uint32_t stream, int rows, int cols, float* out, hipStream_t s);
+// dst[b][c][r] = src[b][r][c] (batched 2-D transpose, tiled through LDS)
+void launch_transpose(const float* src, long batch, int rows, int cols, float* dst, hipStream_t s);
 void launch_tp_level0_rand(const float* far, const float* edges, int R, int N, float near, const float* u_fg,
                            const float* u_bg, float* fg_t, float* bg_s, hipStream_t s);
 int launch_composite_bwd(int mode, const float* rgbsigma, const float* t, int t_row_stride, const float* rays_d,

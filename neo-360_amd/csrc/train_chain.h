@@ -13,6 +13,10 @@
 // three workgroups per CU.  The view means and everything P-sized stay separate launches (train_mlp.hip).
 #pragma once
 
+#ifndef NEO_CHAIN_ABLATE
+#define NEO_CHAIN_ABLATE 0       // timing experiments only (wrong results; tools/build_variant.py): 1 no MFMAs (operands still fetched), 2 no tape /
+                                 // gradient stores, 4 one weight fragment per segment instead of one per chunk (no L2 weight stream)
+#endif
 constexpr int CH_ROWS = 64;      // rows per workgroup
 constexpr int CH_HLD = 128;      // activation tile pitch (floats)
 constexpr int CH_RING = 4;       // weight fragments in flight per wave
@@ -69,6 +73,7 @@ struct ChSeg {
     int kvalid;
     f32x4 a[CH_RING];
     __device__ __forceinline__ f32x4 frag(int c, const LaneCtx& L) const {
+        if ((NEO_CHAIN_ABLATE & 4) && c > 0) return a[0];
         if (TRANS) return ch_wfrag_t(wp, ld, c);
         if (GUARD && c == NCH - 1) return ch_wfrag<true>(wp, c, kvalid, L);        // only the last chunk of a guarded segment can be partial
         return ch_wfrag<false>(wp, c, kvalid, L);
@@ -80,17 +85,28 @@ struct ChSeg {
     }
     // acc[mt] += sum over the NCH chunks of W-fragment x tile rows (both 32-row halves); tile chunk index = tc0 + c
     template <int LD>
-    __device__ __forceinline__ void run(f32x16 (&acc)[2], const float* __restrict__ tile, int tc0, const LaneCtx& L) {
+    __device__ __forceinline__ void run(f32x16 (&acc)[2], const float* __restrict__ tile, int tc0, const LaneCtx& Lin) {
+        // the swizzled LDS addresses are re-derived from an opaque lane id per segment: hoisted out of the whole kernel they cost
+        // ~60 registers (one per chunk and tile) and spill (the same measure as in mlp_tp.hip)
+        LaneCtx L = Lin;
+        asm volatile("" : "+v"(L.l31), "+v"(L.key), "+v"(L.half));
+        // activation fragments one chunk ahead of the MFMAs that use them (the LDS round trip runs under the previous chunk's products)
+        f32x4 b[2][2];
+        b[0][0] = load_b<LD, 15>(tile, 0, tc0, L);
+        b[0][1] = load_b<LD, 15>(tile, 1, tc0, L);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             if (c + CH_RING - 1 < NCH) a[(c + CH_RING - 1) % CH_RING] = frag(c + CH_RING - 1, L);
-            const f32x4 b0 = load_b<LD, 15>(tile, 0, tc0 + c, L);
-            const f32x4 b1 = load_b<LD, 15>(tile, 1, tc0 + c, L);
+            if (c + 1 < NCH) {
+                b[(c + 1) & 1][0] = load_b<LD, 15>(tile, 0, tc0 + c + 1, L);
+                b[(c + 1) & 1][1] = load_b<LD, 15>(tile, 1, tc0 + c + 1, L);
+            }
             __builtin_amdgcn_sched_barrier(0);            // the ring stays 4 deep: no hoisting of later chunks' loads over these MFMAs
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0] = NEO_MFMA(a[c % CH_RING][e], b0[e], acc[0]);
-                acc[1] = NEO_MFMA(a[c % CH_RING][e], b1[e], acc[1]);
+                if (NEO_CHAIN_ABLATE & 1) { asm volatile("" ::"v"(a[c % CH_RING][e]), "v"(b[c & 1][0][e]), "v"(b[c & 1][1][e])); continue; }
+                acc[0] = NEO_MFMA(a[c % CH_RING][e], b[c & 1][0][e], acc[0]);
+                acc[1] = NEO_MFMA(a[c % CH_RING][e], b[c & 1][1][e], acc[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -142,6 +158,7 @@ __device__ __forceinline__ void ch_d_init(f32x16& acc, const float* __restrict__
 template <bool RELU>
 __device__ __forceinline__ void ch_d_store(const f32x16& acc, float* __restrict__ M, long ld, long row, bool valid, int col0, const LaneCtx& L) {
     if (!valid) return;
+    if (NEO_CHAIN_ABLATE & 2) { if (acc[0] != 12345.678f) return; }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 v;

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
     }
     const float* pa = Z + (long)(kbeg + ka) * ldz + m0 + ra;
     const float* pb = X + (long)(kbeg + kb) * ldx + n0 + rb;
-    f32x4 qa[2][4], qb[2][JB];                    // two operand sets: a K step's loads have TWO multiply phases to arrive (round 6)
+    f32x4 qa[4], qb[JB];
     auto guarded = [&](const float* p, unsigned mask, bool kv) -> f32x4 {
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
         if (kv) {
@@ -358,31 +358,29 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
         }
         return v;
     };
-    // operands of the K step starting at k0 -> register set S (FAST: interior tile and a full step, no guards); steps are fetched in order
-    auto fetch = [&](auto fastc, auto setc, int k0) {
+    // operands of the K step starting at k0 -> registers (FAST: interior tile and a full step, no guards)
+    auto fetch = [&](auto fastc, int k0) {
         constexpr bool FAST = decltype(fastc)::value;
-        constexpr int S = decltype(setc)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float* p = pa + (long)(8 * j) * ldz;
-            if constexpr (FAST) qa[S][j] = *reinterpret_cast<const f4u*>(p);
-            else qa[S][j] = guarded(p, mka, k0 + ka + 8 * j < kend);
+            if constexpr (FAST) qa[j] = *reinterpret_cast<const f4u*>(p);
+            else qa[j] = guarded(p, mka, k0 + ka + 8 * j < kend);
         }
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const float* p = pb + (long)((256 / QB) * j) * ldx;
-            if constexpr (FAST) qb[S][j] = *reinterpret_cast<const f4u*>(p);
-            else qb[S][j] = guarded(p, mkb, k0 + kb + (256 / QB) * j < kend);
+            if constexpr (FAST) qb[j] = *reinterpret_cast<const f4u*>(p);
+            else qb[j] = guarded(p, mkb, k0 + kb + (256 / QB) * j < kend);
         }
         pa += (long)GK * ldz;
         pb += (long)GK * ldx;
     };
-    auto stage = [&](auto setc, int buf) {
-        constexpr int S = decltype(setc)::value;
+    auto stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(As[buf] + (ka + 8 * j) * PA + ra) = qa[S][j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(As[buf] + (ka + 8 * j) * PA + ra) = qa[j];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) *reinterpret_cast<f32x4*>(Bs[buf] + (kb + (256 / QB) * j) * PB + rb) = qb[S][j];
+        for (int j = 0; j < JB; ++j) *reinterpret_cast<f32x4*>(Bs[buf] + (kb + (256 / QB) * j) * PB + rb) = qb[j];
     };
     const bool bias_wg = part_db != nullptr && blockIdx.x == 0 && tid < 128;
     float cs = 0.0f;
@@ -410,30 +408,17 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
                     for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = NEO_MFMA(b[mt][e], a[nt][e], acc[mt][nt]);   // D rows = m, D cols = n
         }
     };
-    // nst K steps from k0: one barrier per step; invariant at the top of the loop: LDS buffer 0 = step i, set 0 = step i + 1,
-    // set 1 = step i + 2 (both in flight)
+    // nst K steps from k0: one barrier per step
     auto run = [&](auto fastc, int k0, int nst) {
         if (nst <= 0) return;
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        fetch(fastc, S0(), k0);
-        stage(S0(), 0);
-        if (nst > 1) fetch(fastc, S0(), k0 + GK);
-        if (nst > 2) fetch(fastc, S1(), k0 + 2 * GK);
+        fetch(fastc, k0);
+        stage(0);
         __syncthreads();
-        int i = 0;
-        for (; i + 1 < nst; i += 2) {
-            compute(0);
-            stage(S0(), 1);                                       // waits for set 0 only: set 1's loads stay in flight
-            if (i + 3 < nst) fetch(fastc, S0(), k0 + (i + 3) * GK);
-            __syncthreads();
-            compute(1);
-            if (i + 2 < nst) stage(S1(), 0);
-            if (i + 4 < nst) fetch(fastc, S1(), k0 + (i + 4) * GK);
-            __syncthreads();
-        }
-        if (i < nst) {
-            compute(0);
+        for (int i = 0; i < nst; ++i) {
+            const bool more = i + 1 < nst;
+            if (more) fetch(fastc, k0 + (i + 1) * GK);
+            compute(i & 1);
+            if (more) stage((i + 1) & 1);
             __syncthreads();
         }
     };

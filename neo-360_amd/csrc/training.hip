@@ -586,6 +586,36 @@ void launch_tp_activate_bwd(const float* raw_rgb, const float* raw_sigma, const 
                        reinterpret_cast<const float4*>(g_rgbsigma), g_rgb, g_sigma);
 }
 
+// dst[b][c][r] = src[b][r][c]: batched 2-D transpose through a 64 x 64 LDS tile, 256-B segments on both sides.  NCHW <-> channels-last
+// of the latent under autograd (training.py: the texel-space projection reads (texels, 512) rows; torch's strided copy moved the
+// 472 MB at 0.9 TB/s: 0.66 ms forward + 1.04 ms backward of a 31 ms step)
+namespace {
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const long b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const float* sp = src + b * (long)rows * cols;
+    float* dp = dst + b * (long)rows * cols;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = r0 + ty + 4 * j, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 4 * j][tx] = sp[(long)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = c0 + ty + 4 * j, r = r0 + tx;
+        if (r < rows && c < cols) dp[(long)c * rows + r] = tile[tx][ty + 4 * j];
+    }
+}
+}  // namespace
+
+void launch_transpose(const float* src, long batch, int rows, int cols, float* dst, hipStream_t s) {
+    if (batch <= 0 || rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(k_transpose, dim3((cols + 63) / 64, (rows + 63) / 64, (unsigned)batch), dim3(256), 0, s, src, rows, cols, dst);
+}
+
 void launch_uniform(uint64_t seed, uint32_t stream, int rows, int cols, float* out, hipStream_t s) {
     const long total = (long)rows * cols;
     if (total <= 0) return;

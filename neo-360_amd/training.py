@@ -198,7 +198,7 @@ def eff_distloss(w, m, interval, ctx=None):
 
 class _Gather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx_, module, pts, plane_xz, plane_xy, plane_yz, latent, rays, planes_only=False):
+    def forward(ctx_, module, pts, plane_xz, plane_xy, plane_yz, latent, rays, planes_only=False, shared=None):
         # the module's context holds channels-last copies of the scene: they must be copies of THESE tensors at THIS
         # version (an optimizer step or a fresh encoder output would otherwise leave the forward values stale while
         # gradients still flow to the arguments) - re-upload when the fingerprint differs
@@ -214,7 +214,9 @@ class _Gather(torch.autograd.Function):
         local = None if planes_only else torch.empty(NV * P, 512, device=pts.device)
         _lib.check(c.lib.neo_tp_gather(c.handle, ptr(pts), P, host_poses, NV, focal, cx, cy, ptr(world), ptr(local), c.stream()))
         ctx_.save_for_backward(pts)
-        ctx_.meta = (c, host_poses, NV, focal, cx, cy, plane_xz.shape, latent.shape, bool(planes_only))
+        ctx_.meta = (c, host_poses, NV, focal, cx, cy, plane_xz.shape, latent.shape, bool(planes_only), shared)
+        if shared is not None:
+            shared["uses"] = shared.get("uses", 0) + 1
         if planes_only:
             return world, torch.empty(0, device=pts.device)
         return world, local
@@ -222,18 +224,34 @@ class _Gather(torch.autograd.Function):
     @staticmethod
     def backward(ctx_, g_world, g_local):
         (pts,) = ctx_.saved_tensors
-        c, host_poses, NV, focal, cx, cy, pshape, lshape, planes_only = ctx_.meta
+        c, host_poses, NV, focal, cx, cy, pshape, lshape, planes_only, shared = ctx_.meta
         dev = pts.device
         _, Cw, Hp, Wp = pshape
         _, Cl, Hf, Wf = lshape
-        gp = [torch.zeros(NV, Hp, Wp, Cw, device=dev) for _ in range(3)]
+        # `shared` (round 6): the lookups of one training call scatter into ONE set of channels-last plane-gradient buffers - the first
+        # backward to run allocates them and hands them to autograd, the others add into them and return nothing: one zero fill, one
+        # NHWC -> NCHW conversion and no full-size sums per plane and call instead of one of each per lookup (4 per call)
+        first = True
+        if shared is not None and planes_only:
+            first = shared.get("planes") is None
+            if first:
+                shared["planes"] = [torch.zeros(NV, Hp, Wp, Cw, device=dev) for _ in range(3)]
+                shared["left"] = shared.get("uses", 1)
+            gp = shared["planes"]
+            shared["left"] -= 1
+            if shared["left"] <= 0:                                      # every lookup of the call has reported: a later pass starts afresh
+                shared["planes"] = None
+        else:
+            gp = [torch.zeros(NV, Hp, Wp, Cw, device=dev) for _ in range(3)]
         gl = None if planes_only else torch.zeros(NV, Hf, Wf, Cl, device=dev)
         gw = f32(g_world.contiguous(), "g_world")
         gloc = None if planes_only else f32(g_local.contiguous(), "g_local")
         _lib.check(c.lib.neo_tp_gather_backward(c.handle, ptr(pts), pts.shape[0], host_poses, NV, focal, cx, cy, ptr(gw),
                                                 ptr(gloc), ptr(gp[0]), ptr(gp[1]), ptr(gp[2]), ptr(gl), c.stream()))
         nchw = lambda x: x.permute(0, 3, 1, 2)
-        return None, None, nchw(gp[0]), nchw(gp[1]), nchw(gp[2]), (nchw(gl) if gl is not None else None), None, None
+        if not first:
+            return None, None, None, None, None, None, None, None, None
+        return None, None, nchw(gp[0]), nchw(gp[1]), nchw(gp[2]), (nchw(gl) if gl is not None else None), None, None, None
 
 
 def gather_features(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
@@ -246,11 +264,44 @@ def gather_features(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
     return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays)
 
 
-def gather_planes(module, pts, plane_xz, plane_xy, plane_yz, latent, rays):
+def gather_planes(module, pts, plane_xz, plane_xy, plane_yz, latent, rays, shared=None):
     """The tri-plane half of gather_features alone: world (NV*P,128).  The latent is not looked up (the projected-space
     training path gathers it through `gather_map`); it is still passed so that the device-side scene - geometry included -
     follows these tensors."""
-    return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays, True)[0]
+    return _Gather.apply(module, pts, plane_xz, plane_xy, plane_yz, latent, rays, True, shared)[0]
+
+
+class _ChannelsLast(torch.autograd.Function):
+    """(NV, C, H, W) -> (NV H W, C) rows for the texel-space GEMMs, and the gradient back, each as one tiled transpose
+    (neo_transpose) - torch's permute + reshape is a strided copy both ways (0.66 + 1.04 ms of a 31 ms step for the 472 MB latent)."""
+
+    @staticmethod
+    def forward(ctx_, x, lib_ctx):
+        x = f32(x, "map")
+        if x.dim() != 4:
+            raise ValueError("expected an NCHW map, got %s" % (tuple(x.shape),))
+        if not x.is_contiguous():
+            x = x.contiguous()
+        nv, ch, h, w = x.shape
+        c = _ctx(x, lib_ctx)
+        out = torch.empty(nv * h * w, ch, device=x.device)
+        _lib.check(c.lib.neo_transpose(c.handle, ptr(x), nv, ch, h * w, ptr(out), c.stream()))
+        ctx_.meta = (c, nv, ch, h, w)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx_, g):
+        c, nv, ch, h, w = ctx_.meta
+        g = f32(g.contiguous(), "g")
+        out = torch.empty(nv, ch, h, w, device=g.device)
+        _lib.check(c.lib.neo_transpose(c.handle, ptr(g), nv, h * w, ch, ptr(out), c.stream()))
+        return out, None
+
+
+def channels_last_rows(x, ctx=None):
+    """An NCHW feature map as (NV H W, C) rows, differentiable (neo_transpose both ways)."""
+    return _ChannelsLast.apply(x, ctx)
 
 
 class _MapGather(torch.autograd.Function):
@@ -681,7 +732,7 @@ def tp_render_train(module, rays, randomized, white_bkgd, maps, chunk=None, seed
     projected = getattr(module, "train_projected", None)
     if projected is None:
         projected = os.environ.get("NEO360_TRAIN_PROJECTED", "1") != "0"
-    proj = {"latent_cl": maps[3].permute(0, 2, 3, 1).reshape(-1, maps[3].shape[1])} if projected else None
+    proj = {"latent_cl": channels_last_rows(maps[3], ctx=c), "plane_grads": {}} if projected else None
     parts = []
     for i in range(0, B, max(step, 1)):
         sub = {k: (v[i:i + step] if k in ("rays_o", "rays_d", "viewdirs") else v) for k, v in rays.items()}
@@ -725,7 +776,7 @@ def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws, pr
             if proj is not None:
                 if "G" not in proj:                                     # (texels, 4 x 256): one texel-space GEMM for the four MLPs, once per call
                     proj["G"], proj["shared"] = project_latent_all(mlps, proj["latent_cl"], ctx=c)
-                world = gather_planes(module, look, maps[0], maps[1], maps[2], maps[3], rays)
+                world = gather_planes(module, look, maps[0], maps[1], maps[2], maps[3], rays, shared=proj["plane_grads"])
                 slot = level + (2 if name == "bg" else 0)              # mlps = (fg coarse, fg fine, bg coarse, bg fine)
                 pre = gather_map(module, proj["G"], look, rays, col=256 * slot, width=256, shared=proj["shared"])
                 raw_rgb, raw_sigma = nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, NV, ctx=c)
@@ -936,9 +987,7 @@ def pix_render_train(module, rays, randomized, white_bkgd, near, far, latent, se
         rot = poses[:, :3, :3].transpose(1, 2)                                                  # util.py:45-49: R^T d per view
         dir_cam = (rot[:, None, :, :] * viewdirs[None, :, None, :]).sum(-1)                     # (NV,B,3), as tp_render_train
         d_enc = ops.pos_enc(dir_cam, 0, 4, ctx=c)                                               # (NV,B,27)
-    latent_cl = latent.permute(0, 2, 3, 1).reshape(-1, latent.shape[1])                          # (NV Hf Wf, 512) channels-last, under autograd
-    if latent_cl.dtype != torch.float32:
-        latent_cl = latent_cl.float()
+    latent_cl = channels_last_rows(latent, ctx=c)                                                # (NV Hf Wf, 512) channels-last, under autograd
     out = []
     for level, mlp in enumerate((module.coarse_mlp, module.fine_mlp)):
         N = t.shape[1]

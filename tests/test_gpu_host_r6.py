@@ -338,3 +338,20 @@ def test_merged_projection_shares_one_gradient_buffer_and_survives_a_second_back
     for a, b, c in zip(g1, g2, g3):
         assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-6)          # atomics: the order of the adds differs
         assert float((a - c).abs().max()) <= 2e-5 * max(float(c.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 512, 24, 40), (2, 130, 7, 9), (1, 64, 1, 1)])
+def test_channels_last_rows_is_permute_reshape_both_ways(shape):
+    """training.channels_last_rows (neo_transpose, a tiled transpose each way) = permute(0, 2, 3, 1).reshape(-1, C) under autograd,
+    bitwise (a copy), ragged tiles included."""
+    from neo360_amd import training
+    g = torch.Generator(device=DEV).manual_seed(sum(shape))
+    x = torch.randn(*shape, device=DEV, generator=g).requires_grad_(True)
+    up = torch.randn(shape[0] * shape[2] * shape[3], shape[1], device=DEV, generator=g)
+    with torch.enable_grad():
+        y = training.channels_last_rows(x)
+        want = x.permute(0, 2, 3, 1).reshape(-1, shape[1])
+        assert torch.equal(y.detach(), want.detach())
+        (ga,) = torch.autograd.grad((y * up).sum(), [x])
+        (gb,) = torch.autograd.grad((want * up).sum(), [x])
+    assert torch.equal(ga, gb)

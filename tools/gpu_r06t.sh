@@ -1,8 +1,8 @@
-# round 6: quick A/B after a training-kernel change: the training tests, two step timings, kernel stats
-cd $GRAFT_REPO_ROOT; T=${1:-r06s}; O=gpurun_out/$T; rm -rf $O; mkdir -p $O
+# round 6: quickest A/B of a chain-kernel change: the chain tests, two step timings, kernel stats
+cd $GRAFT_REPO_ROOT; T=${1:-r06t}; O=gpurun_out/$T; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
-timeout 400 python -m pytest tests/test_gpu_host_r6.py tests/test_gpu_training.py tests/test_gpu_host_r5.py tests/test_gpu_pix_training.py tests/test_gpu_mip_training.py -q -m gpu -x > $O/pytest_a.log 2>&1; echo "pytest rc=$?" >> $O/pytest_a.log
-tail -4 $O/pytest_a.log
+timeout 200 python -m pytest tests/test_gpu_host_r6.py -q -m gpu -x -k "fused_training_chain or merged_projection" > $O/pytest_a.log 2>&1; echo "pytest rc=$?" >> $O/pytest_a.log
+tail -3 $O/pytest_a.log
 grep -q "rc=0" $O/pytest_a.log || exit 1
 for m in 1 1; do
   NEO360_TRAIN_CHAIN=$m timeout 150 python bench.py --workload neo360_train --steps 10 --warmup 3 --cpu-rays 0 > $O/train_$m.json 2> $O/train_$m.err || { tail -3 $O/train_$m.err; continue; }
@@ -14,5 +14,4 @@ done
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_train -o train -- python bench.py --workload neo360_train --steps 5 --warmup 2 --cpu-rays 0 > $O/prof_train.log 2>&1
 find $O/prof_train -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_train.csv \;
 find $O/prof_train -name "*kernel_trace.csv" -delete; find $O/prof_train -name "*agent_info.csv" -delete
-head -8 $O/kernel_stats_train.csv | cut -c1-160
-timeout 200 python tools/bench_train_other.py > $O/train_other.log 2>&1; tail -6 $O/train_other.log
+grep "chain" $O/kernel_stats_train.csv | cut -c1-140
