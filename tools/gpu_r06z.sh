@@ -24,7 +24,7 @@ python bench.py --workload neo360_train --steps 10 --warmup 2 > $O/train.json 2>
 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_train -o train -- python bench.py --workload neo360_train --steps 5 --warmup 2 --cpu-rays 0 > $O/prof_train.log 2>&1
 find $O/prof_train -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_train.csv \;
 find $O/prof_train -name "*kernel_trace.csv" -delete; find $O/prof_train -name "*agent_info.csv" -delete
-cp gpurun_out/parity_report.json $O/parity_report.json
+cp gpurun_out/parity_report.json $O/parity_report.json; timeout 300 python tools/bench_train_other.py > $O/train_other.log 2>&1; timeout 200 python tools/bench_train_chain.py > $O/train_chain.log 2>&1; NEO360_TRAIN_CHAIN=0 timeout 200 python tools/bench_train_chain.py >> $O/train_chain.log 2>&1
 find gpurun_out -name "*counter_collection.csv" -size +200k -delete
 find gpurun_out -name "*kernel_trace.csv" -size +200k -delete
 tail -6 $O/pytest.log; tail -2 $O/smoke.log; cut -c1-300 $O/bench.json
