@@ -3,8 +3,12 @@
 //
 // The layer-by-layer chain (k_sgemm per layer) moves every activation through HBM twice per layer - a 128 x 128 layer is 32 flop per
 // byte, the launches run at ~110 TFLOP/s / 3.4 TB/s, bound by neither.  Here a workgroup owns 64 rows (point-views) through
-//     forward : L0 (pre0 + x_enc W0_pe + world W0_w) -> L1 -> L2 -> L3 (pre3 + h2 W3_h + x_enc W3_pe + world W3_w) -> bottleneck -> view layer 0
-//     backward: g_y0 -> g_bott -> (+ g_hm / NV) g_z3 -> g_z2 -> g_z1 -> g_z0, g_world
+//     forward : L0 (pre0 + x_enc W0_pe + world W0_w) -> L1 -> L2 -> L3 (pre3 + h2 W3_h + x_enc W3_pe + world W3_w)
+//     backward: (g_hm / NV) relu'(h3) = g_z3 -> g_z2 -> g_z1 -> g_z0, g_world
+// Everything after relu(L3_v) is linear up to the view means (the bottleneck has no activation, view layer 0 is averaged over the views
+// BEFORE its ReLU: model.py:139-150), so the bottleneck and view layer 0 act on the MEANS - P rows instead of NV P, forward, dX and dW
+// (train_mlp.hip; the reassociation the inference kernels make, FOLD in mlp_tp.hip): W4a mean_v(W6 h3_v + b6) + W4c mean_v(cond_v) + b4 =
+// W4a (W6 hm + b6) + W4c mean_v(cond_v) + b4.  The per-row chain therefore ends at h3.
 // with the current activation (gradient) tile in LDS (64 x 128 floats, XOR-swizzled 16-B chunks: mfma_tile.h) and every layer's output
 // written to HBM ONCE (the tape / the operands of the weight-gradient GEMMs), never read back by the chain.  Exact fp32
 // (v_mfma_f32_32x32x2_f32), weights straight from L2 in row-major order: the forward's fragment is one 16-B load of W[n][k..k+3], the
@@ -22,20 +26,18 @@ constexpr int CH_HLD = 128;      // activation tile pitch (floats)
 constexpr int CH_RING = 4;       // weight fragments in flight per wave
 
 struct ChainFwdArgs {
-    const float* w0; const float* w1; const float* w2; const float* w3; const float* w4; const float* w6;
-    const float* b0; const float* b1; const float* b2; const float* b3; const float* b4; const float* b6;
-    const float* x_enc; const float* world; const float* pre; const float* cond;
-    float* h0; float* h1; float* h2; float* h3; float* bott; float* y0;
+    const float* w0; const float* w1; const float* w2; const float* w3;
+    const float* b0; const float* b1; const float* b2; const float* b3;
+    const float* x_enc; const float* world; const float* pre;
+    float* h0; float* h1; float* h2; float* h3;
     long R;
     int pe;
 };
 
 struct ChainBwdArgs {
-    const float* w0; const float* w1; const float* w2; const float* w3; const float* w4; const float* w6;
+    const float* w0; const float* w1; const float* w2; const float* w3;
     const float* h0; const float* h1; const float* h2; const float* h3;
-    const float* gy0;        // (R, 64)
-    const float* g_hm;       // (P, 128): gradient of the view mean of h3 (density head), added as g_hm[r mod P] / NV
-    float* g_bott;           // (R, 128) out
+    const float* g_hm;       // (P, 128): gradient of the view mean of h3 (density head + bottleneck / view branch): g_h3[r] = g_hm[r mod P] / NV
     float* g_pre;            // (R, 256) out: [g_z0 | g_z3]
     float* gz2; float* gz1;  // (R, 128) out
     float* g_world;          // (R, 128) out or null
@@ -265,39 +267,14 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_fwd(ChainFwdArgs a) {
         }
         __syncthreads();
     }
-    // h3, then the bottleneck (no activation) and the direction encodings into the narrow tile
-    sg.prefetch(a.w6 + (long)wrow * 128 + ko, 0, 128, L);
+    // h3: the last per-row layer (the view means and everything behind them are P-sized: train_mlp.hip)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        store_tile<CH_HLD, 15, true>(acc3[mt], H, L.wv, mt, L);
-        ch_d_store<true>(acc3[mt], a.h3, 128, row[mt], ok[mt], n0, L);
-    }
-    ch_stage_narrow<XLD, 4>(X, a.cond, 27, r0, a.R);
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) ch_d_init(acc[mt], nullptr, 0, 0, false, n0, a.b6, n0, 1.0f, L);
-    sg.template run<CH_HLD>(acc, H, 0, L);
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        store_tile<CH_HLD, 15, false>(acc[mt], H, L.wv, mt, L);
-        ch_d_store<false>(acc[mt], a.bott, 128, row[mt], ok[mt], n0, L);
-    }
-    __syncthreads();
-    // view layer 0 on [bott | cond] (64 outputs): wave = (n-tile wv >> 1, m-tile wv & 1)
-    const int vnt = L.wv >> 1, vmt = L.wv & 1;
-    f32x16 y;
-    ch_d_init(y, nullptr, 0, 0, false, 32 * vnt, a.b4, 32 * vnt, 1.0f, L);
-    const float* w4r = a.w4 + (long)(32 * vnt + L.l31) * 155 + ko;
-    ch_gemm1<CH_HLD, 16, false>(y, w4r, 128, H, vmt, L);
-    ch_gemm1<XLD, 4, true>(y, w4r + 128, 27, X, vmt, L);
-    ch_d_store<false>(y, a.y0, 64, row[vmt], ok[vmt], 32 * vnt, L);
+    for (int mt = 0; mt < 2; ++mt) ch_d_store<true>(acc3[mt], a.h3, 128, row[mt], ok[mt], n0, L);
 }
 
 // ---- backward (input-gradient chain) -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float H[CH_ROWS * CH_HLD];
-    __shared__ __attribute__((aligned(16))) float X[CH_ROWS * 64];
     LaneCtx L;
     L.init();
     const long r0 = (long)blockIdx.x * CH_ROWS;
@@ -307,48 +284,20 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
     const bool ok[2] = {row[0] < a.R, row[1] < a.R};
     const int col = n0 + L.l31;                            // the output column (input feature of the layer) of this lane's weight fragments
     const int ko = 4 * L.half;
-    // g_y0 tile (64 x 64)
-    {
-        const int chunk = threadIdx.x & 15;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = (threadIdx.x >> 4) + 16 * j;
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (r0 + r < a.R) v = *reinterpret_cast<const f4u*>(a.gy0 + (r0 + r) * 64 + chunk * 4);
-            *reinterpret_cast<f32x4*>(X + r * 64 + ((chunk ^ (r & 15)) << 2)) = v;
-        }
-    }
     f32x16 acc[2], accw[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        ch_d_init(acc[mt], nullptr, 0, 0, false, n0, nullptr, n0, 1.0f, L);
-        ch_d_init(accw[mt], nullptr, 0, 0, false, n0, nullptr, n0, 1.0f, L);
-    }
-    __syncthreads();
-    // g_bott = g_y0 W4[:, :128]
-    ch_gemm<64, 8, true, false>(acc, a.w4 + (long)ko * 155 + col, 155, 0, X, 0, L);
     ChSeg<16, true, false> sg;
     ChMask mk[2];
-    sg.prefetch(a.w6 + (long)ko * 128 + col, 128, 0, L);
+    sg.prefetch(a.w3 + (long)ko * K3 + col, K3, 0, L);
+    // g_z3 = (g_hm / NV) relu'(h3)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        store_tile<CH_HLD, 15, false>(acc[mt], H, L.wv, mt, L);
-        ch_d_store<false>(acc[mt], a.g_bott, 128, row[mt], ok[mt], n0, L);
-    }
-    __syncthreads();
-    // g_h3 = g_bott W6 + g_hm / NV, masked -> g_z3
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+        ch_d_init(accw[mt], nullptr, 0, 0, false, n0, nullptr, n0, 1.0f, L);
         ch_d_init(acc[mt], a.g_hm, 128, row[mt] % a.P, ok[mt], n0, nullptr, n0, (float)a.NV, L);
         ch_mask_load(mk[mt], a.h3, row[mt], ok[mt], n0, L);
     }
-    sg.template run<CH_HLD>(acc, H, 0, L);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) ch_mask_apply(acc[mt], mk[mt]);
-    sg.prefetch(a.w3 + (long)ko * K3 + col, K3, 0, L);
-    __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+        ch_mask_apply(acc[mt], mk[mt]);
         store_tile<CH_HLD, 15, false>(acc[mt], H, L.wv, mt, L);
         ch_d_store<false>(acc[mt], a.g_pre + 128, 256, row[mt], ok[mt], n0, L);
     }

@@ -658,15 +658,22 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
     float* h0 = tape; float* h1 = h0 + R * 128; float* h2 = h1 + R * 128; float* h3 = h2 + R * 128;
     float* bott = h3 + R * 128; float* y0 = bott + R * 128; float* hm = y0 + R * 64; float* ym = hm + P * 128; float* y1 = ym + P * 64;
     if (pre && g_chain_fused && (pe == 63 || pe == 84)) {
-        // one kernel for everything per row (train_chain.h); the view means and the P-sized heads below
-        ChainFwdArgs a{w[0], w[1], w[2], w[3], w[4], w[6], b[0], b[1], b[2], b[3], b[4], b[6], x_enc, world, pre, cond,
-                       h0, h1, h2, h3, bott, y0, R, pe};
+        // one kernel for everything per row: layers 0..3 (train_chain.h).  Behind relu(L3_v) the network is linear up to the view means
+        // (no activation on the bottleneck; view layer 0 is averaged over the views before its ReLU), so the bottleneck and view
+        // layer 0 run on the MEANS, P rows instead of NV P: W4a mean_v(W6 h3_v + b6) + W4c mean_v(cond_v) + b4 = W4a (W6 hm + b6) + W4c cm + b4.
+        // The tape's per-row bottleneck / view-layer regions are not written; their first P rows hold bm = W6 hm + b6 and cm = mean_v cond.
+        ChainFwdArgs a{w[0], w[1], w[2], w[3], b[0], b[1], b[2], b[3], x_enc, world, pre, h0, h1, h2, h3, R, pe};
         const dim3 grid((unsigned)((R + CH_ROWS - 1) / CH_ROWS));
         if (pe == 63) hipLaunchKernelGGL((k_tp_chain_fwd<8>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((k_tp_chain_fwd<11>), grid, dim3(256), 0, s, a);
+        float* bm = bott;                                                                                        // (P, 128)
+        float* cm = bott + P * 128;                                                                              // (P, 27)
         hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
         gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
-        hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 64)), dim3(256), 0, s, y0, NV, P, 64, 1, ym);
+        gemm<false, false>((int)P, 128, 128, hm, 128, w[6], 128, bm, 128, epi(b[6], 0), 1, s);                   // mean bottleneck
+        hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 27)), dim3(256), 0, s, cond, NV, P, 27, 0, cm);          // mean direction encoding
+        gemm<false, false>((int)P, 64, 128, bm, 128, w[4], 155, ym, 64, epi(b[4], 0), 1, s);                     // view layer 0 on the means
+        gemm<false, false>((int)P, 64, 27, cm, 27, w[4] + 128, 155, ym, 64, epi(nullptr, 1, 1), 1, s);           // C = relu(C + ..)
         gemm<false, false>((int)P, 64, 64, ym, 64, w[5], 64, y1, 64, epi(b[5], 1), 1, s);
         gemm<false, false>((int)P, 3, 64, y1, 64, w[8], 64, raw_rgb, 3, epi(b[8], 0), 1, s);
         return;
@@ -728,6 +735,21 @@ void launch_pix_train_forward(const float* const* w, const float* const* b, cons
     gemm<false, false>((int)R, 128, 128, h0, 128, w[1], 128, h1, 128, epi(b[1], 1), 1, s);
     gemm<false, false>((int)R, 128, 128, h1, 128, w[2], 128, h2, 128, epi(b[2], 1), 1, s);
     gemm<false, false>((int)R, 128, 128, h2, 128, w[3], 128, h3, 128, epi(b[3], 1), 1, s);
+    if (g_chain_fused) {
+        // the bottleneck has no activation and view layer 0 is averaged over the views before its ReLU (:113-126): both run on the view
+        // MEANS - P rows instead of NV P - as in the NeRFPPMLP chain; bm / cm live in the first P rows of the tape's per-view regions
+        float* bm = bott;
+        float* cm = bott + P * 128;
+        hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
+        gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
+        gemm<false, false>((int)P, 128, 128, hm, 128, w[6], 128, bm, 128, epi(b[6], 0), 1, s);
+        hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 27)), dim3(256), 0, s, cond, NV, P, 27, 0, cm);
+        gemm<false, false>((int)P, VC, 128, bm, 128, w[4], 155, ym, VC, epi(b[4], 0), 1, s);
+        gemm<false, false>((int)P, VC, 27, cm, 27, w[4] + 128, 155, ym, VC, epi(nullptr, 1, 1), 1, s);               // C = relu(C + ..)
+        gemm<false, false>((int)P, VC, VC, ym, VC, w[5], VC, y1, VC, epi(b[5], 1), 1, s);
+        gemm<false, false>((int)P, 3, VC, y1, VC, w[8], VC, raw_rgb, 3, epi(b[8], 0), 1, s);
+        return;
+    }
     gemm<false, false>((int)R, 128, 128, h3, 128, w[6], 128, bott, 128, epi(b[6], 0), 1, s);                         // bottleneck, per view (:113-114)
     hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);                   // combine_interleaved "average"
     gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
@@ -756,6 +778,20 @@ void launch_pix_train_backward(const float* const* w, const float* x_enc, const 
     gemm<false, true>((int)P, VC, 3, g_rgb, 3, w[8], VC, g_y1, VC, epi(nullptr, 0, 0, y1, VC), 1, s);            // x relu'(y1)
     dw_gemm(VC, VC, (int)P, g_y1, VC, ym, VC, gw[5], VC, gb[5], part, s);                                        // view layer 1
     gemm<false, true>((int)P, VC, VC, g_y1, VC, w[5], VC, g_ym, VC, epi(nullptr, 0, 0, ym, VC), 1, s);           // x relu'(mean)
+    if (g_chain_fused) {
+        // backward of the view branch on the means (see the forward): P-sized; g_h3[v, p] = g_hm[p] / NV
+        const float* bm = bott;
+        const float* cm = bott + P * 128;
+        float* g_bm = gy0;                                                                                        // (P, 128) in the R x VC buffer
+        dw_gemm(VC, 128, (int)P, g_ym, VC, bm, 128, gw[4], 155, gb[4], part, s);
+        dw_gemm(VC, 27, (int)P, g_ym, VC, cm, 27, gw[4] + 128, 155, nullptr, part, s);
+        gemm<false, true>((int)P, 128, VC, g_ym, VC, w[4], 155, g_bm, 128, epi(), 1, s);
+        dw_gemm(128, 128, (int)P, g_bm, 128, hm, 128, gw[6], 128, gb[6], part, s);
+        dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);
+        gemm<false, true>((int)P, 128, 128, g_bm, 128, w[6], 128, g_hm, 128, epi(), 1, s);
+        gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(nullptr, 0, 1), 1, s);
+        hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 0, gb2, 128L);
+    } else {
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * VC)), dim3(256), 0, s, g_ym, NV, P, VC, 0, gy0, (long)VC);        // mean over views -> rows
     dw_gemm(VC, 128, (int)R, gy0, VC, bott, 128, gw[4], 155, gb[4], part, s);                                    // view layer 0 on [bott | cond]
     dw_gemm(VC, 27, (int)R, gy0, VC, cond, 27, gw[4] + 128, 155, nullptr, part, s);
@@ -765,6 +801,7 @@ void launch_pix_train_backward(const float* const* w, const float* x_enc, const 
     dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);                                    // density head on the view mean
     gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 1, gb2, 128L);    // g_h3 += g_hm / NV
+    }
     hipLaunchKernelGGL(k_relu_mask, dim3(blocks(R * 128)), dim3(256), 0, s, gb2, 128L, h3, 128, R);              // g_z3
     dw_gemm(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128, gb[3], part, s);                                    // layer 3
     gemm<false, true>((int)R, 128, 128, gb2, 128, w[3], 128, ga, 128, epi(nullptr, 0, 0, h2, 128), 1, s);         // g_z2
@@ -802,21 +839,24 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     // view layer 1
     dw_gemm(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, gb[5], part, s);
     gemm<false, true>((int)P, 64, 64, g_y1, 64, w[5], 64, g_ym, 64, epi(nullptr, 0, 0, ym, 64), 1, s);           // x relu'(mean)
-    // mean over views -> per-view rows; view layer 0 on [bott | cond]
-    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0, 64L);
-    dw_gemm(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, gb[4], part, s);
-    dw_gemm(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, nullptr, part, s);
     if (g_pre && g_chain_fused && (pe == 63 || pe == 84)) {
-        // density head on the view mean of h3, then ONE kernel for the input-gradient chain of every row (train_chain.h), then the
-        // weight-gradient GEMMs on what it wrote: g_bott, g_z3 | g_z0 (the halves of g_pre), g_z2, g_z1
-        float* gbt = part + DW_PART_FLOATS;                                                      // the third R x 128 buffer
-        dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);
-        gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(), 1, s);
-        ChainBwdArgs a{w[0], w[1], w[2], w[3], w[4], w[6], h0, h1, h2, h3, gy0, g_hm, gbt, g_pre, ga, gb2, g_world, R, P, pe, NV};
+        // the forward ran view layer 0 and the bottleneck on the view means (see launch_tp_train_forward): their backward is P-sized too
+        const float* bm = bott;
+        const float* cm = bott + P * 128;
+        float* g_bm = part + DW_PART_FLOATS;                                                     // (P, 128) in the third R x 128 buffer
+        dw_gemm(64, 128, (int)P, g_ym, 64, bm, 128, gw[4], 155, gb[4], part, s);                                  // view layer 0
+        dw_gemm(64, 27, (int)P, g_ym, 64, cm, 27, gw[4] + 128, 155, nullptr, part, s);
+        gemm<false, true>((int)P, 128, 64, g_ym, 64, w[4], 155, g_bm, 128, epi(), 1, s);                          // g of the mean bottleneck
+        dw_gemm(128, 128, (int)P, g_bm, 128, hm, 128, gw[6], 128, gb[6], part, s);                                // bottleneck
+        dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);                                 // density head
+        gemm<false, true>((int)P, 128, 128, g_bm, 128, w[6], 128, g_hm, 128, epi(), 1, s);                        // g_hm = g_bm W6 + g_sigma W7
+        gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(nullptr, 0, 1), 1, s);
+        // ONE kernel for the input-gradient chain of every row: g_h3 = g_hm / NV per view -> g_z3 .. g_z0, g_world (train_chain.h); then
+        // the weight-gradient GEMMs on what it wrote: g_z3 | g_z0 (the halves of g_pre), g_z2, g_z1
+        ChainBwdArgs a{w[0], w[1], w[2], w[3], h0, h1, h2, h3, g_hm, g_pre, ga, gb2, g_world, R, P, pe, NV};
         hipLaunchKernelGGL(k_tp_chain_bwd, dim3((unsigned)((R + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, a);
         float* z3 = g_pre + 128;
         float* z0 = g_pre;
-        dw_gemm(128, 128, (int)R, gbt, 128, h3, 128, gw[6], 128, gb[6], part, s);                                 // bottleneck
         dw_gemm(128, 128, (int)R, z3, 256, h2, 128, gw[3], 128 + K0, gb[3], part, s);                             // layer 3 on [h2 | x_enc | . | world]
         dw_gemm(128, pe, (int)R, z3, 256, x_enc, pe, gw[3] + 128, 128 + K0, nullptr, part, s);
         dw_gemm(128, 128, (int)R, z3, 256, world, 128, gw[3] + 128 + pe + 512, 128 + K0, nullptr, part, s);
@@ -828,6 +868,10 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
         if (g_x_enc) gemm<false, true>((int)R, pe, 128, z0, 256, w[0], K0, g_x_enc, pe, epi(nullptr, 0, 1), 1, s);
         return;
     }
+    // mean over views -> per-view rows; view layer 0 on [bott | cond]
+    hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 64)), dim3(256), 0, s, g_ym, NV, P, 64, 0, gy0, 64L);
+    dw_gemm(64, 128, (int)R, gy0, 64, bott, 128, gw[4], 155, gb[4], part, s);
+    dw_gemm(64, 27, (int)R, gy0, 64, cond, 27, gw[4] + 128, 155, nullptr, part, s);
     gemm<false, true>((int)R, 128, 64, gy0, 64, w[4], 155, ga, 128, epi(), 1, s);                                // g_bott (R x 128)
     // bottleneck
     dw_gemm(128, 128, (int)R, ga, 128, h3, 128, gw[6], 128, gb[6], part, s);

@@ -262,9 +262,10 @@ def test_other_renderers_chunk_loops_overlap_and_stay_bitwise(which):
 @pytest.mark.parametrize("rows_p,nv,input_ch", [(1000, 3, 3), (37, 2, 3), (4133, 3, 3), (777, 3, 4)])
 def test_fused_training_chain_equals_the_layer_by_layer_chain(rows_p, nv, input_ch):
     """neo_train_chain_mode: the per-row part of the projected-space NeRFPPMLP chain as ONE kernel each way (csrc/train_chain.h: the
-    activation tile stays in LDS, every layer goes to HBM once) against one GEMM launch per layer - the same exact-fp32 products, so
-    outputs, all 18 parameter gradients, g_world and g_pre agree to rounding of the summation order; ragged last tiles (rows not a
-    multiple of 64) and tiles that straddle two views included."""
+    activation tile stays in LDS, every layer goes to HBM once; bottleneck and view layer 0 on the view MEANS - P rows instead of NV P,
+    by linearity) against one GEMM launch per layer in the reference's order: outputs, all 18 parameter gradients, g_world and g_pre
+    agree to rounding of the summation order; ragged last tiles (rows not a multiple of 64) and tiles that straddle two views
+    included."""
     from neo360_amd import training
     lib = _lib.load()
     mlp = models.NeRFPPMLP(0, 10, 4, input_ch=input_ch, num_src_views=nv).to(DEV)              # input_ch 4: the outside-sphere MLPs (84-d encoding)
@@ -281,29 +282,36 @@ def test_fused_training_chain_equals_the_layer_by_layer_chain(rows_p, nv, input_
     layers = mlp.ordered_layers()
     params = [l.weight for l in layers] + [l.bias for l in layers]
     old = lib.neo_train_chain_mode(-1)
+    res = {}
     try:
         with torch.enable_grad():
             for p in params:
                 p.requires_grad_(True)
-            # forward in both schedules: same values
-            fwd = {}
-            for mode in (0, 1):
+            for mode in (1, 0):
                 lib.neo_train_chain_mode(mode)
                 world, pre = world0.clone().requires_grad_(True), pre0.clone().requires_grad_(True)
-                fwd[mode] = training.nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, nv)
-            # backward in both schedules FROM ONE TAPE (the fused forward's; both schedules keep the same tape layout): a unit whose
-            # pre-activation rounds to +0 in one forward and to a tiny positive number in the other would otherwise take the other
-            # derivative (1 unit in ~6 M here) and move its row's gradients by a finite amount - a property of ReLU, not of a schedule
-            loss = (fwd[1][0] * up_rgb).sum() + (fwd[1][1] * up_sigma).sum()
-            g_a = torch.autograd.grad(loss, [world, pre] + params, retain_graph=True)
-            lib.neo_train_chain_mode(0)
-            g_b = torch.autograd.grad(loss, [world, pre] + params)
+                rgb, sigma = training.nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, nv)
+                grads = torch.autograd.grad((rgb * up_rgb).sum() + (sigma * up_sigma).sum(), [world, pre] + params)
+                res[mode] = (rgb.detach(), sigma.detach(), grads)
     finally:
         lib.neo_train_chain_mode(old)
-    for j in (0, 1):
-        assert max_abs(fwd[1][j].detach(), fwd[0][j].detach()) <= 3e-6 * max(1.0, float(fwd[0][j].abs().max()))
-    for i, (a, b) in enumerate(zip(g_a, g_b)):
-        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6), (i, float((a - b).abs().max()), float(b.abs().max()))
+    (rgb_a, sig_a, g_a), (rgb_b, sig_b, g_b) = res[1], res[0]
+    assert max_abs(rgb_a, rgb_b) <= 5e-6 * max(1.0, float(rgb_b.abs().max())) and max_abs(sig_a, sig_b) <= 5e-6 * max(1.0, float(sig_b.abs().max()))
+    # A unit whose pre-activation rounds to +0 in one schedule and to a tiny positive number in the other takes the other ReLU derivative
+    # (about one unit in 6 M at the largest size): its ROW's input gradients then differ by a finite amount - a property of ReLU under any
+    # change of summation order, not of a schedule.  Rows are therefore compared one by one, a handful may differ, and the parameter
+    # gradients (sums over all rows) are held to the tight bound only when no row flipped.
+    flipped = 0
+    for a, b in zip(g_a[:2], g_b[:2]):
+        bad = ((a - b).abs().amax(dim=1) > 1e-5 * max(float(b.abs().max()), 1e-6))
+        flipped = max(flipped, int(bad.sum()))
+    assert flipped <= 3, flipped
+    for i, (a, b) in enumerate(zip(g_a[2:], g_b[2:])):
+        err, ref = float((a - b).abs().max()), max(float(b.abs().max()), 1e-6)
+        if flipped == 0:
+            assert err <= 2e-5 * ref, (i, err, ref)
+        else:
+            assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-12, (i, err, ref, flipped)
 
 
 def test_merged_projection_shares_one_gradient_buffer_and_survives_a_second_backward():
