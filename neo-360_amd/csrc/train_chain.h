@@ -38,7 +38,8 @@ struct ChainBwdArgs {
     const float* w0; const float* w1; const float* w2; const float* w3;
     const float* h0; const float* h1; const float* h2; const float* h3;
     const float* g_hm;       // (P, 128): gradient of the view mean of h3 (density head + bottleneck / view branch): g_h3[r] = g_hm[r mod P] / NV
-    float* g_pre;            // (R, 256) out: [g_z0 | g_z3]
+    float* gz3; long ldz3;   // out: g_z3 (NeRFPPMLP: columns 128.. of g_pre (R, 256), pitch 256)
+    float* gz0; long ldz0;   // out: g_z0 (NeRFPPMLP: columns 0..127 of g_pre)
     float* gz2; float* gz1;  // (R, 128) out
     float* g_world;          // (R, 128) out or null
     long R, P;
@@ -212,7 +213,9 @@ __device__ __forceinline__ void ch_stage_narrow(float* __restrict__ tile, const 
 
 // ---- forward --------------------------------------------------------------------------------------------------------------------------
 // PEC: 8-column chunks of the encoding (8: pe = 63, 11: pe = 84); XLD: pitch of the narrow tile (power-of-two chunk count >= 16)
-template <int PEC>
+// PIX: PixelNeRF's MLP (vanilla_nerf/model_pixel.py:96-131; 4 x 128, the skip never fires): the same chain without the world features and
+// without the skip - h0 = relu(pre + x_enc W0_pe + b0) with pre (R, 128) and W0 (128, pe + 512), layers 1..3 plain.
+template <int PEC, bool PIX>
 __global__ __launch_bounds__(256, 3) void k_tp_chain_fwd(ChainFwdArgs a) {
     constexpr int XLD = PEC <= 8 ? 64 : 128;
     __shared__ __attribute__((aligned(16))) float H[CH_ROWS * CH_HLD];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_fwd(ChainFwdArgs a) {
     LaneCtx L;
     L.init();
     const long r0 = (long)blockIdx.x * CH_ROWS;
-    const int pe = a.pe, K0 = pe + 640, K3 = 128 + K0;
+    const int pe = a.pe, K0 = PIX ? pe + 512 : pe + 640, K3 = PIX ? 128 : 128 + K0;
     const int n0 = 32 * L.wv;                              // this wave's output columns of a 128-wide layer
     const long row[2] = {r0 + L.l31, r0 + 32 + L.l31};
     const bool ok[2] = {row[0] < a.R, row[1] < a.R};
@@ -228,24 +231,26 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_fwd(ChainFwdArgs a) {
     const int ko = 4 * L.half;
 
     ch_stage_narrow<XLD, PEC>(X, a.x_enc, pe, r0, a.R);
-    ch_stage128(H, a.world, 128, r0, a.R);
+    if (!PIX) ch_stage128(H, a.world, 128, r0, a.R);
     __builtin_amdgcn_sched_barrier(0);                     // the staging registers are dead before the 64 accumulator registers fill
     f32x16 acc[2], acc3[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        ch_d_init(acc[mt], a.pre, 256, row[mt], ok[mt], n0, a.b0, n0, 1.0f, L);
-        ch_d_init(acc3[mt], a.pre, 256, row[mt], ok[mt], 128 + n0, a.b3, n0, 1.0f, L);
+        ch_d_init(acc[mt], a.pre, PIX ? 128 : 256, row[mt], ok[mt], n0, a.b0, n0, 1.0f, L);
+        if (!PIX) ch_d_init(acc3[mt], a.pre, 256, row[mt], ok[mt], 128 + n0, a.b3, n0, 1.0f, L);
     }
     __syncthreads();
     // layer 0 and the input segments of layer 3 while x_enc / world are in LDS
     ch_gemm<XLD, PEC, false, true>(acc, a.w0 + (long)wrow * K0 + ko, 0, pe, X, 0, L);
-    ch_gemm<CH_HLD, 16, false, false>(acc, a.w0 + (long)wrow * K0 + pe + 512 + ko, 0, 128, H, 0, L);
-    ch_gemm<XLD, PEC, false, true>(acc3, a.w3 + (long)wrow * K3 + 128 + ko, 0, pe, X, 0, L);
-    ch_gemm<CH_HLD, 16, false, false>(acc3, a.w3 + (long)wrow * K3 + 128 + pe + 512 + ko, 0, 128, H, 0, L);
-    __syncthreads();
+    if (!PIX) {
+        ch_gemm<CH_HLD, 16, false, false>(acc, a.w0 + (long)wrow * K0 + pe + 512 + ko, 0, 128, H, 0, L);
+        ch_gemm<XLD, PEC, false, true>(acc3, a.w3 + (long)wrow * K3 + 128 + ko, 0, pe, X, 0, L);
+        ch_gemm<CH_HLD, 16, false, false>(acc3, a.w3 + (long)wrow * K3 + 128 + pe + 512 + ko, 0, 128, H, 0, L);
+        __syncthreads();
+    }
     float* const tape[3] = {a.h0, a.h1, a.h2};
     const float* const wl[3] = {a.w1 + (long)wrow * 128 + ko, a.w2 + (long)wrow * 128 + ko, a.w3 + (long)wrow * K3 + ko};   // layer 1, 2, h2 segment of 3
-    const float* const bl[2] = {a.b1, a.b2};
+    const float* const bl[3] = {a.b1, a.b2, a.b3};
     ChSeg<16, false, false> sg;
 #pragma unroll
     for (int layer = 0; layer < 3; ++layer) {
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_fwd(ChainFwdArgs a) {
             ch_d_store<true>(acc[mt], tape[layer], 128, row[mt], ok[mt], n0, L);
         }
         __syncthreads();
-        if (layer < 2) {
+        if (layer < 2 || PIX) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) ch_d_init(acc[mt], nullptr, 0, 0, false, n0, bl[layer], n0, 1.0f, L);
             sg.template run<CH_HLD>(acc, H, 0, L);
@@ -269,16 +274,17 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_fwd(ChainFwdArgs a) {
     }
     // h3: the last per-row layer (the view means and everything behind them are P-sized: train_mlp.hip)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) ch_d_store<true>(acc3[mt], a.h3, 128, row[mt], ok[mt], n0, L);
+    for (int mt = 0; mt < 2; ++mt) ch_d_store<true>(PIX ? acc[mt] : acc3[mt], a.h3, 128, row[mt], ok[mt], n0, L);
 }
 
 // ---- backward (input-gradient chain) -------------------------------------------------------------------------------------------------
+template <bool PIX>
 __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float H[CH_ROWS * CH_HLD];
     LaneCtx L;
     L.init();
     const long r0 = (long)blockIdx.x * CH_ROWS;
-    const int pe = a.pe, K0 = pe + 640, K3 = 128 + K0;
+    const int pe = a.pe, K0 = PIX ? pe + 512 : pe + 640, K3 = PIX ? 128 : 128 + K0;
     const int n0 = 32 * L.wv;
     const long row[2] = {r0 + L.l31, r0 + 32 + L.l31};
     const bool ok[2] = {row[0] < a.R, row[1] < a.R};
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
         ch_mask_apply(acc[mt], mk[mt]);
         store_tile<CH_HLD, 15, false>(acc[mt], H, L.wv, mt, L);
-        ch_d_store<false>(acc[mt], a.g_pre + 128, 256, row[mt], ok[mt], n0, L);
+        ch_d_store<false>(acc[mt], a.gz3, a.ldz3, row[mt], ok[mt], n0, L);
     }
     __syncthreads();
     // g_z2 = (g_z3 W3[:, :128]) relu'(h2);  g_world = g_z3 W3_w (+ g_z0 W0_w below)
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
         ch_mask_load(mk[mt], a.h2, row[mt], ok[mt], n0, L);
     }
     sg.template run<CH_HLD>(acc, H, 0, L);
-    if (a.g_world != nullptr) ch_gemm<CH_HLD, 16, true, false>(accw, a.w3 + (long)ko * K3 + 128 + pe + 512 + col, K3, 0, H, 0, L);
+    if (!PIX && a.g_world != nullptr) ch_gemm<CH_HLD, 16, true, false>(accw, a.w3 + (long)ko * K3 + 128 + pe + 512 + col, K3, 0, H, 0, L);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) ch_mask_apply(acc[mt], mk[mt]);
     sg.prefetch(a.w2 + (long)ko * 128 + col, 128, 0, L);
@@ -317,8 +323,8 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
     const float* const wnext[3] = {a.w1 + (long)ko * 128 + col, a.w0 + (long)ko * K0 + pe + 512 + col, nullptr};
     const long ldnext[3] = {128, K0, 0};
     const float* const ml[2] = {a.h1, a.h0};
-    float* const outp[3] = {a.gz2, a.gz1, a.g_pre};
-    const long outld[3] = {128, 128, 256};
+    float* const outp[3] = {a.gz2, a.gz1, a.gz0};
+    const long outld[3] = {128, 128, a.ldz0};
 #pragma unroll
     for (int step = 0; step < 3; ++step) {
         // acc = g_z(2 - step): -> LDS + HBM, then through the layer below (sg holds that layer's first weight fragments)
@@ -337,9 +343,9 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
             sg.template run<CH_HLD>(acc, H, 0, L);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) ch_mask_apply(acc[mt], mk[mt]);
-            if (step == 0 || a.g_world != nullptr) sg.prefetch(wnext[step], ldnext[step], 0, L);
+            if (step == 0 || (!PIX && a.g_world != nullptr)) sg.prefetch(wnext[step], ldnext[step], 0, L);
             __syncthreads();
-        } else if (a.g_world != nullptr) {
+        } else if (!PIX && a.g_world != nullptr) {
             sg.template run<CH_HLD>(accw, H, 0, L);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) ch_d_store<false>(accw[mt], a.g_world, 128, row[mt], ok[mt], n0, L);

@@ -664,8 +664,8 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
         // The tape's per-row bottleneck / view-layer regions are not written; their first P rows hold bm = W6 hm + b6 and cm = mean_v cond.
         ChainFwdArgs a{w[0], w[1], w[2], w[3], b[0], b[1], b[2], b[3], x_enc, world, pre, h0, h1, h2, h3, R, pe};
         const dim3 grid((unsigned)((R + CH_ROWS - 1) / CH_ROWS));
-        if (pe == 63) hipLaunchKernelGGL((k_tp_chain_fwd<8>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((k_tp_chain_fwd<11>), grid, dim3(256), 0, s, a);
+        if (pe == 63) hipLaunchKernelGGL((k_tp_chain_fwd<8, false>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((k_tp_chain_fwd<11, false>), grid, dim3(256), 0, s, a);
         float* bm = bott;                                                                                        // (P, 128)
         float* cm = bott + P * 128;                                                                              // (P, 27)
         hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
@@ -730,11 +730,17 @@ void launch_pix_train_forward(const float* const* w, const float* const* b, cons
     const int pe = 63, K0 = pe + 512, VC = 128;                     // VC: netwidth_condition (model_pixel.py:44)
     float* h0 = tape; float* h1 = h0 + R * 128; float* h2 = h1 + R * 128; float* h3 = h2 + R * 128;
     float* bott = h3 + R * 128; float* y0 = bott + R * 128; float* hm = y0 + R * VC; float* ym = hm + P * 128; float* y1 = ym + P * VC;
+    if (g_chain_fused) {
+        // the four per-row layers as ONE kernel (train_chain.h, PIX form)
+        ChainFwdArgs a{w[0], w[1], w[2], w[3], b[0], b[1], b[2], b[3], x_enc, nullptr, pre, h0, h1, h2, h3, R, pe};
+        hipLaunchKernelGGL((k_tp_chain_fwd<8, true>), dim3((unsigned)((R + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, a);
+    } else {
     hipLaunchKernelGGL(k_copy_cols, dim3(blocks(R * 32)), dim3(256), 0, s, pre, 128L, h0, 128L, R, 128);
     gemm<false, false>((int)R, 128, pe, x_enc, pe, w[0], K0, h0, 128, epi(b[0], 1, 1), 1, s);                        // relu(pre + x_enc W0_pe + b0)
     gemm<false, false>((int)R, 128, 128, h0, 128, w[1], 128, h1, 128, epi(b[1], 1), 1, s);
     gemm<false, false>((int)R, 128, 128, h1, 128, w[2], 128, h2, 128, epi(b[2], 1), 1, s);
     gemm<false, false>((int)R, 128, 128, h2, 128, w[3], 128, h3, 128, epi(b[3], 1), 1, s);
+    }
     if (g_chain_fused) {
         // the bottleneck has no activation and view layer 0 is averaged over the views before its ReLU (:113-126): both run on the view
         // MEANS - P rows instead of NV P - as in the NeRFPPMLP chain; bm / cm live in the first P rows of the tape's per-view regions
@@ -790,7 +796,16 @@ void launch_pix_train_backward(const float* const* w, const float* x_enc, const 
         dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);
         gemm<false, true>((int)P, 128, 128, g_bm, 128, w[6], 128, g_hm, 128, epi(), 1, s);
         gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(nullptr, 0, 1), 1, s);
-        hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * 128)), dim3(256), 0, s, g_hm, NV, P, 128, 0, gb2, 128L);
+        // ONE kernel for the input-gradient chain of every row (train_chain.h, PIX form): g_z3 -> gb2, g_z2 -> ga, g_z1 -> gy0, g_z0 -> g_pre
+        float* gz1 = gy0;                                                                        // the R x VC buffer: g_bm (its first P rows) is consumed by now
+        ChainBwdArgs a{w[0], w[1], w[2], w[3], h0, h1, h2, h3, g_hm, gb2, 128L, g_pre, 128L, ga, gz1, nullptr, R, P, pe, NV};
+        hipLaunchKernelGGL(k_tp_chain_bwd<true>, dim3((unsigned)((R + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, a);
+        dw_gemm(128, 128, (int)R, gb2, 128, h2, 128, gw[3], 128, gb[3], part, s);                                 // layer 3
+        dw_gemm(128, 128, (int)R, ga, 128, h1, 128, gw[2], 128, gb[2], part, s);                                  // layer 2
+        dw_gemm(128, 128, (int)R, gz1, 128, h0, 128, gw[1], 128, gb[1], part, s);                                 // layer 1
+        dw_gemm(128, pe, (int)R, g_pre, 128, x_enc, pe, gw[0], K0, gb[0], part, s);                               // layer 0, encoding columns
+        if (g_x_enc) gemm<false, true>((int)R, pe, 128, g_pre, 128, w[0], K0, g_x_enc, pe, epi(), 1, s);
+        return;
     } else {
     hipLaunchKernelGGL(k_view_bcast, dim3(blocks(P * VC)), dim3(256), 0, s, g_ym, NV, P, VC, 0, gy0, (long)VC);        // mean over views -> rows
     dw_gemm(VC, 128, (int)R, gy0, VC, bott, 128, gw[4], 155, gb[4], part, s);                                    // view layer 0 on [bott | cond]
@@ -853,8 +868,8 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
         gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(nullptr, 0, 1), 1, s);
         // ONE kernel for the input-gradient chain of every row: g_h3 = g_hm / NV per view -> g_z3 .. g_z0, g_world (train_chain.h); then
         // the weight-gradient GEMMs on what it wrote: g_z3 | g_z0 (the halves of g_pre), g_z2, g_z1
-        ChainBwdArgs a{w[0], w[1], w[2], w[3], h0, h1, h2, h3, g_hm, g_pre, ga, gb2, g_world, R, P, pe, NV};
-        hipLaunchKernelGGL(k_tp_chain_bwd, dim3((unsigned)((R + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, a);
+        ChainBwdArgs a{w[0], w[1], w[2], w[3], h0, h1, h2, h3, g_hm, g_pre + 128, 256L, g_pre, 256L, ga, gb2, g_world, R, P, pe, NV};
+        hipLaunchKernelGGL(k_tp_chain_bwd<false>, dim3((unsigned)((R + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, a);
         float* z3 = g_pre + 128;
         float* z0 = g_pre;
         dw_gemm(128, 128, (int)R, z3, 256, h2, 128, gw[3], 128 + K0, gb[3], part, s);                             // layer 3 on [h2 | x_enc | . | world]
