@@ -601,17 +601,18 @@ def run_train(args, dev):
            "phases_ms": {"forward": ev[0].elapsed_time(ev[1]), "loss_and_backward": ev[1].elapsed_time(ev[2]), "optimizer": ev[2].elapsed_time(ev[3])},
            "loss": float(loss.detach())}
     # roofline of the step (round 6; VERDICT r5 task 6): the matrix work the training operators EXECUTE per step on the fp32 MFMA
-    # pipe (k_sgemm forward / dX, k_dw weight gradients - the library's own GEMMs, texel-space projection included), counted from
+    # pipe (the fused per-row chain kernels, k_sgemm forward / dX, k_dw weight gradients - the library's own GEMMs, texel-space projection included), counted from
     # the operator shapes: per point-view the NeRFPPMLP chain without the 512 latent columns (they are applied once per texel:
     # 4 MLPs x texels x 512 x 256), per point the heads; backward = dX + dW = 2 x forward
+    # (round 6: the bottleneck and view layer 0 act on the view means - 26,304 MACs per point-view moved to 26,304 per point)
     pts = B * (129 + 385)
-    fwd_mac = pts * nv * ((255424 - 131072) + (260800 - 131072)) + 2 * pts * 4416
+    fwd_mac = pts * nv * ((255424 - 131072 - 26304) + (260800 - 131072 - 26304)) + 2 * pts * (4416 + 26304)
     texels = nv * 240 * 320
     proj_mac = 4 * texels * 512 * 256
     executed = 2.0 * 3.0 * (fwd_mac + proj_mac)
     out["roofline"] = {"bound": "mfma", "achieved": executed / dt / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": executed / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                       "executed_flop_per_step": executed, "kernel": "k_sgemm + k_dw (exact fp32 MFMA) over the whole step",
+                       "executed_flop_per_step": executed, "kernel": "k_tp_chain_fwd / _bwd + k_sgemm + k_dw (exact fp32 MFMA) over the whole step",
                        "note": "executed matrix flops of forward + dX + dW per step (operator shapes: %d points x %d views, texel-space "
                                "projection of %d texels for 4 MLPs) / the step's wall time - lookups, scatters, compositing, the "
                                "optimizer and launch gaps are inside that time, so this is the step's matrix-pipe occupancy, not a "

@@ -58,3 +58,23 @@ def test_bench_executed_flop_accounting():
     # tri-planes pre-projected: the 8 world k-steps are gone
     assert f(3, True, planes_projected=True) == (3 * (6 * 16 * 256 + 3 * 128 * 128) + tail) * 6
     assert f(3, False, planes_projected=True) < f(3, False) < 2 * 778752 * 3       # fewer than the reference formulation's MACs x 3 products
+
+
+def test_chain_gradient_buffers_are_views_of_one_zero_fill():
+    """training._zeros_like_shapes: the 18 weight / bias gradient tensors of a chain call as views of ONE zeroed buffer (one fill kernel
+    instead of 18), every view starting at a multiple of 4 floats (the library's 16-byte stores) and none overlapping."""
+    import torch
+    from neo360_amd import training
+    wshapes = [(128, 703), (128, 128), (128, 128), (128, 831), (64, 155), (64, 64), (128, 128), (1, 128), (3, 64)]
+    bshapes = [(s[0],) for s in wshapes]
+    gw, gb = training._zeros_like_shapes(wshapes, bshapes, "cpu")
+    assert [tuple(t.shape) for t in gw] == wshapes and [tuple(t.shape) for t in gb] == bshapes
+    base = gw[0].untyped_storage().data_ptr()
+    spans = []
+    for t in gw + gb:
+        assert t.untyped_storage().data_ptr() == base and t.is_contiguous() and float(t.abs().sum()) == 0.0
+        off = (t.data_ptr() - base) // 4
+        assert off % 4 == 0
+        spans.append((off, off + t.numel()))
+    spans.sort()
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
