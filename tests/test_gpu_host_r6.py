@@ -363,3 +363,35 @@ def test_channels_last_rows_is_permute_reshape_both_ways(shape):
         (ga,) = torch.autograd.grad((y * up).sum(), [x])
         (gb,) = torch.autograd.grad((want * up).sum(), [x])
     assert torch.equal(ga, gb)
+
+
+def test_shared_gradient_buffers_across_chunks_and_partial_losses():
+    """The lookups of one training call scatter into shared gradient buffers (one per tri-plane, one for the merged projected map) whatever
+    the chunking; a loss that reads only the fine level (the coarse lookups never run their backward) still gets the complete
+    gradient.  Against the per-row path (no projection, no sharing), which the fp64-autograd tests pin to the oracle."""
+    sc = cases.small_scene()
+    R = 96
+    gb = _batch(R)
+    target = synth.uniform(23, "chunk_target", (R, 3), 0.0, 1.0).to(DEV)
+    results = {}
+    # (the reference takes the same chunk: quirk Q1 makes the direction encodings of a call depend on its chunk size)
+    for tag, projected, chunk, fine_only in (("ref", False, 32, False), ("chunked", True, 32, False), ("ref_fine", False, 32, True),
+                                             ("chunked_fine", True, 32, True)):
+        net = models.NeRF_TP(num_coarse_samples=16, num_fine_samples=24, num_src_views=cases.NV).to(DEV)
+        net.load_state_dict(synth.nerf_tp_state(0))
+        net.train_projected = projected
+        maps = [sc[k].to(DEV).clone().requires_grad_(True) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")]
+        with torch.enable_grad():
+            net.set_scene(*maps, sc["image_wh"])
+            for p in net.parameters():
+                p.requires_grad_(True)
+            kw = {} if chunk is None else {"chunk": chunk}
+            out = net(gb, True, False, 0.0, 0.0, out_depth=False, seed=5, **kw)
+            levels = out[1:] if fine_only else out
+            loss = sum(((lv[0] - target) ** 2).mean() for lv in levels)
+            grads = torch.autograd.grad(loss, maps, allow_unused=True)
+        results[tag] = [g.detach() for g in grads]
+    for a_tag, b_tag in (("ref", "chunked"), ("ref_fine", "chunked_fine")):
+        for nm, a, b in zip(("plane_xz", "plane_xy", "plane_yz", "latent"), results[a_tag], results[b_tag]):
+            rel = float((a - b).norm()) / (float(a.norm()) + 1e-20)
+            assert rel < 2e-3 and float(b.abs().max()) > 0.0, (a_tag, nm, rel)
