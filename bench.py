@@ -534,7 +534,7 @@ class Runner:
         return roof
 
 
-def run_train(args, dev):
+def run_train(args, dev, emit=True):
     """`--workload neo360_train`: the reference's NeO-360 training step on this path (neo360/model.py:697-820: the module's
     randomized forward on a batch of rays, rgb L2 on both levels + 0.01 x eff_distloss on the fine inside / outside weights,
     backward, optimizer step on the four MLPs) at the reference's training batch - 500 rays (opt.py batch_size), 3 source views,
@@ -651,7 +651,9 @@ def run_train(args, dev):
                                          "GPU's %d rays - not a measured 500-ray CPU step" % (n1, n2, B)}
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         out["speedup_note"] = "GPU step measured at %d rays (randomized sampling) vs the CPU step extrapolated to %d rays (deterministic samples): indicative, not like-for-like" % (B, B)
-    print(json.dumps(out))
+    if emit:
+        print(json.dumps(out))
+    return out
 
 
 class FakeRunner:
@@ -797,6 +799,8 @@ def main():
                     help="0: skip the scene_setup_ms measurement (two extra one-chunk renders; counter passes want only the frame's launches)")
     ap.add_argument("--exact-f32", type=int, default=-1, dest="exact_f32",
                     help="1/0: also time 2 frames of the same workload on the exact fp32-MFMA kernels (default: as --others)")
+    ap.add_argument("--train-step", type=int, default=1, dest="train_step",
+                    help="1/0: with the other workloads (N == 1), also time five steps of the NeO-360 training step (`training_step` record)")
     ap.add_argument("--chunk-loop", type=int, default=1, dest="chunk_loop",
                     help="1/0: also time the frame as the reference's own chunk loop drives the module (300 forward calls; neo360, N = 1)")
     ap.add_argument("--fake", action="store_true", help=argparse.SUPPRESS)     # CPU plumbing test: gloo + FakeRunner (tests/test_bench_cpu.py)
@@ -841,7 +845,8 @@ def main():
     if args.workload == "neo360_train":
         if world != 1:
             sys.exit("bench.py: --workload neo360_train is a single-GPU line")
-        return run_train(args, dev)
+        run_train(args, dev)
+        return
     torch.set_grad_enabled(False)
     dist = None
     # one process per GPU over RCCL; a launch under torch.distributed.run with ONE rank (RANK set, world 1) initialises the
@@ -965,6 +970,21 @@ def main():
                                               "frac_of_split_ceiling": roof.get("frac_of_split_ceiling"), "workload": r2.desc}
                 r2.net.close()
                 del r2, f2
+                torch.cuda.empty_cache()
+            # the training step of the same model on this path, so that the driver's record carries it too: five
+            # 500-ray steps of --workload neo360_train, no CPU leg (bench.py --workload neo360_train is the full line)
+            if args.workload == "neo360" and args.train_step:
+                import copy
+                ta = copy.copy(args)
+                ta.steps, ta.warmup, ta.cpu_rays = 5, 2, 0
+                try:
+                    tr = run_train(ta, dev, emit=False)
+                    out["training_step"] = {"ms_per_step": tr["ms_per_step"], "value": tr["value"], "unit": tr["unit"], "steps": 5,
+                                            "rays_per_step": tr["config"]["rays_per_step"], "phases_ms": tr["phases_ms"],
+                                            "matrix_pipe_frac_of_157.3": tr["roofline"]["frac"], "dtype": tr["dtype"],
+                                            "workload": tr["config"]["workload"]}
+                finally:
+                    torch.set_grad_enabled(False)
                 torch.cuda.empty_cache()
         out["config"]["launch"] = ("self-spawned ranks (python bench.py --gpus N)" if os.environ.get("NEO360_BENCH_SELF_SPAWNED")
                                    else "torch.distributed.run" if "RANK" in os.environ else "single process")
