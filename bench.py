@@ -312,20 +312,24 @@ class Runner:
             torch.cuda.synchronize()
             net.check_flags()
             first, steady = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
-            return ev[0].elapsed_time(ev_mid), max(0.0, first - steady), steady
+            return ev[0].elapsed_time(ev_mid), first, steady
 
         once(False)                                                                 # loads code objects, grows workspaces
         # The window holds ~150 enqueues and 72 small H2D copies: whatever delays the host thread (another tenant of the box, a
         # page fault) leaves the GPU idle INSIDE the window and can only ADD to it - one builder box gave 93, 95, 7.6, 7.7, 15, 174 ms
         # in one call.  The number of record is therefore the second smallest of the runs (the smallest alone could be a timing
         # glitch; an un-delayed run is reproducible to a few per cent); all runs are in the line.
+        # A delay inside the STEADY window would subtract instead (one closing run of round 6 had a run of "0.0"): both windows are
+        # picked separately - each can only be inflated - and then differenced.
         runs = [once(True) for _ in range(reps)]
         pick = lambda xs: sorted(xs)[1 if len(xs) > 1 else 0]
+        steady = pick([r[2] for r in runs])
+        runs = [(r[0], max(0.0, r[1] - steady), r[2]) for r in runs]
         total = pick([r[1] for r in runs])
         import statistics
         return {"total_ms": total, "median_ms": statistics.median(r[1] for r in runs), "runs_ms": [r[1] for r in runs],
                 "set_scene_ms": pick([r[0] for r in runs]),
-                "one_chunk_steady_ms": pick([r[2] for r in runs]),
+                "one_chunk_steady_ms": steady,
                 "method": "HIP events on the launch stream, warm, second smallest of %d runs (host delays only add to the window): "
                           "(set_scene + repack + one-chunk render) - (the same render in the steady state)" % reps,
                 "note": "once per scene / per weight update, not part of ms_per_step: channels-last re-layout of 3 tri-planes + latent, "
