@@ -75,6 +75,7 @@ KERNEL_SOURCES = {
     "mip360": ("mlp_mip_h.hip", "mip_gemm_h.h", "mip_layered.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
     "mip360_128": ("mlp_mip_h.hip", "mip_gemm_h.h", "mip_layered.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
     "pixelnerf": ("mlp_pix_h.hip", "tp_common.h", "split_tile.h", "mfma_tile.h", "common.h", "kernels.h"),
+    "neo360_train": ("train_mlp.hip", "train_chain.h", "training.hip", "train_kernels.h", "mfma_tile.h", "common.h", "kernels.h"),
 }
 
 
@@ -621,6 +622,17 @@ def run_train(args, dev, emit=True):
                                "projection of %d texels for 4 MLPs) / the step's wall time - lookups, scatters, compositing, the "
                                "optimizer and launch gaps are inside that time, so this is the step's matrix-pipe occupancy, not a "
                                "single kernel's" % (2 * pts, nv, texels)}
+    # HBM traffic of a step: tools/pmc_train_step.py's stamped summary (two counter-only rocprofv3 passes over this command), attached
+    # only when it was taken on this tree's training kernels
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_pmc_train_step.json")) as f:
+            pm = json.load(f)
+        if pm.get("kernel_source_sha16") == kernel_source_hash("neo360_train"):
+            out["roofline"]["traffic"] = pm["hbm_GB_per_step"] * 1e9
+            out["roofline"]["traffic_note"] = "HBM bytes per step, all kernels (FETCH_SIZE x 2 + WRITE_SIZE, KiB), profiles/r06_pmc_train_step.json"
+            out["roofline"]["hbm_frac"] = pm["hbm_GB_per_step"] * 1e9 / dt / PEAK_HBM_BYTES
+    except (OSError, KeyError, ValueError):
+        pass
     if args.cpu_rays != 0:
         import oracle
         from oracle import training as T

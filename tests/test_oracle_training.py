@@ -107,3 +107,42 @@ def test_given_samples_hooks_of_the_pixelnerf_and_mip_oracles():
     r3, h3 = mip360.render(msd, rays, 0.5, 0.2, 3.0, num_prop_samples=8, num_nerf_samples=4,
                            jitters=[torch.full((6, 1), 0.9 * mj(8)), torch.full((6, 1), 0.5 * mj(8)), torch.full((6, 1), 0.3 * mj(4))])
     assert max_abs(h3[0]["sdist"], h[0]["sdist"]) > 1e-4 and all(not x["sdist"].requires_grad for x in h3)
+
+
+def test_view_branch_on_the_view_means_is_a_reassociation():
+    """What the fused training chains rely on (csrc/train_chain.h, round 6): behind relu(L3_v) the reference's NeRFPPMLP is linear up to
+    the view means - no activation on the bottleneck, view layer 0 averaged over the views BEFORE its ReLU (neo360/model.py:139-150) -
+    so views_linear.0([bottleneck(h3_v) | cond_v]) averaged over v equals views_linear.0([bottleneck(mean_v h3_v) | mean_v cond_v]).
+    Checked on the oracle's own forward in float64 (values and parameter gradients): equal to rounding."""
+    from oracle import mlp as M
+    nv, P = 3, 50
+    g = torch.Generator().manual_seed(3)
+    sd = {k: v.double() for k, v in synth.nerf_tp_state(0).items() if k.startswith("fg_fine_mlp.")}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x_enc = torch.randn(nv, P, 63, generator=g, dtype=torch.float64)
+    cond = torch.randn(nv * P, 27, generator=g, dtype=torch.float64)
+    world = torch.randn(nv * P, 128, generator=g, dtype=torch.float64) * 0.3
+    local = torch.randn(nv * P, 512, generator=g, dtype=torch.float64) * 0.3
+    pre = "fg_fine_mlp."
+    with torch.enable_grad():
+        rgb_ref, sig_ref = M.nerfpp_mlp(params, pre, x_enc, cond, world, local, nv)
+
+        lin = lambda name, x: torch.nn.functional.linear(x, params[pre + name + ".weight"], params[pre + name + ".bias"])
+        x0 = torch.cat([x_enc.reshape(-1, 63), local, world], dim=-1)
+        h = x0
+        for i in range(4):
+            h = torch.relu(lin("pts_linears.%d" % i, h))
+            if i == 2:
+                h = torch.cat([h, x0], dim=-1)
+        hm = h.reshape(nv, P, -1).mean(0)                                   # mean_v relu(L3_v)
+        cm = cond.reshape(nv, P, -1).mean(0)
+        y = torch.relu(lin("views_linear.0", torch.cat([lin("bottleneck_layer", hm), cm], dim=-1)))
+        y = torch.relu(lin("views_linear.1", y))
+        rgb, sig = lin("rgb_layer", y), lin("density_layer", hm)
+        assert max_abs(rgb, rgb_ref) < 1e-12 and max_abs(sig, sig_ref) < 1e-12
+        names = sorted(params)
+        up = torch.randn(P, 3, generator=g, dtype=torch.float64)
+        g_ref = torch.autograd.grad((rgb_ref * up).sum() + sig_ref.sum(), [params[k] for k in names])
+        g_new = torch.autograd.grad((rgb * up).sum() + sig.sum(), [params[k] for k in names])
+    for k, a, b in zip(names, g_ref, g_new):
+        assert float((a - b).abs().max()) <= 1e-11 * max(1.0, float(a.abs().max())), k
