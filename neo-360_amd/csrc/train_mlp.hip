@@ -42,6 +42,26 @@ constexpr int AS_FLOATS = GTM * GP > GK * PRA ? GTM * GP : GK * PRA;
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // 16-B global access at 4-B alignment (rows of 703 floats)
 
+#ifndef NEO_GEMM_XCD
+#define NEO_GEMM_XCD 1        // 0: plain blockIdx -> tile map (A/B)
+#endif
+// XCD-aware workgroup -> tile map (round 6).  Workgroups are dealt to the 8 XCDs round-robin in linear-id order (x fastest), and each
+// XCD has its own L2: with the plain map the `inner` tiles that share an operand block - the column tiles of one 128-row block of A in
+// k_sgemm, the output tiles of one K slice in k_dw - land on `inner` different XCDs and every one of them pulls that block through the
+// fabric again (measured: the texel-space projection moved 8-9 GB per GEMM for 1.4 GB of operands + result).  Here the workgroups with
+// linear id = 8 s + x (s = slot, x = XCD) take outer block (s / inner) * 8 + x and inner tile s % inner: the `inner` sharers run on one
+// XCD back to back.  Outer blocks beyond the last complete group of 8 keep the plain map (a bijection either way).
+__device__ __forceinline__ void xcd_pair(long lin, int inner, long outer_n, long& outer, int& in_tile) {
+    const long full = (outer_n / 8) * 8;
+    outer = lin / inner;
+    in_tile = (int)(lin - outer * inner);
+    if (NEO_GEMM_XCD && lin < full * inner) {
+        const long slot = lin >> 3;
+        outer = (slot / inner) * 8 + (lin & 7);
+        in_tile = (int)(slot % inner);
+    }
+}
+
 struct GemmEpi {
     const float* bias;        // [N] or null
     const float* mask;        // [M][ldm]: output multiplied by (mask > 0) - ReLU backward - or null
@@ -76,7 +96,10 @@ __global__ __launch_bounds__(256, 2) void k_sgemm(int M, int N, int K, const flo
     LaneCtx L;
     L.init();
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * GTM, n0 = blockIdx.x * TN;
+    long row_block;
+    int col_tile;
+    xcd_pair((long)blockIdx.x + (long)gridDim.x * blockIdx.y, (int)gridDim.x, (long)gridDim.y, row_block, col_tile);
+    const int m0 = (int)row_block * GTM, n0 = col_tile * TN;
     // the operand range being accumulated (one per segment)
     const float* A = A_in;
     const float* B = B_in;
@@ -325,8 +348,14 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
     LaneCtx L;
     L.init();
     const int tid = threadIdx.x;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * NT;
-    const int kbeg = blockIdx.z * k_per_split, kend = min(K, kbeg + k_per_split);
+    // all output tiles of one K slice on one XCD: the slice's rows of Z and X cross the fabric once
+    const int tiles_xy = (int)(gridDim.x * gridDim.y);
+    long slice;
+    int txy;
+    xcd_pair((long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z), tiles_xy, (long)gridDim.z, slice, txy);
+    const int bx = txy % (int)gridDim.x, by = txy / (int)gridDim.x, bz = (int)slice;
+    const int m0 = by * 128, n0 = bx * NT;
+    const int kbeg = bz * k_per_split, kend = min(K, kbeg + k_per_split);
     const int wm = L.wv & 1, wn = L.wv >> 1;
     f32x16 acc[2][NF];
 #pragma unroll
@@ -382,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
 #pragma unroll
         for (int j = 0; j < JB; ++j) *reinterpret_cast<f32x4*>(Bs[buf] + (kb + (256 / QB) * j) * PB + rb) = qb[j];
     };
-    const bool bias_wg = part_db != nullptr && blockIdx.x == 0 && tid < 128;
+    const bool bias_wg = part_db != nullptr && bx == 0 && tid < 128;
     float cs = 0.0f;
     auto compute = [&](int buf) {
         if (bias_wg) {
@@ -432,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
     //      64 KB (profiles/r05_train_dw.log, dW of a 1.18 M-row training op: k_sgemm<true, true> + k_colsum 13.0 ms, this kernel
     //      with atomics 10.4 ms (lane = m) / 6.1 ms (lane = n), with partial tiles 5.5 ms = 110 TFLOP/s).
     //      lane = n (l31), registers 4 g + e = m = 8 g + 4 half + e: a store instruction covers 32 consecutive floats of two rows ----
-    const long tile = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const long tile = ((long)bz * gridDim.y + by) * gridDim.x + bx;
     float* pt = part + tile * (128 * NT);
 #pragma unroll
     for (int nt = 0; nt < NF; ++nt)
@@ -443,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void k_dw(int M, int N, int K, const float*
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     pt[(wm * 64 + 32 * mt + 8 * g + 4 * L.half + e) * NT + wn * (NT / 2) + 32 * nt + L.l31] = acc[mt][nt][4 * g + e];
-    if (bias_wg) part_db[((long)blockIdx.z * gridDim.y + blockIdx.y) * 128 + tid] = cs;
+    if (bias_wg) part_db[((long)bz * gridDim.y + by) * 128 + tid] = cs;
 }
 
 // W[m][n] += sum over slices of part[slice][tile][m][n], db[m] += sum of part_db: one float4 of one tile row per thread and
