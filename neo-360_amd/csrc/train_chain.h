@@ -188,15 +188,23 @@ __device__ __forceinline__ void ch_mask_apply(f32x16& acc, const ChMask& k) {
 }
 
 // ---- LDS staging --------------------------------------------------------------------------------------------------------------------
-// 64 rows x 128 floats (row pitch `ld` floats in global memory, 16-B aligned rows) -> swizzled tile
+// 64 rows x 128 floats (row pitch `ld` floats in global memory, 16-B aligned rows) -> swizzled tile, by LDS-DMA: one
+// global_load_lds_dwordx4 per wave moves two rows (1 KB) straight into LDS - no staging registers, no ds_write pass.  The DMA writes
+// lane-linearly (wave-uniform base + 16 lane), so the XOR swizzle is applied to the SOURCE: slot p of a row receives logical chunk
+// p ^ (row & 15), the involution the fragment reads (load_b) apply.  Rows past the end are clamped to the last row (their results are
+// never stored).  The barrier that publishes the tile carries the vmcnt(0) (the compiler knows the DMA is in flight).
 __device__ __forceinline__ void ch_stage128(float* __restrict__ tile, const float* __restrict__ M, long ld, long r0, long R) {
-    const int chunk = threadIdx.x & 31;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int row = (threadIdx.x >> 5) + 8 * j;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (r0 + row < R) v = *reinterpret_cast<const f4u*>(M + (r0 + row) * ld + chunk * 4);
-        *reinterpret_cast<f32x4*>(tile + row * CH_HLD + ((chunk ^ (row & 15)) << 2)) = v;
+        const int row_first = 2 * wv + 8 * j;
+        const int row = row_first + (lane >> 5);
+        long gr = r0 + row;
+        gr = gr < R ? gr : R - 1;
+        const float* src = M + gr * ld + (((lane & 31) ^ (row & 15)) << 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(tile + row_first * CH_HLD), 16, 0, 0);
     }
 }
 // 64 rows x `cols` floats (dense rows of pitch `cols`, any alignment) -> swizzled tile of pitch LD, zero-padded to 8 NCH columns
