@@ -13,8 +13,8 @@
 // written to HBM ONCE (the tape / the operands of the weight-gradient GEMMs), never read back by the chain.  Exact fp32
 // (v_mfma_f32_32x32x2_f32), weights straight from L2 in row-major order: the forward's fragment is one 16-B load of W[n][k..k+3], the
 // backward's the four dwords W[k..k+3][n] (coalesced over n).  Wave w owns output columns 32 w .. 32 w + 31 of a 128-wide layer for both
-// 32-row halves (2 accumulator tiles; a weight fragment feeds 2 MFMAs, fragments requested 4 chunks = 32 MFMAs ahead); 48 KB of LDS,
-// three workgroups per CU.  The view means and everything P-sized stay separate launches (train_mlp.hip).
+// 32-row halves (2 accumulator tiles; a weight fragment feeds 2 MFMAs, fragments requested 4 chunks = 32 MFMAs ahead); 48 KB (forward) /
+// 32 KB (backward) of LDS, three workgroups per CU.  The view means and everything P-sized stay separate launches (train_mlp.hip).
 #pragma once
 
 #ifndef NEO_CHAIN_ABLATE
@@ -122,28 +122,6 @@ __device__ __forceinline__ void ch_gemm(f32x16 (&acc)[2], const float* __restric
     sg.prefetch(wp, ld, kvalid, L);
     sg.template run<LD>(acc, tile, tc0, L);
 }
-// one accumulator tile (the 64-wide view layer): rows of half mt
-template <int LD, int NCH, bool GUARD>
-__device__ __forceinline__ void ch_gemm1(f32x16& acc, const float* __restrict__ wp, int kvalid, const float* __restrict__ tile, int mt,
-                                         const LaneCtx& L) {
-    f32x4 a[CH_RING];
-    auto frag = [&](int c) -> f32x4 {
-        if (GUARD && c == NCH - 1) return ch_wfrag<true>(wp, c, kvalid, L);
-        return ch_wfrag<false>(wp, c, kvalid, L);
-    };
-#pragma unroll
-    for (int c = 0; c < CH_RING - 1 && c < NCH; ++c) a[c] = frag(c);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        if (c + CH_RING - 1 < NCH) a[(c + CH_RING - 1) % CH_RING] = frag(c + CH_RING - 1);
-        const f32x4 b = load_b<LD, 15>(tile, mt, c, L);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = NEO_MFMA(a[c % CH_RING][e], b[e], acc);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // ---- D-layout global I/O: acc[4 g + e] <-> M[row][col0 + 8 g + 4 half + e] (row = this lane's row; 4 instructions cover one 128-B line) ----
 // (bias indexed by the layer's output column n0 + .., the matrix by col0 + ..: the skip layer's half of `pre` starts at column 128)
 __device__ __forceinline__ void ch_d_init(f32x16& acc, const float* __restrict__ M, long ld, long row, bool valid, int col0,

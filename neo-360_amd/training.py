@@ -321,7 +321,7 @@ class _MapGather(torch.autograd.Function):
         P = pts.shape[0]
         sliced = col is not None
         if sliced:
-            if kind != "tp" or width % 64 or col % 4 or col < 0 or col + width > gmap.shape[1] or shared is None:
+            if kind != "tp" or width % 64 or col % 4 or col < 0 or col + width > gmap.shape[1]:
                 raise ValueError("bad map slice [%s, +%s) of %s (kind %s)" % (col, width, tuple(gmap.shape), kind))
             C = int(width)
         else:
@@ -346,10 +346,15 @@ class _MapGather(torch.autograd.Function):
         c, host_poses, NV, focal, cx, cy, mshape, kind, col, C, shared = ctx_.meta
         g = f32(g_out.contiguous(), "g_out")
         if col is not None:
-            first = shared.get("buf") is None
-            if first:
-                shared["buf"] = torch.zeros(mshape, device=pts.device)
-            buf = shared["buf"]
+            # shared = None (module.train_shared_grads = False): a private full-size buffer per lookup, summed by autograd - the plain
+            # contract of a custom Function, without the in-place accumulation into a tensor already handed to the engine
+            first = shared is None or shared.get("buf") is None
+            if shared is None:
+                buf = torch.zeros(mshape, device=pts.device)
+            else:
+                if first:
+                    shared["buf"] = torch.zeros(mshape, device=pts.device)
+                buf = shared["buf"]
             _lib.check(c.lib.neo_tp_gather_map_slice_backward(c.handle, mshape[0], mshape[1], C, ptr(pts), pts.shape[0], host_poses, NV, focal,
                                                               cx, cy, ptr(g), buf.data_ptr() + 4 * int(col), c.stream()))
             return None, (buf if first else None), None, None, None, None, None, None
@@ -776,9 +781,10 @@ def _tp_render_train_chunk(module, rays, randomized, white_bkgd, maps, draws, pr
             if proj is not None:
                 if "G" not in proj:                                     # (texels, 4 x 256): one texel-space GEMM for the four MLPs, once per call
                     proj["G"], proj["shared"] = project_latent_all(mlps, proj["latent_cl"], ctx=c)
-                world = gather_planes(module, look, maps[0], maps[1], maps[2], maps[3], rays, shared=proj["plane_grads"])
+                share = getattr(module, "train_shared_grads", True)     # False: one private gradient buffer per lookup (slower, no sharing)
+                world = gather_planes(module, look, maps[0], maps[1], maps[2], maps[3], rays, shared=proj["plane_grads"] if share else None)
                 slot = level + (2 if name == "bg" else 0)              # mlps = (fg coarse, fg fine, bg coarse, bg fine)
-                pre = gather_map(module, proj["G"], look, rays, col=256 * slot, width=256, shared=proj["shared"])
+                pre = gather_map(module, proj["G"], look, rays, col=256 * slot, width=256, shared=proj["shared"] if share else None)
                 raw_rgb, raw_sigma = nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, NV, ctx=c)
             else:
                 world, local = gather_features(module, look, maps[0], maps[1], maps[2], maps[3], rays)

@@ -376,10 +376,11 @@ def test_shared_gradient_buffers_across_chunks_and_partial_losses():
     results = {}
     # (the reference takes the same chunk: quirk Q1 makes the direction encodings of a call depend on its chunk size)
     for tag, projected, chunk, fine_only in (("ref", False, 32, False), ("chunked", True, 32, False), ("ref_fine", False, 32, True),
-                                             ("chunked_fine", True, 32, True)):
+                                             ("chunked_fine", True, 32, True), ("private", True, 32, False)):
         net = models.NeRF_TP(num_coarse_samples=16, num_fine_samples=24, num_src_views=cases.NV).to(DEV)
         net.load_state_dict(synth.nerf_tp_state(0))
         net.train_projected = projected
+        net.train_shared_grads = tag != "private"          # "private": one gradient buffer per lookup, summed by autograd
         maps = [sc[k].to(DEV).clone().requires_grad_(True) for k in ("plane_xz", "plane_xy", "plane_yz", "latent")]
         with torch.enable_grad():
             net.set_scene(*maps, sc["image_wh"])
@@ -391,7 +392,7 @@ def test_shared_gradient_buffers_across_chunks_and_partial_losses():
             loss = sum(((lv[0] - target) ** 2).mean() for lv in levels)
             grads = torch.autograd.grad(loss, maps, allow_unused=True)
         results[tag] = [g.detach() for g in grads]
-    for a_tag, b_tag in (("ref", "chunked"), ("ref_fine", "chunked_fine")):
+    for a_tag, b_tag in (("ref", "chunked"), ("ref_fine", "chunked_fine"), ("ref", "private")):
         for nm, a, b in zip(("plane_xz", "plane_xy", "plane_yz", "latent"), results[a_tag], results[b_tag]):
             rel = float((a - b).norm()) / (float(a.norm()) + 1e-20)
             assert rel < 2e-3 and float(b.abs().max()) > 0.0, (a_tag, nm, rel)
