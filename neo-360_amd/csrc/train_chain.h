@@ -122,6 +122,28 @@ __device__ __forceinline__ void ch_gemm(f32x16 (&acc)[2], const float* __restric
     sg.prefetch(wp, ld, kvalid, L);
     sg.template run<LD>(acc, tile, tc0, L);
 }
+// one accumulator tile (the 64-wide view layers of the heads kernel): rows of half mt
+template <int LD, int NCH, bool GUARD>
+__device__ __forceinline__ void ch_gemm1(f32x16& acc, const float* __restrict__ wp, int kvalid, const float* __restrict__ tile, int mt,
+                                         const LaneCtx& L) {
+    f32x4 a[CH_RING];
+    auto frag = [&](int c) -> f32x4 {
+        if (GUARD && c == NCH - 1) return ch_wfrag<true>(wp, c, kvalid, L);
+        return ch_wfrag<false>(wp, c, kvalid, L);
+    };
+#pragma unroll
+    for (int c = 0; c < CH_RING - 1 && c < NCH; ++c) a[c] = frag(c);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + CH_RING - 1 < NCH) a[(c + CH_RING - 1) % CH_RING] = frag(c + CH_RING - 1);
+        const f32x4 b = load_b<LD, 15>(tile, mt, c, L);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = NEO_MFMA(a[c % CH_RING][e], b[e], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---- D-layout global I/O: acc[4 g + e] <-> M[row][col0 + 8 g + 4 half + e] (row = this lane's row; 4 instructions cover one 128-B line) ----
 // (bias indexed by the layer's output column n0 + .., the matrix by col0 + ..: the skip layer's half of `pre` starts at column 128)
 __device__ __forceinline__ void ch_d_init(f32x16& acc, const float* __restrict__ M, long ld, long row, bool valid, int col0,
@@ -336,5 +358,127 @@ __global__ __launch_bounds__(256, 3) void k_tp_chain_bwd(ChainBwdArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) ch_d_store<false>(accw[mt], a.g_world, 128, row[mt], ok[mt], n0, L);
         }
+    }
+}
+
+// ---- the P-sized forward tail of the NeRFPPMLP chain as ONE kernel (round 6) ------------------------------------------------------------
+// Behind the per-row layers everything acts on the view means (see the top of this file): per 64 points
+//     hm = mean_v h3_v, cm = mean_v cond_v -> sigma = hm w7 + b7, bm = hm W6^T + b6, ym = relu(bm W4a^T + cm W4c^T + b4),
+//     y1 = relu(ym W5^T + b5), rgb = y1 W8^T + b8
+// with hm / bm in the 64 x 128 tile and cm / ym / y1 in the 64 x 64 tile; hm, bm, cm, ym, y1 go to the tape (the backward's operands).  It
+// replaces two view-mean launches and six small GEMMs whose time was launches and reading the same P rows again and again; what it
+// has to move is h3 once (NV x 512 B per point).  The two heads with 1 / 3 outputs are plain dot products (4 lanes per point).
+struct HeadsFwdArgs {
+    const float* h3; const float* cond;                       // (NV P, 128), (NV P, 27), view-major rows
+    const float* w4; const float* b4; const float* w5; const float* b5; const float* w6; const float* b6;
+    const float* w7; const float* b7; const float* w8; const float* b8;
+    float* hm; float* bm; float* cm; float* ym; float* y1; float* raw_sigma; float* raw_rgb;
+    long P;
+    int NV;
+};
+
+__global__ __launch_bounds__(256, 3) void k_tp_heads_fwd(HeadsFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float H[CH_ROWS * CH_HLD];
+    __shared__ __attribute__((aligned(16))) float X[CH_ROWS * 64];
+    LaneCtx L;
+    L.init();
+    const int tid = threadIdx.x;
+    const long p0 = (long)blockIdx.x * CH_ROWS;
+    const int n0 = 32 * L.wv;
+    const long prow[2] = {p0 + L.l31, p0 + 32 + L.l31};
+    const bool ok[2] = {prow[0] < a.P, prow[1] < a.P};
+    const int ko = 4 * L.half;
+    // view means: the summation order of k_view_mean (v = 0, 1, ..), one division
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        if (ok[mt])
+            for (int v = 0; v < a.NV; ++v) {
+                const float* src = a.h3 + ((long)v * a.P + prow[mt]) * 128 + n0 + ko;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 t = *reinterpret_cast<const f4u*>(src + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][4 * g + e] += t[e];
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = acc[mt][r] / (float)a.NV;
+        store_tile<CH_HLD, 15, false>(acc[mt], H, L.wv, mt, L);
+        ch_d_store<false>(acc[mt], a.hm, 128, prow[mt], ok[mt], n0, L);
+    }
+    for (int idx = tid; idx < CH_ROWS * 32; idx += 256) {
+        const int p = idx >> 5, c = idx & 31;
+        float sacc = 0.0f;
+        const bool valid = c < 27 && p0 + p < a.P;
+        if (valid) {
+            for (int v = 0; v < a.NV; ++v) sacc += a.cond[((long)v * a.P + p0 + p) * 27 + c];
+            sacc = sacc / (float)a.NV;
+            a.cm[(p0 + p) * 27 + c] = sacc;
+        }
+        X[swz_index<64, 15>(p, c)] = sacc;
+    }
+    __syncthreads();
+    // density head: 4 lanes per point, 32 features each
+    {
+        const int p = tid >> 2, q = tid & 3;
+        float d = 0.0f;
+#pragma unroll 8
+        for (int k = 32 * q; k < 32 * q + 32; ++k) d = __builtin_fmaf(H[swz_index<CH_HLD, 15>(p, k)], a.w7[k], d);
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        if (q == 0 && p0 + p < a.P) a.raw_sigma[p0 + p] = d + a.b7[0];
+    }
+    // mean bottleneck
+    f32x16 bmv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) ch_d_init(bmv[mt], nullptr, 0, 0, false, n0, a.b6, n0, 1.0f, L);
+    ch_gemm<CH_HLD, 16, false, false>(bmv, a.w6 + (long)(n0 + L.l31) * 128 + ko, 0, 128, H, 0, L);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        store_tile<CH_HLD, 15, false>(bmv[mt], H, L.wv, mt, L);
+        ch_d_store<false>(bmv[mt], a.bm, 128, prow[mt], ok[mt], n0, L);
+    }
+    __syncthreads();
+    // view layer 0 on [bm | cm], view layer 1: wave = (n-tile wv >> 1, m-tile wv & 1) of a 64-wide layer
+    const int vnt = L.wv >> 1, vmt = L.wv & 1;
+    const long vrow = p0 + 32 * vmt + L.l31;
+    const bool vok = vrow < a.P;
+    f32x16 y;
+    ch_d_init(y, nullptr, 0, 0, false, 32 * vnt, a.b4, 32 * vnt, 1.0f, L);
+    const float* w4r = a.w4 + (long)(32 * vnt + L.l31) * 155 + ko;
+    ch_gemm1<CH_HLD, 16, false>(y, w4r, 128, H, vmt, L);
+    ch_gemm1<64, 4, true>(y, w4r + 128, 27, X, vmt, L);
+    ch_d_store<true>(y, a.ym, 64, vrow, vok, 32 * vnt, L);
+    __syncthreads();                                       // every wave has read cm
+    store_tile<64, 15, true>(y, X, vnt, vmt, L);
+    __syncthreads();
+    ch_d_init(y, nullptr, 0, 0, false, 32 * vnt, a.b5, 32 * vnt, 1.0f, L);
+    ch_gemm1<64, 8, false>(y, a.w5 + (long)(32 * vnt + L.l31) * 64 + ko, 64, X, vmt, L);
+    ch_d_store<true>(y, a.y1, 64, vrow, vok, 32 * vnt, L);
+    __syncthreads();                                       // every wave has read ym
+    store_tile<64, 15, true>(y, X, vnt, vmt, L);
+    __syncthreads();
+    // rgb head: 4 lanes per point, 16 features each, 3 outputs
+    {
+        const int p = tid >> 2, q = tid & 3;
+        float d[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+        for (int k = 16 * q; k < 16 * q + 16; ++k) {
+            const float x = X[swz_index<64, 15>(p, k)];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = __builtin_fmaf(x, a.w8[c * 64 + k], d[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            d[c] += __shfl_xor(d[c], 1);
+            d[c] += __shfl_xor(d[c], 2);
+        }
+        if (q == 0 && p0 + p < a.P)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.raw_rgb[(p0 + p) * 3 + c] = d[c] + a.b8[c];
     }
 }

@@ -18,6 +18,7 @@
 //   k_view_mean / k_view_bcast / k_colsum / k_relu_mask: the few elementwise / reduction pieces in between.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -635,6 +636,7 @@ void dw_gemm(int M, int N, int K, const float* Z, long ldz, const float* X, long
 
 #include "train_chain.h"
 
+const int g_heads_fused = [] { const char* e = getenv("NEO360_TRAIN_HEADS"); return e ? atoi(e) : 1; }();    // 0: the P-sized forward tail as separate launches (A/B)
 int g_chain_fused = 1;      // 1: the per-row part of the projected-space NeRFPPMLP chain as one kernel each way (train_chain.h); 0: layer by layer
 
 }  // namespace
@@ -697,6 +699,12 @@ void launch_tp_train_forward(int pe, const float* const* w, const float* const* 
         else hipLaunchKernelGGL((k_tp_chain_fwd<11, false>), grid, dim3(256), 0, s, a);
         float* bm = bott;                                                                                        // (P, 128)
         float* cm = bott + P * 128;                                                                              // (P, 27)
+        if (g_heads_fused) {
+            // the whole P-sized tail - two view means, six small products - as one kernel (train_chain.h)
+            HeadsFwdArgs ha{h3, cond, w[4], b[4], w[5], b[5], w[6], b[6], w[7], b[7], w[8], b[8], hm, bm, cm, ym, y1, raw_sigma, raw_rgb, P, NV};
+            hipLaunchKernelGGL(k_tp_heads_fwd, dim3((unsigned)((P + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, ha);
+            return;
+        }
         hipLaunchKernelGGL(k_view_mean, dim3(blocks(P * 128)), dim3(256), 0, s, h3, NV, P, 128, 0, hm);
         gemm<false, false>((int)P, 1, 128, hm, 128, w[7], 128, raw_sigma, 1, epi(b[7], 0), 1, s);
         gemm<false, false>((int)P, 128, 128, hm, 128, w[6], 128, bm, 128, epi(b[6], 0), 1, s);                   // mean bottleneck
