@@ -482,3 +482,99 @@ __global__ __launch_bounds__(256, 3) void k_tp_heads_fwd(HeadsFwdArgs a) {
             for (int c = 0; c < 3; ++c) a.raw_rgb[(p0 + p) * 3 + c] = d[c] + a.b8[c];
     }
 }
+
+// ---- the input-gradient part of the P-sized backward as ONE kernel: g_rgb, g_sigma -> g_y1, g_ym, g_bm, g_hm ------------------------------
+//     g_y1 = (g_rgb W8) relu'(y1), g_ym = (g_y1 W5) relu'(ym), g_bm = g_ym W4a, g_hm = g_bm W6 + g_sigma w7
+// (five small GEMM launches before); the four results are the operands of the weight-gradient launches and of k_tp_chain_bwd.
+struct HeadsBwdArgs {
+    const float* g_rgb; const float* g_sigma;               // (P, 3), (P, 1)
+    const float* y1; const float* ym;                       // (P, 64) post-ReLU (masks)
+    const float* w4; const float* w5; const float* w6; const float* w7; const float* w8;
+    float* g_y1; float* g_ym; float* g_bm; float* g_hm;     // (P, 64), (P, 64), (P, 128), (P, 128)
+    long P;
+};
+
+__global__ __launch_bounds__(256, 3) void k_tp_heads_bwd(HeadsBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float H[CH_ROWS * CH_HLD];
+    __shared__ __attribute__((aligned(16))) float X[CH_ROWS * 64];
+    LaneCtx L;
+    L.init();
+    const int tid = threadIdx.x;
+    const long p0 = (long)blockIdx.x * CH_ROWS;
+    const int n0 = 32 * L.wv;
+    const long prow[2] = {p0 + L.l31, p0 + 32 + L.l31};
+    const bool ok[2] = {prow[0] < a.P, prow[1] < a.P};
+    const int ko = 4 * L.half;
+    // g_y1: 3-term sums, one (point, 4 features) piece per thread and pass
+    for (int idx = tid; idx < CH_ROWS * 16; idx += 256) {
+        const int p = idx >> 4, c4 = idx & 15;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p0 + p < a.P) {
+            const float g0 = a.g_rgb[(p0 + p) * 3], g1 = a.g_rgb[(p0 + p) * 3 + 1], g2 = a.g_rgb[(p0 + p) * 3 + 2];
+            const f32x4 m = *reinterpret_cast<const f4u*>(a.y1 + (p0 + p) * 64 + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 4 * c4 + e;
+                const float x = __builtin_fmaf(g2, a.w8[128 + k], __builtin_fmaf(g1, a.w8[64 + k], g0 * a.w8[k]));
+                v[e] = m[e] > 0.0f ? x : 0.0f;
+            }
+            *reinterpret_cast<f4u*>(a.g_y1 + (p0 + p) * 64 + 4 * c4) = v;
+        }
+        *reinterpret_cast<f32x4*>(X + p * 64 + ((c4 ^ (p & 15)) << 2)) = v;
+    }
+    __syncthreads();
+    // g_ym = (g_y1 W5) relu'(ym): a 64-wide layer, wave = (n-tile wv >> 1, m-tile wv & 1), transposed fragments of W5 (64 x 64)
+    const int vnt = L.wv >> 1, vmt = L.wv & 1;
+    const long vrow = p0 + 32 * vmt + L.l31;
+    const bool vok = vrow < a.P;
+    f32x16 y;
+    ch_d_init(y, nullptr, 0, 0, false, 32 * vnt, nullptr, 32 * vnt, 1.0f, L);
+    {
+        const float* wp = a.w5 + (long)ko * 64 + 32 * vnt + L.l31;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 w = ch_wfrag_t(wp, 64, c);
+            const f32x4 b = load_b<64, 15>(X, vmt, c, L);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y = NEO_MFMA(w[e], b[e], y);
+        }
+    }
+    {
+        ChMask mk;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mk.m[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (vok) mk.m[g] = *reinterpret_cast<const f4u*>(a.ym + vrow * 64 + 32 * vnt + 8 * g + ko);
+        }
+        ch_mask_apply(y, mk);
+    }
+    ch_d_store<false>(y, a.g_ym, 64, vrow, vok, 32 * vnt, L);
+    __syncthreads();                                       // every wave has read g_y1
+    store_tile<64, 15, false>(y, X, vnt, vmt, L);
+    __syncthreads();
+    // g_bm = g_ym W4[:, :128]
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) ch_d_init(acc[mt], nullptr, 0, 0, false, n0, nullptr, n0, 1.0f, L);
+    ch_gemm<64, 8, true, false>(acc, a.w4 + (long)ko * 155 + n0 + L.l31, 155, 0, X, 0, L);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        store_tile<CH_HLD, 15, false>(acc[mt], H, L.wv, mt, L);
+        ch_d_store<false>(acc[mt], a.g_bm, 128, prow[mt], ok[mt], n0, L);
+    }
+    __syncthreads();
+    // g_hm = g_bm W6 + g_sigma w7
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const float gs = ok[mt] ? a.g_sigma[prow[mt]] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 w = *reinterpret_cast<const f4u*>(a.w7 + n0 + 8 * g + ko);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mt][4 * g + e] = gs * w[e];
+        }
+    }
+    ch_gemm<CH_HLD, 16, true, false>(acc, a.w6 + (long)ko * 128 + n0 + L.l31, 128, 0, H, 0, L);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) ch_d_store<false>(acc[mt], a.g_hm, 128, prow[mt], ok[mt], n0, L);
+}

@@ -885,24 +885,35 @@ void launch_tp_train_backward(int pe, const float* const* w, const float* x_enc,
     const float* in[3] = {x_enc, local, world};
     float* g_in[3] = {g_x_enc, g_local, g_world};
     const int kin[3] = {pe, 512, 128}, off[3] = {0, pe, pe + 512};
+    const bool fused = g_pre && g_chain_fused && (pe == 63 || pe == 84);
+    if (fused && g_heads_fused) {
+        // the input-gradient part of everything P-sized as one kernel: g_y1, g_ym, g_bm, g_hm (train_chain.h)
+        HeadsBwdArgs hb{g_rgb, g_sigma, y1, ym, w[4], w[5], w[6], w[7], w[8], g_y1, g_ym, part + DW_PART_FLOATS, g_hm, P};
+        hipLaunchKernelGGL(k_tp_heads_bwd, dim3((unsigned)((P + CH_ROWS - 1) / CH_ROWS)), dim3(256), 0, s, hb);
+        dw_gemm(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, gb[8], part, s);                                     // rgb head
+        dw_gemm(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, gb[5], part, s);                                    // view layer 1
+    } else {
     // rgb head
     dw_gemm(3, 64, (int)P, g_rgb, 3, y1, 64, gw[8], 64, gb[8], part, s);
     gemm<false, true>((int)P, 64, 3, g_rgb, 3, w[8], 64, g_y1, 64, epi(nullptr, 0, 0, y1, 64), 1, s);            // x relu'(y1)
     // view layer 1
     dw_gemm(64, 64, (int)P, g_y1, 64, ym, 64, gw[5], 64, gb[5], part, s);
     gemm<false, true>((int)P, 64, 64, g_y1, 64, w[5], 64, g_ym, 64, epi(nullptr, 0, 0, ym, 64), 1, s);           // x relu'(mean)
-    if (g_pre && g_chain_fused && (pe == 63 || pe == 84)) {
+    }
+    if (fused) {
         // the forward ran view layer 0 and the bottleneck on the view means (see launch_tp_train_forward): their backward is P-sized too
         const float* bm = bott;
         const float* cm = bott + P * 128;
         float* g_bm = part + DW_PART_FLOATS;                                                     // (P, 128) in the third R x 128 buffer
         dw_gemm(64, 128, (int)P, g_ym, 64, bm, 128, gw[4], 155, gb[4], part, s);                                  // view layer 0
         dw_gemm(64, 27, (int)P, g_ym, 64, cm, 27, gw[4] + 128, 155, nullptr, part, s);
-        gemm<false, true>((int)P, 128, 64, g_ym, 64, w[4], 155, g_bm, 128, epi(), 1, s);                          // g of the mean bottleneck
+        if (!g_heads_fused) gemm<false, true>((int)P, 128, 64, g_ym, 64, w[4], 155, g_bm, 128, epi(), 1, s);      // g of the mean bottleneck
         dw_gemm(128, 128, (int)P, g_bm, 128, hm, 128, gw[6], 128, gb[6], part, s);                                // bottleneck
         dw_gemm(1, 128, (int)P, g_sigma, 1, hm, 128, gw[7], 128, gb[7], part, s);                                 // density head
-        gemm<false, true>((int)P, 128, 128, g_bm, 128, w[6], 128, g_hm, 128, epi(), 1, s);                        // g_hm = g_bm W6 + g_sigma W7
-        gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(nullptr, 0, 1), 1, s);
+        if (!g_heads_fused) {
+            gemm<false, true>((int)P, 128, 128, g_bm, 128, w[6], 128, g_hm, 128, epi(), 1, s);                    // g_hm = g_bm W6 + g_sigma W7
+            gemm<false, true>((int)P, 128, 1, g_sigma, 1, w[7], 128, g_hm, 128, epi(nullptr, 0, 1), 1, s);
+        }
         // ONE kernel for the input-gradient chain of every row: g_h3 = g_hm / NV per view -> g_z3 .. g_z0, g_world (train_chain.h); then
         // the weight-gradient GEMMs on what it wrote: g_z3 | g_z0 (the halves of g_pre), g_z2, g_z1
         ChainBwdArgs a{w[0], w[1], w[2], w[3], h0, h1, h2, h3, g_hm, g_pre + 128, 256L, g_pre, 256L, ga, gb2, g_world, R, P, pe, NV};
