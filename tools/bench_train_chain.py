@@ -18,7 +18,10 @@ cond = torch.randn(NV * P, 27, device=dev, generator=g)
 world = (torch.randn(NV * P, 128, device=dev, generator=g) * 0.3).requires_grad_(True)
 pre = (torch.randn(NV * P, 256, device=dev, generator=g) * 0.3).requires_grad_(True)
 pe = 21 * CH
-fwd_flop = 2.0 * NV * P * (128 * (pe + 128) + 2 * 128 * 128 + 128 * (128 + pe + 128) + 128 * 128 + 64 * 155)
+# executed flops: mode 1 runs the bottleneck and view layer 0 on the view means (P rows), mode 0 per row (NV P rows)
+row_mac, head_mac = 128 * (pe + 128) + 2 * 128 * 128 + 128 * (128 + pe + 128), 128 * 128 + 64 * 155
+mode = _lib.load().neo_train_chain_mode(-1)
+fwd_flop = 2.0 * (NV * P * row_mac + (P if mode else NV * P) * head_mac + P * (128 + 64 * 64 + 3 * 64))
 def step():
     rgb, sig = training.nerfpp_mlp_projected(mlp, x_enc, cond, world, pre, NV)
     (rgb.sum() + sig.sum()).backward()
