@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
                 for (int i = 0; i < 2; ++i) write_x(buf, rg + 16 * (2 * hf + i), sum[i]);
             };
             // pos_enc of the camera-frame point: 64 features per stage; half hf = feature chunks 8hf..8hf+7
-            auto finish_pe = [&](float* buf, int pstage, int hf) {
+            [[maybe_unused]] auto finish_pe = [&](float* buf, int pstage, int hf) {
                 const int row = tid & 63, q = tid >> 6;
                 const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
 #pragma unroll
@@ -292,6 +292,56 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
 #pragma unroll
                     for (int e = 0; e < 4; ++e) vv[e] = pe_feature<PE_C>(xc, pstage * 64 + ch * 4 + e);
                     *reinterpret_cast<f32x4*>(buf + row * XB_LD + ((ch ^ (row & 15)) << 2)) = vv;
+                }
+            };
+            // PROJ == 2 (pos_enc is the only streamed input): ONE argument reduction per (sin, cos) pair (common.h:sincos_pair, as
+            // the split kernels do; the sin half is bitwise sin_cw's, the phase-shifted half within 1.5e-7 of the reference's
+            // fl32(a + fl32(pi/2))).  Pair p = 4 i + wave: coordinate p % C, octave p / C, features C + p and 11 C + p
+            // (neo360/helper.py:121-125).  C = 3: the whole encoding in the prologue (part 0).  C = 4: the pairs whose two features
+            // both lie in the first 64-feature stage (octaves 0..4) + the single sines of octaves 5..9 in the prologue (part 0), the
+            // phase-shifted halves of octaves 5..9 (features 64..83, second stage's tile `b1`) between the k-steps of the first stage
+            // (part 1) - all 40 pairs in the prologue measured 3.7 % SLOWER on the outside launches (profiles/r06_f32_pairs.log).
+            [[maybe_unused]] auto encode_pairs = [&](float* b0, float* b1, int part) {
+                const int row = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const float xc[4] = {cam_enc[row * 4], cam_enc[row * 4 + 1], cam_enc[row * 4 + 2], cam_enc[row * 4 + 3]};
+                auto put = [&](int f, float val) {
+                    float* b = f < 64 ? b0 : b1;
+                    const int g = f & 63;
+                    b[row * XB_LD + (((g >> 2) ^ (row & 15)) << 2) + (g & 3)] = val;
+                };
+                if constexpr (PE_C == 3) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int pr = 4 * i + q;
+                        if (pr < 30) {
+                            const int oct = pr / 3, ci = pr - 3 * oct;
+                            float sn, cs;
+                            sincos_pair(ldexpf(ci == 0 ? xc[0] : ci == 1 ? xc[1] : xc[2], oct), sn, cs);
+                            put(3 + pr, sn);
+                            put(33 + pr, cs);
+                        }
+                    }
+                    if (q == 3) {               // the raw coordinates and the zero pad of the last k-chunk
+                        put(0, xc[0]); put(1, xc[1]); put(2, xc[2]); put(63, 0.0f);
+                    }
+                } else {
+                    const float xq = q == 0 ? xc[0] : q == 1 ? xc[1] : q == 2 ? xc[2] : xc[3];      // p % 4 = wave
+                    if (part == 0) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            float sn, cs;
+                            sincos_pair(ldexpf(xq, i), sn, cs);
+                            put(4 + 4 * i + q, sn);
+                            put(44 + 4 * i + q, cs);
+                        }
+#pragma unroll
+                        for (int i = 5; i < 10; ++i) put(4 + 4 * i + q, sin_cw(ldexpf(xq, i)));
+                        if (q == 3) { put(0, xc[0]); put(1, xc[1]); put(2, xc[2]); put(3, xc[3]); }
+                    } else {
+#pragma unroll
+                        for (int i = 5; i < 10; ++i) put(44 + 4 * i + q, sin_cw(ldexpf(xq, i) + HALF_PI_F32));
+                        if (q == 3) { put(84, 0.0f); put(85, 0.0f); put(86, 0.0f); put(87, 0.0f); }
+                    }
                 }
             };
             // ---- pre-projected maps: 4 chunks of 64 output channels x 4 row groups; the maps' blends of a (chunk, row group)
@@ -364,8 +414,7 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
                 issue_plane(0, 0, 1);
                 finish_planes(act, 0, 1);
             } else {
-                finish_pe(act, 0, 0);
-                finish_pe(act, 0, 1);
+                encode_pairs(act, act + TM * XB_LD, 0);
             }
             __syncthreads();
 #pragma unroll 1
@@ -383,7 +432,10 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
                     else if (nchunks > 4) gemm2x<2, XB_LD, 15>(accx, wp + off_x() / 4, KCX, nts_x, s * 8, 4, nchunks - 4, cur, L);
                     if (sn < 8) finish_local(nxt, hf);
                     else if (sn < 10) finish_planes(nxt, sn - 8, hf);
-                    else if (sn < NST) finish_pe(nxt, sn - 10, hf);
+                    else if (sn < NST) {
+                        if constexpr (PROJ == 2) { if (hf == 0) encode_pairs(act, act + TM * XB_LD, 1); }
+                        else finish_pe(nxt, sn - 10, hf);
+                    }
                 }
                 __syncthreads();
             }
