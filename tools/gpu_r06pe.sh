@@ -1,3 +1,4 @@
+# NOTE: the NEO_TP32_PAIRS switch and the lib/ab/ variant libraries this script compares were removed after the measurement (the paired encoding is the shipped code; profiles/r06_f32_pairs.log)
 # round 6: exact-fp32 NeO-360 evaluator k_tp_mlp<., 2> - pos_enc by (sin, cos) pairs in the prologue (NEO_TP32_PAIRS) against
 # feature by feature; variant libraries are built on the CPU side into neo-360_amd/lib/ab/ (see profiles/r06_f32_pairs.log)
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r06pe; rm -rf $O; mkdir -p $O

@@ -1,3 +1,4 @@
+# NOTE: the NEO_TP32_PAIRS switch and the lib/ab/ variant libraries this script compares were removed after the measurement (the paired encoding is the shipped code; profiles/r06_f32_pairs.log)
 # round 6: exact-fp32 evaluator, outside launches (C = 4): pairs of the first stage in the prologue + singles (hybrid) against feature by feature
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r06pe2; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
