@@ -138,10 +138,15 @@ int tp_launch(neo_ctx* ctx, MlpSlot& sl, const neo::TpScene& sc, const neo::TpVi
             if (int rc = ensure_projections(ctx, sl, sc, planes, s, plane_base)) return rc;
         const float* pbase = sl.proj.as<float>();
         const neo::TpPlaneProj pp{{pbase + plane_base[0] * 256, pbase + plane_base[1] * 256, pbase + plane_base[2] * 256}};
+        if (ctx->preproject) {      // as on the split path: the direction encodings summed over the views once per ray
+            if (ctx->tp_dirsum->reserve(static_cast<size_t>(R) * 32 * sizeof(float))) return NEO_ERR_NOMEM;
+            neo::launch_tp_dirsum(viewdirs, R, views, sc.nv, ctx->tp_dirsum->as<float>(), s);
+        }
         ctx->span_kernel_next = 4;
         ctx->span_begin(s);
         neo::launch_tp_mlp(sl.input_ch, m, scp, views, rays_o, rays_d, viewdirs, tvals, far, R, N, chunk, ctx->flags, out, s,
-                           ctx->preproject ? sl.proj.as<float>() : nullptr, planes ? &pp : nullptr);
+                           ctx->preproject ? sl.proj.as<float>() : nullptr, planes ? &pp : nullptr,
+                           ctx->preproject ? ctx->tp_dirsum->as<float>() : nullptr);
     }
     ctx->span_end(s, static_cast<double>(R) * N, tp_flop_per_point(sl.input_ch, sc.nv));
     return NEO_OK;

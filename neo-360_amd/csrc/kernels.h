@@ -133,11 +133,12 @@ void launch_tp_pack(int input_ch, const float* const* w, const float* const* b, 
 void launch_channels_last(const float* src, int NV, int C, int H, int W, float* dst, hipStream_t s);
 struct TpPlaneProj;
 // proj != null: the latent pre-projected through [W0_loc | W3_loc] is gathered instead of the latent (k_tp_preproject);
-// pp != null as well: the three tri-planes pre-projected through [W0_world | W3_world] likewise
+// pp != null as well: the three tri-planes pre-projected through [W0_world | W3_world] likewise.  With proj the kernel reads the
+// view-summed direction encodings from `dirsum` (rays, 32; launch_tp_dirsum below, on the same stream before this launch)
 void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
                    const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
                    int chunk, uint32_t* flags, float* out, hipStream_t s, const float* proj = nullptr,
-                   const TpPlaneProj* pp = nullptr);
+                   const TpPlaneProj* pp = nullptr, const float* dirsum = nullptr);
 
 // weight re-packing into MFMA fragment order (defined in mlp_tp.hip)
 struct PackSegs { int k0[3], len[3], col[3]; };

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
                                                     const float* __restrict__ viewdirs,
                                                     const float* __restrict__ tvals,
                                                     const float* __restrict__ far_arr, int R, int N, int chunk,
-                                                    uint32_t* __restrict__ flags, float4* __restrict__ out) {
+                                                    uint32_t* __restrict__ flags, float4* __restrict__ out,
+                                                    const float* __restrict__ dirsum) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* act = smem + OFF_ACT;
     float* dsm = smem + OFF_DIR;
@@ -195,6 +196,17 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
 #endif
     tp::point_setup<PE_C>(S, tid, tile0, P, N, R, chunk, rays_o, rays_d, viewdirs, tvals, far_arr, flags, false, sc.grid_w, sc.grid_first, sc.grid_pw, sc.grid_ph);
     __syncthreads();
+    if constexpr (FOLD) {
+        // the view branch needs only the SUM over the views of each point's direction encoding, and that depends on the ray alone:
+        // it comes ready-made from the per-ray table of this launch (mlp_tp_hp.hip:k_tp_dirsum - the arithmetic and the summation
+        // order of the per-view accumulation it replaces, so the outputs are bitwise the same), 8 features per thread
+        const int p = tid >> 2, f0 = (tid & 3) << 3;
+        const int dray = __float_as_int(S.vdir_world[p * 4 + 3]);      // the ray whose direction this row carries (quirk Q1)
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(dirsum + (long)dray * 32 + f0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(dirsum + (long)dray * 32 + f0 + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsm[swz_index<DIR_LD, 7>(p, f0 + j)] = j < 4 ? s0[j] : s1[j - 4];
+    }
     TP32_MARK(0);
 
     f32x16 hsum[2], ysum;
@@ -215,13 +227,9 @@ __global__ __launch_bounds__(256, NEO_TP_F32_WGS) void k_tp_mlp(TpMlpDev m, cons
         L.key = L.lane & 15;
         const float* rot = views.rot[v];
         const float* trn = views.trans[v];
-        tp::view_descriptors<(PROJ >= 1 ? hp::PROJ_TEXEL_BYTES : 2048), true, (PROJ == 2 ? hp::PROJ_TEXEL_BYTES : 128 * 4)>(
-            S, L, sc, rot, trn, v, [&](int p, int f, float val) {
-                // FOLD: only the SUM over the views of the direction encoding is needed (the view branch is linear up to the
-                // view mean); every (point, feature) is written by one thread per view
-                float* d = dsm + swz_index<DIR_LD, 7>(p, f);
-                if (FOLD && v > 0) *d += val; else *d = val;
-            });
+        // FOLD: no per-view direction encoding (the table above); otherwise every (point, feature) is written by one thread per view
+        tp::view_descriptors<(PROJ >= 1 ? hp::PROJ_TEXEL_BYTES : 2048), !FOLD, (PROJ == 2 ? hp::PROJ_TEXEL_BYTES : 128 * 4)>(
+            S, L, sc, rot, trn, v, [&](int p, int f, float val) { dsm[swz_index<DIR_LD, 7>(p, f)] = val; });
         __syncthreads();
         TP32_MARK(1);
 
@@ -684,7 +692,8 @@ void launch_channels_last(const float* src, int NV, int C, int H, int W, float* 
 
 void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpViews& views, const float* rays_o,
                    const float* rays_d, const float* viewdirs, const float* tvals, const float* far, int R, int N,
-                   int chunk, uint32_t* flags, float* out, hipStream_t s, const float* proj, const TpPlaneProj* pp) {
+                   int chunk, uint32_t* flags, float* out, hipStream_t s, const float* proj, const TpPlaneProj* pp,
+                   const float* dirsum) {
     const long P = (long)R * N;
     if (P <= 0) return;
     const size_t lds = LDS_FLOATS * sizeof(float);
@@ -694,7 +703,7 @@ void launch_tp_mlp(int input_ch, const TpMlpDev& m, const TpScene& sc, const TpV
     const int mode = !proj ? 0 : pp ? 2 : 1;      // gather the latent itself | the projected latent | projected latent + planes
 #define NEO_TP_F32_LAUNCH(C, PR)                                                                                          \
     hipLaunchKernelGGL((k_tp_mlp<C, PR>), grid, dim3(256), lds, s, m, proj, planes, sc, views, rays_o, rays_d, viewdirs, \
-                       tvals, far, R, N, chunk, flags, o4)
+                       tvals, far, R, N, chunk, flags, o4, dirsum)
     if (input_ch == 3) {
         if (mode == 0) NEO_TP_F32_LAUNCH(3, 0); else if (mode == 1) NEO_TP_F32_LAUNCH(3, 1); else NEO_TP_F32_LAUNCH(3, 2);
     } else {
